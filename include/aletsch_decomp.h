@@ -1,0 +1,194 @@
+/*
+ * aletsch_decomp.h -- C ABI of the MI355X splice-graph decomposition path.
+ *
+ * This is the drop-in boundary for ONE hot path of Shao-Group/aletsch: the
+ * per-bundle "Scallop core" (reference meta/assembler.cc:1110-1111,
+ *   scallop sx(gx, hx, pa, false); sx.assemble();   -> sx.paths / sx.trsts
+ * reference scallop/scallop.h:31-35,50-51).  A maintainer binds these entry
+ * points from the reference's C++ host code (INTEGRATION.md shows the 2-line
+ * swap through aletsch_amd/host/gpu_scallop.hpp).
+ *
+ * Plain C: pointers + sizes only, no C++ / torch types.  Every function returns
+ * an int status (0 = ALD_OK); nothing throws across this boundary and nothing
+ * aborts the process (the reference aborts on assert; here an invariant
+ * violation becomes a per-graph status word, see ALD_ST_*).
+ *
+ * Canonical order: the reference orders edges by raw
+ * pointer value; this ABI defines the order as "edge creation sequence", and
+ * the creation sequence of the input edges is their CSR position.
+ */
+#ifndef ALETSCH_DECOMP_H
+#define ALETSCH_DECOMP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library-level status codes ---- */
+#define ALD_OK                 0
+#define ALD_ERR_INVALID       -1   /* bad argument / malformed graph            */
+#define ALD_ERR_NO_DEVICE     -2   /* no HIP device: the product path has NO CPU fallback */
+#define ALD_ERR_HIP           -3   /* a HIP runtime call failed (see ald_last_error) */
+#define ALD_ERR_STATE         -4   /* call sequence error (e.g. run before upload)    */
+#define ALD_ERR_NOMEM         -5
+
+/* ---- per-graph status words (ald_result_view.status) ---- */
+#define ALD_ST_OK              0
+#define ALD_ST_SKIPPED_LARGE   1   /* |V| > max_num_exons: main loop skipped (scallop.cc:49), greedy still ran */
+#define ALD_ST_CAPACITY        2   /* device working-set capacity exceeded after all retries  */
+#define ALD_ST_INVARIANT     100   /* 100+n: the reference would have hit assert class n      */
+
+/* assert classes (status = ALD_ST_INVARIANT + class) */
+#define ALD_INV_WEIGHT         1   /* w >= min_guaranteed_edge_weight - SMIN  (scallop.cc:1727,2396,2435) */
+#define ALD_INV_MERGE_EQUAL    2   /* |wx-wy| <= SMIN before merge             (scallop.cc:2270) */
+#define ALD_INV_COUNT          3   /* edge_info.count > 0 / empty sample intersection (scallop.cc:1915,2300) */
+#define ALD_INV_ROUTER         4   /* router precondition (mixed strand, isolated w/o partner, one-side connected) */
+#define ALD_INV_DEGREE         5   /* degree(root)==0 after decomposition      (scallop.cc:1973,2139) */
+#define ALD_INV_OTHER          9
+
+/* Parameters the path reads (reference util/parameters.cc:85-105). */
+typedef struct ald_params {
+    double  max_decompose_error_ratio[8]; /* {.30,0,1.10,1.10,.75,.30,0,1.00} */
+    double  min_guaranteed_edge_weight;   /* 0.01 */
+    double  min_transcript_coverage;      /* 2.0  */
+    int32_t max_num_exons;                /* 10000 */
+    int32_t reserved;
+} ald_params;
+
+/* One splice graph, caller-owned arrays, borrowed for the duration of the call.
+ * Vertex 0 is the source, vertex V-1 the sink (reference rnacore/splice_graph.h).
+ * Edges are CSR by source vertex; edge id == CSR position == creation order. */
+typedef struct ald_graph_view {
+    int32_t        num_vertices;        /* V >= 2                                        */
+    int32_t        num_edges;           /* E                                             */
+    const int32_t *vertex_offset;       /* [V+1] out-CSR                                 */
+    const int32_t *edge_target;         /* [E]   target > source (DAG, forward edges)    */
+    const double  *edge_weight;         /* [E]   splice_graph::ewrt                      */
+    const uint8_t *edge_strand;         /* [E]   edge_info.strand 0/1/2; NULL => all 0   */
+    const double  *edge_abd;            /* [E]   edge_info.abd;      NULL => sum(sample_abd) */
+    const int32_t *edge_sample_offset;  /* [E+1] per-edge slice into sample_id/sample_abd; edge_info.count = slice length */
+    const int32_t *sample_id;           /* [S]   edge_info.samples, ascending per edge   */
+    const double  *sample_abd;          /* [S]   edge_info.spAbd                         */
+    const double  *vertex_weight;       /* [V]   splice_graph::vwrt                      */
+    const int32_t *vertex_lpos;         /* [V]   vertex_info.lpos                        */
+    const int32_t *vertex_rpos;         /* [V]   vertex_info.rpos                        */
+    const int32_t *vertex_type;         /* [V]   vertex_info.type; NULL => -1 (EMPTY_VERTEX is -9) */
+    int32_t        num_phasing;         /* P: entries of hyper_set::nodes after filter_nodes */
+    const int32_t *phasing_offset;      /* [P+1]                                         */
+    const int32_t *phasing_vertex;      /* vertex lists, ascending                       */
+    const int32_t *phasing_count;       /* [P]                                           */
+    char           strand;              /* splice_graph::strand '+','-','.'              */
+} ald_graph_view;
+
+/* One decomposed s-t path (reference rnacore/path.h:14-35, scallop.cc:2766-2834). */
+typedef struct ald_path_view {
+    int32_t        num_vertices;   /* includes source 0 and the sink (original index V-1) */
+    const int32_t *vertices;       /* ascending original vertex indices                    */
+    double         weight;         /* path.weight  */
+    double         abd;            /* path.abd     */
+    double         conf;           /* path.conf = exp(edge_info.confidence) */
+    double         reads;          /* path.reads (med) */
+    int32_t        length;         /* path.length (mei) */
+    int32_t        count;          /* path.count   */
+    char           strand;         /* '+','-','.'  */
+} ald_path_view;
+
+typedef struct ald_result_view {
+    int32_t status;        /* ALD_ST_*                                */
+    int32_t num_paths;     /* in reference order (scallop::paths)     */
+    int32_t num_iterations;/* main-loop rule firings (diagnostic)     */
+    int32_t reserved;
+} ald_result_view;
+
+typedef struct ald_batch ald_batch;   /* opaque */
+
+/* ---- lifecycle (replaces per-graph `scallop sx(...)` construction, scallop.cc:19-32) ---- */
+int  ald_default_params(ald_params *p);
+int  ald_batch_create(const ald_params *p, int device, ald_batch **out);
+int  ald_batch_destroy(ald_batch *b);
+int  ald_batch_clear(ald_batch *b);                       /* forget graphs, keep buffers */
+
+/* ---- staging: copy one graph / many packed graphs into the pinned wire buffer ---- */
+int  ald_batch_add_graph(ald_batch *b, const ald_graph_view *g);
+/* Bulk form for n graphs concatenated: every per-vertex / per-edge / per-sample array is the
+ * concatenation over graphs; g_nv[n], g_ne[n], g_np[n] give sizes; vertex_offset, edge_sample_offset
+ * and phasing_offset are per-graph LOCAL (each restarts at 0; lengths V+1, E+1, P+1). */
+int  ald_batch_add_packed(ald_batch *b, int32_t n,
+                          const int32_t *g_nv, const int32_t *g_ne, const int32_t *g_np,
+                          const int32_t *vertex_offset, const int32_t *edge_target,
+                          const double *edge_weight, const uint8_t *edge_strand, const double *edge_abd,
+                          const int32_t *edge_sample_offset, const int32_t *sample_id, const double *sample_abd,
+                          const double *vertex_weight, const int32_t *vertex_lpos, const int32_t *vertex_rpos,
+                          const int32_t *vertex_type,
+                          const int32_t *phasing_offset, const int32_t *phasing_vertex, const int32_t *phasing_count,
+                          const char *graph_strand);
+int  ald_batch_num_graphs(const ald_batch *b);
+
+/* ---- execution (replaces `sx.assemble()`, scallop.cc:38-188) ---- */
+int  ald_batch_upload(ald_batch *b);      /* H2D of the wire buffer (one coalesced copy)      */
+int  ald_batch_run(ald_batch *b);         /* launch decomposition kernels on the batch stream */
+int  ald_batch_sync(ald_batch *b);        /* wait for the stream                              */
+int  ald_batch_download(ald_batch *b);    /* D2H of status + packed path records, index build */
+/* device milliseconds of the last ald_batch_run (hipEvents on the batch stream); <0 if n/a */
+double ald_batch_last_kernel_ms(const ald_batch *b);
+/* algorithmic bytes: packed input bytes + packed path-record bytes of the last run */
+int  ald_batch_algorithmic_bytes(const ald_batch *b, int64_t *in_bytes, int64_t *out_bytes);
+
+/* ---- results (replaces reading sx.paths, scallop.h:50) ---- */
+int  ald_batch_get_result(const ald_batch *b, int32_t graph, ald_result_view *out);
+int  ald_batch_get_path(const ald_batch *b, int32_t graph, int32_t path, ald_path_view *out);
+/* Bulk export: fills caller arrays. path_offset[n+1] (paths per graph prefix), then per path the
+ * scalar fields and pv_offset[num_paths_total+1] into path_vertices. Pass NULL to query sizes. */
+int  ald_batch_export(const ald_batch *b, int64_t *total_paths, int64_t *total_path_vertices,
+                      int32_t *status, int32_t *path_offset,
+                      double *weight, double *abd, double *conf, double *reads,
+                      int32_t *length, int32_t *count, char *strand,
+                      int64_t *pv_offset, int32_t *path_vertices);
+
+/* optional per-graph operation trace (debug builds of the parity tests): rule id, vertex/edge, ratio */
+int  ald_batch_enable_trace(ald_batch *b, int32_t max_events_per_graph);
+int  ald_batch_get_trace(const ald_batch *b, int32_t graph, int32_t *n_events,
+                         const int32_t **codes /* 3 ints per event */, const double **values);
+
+/* ---- subset-sum (reference scallop/subsetsum.cc:20-206; dead in the live path, KAT-pinned) ----
+ * n instances; instance i has ns[i] source and nt[i] target integers (values concatenated).
+ * Outputs per instance: error e (eqn.e), and the chosen item labels (eqn.s / eqn.t), max 64 each. */
+int  ald_subsetsum_batch(int device, int32_t n,
+                         const int32_t *ns, const int32_t *nt,
+                         const int32_t *src_val, const int32_t *src_lab,
+                         const int32_t *tgt_val, const int32_t *tgt_lab,
+                         double *err, int32_t *out_ns, int32_t *out_nt,
+                         int32_t *out_s /* [n*64] */, int32_t *out_t /* [n*64] */);
+
+/* ---- deterministic synthetic batches (SURVEY 8d generator; used by bench and tests) ---- */
+typedef struct ald_synth_spec {
+    uint64_t seed;
+    int32_t  n_graphs;
+    int32_t  v_min, v_max;      /* V ~ U{v_min..v_max}                       */
+    int32_t  edges_per_vertex;  /* E = V * edges_per_vertex, unless ...      */
+    int32_t  fixed_edges;       /* ... fixed_edges > 0: E = fixed_edges      */
+    int32_t  weight_mode;       /* 0 = U[1,100) f64, 1 = integer U{1..100}, 2 = flow-conserving (sum of s-t paths) */
+    int32_t  n_samples;         /* samples per edge drawn from {0..n_samples-1}; 1 => {0} */
+    int32_t  phasing_per_graph; /* number of random phasing paths (count in 2..10)   */
+    int32_t  strand_mode;       /* 0 = all '.', 1 = per-graph single strand on ~70% of edges  */
+    int32_t  layout_mode;       /* 0 = exons 1000 apart (every edge a junction), 1 = ~30% of consecutive vertices touch */
+} ald_synth_spec;
+/* Two-pass: call with all output pointers NULL to get totals, then with buffers. */
+int  ald_synth_sizes(const ald_synth_spec *s, int64_t *tot_v, int64_t *tot_e, int64_t *tot_s, int64_t *tot_p, int64_t *tot_pv);
+int  ald_synth_fill(const ald_synth_spec *s,
+                    int32_t *g_nv, int32_t *g_ne, int32_t *g_np,
+                    int32_t *vertex_offset, int32_t *edge_target, double *edge_weight, uint8_t *edge_strand,
+                    double *edge_abd, int32_t *edge_sample_offset, int32_t *sample_id, double *sample_abd,
+                    double *vertex_weight, int32_t *vertex_lpos, int32_t *vertex_rpos, int32_t *vertex_type,
+                    int32_t *phasing_offset, int32_t *phasing_vertex, int32_t *phasing_count, char *graph_strand);
+
+const char *ald_last_error(void);
+const char *ald_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALETSCH_DECOMP_H */

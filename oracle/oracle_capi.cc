@@ -1,0 +1,216 @@
+/*
+ * oracle_capi.cc -- TEST INFRASTRUCTURE ONLY.  C entry points over scallop_oracle.hpp so that
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can drive the CPU restatement
+ * with exactly the packed arrays the GPU ABI (include/aletsch_decomp.h, ald_batch_add_packed)
+ * takes.  The product library never links or loads this file.
+ */
+#include "scallop_oracle.hpp"
+#include "subsetsum_oracle.hpp"
+#include "../include/aletsch_decomp.h"
+#include <thread>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+
+namespace {
+
+struct GraphResult {
+    int status = 0;
+    int iterations = 0;
+    std::vector<ora::Path> paths;
+    std::vector<ora::Transcript> trsts;
+    std::vector<ora::TraceEvent> trace;
+    ora::Stats st;
+};
+
+struct Packed {
+    int32_t n;
+    const int32_t *g_nv, *g_ne, *g_np;
+    const int32_t *vertex_offset, *edge_target; const double *edge_weight; const uint8_t *edge_strand; const double *edge_abd;
+    const int32_t *edge_sample_offset, *sample_id; const double *sample_abd;
+    const double *vertex_weight; const int32_t *vertex_lpos, *vertex_rpos, *vertex_type;
+    const int32_t *phasing_offset, *phasing_vertex, *phasing_count; const char *graph_strand;
+};
+
+struct Offsets { int64_t v, vo, e, eo, s, p, po, pv; };
+
+void run_one(const Packed &P, const Offsets &o, int g, const ora::Params &cfg, bool want_trace, GraphResult &out)
+{
+    int V = P.g_nv[g], E = P.g_ne[g], NP = P.g_np ? P.g_np[g] : 0;
+    ora::Graph gr;
+    for(int i = 0; i < V; i++) gr.add_vertex();
+    gr.strand = P.graph_strand ? P.graph_strand[g] : '.';
+    for(int i = 0; i < V; i++) {
+        gr.vwrt[i] = P.vertex_weight[o.v + i];
+        gr.vinf[i].lpos = P.vertex_lpos[o.v + i]; gr.vinf[i].rpos = P.vertex_rpos[o.v + i];
+        gr.vinf[i].type = P.vertex_type ? P.vertex_type[o.v + i] : -1;
+    }
+    const int32_t *vo = P.vertex_offset + o.vo; const int32_t *so = P.edge_sample_offset + o.eo;
+    for(int s = 0; s < V; s++) for(int k = vo[s]; k < vo[s + 1]; k++) {
+        int e = gr.add_edge(s, P.edge_target[o.e + k]);
+        gr.ewrt[e] = P.edge_weight[o.e + k];
+        ora::EdgeInfo &ei = gr.einf[e];
+        ei.strand = P.edge_strand ? P.edge_strand[o.e + k] : 0;
+        double sum = 0;
+        for(int j = so[k]; j < so[k + 1]; j++) { int sid = P.sample_id[o.s + j]; double a = P.sample_abd[o.s + j]; ei.samples.insert(sid); ei.spAbd[sid] = a; sum += a; }
+        ei.count = so[k + 1] - so[k];
+        ei.abd = P.edge_abd ? P.edge_abd[o.e + k] : sum;
+    }
+    ora::HyperSet hs;
+    if(NP > 0) {
+        const int32_t *po = P.phasing_offset + o.po;
+        for(int p = 0; p < NP; p++) {
+            std::vector<int> v(P.phasing_vertex + o.pv + po[p], P.phasing_vertex + o.pv + po[p + 1]);
+            int c = P.phasing_count[o.p + p];
+            if(hs.nodes.count(v)) hs.nodes[v] += c; else hs.nodes[v] = c;     // hyper_set.cc:40-48 add_node_list
+        }
+    }
+    try {
+        ora::Scallop sc(gr, hs, cfg);
+        if(want_trace) sc.trace = &out.trace;
+        if(V > cfg.max_num_exons) out.status = ALD_ST_SKIPPED_LARGE;
+        sc.assemble();
+        out.paths = sc.paths; out.trsts = sc.trsts; out.st = sc.st; out.iterations = sc.st.iterations;
+    } catch(const ora::AssertFail &a) {
+        out.status = ALD_ST_INVARIANT + a.cls;
+        out.paths.clear(); out.trsts.clear();
+        if(getenv("ORA_VERBOSE")) fprintf(stderr, "oracle: graph %d assert class %d line %d: %s\n", g, a.cls, a.line, a.what);
+    }
+}
+
+} // namespace
+
+struct ora_result {
+    std::vector<GraphResult> gr;
+    double seconds = 0;
+};
+
+extern "C" {
+
+int ora_run_packed(int32_t n,
+                   const int32_t *g_nv, const int32_t *g_ne, const int32_t *g_np,
+                   const int32_t *vertex_offset, const int32_t *edge_target,
+                   const double *edge_weight, const uint8_t *edge_strand, const double *edge_abd,
+                   const int32_t *edge_sample_offset, const int32_t *sample_id, const double *sample_abd,
+                   const double *vertex_weight, const int32_t *vertex_lpos, const int32_t *vertex_rpos,
+                   const int32_t *vertex_type,
+                   const int32_t *phasing_offset, const int32_t *phasing_vertex, const int32_t *phasing_count,
+                   const char *graph_strand,
+                   const ald_params *prm, int32_t n_threads, int32_t want_trace, ora_result **out)
+{
+    Packed P{n, g_nv, g_ne, g_np, vertex_offset, edge_target, edge_weight, edge_strand, edge_abd, edge_sample_offset, sample_id, sample_abd,
+             vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand};
+    ora::Params cfg;
+    if(prm) {
+        for(int i = 0; i < 8; i++) cfg.max_decompose_error_ratio[i] = prm->max_decompose_error_ratio[i];
+        cfg.min_guaranteed_edge_weight = prm->min_guaranteed_edge_weight;
+        cfg.min_transcript_coverage = prm->min_transcript_coverage;
+        cfg.max_num_exons = prm->max_num_exons;
+    }
+    std::vector<Offsets> off(n + 1);
+    Offsets o{0, 0, 0, 0, 0, 0, 0, 0};
+    for(int g = 0; g < n; g++) {
+        off[g] = o;
+        int V = g_nv[g], E = g_ne[g], NP = g_np ? g_np[g] : 0;
+        int64_t ns = (edge_sample_offset + o.eo)[E];
+        int64_t npv = NP > 0 ? (phasing_offset + o.po)[NP] : 0;
+        o.v += V; o.vo += V + 1; o.e += E; o.eo += E + 1; o.s += ns; o.p += NP; o.po += NP + 1; o.pv += npv;
+    }
+    ora_result *R = new ora_result();
+    R->gr.resize(n);
+    auto t0 = std::chrono::steady_clock::now();
+    if(n_threads <= 1) {
+        for(int g = 0; g < n; g++) run_one(P, off[g], g, cfg, want_trace != 0, R->gr[g]);
+    } else {
+        std::atomic<int> next(0);
+        std::vector<std::thread> th;
+        for(int t = 0; t < n_threads; t++) th.emplace_back([&]() {
+            while(true) { int g = next.fetch_add(1); if(g >= n) break; run_one(P, off[g], g, cfg, want_trace != 0, R->gr[g]); }
+        });
+        for(auto &t : th) t.join();
+    }
+    R->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *out = R;
+    return 0;
+}
+
+double ora_result_seconds(const ora_result *R) { return R->seconds; }
+void ora_result_free(ora_result *R) { delete R; }
+
+int ora_result_export(const ora_result *R, int64_t *total_paths, int64_t *total_path_vertices,
+                      int32_t *status, int32_t *path_offset,
+                      double *weight, double *abd, double *conf, double *reads,
+                      int32_t *length, int32_t *count, char *strand,
+                      int64_t *pv_offset, int32_t *path_vertices)
+{
+    int64_t tp = 0, tv = 0;
+    for(auto &g : R->gr) { tp += (int64_t)g.paths.size(); for(auto &p : g.paths) tv += (int64_t)p.v.size(); }
+    if(total_paths) *total_paths = tp;
+    if(total_path_vertices) *total_path_vertices = tv;
+    if(!status) return 0;
+    int64_t ip = 0, iv = 0;
+    for(size_t g = 0; g < R->gr.size(); g++) {
+        status[g] = R->gr[g].status; path_offset[g] = (int32_t)ip;
+        for(auto &p : R->gr[g].paths) {
+            weight[ip] = p.weight; abd[ip] = p.abd; conf[ip] = p.conf; reads[ip] = p.reads; length[ip] = p.length; count[ip] = p.count; strand[ip] = p.strand;
+            pv_offset[ip] = iv;
+            for(int x : p.v) path_vertices[iv++] = x;
+            ip++;
+        }
+    }
+    path_offset[R->gr.size()] = (int32_t)ip; pv_offset[ip] = iv;
+    return 0;
+}
+
+/* transcripts: exon lists + coverage (scallop.cc:3250-3266, essential.cc:719-748) */
+int ora_result_export_transcripts(const ora_result *R, int64_t *total_exons, double *coverage, int64_t *exon_offset, int32_t *exon_lr)
+{
+    int64_t te = 0; for(auto &g : R->gr) for(auto &t : g.trsts) te += (int64_t)t.exons.size();
+    if(total_exons) *total_exons = te;
+    if(!coverage) return 0;
+    int64_t it = 0, ie = 0;
+    for(auto &g : R->gr) for(auto &t : g.trsts) {
+        coverage[it] = t.coverage; exon_offset[it] = ie;
+        for(auto &x : t.exons) { exon_lr[2 * ie] = x.first; exon_lr[2 * ie + 1] = x.second; ie++; }
+        it++;
+    }
+    exon_offset[it] = ie;
+    return 0;
+}
+
+/* per-graph diagnostics: [max_live_edges, max_vertices, total_edge_ids, iterations, router_builds, max_mev] */
+int ora_result_stats(const ora_result *R, int32_t *stats6)
+{
+    for(size_t g = 0; g < R->gr.size(); g++) {
+        const ora::Stats &s = R->gr[g].st;
+        int32_t *o = stats6 + 6 * g;
+        o[0] = s.max_live_edges; o[1] = s.max_vertices; o[2] = s.total_edge_ids; o[3] = s.iterations; o[4] = s.router_builds; o[5] = s.max_mev;
+    }
+    return 0;
+}
+
+int ora_result_trace(const ora_result *R, int32_t graph, int32_t *n_events, int32_t *codes3, double *values, int32_t cap)
+{
+    const auto &t = R->gr[graph].trace;
+    *n_events = (int32_t)t.size();
+    if(!codes3) return 0;
+    for(int i = 0; i < (int)t.size() && i < cap; i++) { codes3[3 * i] = t[i].code; codes3[3 * i + 1] = t[i].a; codes3[3 * i + 2] = t[i].b; values[i] = t[i].val; }
+    return 0;
+}
+
+/* subset-sum restatement (oracle/subsetsum_oracle.hpp), one instance */
+int ora_subsetsum(int32_t ns, int32_t nt, const int32_t *src_val, const int32_t *src_lab, const int32_t *tgt_val, const int32_t *tgt_lab,
+                  double *err, int32_t *out_ns, int32_t *out_nt, int32_t *out_s, int32_t *out_t)
+{
+    std::vector<std::pair<int, int>> s, t;
+    for(int i = 0; i < ns; i++) s.push_back({src_val[i], src_lab[i]});
+    for(int i = 0; i < nt; i++) t.push_back({tgt_val[i], tgt_lab[i]});
+    ora::SubsetSum ss(s, t);
+    if(ss.solve() != 0) return -1;
+    *err = ss.e; *out_ns = (int)ss.eqn_s.size(); *out_nt = (int)ss.eqn_t.size();
+    for(size_t i = 0; i < ss.eqn_s.size(); i++) out_s[i] = ss.eqn_s[i];
+    for(size_t i = 0; i < ss.eqn_t.size(); i++) out_t[i] = ss.eqn_t[i];
+    return 0;
+}
+
+} // extern "C"
