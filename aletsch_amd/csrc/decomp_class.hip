@@ -1,0 +1,27 @@
+// decomp_class.hip -- one size class of the decomposition kernel (compile with -DALD_CLASS_ID=0..4).
+//
+// gfx950 kernel: one 64-lane workgroup (= one wavefront) per splice graph, persistent over an atomic
+// work counter.  Every wave reaches the `break` in wave_main once the class is drained, so the grid
+// always drains.  No MFMA: integer / pointer-chasing work with FP64 compares.
+#include <hip/hip_runtime.h>
+#include "decomp_device.h"
+
+#define ALD_KERNEL_NAME ALD_CAT(ald_decomp_kernel_c, ALD_CLASS_ID)
+
+extern "C" __global__ void __launch_bounds__(64) ALD_KERNEL_NAME(const ald::KernelArgs *A)
+{
+    ALD_CLASS_NS::wave_main((ALD_GLOBAL const ald::KernelArgs*)A, (int)blockIdx.x);
+}
+
+extern "C" int ALD_CAT(ald_launch_c, ALD_CLASS_ID)(const ald::KernelArgs *dA, int blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ALD_KERNEL_NAME, dim3(blocks), dim3(64), 0, stream, dA);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int ALD_CAT(ald_occupancy_c, ALD_CLASS_ID)()
+{
+    int nb = 0;
+    if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ALD_KERNEL_NAME, 64, 0) != hipSuccess) return 0;
+    return nb;
+}

@@ -1,0 +1,151 @@
+// decomp_common.h -- types shared by the device engine (decomp_device.h), the kernels and the host ABI.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include <float.h>
+#include <limits.h>
+#include "../../include/aletsch_decomp.h"
+
+#ifdef ALD_EMU
+  // single-lane emulation of the engine, compiled ONLY by tests/kernel_emu (never part of the product library)
+  #include <string.h>
+  #define ALD_FN static
+  #define ALD_INL static inline
+  #define ALD_GLOBAL
+  #define ALD_WAVE 1
+  namespace ald {
+  static inline int      lane_id() { return 0; }
+  static inline uint64_t wballot(bool p) { return p ? 1ull : 0ull; }
+  template<class T> static inline T wshfl(T v, int) { return v; }
+  static inline void     wsync() {}
+  static inline unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
+  static inline int      atomic_add_i32(int *p, int v) { int o = *p; *p += v; return o; }
+  static inline int      ffs64(uint64_t m) { return __builtin_ffsll((long long)m) - 1; }
+  }
+#else
+  #include <hip/hip_runtime.h>
+  #define ALD_FN  static __device__ __attribute__((noinline))
+  #define ALD_INL static __device__ __forceinline__
+  #if defined(__HIP_DEVICE_COMPILE__)
+    #define ALD_GLOBAL __attribute__((address_space(1)))   /* device pass: global_* instead of flat_* memory ops */
+  #else
+    #define ALD_GLOBAL                                     /* host pass of the same source: plain pointers, same layout */
+  #endif
+  #define ALD_WAVE 64
+  namespace ald {
+  __device__ __forceinline__ int      lane_id() { return (int)threadIdx.x; }
+  __device__ __forceinline__ uint64_t wballot(bool p) { return __ballot(p); }
+  template<class T> __device__ __forceinline__ T wshfl(T v, int src) { return __shfl(v, src, 64); }
+  __device__ __forceinline__ void     wsync() { __syncthreads(); }   // workgroup == one wave: orders LDS traffic, fences the compiler
+  __device__ __forceinline__ unsigned long long atomic_add_u64(ALD_GLOBAL unsigned long long *p, unsigned long long v) { return atomicAdd((unsigned long long*)p, v); }
+  __device__ __forceinline__ int      atomic_add_i32(ALD_GLOBAL int *p, int v) { return atomicAdd((int*)p, v); }
+  __device__ __forceinline__ int      ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
+  }
+#endif
+
+namespace ald {
+
+static const double kSMIN = 0.00001;            // rnacore/splice_graph.h:18
+enum { T_TRIVIAL = 0, T_SPLITTABLE_PURE = 4, T_UNSPLITTABLE_SINGLE = 5 };   // util/constants.h:30-40
+enum { K_EMPTY_VERTEX = -9 };                   // util/constants.h:53
+enum { OP_BROKEN = 1, OP_TRIVIAL_FAST = 2, OP_TRIVIAL_NOW = 3, OP_TRIVIAL_BEST = 4, OP_SMALL_NOW = 5, OP_SMALLEST = 6,
+       OP_UNSPLIT_NOW = 7, OP_UNSPLIT_BEST = 8, OP_GREEDY = 9, OP_COLLECT = 10 };
+enum { HF_OCC = 1, HF_LEXT = 2, HF_REXT = 4, HF_PROT = 8 };
+// path record (4-byte words): [0]=graph [1]=path index [2]=#vertices [3]=length [4]=count [5]=strand char
+//                             [6..13] = weight, abd, conf, reads (f64)   [14..14+nv) vertices, padded to an even word count
+enum { REC_HDR_WORDS = 14 };
+
+// ---- wire format as the kernel sees it: device pointers into ONE coalesced HBM buffer ----
+struct BatchIn {
+    int32_t n_graphs;
+    ALD_GLOBAL const int32_t *g_nv, *g_ne, *g_np;
+    ALD_GLOBAL const int64_t *off_v, *off_e, *off_s, *off_p, *off_pv;   // [n+1] prefix sums; local CSR arrays start at off_x[g] + g
+    ALD_GLOBAL const int32_t *vertex_offset, *edge_target;
+    ALD_GLOBAL const double  *edge_weight; ALD_GLOBAL const uint8_t *edge_strand; ALD_GLOBAL const double *edge_abd;
+    ALD_GLOBAL const int32_t *edge_sample_offset, *sample_id; ALD_GLOBAL const double *sample_abd;
+    ALD_GLOBAL const double  *vertex_weight; ALD_GLOBAL const int32_t *vertex_lpos, *vertex_rpos, *vertex_type;
+    ALD_GLOBAL const int32_t *in_offset, *in_edge;                      // host-built in-CSR: ids sorted by (target, source, id)
+    ALD_GLOBAL const int32_t *phasing_offset, *phasing_vertex, *phasing_count;
+    ALD_GLOBAL const char    *graph_strand;
+};
+struct BatchOut {
+    ALD_GLOBAL int32_t *status, *n_paths, *n_iters;        // [n]
+    ALD_GLOBAL unsigned long long *pool_used;              // words used (atomic bump)
+    ALD_GLOBAL uint32_t *pool; unsigned long long pool_cap;// path-record pool (4-byte words)
+    ALD_GLOBAL int32_t *trace_n, *trace_codes; ALD_GLOBAL double *trace_vals; int32_t trace_cap;   // optional op trace
+};
+struct Params { double max_ratio[8]; double min_w; double min_cov; int32_t max_num_exons; int32_t pad; };
+struct KernelArgs {                               // lives in device memory; every wave keeps a pointer to it in LDS
+    BatchIn in; BatchOut out; Params prm;
+    ALD_GLOBAL const int32_t *work; int32_t n_work; int32_t attempt;   // attempt tags the records of a retry pass
+    ALD_GLOBAL int32_t *counter;
+    ALD_GLOBAL uint8_t *slabs; uint64_t slab_stride;
+};
+
+// ---- size classes ----
+#define ALD_NUM_CLASSES 5
+template<int ID> struct ClassDims;
+template<> struct ClassDims<0> { enum { MAXV = 64,   MAXE = 160,  NW = 1 }; };
+template<> struct ClassDims<1> { enum { MAXV = 128,  MAXE = 320,  NW = 1 }; };
+template<> struct ClassDims<2> { enum { MAXV = 256,  MAXE = 640,  NW = 2 }; };
+template<> struct ClassDims<3> { enum { MAXV = 512,  MAXE = 1280, NW = 4 }; };
+template<> struct ClassDims<4> { enum { MAXV = 1024, MAXE = 2560, NW = 8 }; };
+
+// per-wave HBM slab, laid out at compile time (so that cold pointers cost no registers)
+template<int MAXV, int MAXE, int NW>
+struct ColdLayoutT {
+    static constexpr uint64_t al(uint64_t x) { return (x + 15) / 16 * 16; }
+    static constexpr uint32_t SP_CAP = 8u * MAXE;        // sample-support pool entries (input + intersections)
+    static constexpr uint32_t HL_CAP = 8u * MAXE;        // phasing-list pool (ints)
+    static constexpr int32_t  HL_MAXLISTS = MAXE;
+    static constexpr int32_t  W_CAP = 8 * MAXE;          // scalar work arrays (ints / doubles)
+    static constexpr uint64_t o_vw = 0;
+    static constexpr uint64_t o_lpos = al(o_vw + 8ull * MAXV);
+    static constexpr uint64_t o_rpos = al(o_lpos + 4ull * MAXV);
+    static constexpr uint64_t o_vtype = al(o_rpos + 4ull * MAXV);
+    static constexpr uint64_t o_v2v = al(o_vtype + 4ull * MAXV);
+    static constexpr uint64_t o_med = al(o_v2v + 4ull * MAXV);
+    static constexpr uint64_t o_eabd = al(o_med + 8ull * MAXE);
+    static constexpr uint64_t o_econf = al(o_eabd + 8ull * MAXE);
+    static constexpr uint64_t o_mei = al(o_econf + 8ull * MAXE);
+    static constexpr uint64_t o_ecount = al(o_mei + 4ull * MAXE);
+    static constexpr uint64_t o_estrand = al(o_ecount + 4ull * MAXE);
+    static constexpr uint64_t o_spoff = al(o_estrand + 1ull * MAXE);
+    static constexpr uint64_t o_splen = al(o_spoff + 4ull * MAXE);
+    static constexpr uint64_t o_mask = al(o_splen + 4ull * MAXE);
+    static constexpr uint64_t o_spid = al(o_mask + 8ull * MAXE * NW);
+    static constexpr uint64_t o_spabd = al(o_spid + 4ull * SP_CAP);
+    static constexpr uint64_t o_hl = al(o_spabd + 8ull * SP_CAP);
+    static constexpr uint64_t o_hloff = al(o_hl + 4ull * HL_CAP);
+    static constexpr uint64_t o_hllen = al(o_hloff + 4ull * HL_MAXLISTS);
+    static constexpr uint64_t o_hlcapk = al(o_hllen + 4ull * HL_MAXLISTS);
+    static constexpr uint64_t o_hlcnt = al(o_hlcapk + 4ull * HL_MAXLISTS);
+    static constexpr uint64_t o_wi = al(o_hlcnt + 4ull * HL_MAXLISTS);
+    static constexpr uint64_t o_wd = al(o_wi + 4ull * W_CAP);
+    static constexpr uint64_t total = (o_wd + 8ull * W_CAP + 255) / 256 * 256;
+};
+
+struct ClassInfo { int maxv, maxe, nw; uint32_t sp_cap, hl_cap; uint64_t slab_bytes; };
+static inline ClassInfo class_info(int c)
+{
+    switch(c) {
+#define ALD_CI(ID) case ID: { typedef ColdLayoutT<ClassDims<ID>::MAXV, ClassDims<ID>::MAXE, ClassDims<ID>::NW> L; \
+        return ClassInfo{ClassDims<ID>::MAXV, ClassDims<ID>::MAXE, ClassDims<ID>::NW, L::SP_CAP, L::HL_CAP, L::total}; }
+    ALD_CI(0) ALD_CI(1) ALD_CI(2) ALD_CI(3) ALD_CI(4)
+#undef ALD_CI
+    }
+    return ClassInfo{0, 0, 0, 0, 0, 0};
+}
+// smallest class whose working set can hold the graph: vertices may double (decompose_vertex_extend adds pseudo vertices,
+// scallop.cc:1793-1806); edges need transient head-room (split_edge before merge); the sample pool must hold the input
+// plus the intersections created by merges.
+static inline int pick_class(int V, int E, int64_t n_samples, int64_t n_phasing_vertices, int first = 0)
+{
+    for(int c = first < 0 ? 0 : first; c < ALD_NUM_CLASSES; c++) {
+        ClassInfo k = class_info(c);
+        if(V <= k.nw * 64 && 2 * V <= k.maxv && E + k.maxe / 10 <= k.maxe && 2 * n_samples <= (int64_t)k.sp_cap && 4 * n_phasing_vertices <= (int64_t)k.hl_cap) return c;
+    }
+    return -1;
+}
+
+} // namespace ald

@@ -1,0 +1,257 @@
+// host_pack.h -- host-side staging of splice-graph batches into the wire format (one contiguous buffer), and
+// parsing of the packed path records the kernels emit.  Plain C++; shared by the C ABI (ald_abi.cpp) and by the
+// tests' single-lane emulation harness (tests/kernel_emu).
+//
+// Staging normalises what the reference gets for free from its containers:
+//   * CSR rows sorted by target (stable)  -> edge id == position == the canonical creation order;
+//   * per-edge sample lists ascending     -> std::set<int> iteration order (rnacore/edge_info.h:32);
+//   * phasing lists sorted lexicographically, duplicates merged by adding counts -> hyper_set::add_node_list
+//     (scallop/hyper_set.cc:40-48) into the std::map `nodes`;
+//   * an in-CSR (edge ids ordered by (target, source, id)) so that the kernel links in-lists without sorting.
+#pragma once
+#include "decomp_common.h"
+#include <vector>
+#include <algorithm>
+#include <numeric>
+#include <cstring>
+#include <string>
+#include <map>
+
+namespace ald {
+
+struct HostBatch {
+    std::vector<int32_t> g_nv, g_ne, g_np;
+    std::vector<int64_t> off_v{0}, off_e{0}, off_s{0}, off_p{0}, off_pv{0};
+    std::vector<int32_t> vertex_offset, edge_target; std::vector<double> edge_weight; std::vector<uint8_t> edge_strand; std::vector<double> edge_abd;
+    std::vector<int32_t> edge_sample_offset, sample_id; std::vector<double> sample_abd;
+    std::vector<double> vertex_weight; std::vector<int32_t> vertex_lpos, vertex_rpos, vertex_type;
+    std::vector<int32_t> in_offset, in_edge;
+    std::vector<int32_t> phasing_offset, phasing_vertex, phasing_count; std::vector<char> graph_strand;
+    std::string err;
+
+    int n() const { return (int)g_nv.size(); }
+    void clear() { *this = HostBatch(); }
+
+    int add_graph(const ald_graph_view &g)
+    {
+        const int V = g.num_vertices, E = g.num_edges, P = g.num_phasing;
+        if(V < 2 || E < 0 || P < 0 || !g.vertex_offset || (E > 0 && (!g.edge_target || !g.edge_weight || !g.edge_sample_offset)) || !g.vertex_weight || !g.vertex_lpos || !g.vertex_rpos) { err = "null or negative field"; return ALD_ERR_INVALID; }
+        if(g.vertex_offset[0] != 0 || g.vertex_offset[V] != E) { err = "vertex_offset does not span the edges"; return ALD_ERR_INVALID; }
+        for(int i = 0; i < V; i++) if(g.vertex_offset[i + 1] < g.vertex_offset[i]) { err = "vertex_offset not monotone"; return ALD_ERR_INVALID; }
+        if(E > 0 && g.edge_sample_offset[0] != 0) { err = "edge_sample_offset[0] != 0"; return ALD_ERR_INVALID; }
+        // ---- edges: per-row order by target (stable) ----
+        std::vector<int32_t> perm(E); std::iota(perm.begin(), perm.end(), 0);
+        for(int s = 0; s < V; s++) {
+            int a = g.vertex_offset[s], b = g.vertex_offset[s + 1];
+            bool sorted = true;
+            for(int k = a; k < b; k++) { int t = g.edge_target[k]; if(t < 0 || t >= V || t == s) { err = "edge target out of range"; return ALD_ERR_INVALID; } if(k > a && g.edge_target[k - 1] > t) sorted = false; }
+            if(!sorted) std::stable_sort(perm.begin() + a, perm.begin() + b, [&](int x, int y) { return g.edge_target[x] < g.edge_target[y]; });
+        }
+        size_t e0 = edge_target.size(), s0 = sample_id.size();
+        edge_sample_offset.push_back(0);
+        for(int k = 0; k < E; k++) {
+            int q = perm[k];
+            edge_target.push_back(g.edge_target[q]); edge_weight.push_back(g.edge_weight[q]);
+            int st = g.edge_strand ? g.edge_strand[q] : 0;
+            if(st < 0 || st > 2) { err = "edge strand not in 0..2"; return ALD_ERR_INVALID; }
+            edge_strand.push_back((uint8_t)st);
+            int a = g.edge_sample_offset[q], b = g.edge_sample_offset[q + 1];
+            if(b < a) { err = "edge_sample_offset not monotone"; return ALD_ERR_INVALID; }
+            size_t base = sample_id.size(); double sum = 0; bool asc = true;
+            for(int j = a; j < b; j++) { sample_id.push_back(g.sample_id[j]); sample_abd.push_back(g.sample_abd[j]); sum += g.sample_abd[j]; if(j > a && g.sample_id[j - 1] >= g.sample_id[j]) asc = false; }
+            if(!asc) {
+                std::vector<std::pair<int32_t, double>> t; for(size_t j = base; j < sample_id.size(); j++) t.push_back({sample_id[j], sample_abd[j]});
+                std::sort(t.begin(), t.end());
+                for(size_t j = 1; j < t.size(); j++) if(t[j].first == t[j - 1].first) { err = "duplicate sample id on an edge"; return ALD_ERR_INVALID; }
+                for(size_t j = 0; j < t.size(); j++) { sample_id[base + j] = t[j].first; sample_abd[base + j] = t[j].second; }
+            }
+            edge_abd.push_back(g.edge_abd ? g.edge_abd[q] : sum);
+            edge_sample_offset.push_back((int32_t)(sample_id.size() - s0));
+        }
+        for(int i = 0; i <= V; i++) vertex_offset.push_back(g.vertex_offset[i]);
+        // ---- in-CSR: counting sort of edge ids by target; ids ascend within a target == (source, id) order ----
+        {
+            size_t b0 = in_offset.size(); in_offset.resize(b0 + V + 1, 0);
+            int32_t *io = in_offset.data() + b0;
+            for(int k = 0; k < E; k++) io[edge_target[e0 + k] + 1]++;
+            for(int i = 0; i < V; i++) io[i + 1] += io[i];
+            size_t ie0 = in_edge.size(); in_edge.resize(ie0 + E);
+            std::vector<int32_t> cur(io, io + V);
+            for(int k = 0; k < E; k++) in_edge[ie0 + cur[edge_target[e0 + k]]++] = k;
+        }
+        for(int i = 0; i < V; i++) { vertex_weight.push_back(g.vertex_weight[i]); vertex_lpos.push_back(g.vertex_lpos[i]); vertex_rpos.push_back(g.vertex_rpos[i]); vertex_type.push_back(g.vertex_type ? g.vertex_type[i] : -1); }
+        // ---- phasing lists -> the std::map `nodes` ----
+        int np_kept = 0; size_t pv0 = phasing_vertex.size();
+        phasing_offset.push_back(0);
+        if(P > 0) {
+            if(!g.phasing_offset || !g.phasing_count || (g.phasing_offset[P] > 0 && !g.phasing_vertex)) { err = "null phasing arrays"; return ALD_ERR_INVALID; }
+            bool need_map = false;
+            for(int p = 0; p < P && !need_map; p++) {
+                int a = g.phasing_offset[p], b = g.phasing_offset[p + 1];
+                if(b < a) { err = "phasing_offset not monotone"; return ALD_ERR_INVALID; }
+                for(int k = a + 1; k < b; k++) if(g.phasing_vertex[k - 1] >= g.phasing_vertex[k]) need_map = true;   // add_node_list sorts
+                if(p > 0) { int a0 = g.phasing_offset[p - 1];
+                    if(!std::lexicographical_compare(g.phasing_vertex + a0, g.phasing_vertex + a, g.phasing_vertex + a, g.phasing_vertex + b)) need_map = true; }
+            }
+            if(!need_map) {
+                for(int p = 0; p < P; p++) { for(int k = g.phasing_offset[p]; k < g.phasing_offset[p + 1]; k++) phasing_vertex.push_back(g.phasing_vertex[k]); phasing_offset.push_back((int32_t)(phasing_vertex.size() - pv0)); phasing_count.push_back(g.phasing_count[p]); np_kept++; }
+            } else {
+                std::map<std::vector<int32_t>, int> nodes;
+                for(int p = 0; p < P; p++) { std::vector<int32_t> v(g.phasing_vertex + g.phasing_offset[p], g.phasing_vertex + g.phasing_offset[p + 1]); std::sort(v.begin(), v.end()); nodes[v] += g.phasing_count[p]; }
+                for(auto &kv : nodes) { for(int x : kv.first) phasing_vertex.push_back(x); phasing_offset.push_back((int32_t)(phasing_vertex.size() - pv0)); phasing_count.push_back(kv.second); np_kept++; }
+            }
+        }
+        g_nv.push_back(V); g_ne.push_back(E); g_np.push_back(np_kept); graph_strand.push_back(g.strand ? g.strand : '.');
+        off_v.push_back(off_v.back() + V); off_e.push_back(off_e.back() + E); off_s.push_back(off_s.back() + (int64_t)(sample_id.size() - s0));
+        off_p.push_back(off_p.back() + np_kept); off_pv.push_back(off_pv.back() + (int64_t)(phasing_vertex.size() - pv0));
+        return ALD_OK;
+    }
+
+    int add_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_t *np,
+                   const int32_t *voff, const int32_t *etgt, const double *ew, const uint8_t *estrand, const double *eabd,
+                   const int32_t *esoff, const int32_t *sid, const double *sabd,
+                   const double *vw, const int32_t *lpos, const int32_t *rpos, const int32_t *vtype,
+                   const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand)
+    {
+        int64_t ov = 0, ovo = 0, oe = 0, oeo = 0, os = 0, op = 0, opo = 0, opv = 0;
+        for(int i = 0; i < n; i++) {
+            ald_graph_view g; memset(&g, 0, sizeof(g));
+            int V = nv[i], E = ne[i], P = np ? np[i] : 0;
+            g.num_vertices = V; g.num_edges = E; g.num_phasing = P;
+            g.vertex_offset = voff + ovo; g.edge_target = etgt + oe; g.edge_weight = ew + oe; g.edge_strand = estrand ? estrand + oe : nullptr; g.edge_abd = eabd ? eabd + oe : nullptr;
+            g.edge_sample_offset = esoff + oeo; g.sample_id = sid + os; g.sample_abd = sabd + os;
+            g.vertex_weight = vw + ov; g.vertex_lpos = lpos + ov; g.vertex_rpos = rpos + ov; g.vertex_type = vtype ? vtype + ov : nullptr;
+            g.phasing_offset = poff ? poff + opo : nullptr; g.phasing_vertex = pv ? pv + opv : nullptr; g.phasing_count = pc ? pc + op : nullptr;
+            g.strand = gstrand ? gstrand[i] : '.';
+            if(V < 2 || E < 0) { err = "bad graph size"; return ALD_ERR_INVALID; }
+            int64_t ns = E > 0 ? g.edge_sample_offset[E] : 0, npv = (P > 0 && poff) ? g.phasing_offset[P] : 0;
+            int rc = add_graph(g);
+            if(rc != ALD_OK) return rc;
+            ov += V; ovo += V + 1; oe += E; oeo += E + 1; os += ns; op += P; opo += P + 1; opv += npv;
+        }
+        return ALD_OK;
+    }
+
+    // ---- one contiguous buffer; section offsets are 256-byte aligned ----
+    struct Section { const void *src; uint64_t bytes; uint64_t off; };
+    enum { S_NV, S_NE, S_NP, S_OFFV, S_OFFE, S_OFFS, S_OFFP, S_OFFPV, S_VOFF, S_ETGT, S_EW, S_ESTRAND, S_EABD, S_ESOFF, S_SID, S_SABD,
+           S_VW, S_LPOS, S_RPOS, S_VTYPE, S_INOFF, S_INEDGE, S_POFF, S_PV, S_PC, S_GSTRAND, S_COUNT };
+    uint64_t layout(Section sec[S_COUNT]) const
+    {
+        auto set = [&](int i, const void *p, uint64_t b) { sec[i].src = p; sec[i].bytes = b; };
+        set(S_NV, g_nv.data(), 4ull * g_nv.size()); set(S_NE, g_ne.data(), 4ull * g_ne.size()); set(S_NP, g_np.data(), 4ull * g_np.size());
+        set(S_OFFV, off_v.data(), 8ull * off_v.size()); set(S_OFFE, off_e.data(), 8ull * off_e.size()); set(S_OFFS, off_s.data(), 8ull * off_s.size());
+        set(S_OFFP, off_p.data(), 8ull * off_p.size()); set(S_OFFPV, off_pv.data(), 8ull * off_pv.size());
+        set(S_VOFF, vertex_offset.data(), 4ull * vertex_offset.size()); set(S_ETGT, edge_target.data(), 4ull * edge_target.size());
+        set(S_EW, edge_weight.data(), 8ull * edge_weight.size()); set(S_ESTRAND, edge_strand.data(), edge_strand.size()); set(S_EABD, edge_abd.data(), 8ull * edge_abd.size());
+        set(S_ESOFF, edge_sample_offset.data(), 4ull * edge_sample_offset.size()); set(S_SID, sample_id.data(), 4ull * sample_id.size()); set(S_SABD, sample_abd.data(), 8ull * sample_abd.size());
+        set(S_VW, vertex_weight.data(), 8ull * vertex_weight.size()); set(S_LPOS, vertex_lpos.data(), 4ull * vertex_lpos.size()); set(S_RPOS, vertex_rpos.data(), 4ull * vertex_rpos.size());
+        set(S_VTYPE, vertex_type.data(), 4ull * vertex_type.size()); set(S_INOFF, in_offset.data(), 4ull * in_offset.size()); set(S_INEDGE, in_edge.data(), 4ull * in_edge.size());
+        set(S_POFF, phasing_offset.data(), 4ull * phasing_offset.size()); set(S_PV, phasing_vertex.data(), 4ull * phasing_vertex.size()); set(S_PC, phasing_count.data(), 4ull * phasing_count.size());
+        set(S_GSTRAND, graph_strand.data(), graph_strand.size());
+        uint64_t o = 0;
+        for(int i = 0; i < S_COUNT; i++) { sec[i].off = o; o = (o + sec[i].bytes + 255) / 256 * 256; }
+        return o < 256 ? 256 : o;
+    }
+    void pack_into(uint8_t *dst, const Section sec[S_COUNT]) const { for(int i = 0; i < S_COUNT; i++) if(sec[i].bytes) memcpy(dst + sec[i].off, sec[i].src, sec[i].bytes); }
+    // BatchIn whose pointers are `base + section offset` (base = device address, or the host buffer for the emulation)
+    BatchIn make_batch_in(uint8_t *base, const Section sec[S_COUNT]) const
+    {
+        BatchIn b; memset(&b, 0, sizeof(b));
+        b.n_graphs = n();
+#define ALD_P(T, i) ((ALD_GLOBAL const T*)(base + sec[i].off))
+        b.g_nv = ALD_P(int32_t, S_NV); b.g_ne = ALD_P(int32_t, S_NE); b.g_np = ALD_P(int32_t, S_NP);
+        b.off_v = ALD_P(int64_t, S_OFFV); b.off_e = ALD_P(int64_t, S_OFFE); b.off_s = ALD_P(int64_t, S_OFFS); b.off_p = ALD_P(int64_t, S_OFFP); b.off_pv = ALD_P(int64_t, S_OFFPV);
+        b.vertex_offset = ALD_P(int32_t, S_VOFF); b.edge_target = ALD_P(int32_t, S_ETGT); b.edge_weight = ALD_P(double, S_EW); b.edge_strand = ALD_P(uint8_t, S_ESTRAND); b.edge_abd = ALD_P(double, S_EABD);
+        b.edge_sample_offset = ALD_P(int32_t, S_ESOFF); b.sample_id = ALD_P(int32_t, S_SID); b.sample_abd = ALD_P(double, S_SABD);
+        b.vertex_weight = ALD_P(double, S_VW); b.vertex_lpos = ALD_P(int32_t, S_LPOS); b.vertex_rpos = ALD_P(int32_t, S_RPOS); b.vertex_type = ALD_P(int32_t, S_VTYPE);
+        b.in_offset = ALD_P(int32_t, S_INOFF); b.in_edge = ALD_P(int32_t, S_INEDGE);
+        b.phasing_offset = ALD_P(int32_t, S_POFF); b.phasing_vertex = ALD_P(int32_t, S_PV); b.phasing_count = ALD_P(int32_t, S_PC); b.graph_strand = ALD_P(char, S_GSTRAND);
+#undef ALD_P
+        return b;
+    }
+    // algorithmic input bytes per SURVEY.md 8d: out-CSR offsets + targets + weights + strand + vertex weight + lpos/rpos + samples + phasing
+    int64_t algorithmic_in_bytes() const
+    {
+        int64_t V = off_v.back(), E = off_e.back(), S = off_s.back(), P = off_p.back(), PV = off_pv.back(), N = n();
+        return 4 * (V + N) + 4 * E + 8 * E + E + 8 * V + 8 * V + 12 * S + 4 * PV + 4 * P;
+    }
+};
+
+// ---- results ----
+struct PathRec { int32_t graph, index, nv, length, count; char strand; int attempt; double weight, abd, conf, reads; uint64_t vert_off; };
+struct HostResults {
+    std::vector<int32_t> status, n_iters, attempt;       // per graph (attempt = pass that produced the final answer)
+    std::vector<int64_t> path_begin;                     // [n+1] into paths (sorted by graph, index)
+    std::vector<PathRec> paths;
+    std::vector<uint32_t> pool;                          // raw record words (vertex lists are read in place)
+    int64_t out_bytes = 0;                               // algorithmic output bytes: sum(4*len + 40)
+    void clear() { status.clear(); n_iters.clear(); attempt.clear(); path_begin.clear(); paths.clear(); pool.clear(); out_bytes = 0; }
+    const uint32_t *vertices(const PathRec &p) const { return pool.data() + p.vert_off; }
+
+    // parse `words` record words; keep only records whose attempt tag matches the graph's final attempt
+    int build(int n, const std::vector<int32_t> &n_paths_dev)
+    {
+        paths.clear(); out_bytes = 0;
+        std::vector<int64_t> cnt(n + 1, 0);
+        uint64_t o = 0, W = pool.size();
+        std::vector<PathRec> tmp;
+        while(o + REC_HDR_WORDS <= W) {
+            const uint32_t *r = pool.data() + o;
+            PathRec p; p.graph = (int32_t)r[0]; p.index = (int32_t)r[1]; p.nv = (int32_t)r[2]; p.length = (int32_t)r[3]; p.count = (int32_t)r[4];
+            p.strand = (char)(r[5] & 0xFF); p.attempt = (int)((r[5] >> 8) & 0xFF);
+            if(p.nv < 2 || p.graph < 0 || p.graph >= n) return -1;
+            memcpy(&p.weight, r + 6, 8); memcpy(&p.abd, r + 8, 8); memcpy(&p.conf, r + 10, 8); memcpy(&p.reads, r + 12, 8);
+            p.vert_off = o + REC_HDR_WORDS;
+            uint64_t words = REC_HDR_WORDS + (uint64_t)p.nv; words += words & 1;
+            if(o + words > W) return -1;
+            o += words;
+            bool ok = (status[p.graph] == ALD_ST_OK || status[p.graph] == ALD_ST_SKIPPED_LARGE) && p.attempt == attempt[p.graph];
+            if(ok) tmp.push_back(p);
+        }
+        for(auto &p : tmp) cnt[p.graph + 1]++;
+        path_begin.assign(n + 1, 0);
+        for(int g = 0; g < n; g++) path_begin[g + 1] = path_begin[g] + cnt[g + 1];
+        paths.resize(tmp.size());
+        for(auto &p : tmp) {
+            if(p.index < 0 || p.index >= cnt[p.graph + 1]) return -2;
+            paths[path_begin[p.graph] + p.index] = p;
+            out_bytes += 4ll * p.nv + 40;
+        }
+        for(int g = 0; g < n; g++) if((status[g] == ALD_ST_OK || status[g] == ALD_ST_SKIPPED_LARGE) && cnt[g + 1] != n_paths_dev[g]) return -3;
+        return 0;
+    }
+};
+
+static inline int export_results(const HostResults &R, int n, int64_t *total_paths, int64_t *total_path_vertices,
+                                 int32_t *status, int32_t *path_offset, double *weight, double *abd, double *conf, double *reads,
+                                 int32_t *length, int32_t *count, char *strand, int64_t *pv_offset, int32_t *path_vertices)
+{
+    int64_t tp = (int64_t)R.paths.size(), tv = 0;
+    for(auto &p : R.paths) tv += p.nv;
+    if(total_paths) *total_paths = tp;
+    if(total_path_vertices) *total_path_vertices = tv;
+    if(!status) return ALD_OK;
+    int64_t iv = 0;
+    for(int g = 0; g < n; g++) { status[g] = R.status[g]; path_offset[g] = (int32_t)R.path_begin[g]; }
+    path_offset[n] = (int32_t)R.path_begin[n];
+    for(int64_t i = 0; i < tp; i++) {
+        const PathRec &p = R.paths[i];
+        weight[i] = p.weight; abd[i] = p.abd; conf[i] = p.conf; reads[i] = p.reads; length[i] = p.length; count[i] = p.count; strand[i] = p.strand;
+        pv_offset[i] = iv;
+        const uint32_t *v = R.vertices(p);
+        for(int k = 0; k < p.nv; k++) path_vertices[iv++] = (int32_t)v[k];
+    }
+    pv_offset[tp] = iv;
+    return ALD_OK;
+}
+
+static inline void params_from_abi(const ald_params *p, Params &q)
+{
+    ald_params d;
+    if(!p) { const double r[8] = {0.30, 0.00, 1.10, 1.10, 0.75, 0.30, 0.00, 1.00}; for(int i = 0; i < 8; i++) d.max_decompose_error_ratio[i] = r[i]; d.min_guaranteed_edge_weight = 0.01; d.min_transcript_coverage = 2.0; d.max_num_exons = 10000; d.reserved = 0; p = &d; }
+    for(int i = 0; i < 8; i++) q.max_ratio[i] = p->max_decompose_error_ratio[i];
+    q.min_w = p->min_guaranteed_edge_weight; q.min_cov = p->min_transcript_coverage; q.max_num_exons = p->max_num_exons; q.pad = 0;
+}
+
+} // namespace ald

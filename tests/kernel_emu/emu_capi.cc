@@ -1,0 +1,99 @@
+// emu_capi.cc -- TEST-ONLY driver of the single-lane engine emulation: same staging (host_pack.h), same class
+// selection / retry policy and same record parsing as the GPU ABI (aletsch_amd/csrc/ald_abi.cpp), with the
+// kernel launch replaced by a direct call.
+#ifndef ALD_EMU
+#error "emulation build only"
+#endif
+#include "../../aletsch_amd/csrc/host_pack.h"
+#include <cstdlib>
+
+extern "C" {
+void emu_run_class_0(const ald::KernelArgs *); void emu_run_class_1(const ald::KernelArgs *); void emu_run_class_2(const ald::KernelArgs *);
+void emu_run_class_3(const ald::KernelArgs *); void emu_run_class_4(const ald::KernelArgs *);
+}
+using namespace ald;
+
+struct emu_result { HostResults R; int n = 0; std::vector<int32_t> trace_n, trace_codes; std::vector<double> trace_vals; int trace_cap = 0; std::vector<int32_t> cls; };
+
+extern "C" {
+
+int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_t *np,
+                   const int32_t *voff, const int32_t *etgt, const double *ew, const uint8_t *estrand, const double *eabd,
+                   const int32_t *esoff, const int32_t *sid, const double *sabd,
+                   const double *vw, const int32_t *lpos, const int32_t *rpos, const int32_t *vtype,
+                   const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand,
+                   const ald_params *prm, int32_t trace_cap, int32_t force_class, emu_result **out)
+{
+    HostBatch B;
+    int rc = B.add_packed(n, nv, ne, np, voff, etgt, ew, estrand, eabd, esoff, sid, sabd, vw, lpos, rpos, vtype, poff, pv, pc, gstrand);
+    if(rc != ALD_OK) { fprintf(stderr, "emu: add_packed failed: %s\n", B.err.c_str()); return rc; }
+    HostBatch::Section sec[HostBatch::S_COUNT];
+    uint64_t bytes = B.layout(sec);
+    std::vector<uint8_t> buf(bytes);
+    B.pack_into(buf.data(), sec);
+    KernelArgs A; memset(&A, 0, sizeof(A));
+    A.in = B.make_batch_in(buf.data(), sec);
+    params_from_abi(prm, A.prm);
+    std::vector<int32_t> status(n, 0), n_paths(n, 0), n_iters(n, 0);
+    uint64_t pool_cap = 0; for(int g = 0; g < n; g++) pool_cap += 16ull * B.g_ne[g] + 256;
+    std::vector<uint32_t> pool(pool_cap); unsigned long long pool_used = 0;
+    emu_result *E = new emu_result(); E->n = n; E->trace_cap = trace_cap;
+    if(trace_cap > 0) { E->trace_n.assign(n, 0); E->trace_codes.assign(3ull * n * trace_cap, 0); E->trace_vals.assign((size_t)n * trace_cap, 0); }
+    A.out.status = status.data(); A.out.n_paths = n_paths.data(); A.out.n_iters = n_iters.data();
+    A.out.pool_used = &pool_used; A.out.pool = pool.data(); A.out.pool_cap = pool_cap;
+    A.out.trace_cap = trace_cap; A.out.trace_n = E->trace_n.data(); A.out.trace_codes = E->trace_codes.data(); A.out.trace_vals = E->trace_vals.data();
+    std::vector<int32_t> cls(n), attempt(n, 0);
+    std::vector<int32_t> work[ALD_NUM_CLASSES];
+    for(int g = 0; g < n; g++) {
+        int64_t ns = B.off_s[g + 1] - B.off_s[g], npv = B.off_pv[g + 1] - B.off_pv[g];
+        cls[g] = pick_class(B.g_nv[g], B.g_ne[g], ns, npv, force_class);
+        if(cls[g] < 0) status[g] = ALD_ST_CAPACITY; else work[cls[g]].push_back(g);
+    }
+    typedef void (*run_fn)(const KernelArgs *);
+    run_fn runs[ALD_NUM_CLASSES] = {emu_run_class_0, emu_run_class_1, emu_run_class_2, emu_run_class_3, emu_run_class_4};
+    for(int pass = 0; pass < ALD_NUM_CLASSES + 1; pass++) {
+        bool any = false;
+        for(int c = 0; c < ALD_NUM_CLASSES; c++) {
+            if(work[c].empty()) continue;
+            any = true;
+            ClassInfo ci = class_info(c);
+            std::vector<uint8_t> slab(ci.slab_bytes);
+            int32_t counter = 0;
+            A.work = work[c].data(); A.n_work = (int32_t)work[c].size(); A.attempt = pass; A.counter = &counter; A.slabs = slab.data(); A.slab_stride = ci.slab_bytes;
+            runs[c](&A);
+        }
+        if(!any) break;
+        std::vector<int32_t> next[ALD_NUM_CLASSES];
+        for(int c = 0; c < ALD_NUM_CLASSES; c++) for(int g : work[c]) {
+            attempt[g] = pass;
+            if(status[g] == ALD_ST_CAPACITY && c + 1 < ALD_NUM_CLASSES) { cls[g] = c + 1; next[c + 1].push_back(g); }
+        }
+        for(int c = 0; c < ALD_NUM_CLASSES; c++) work[c].swap(next[c]);
+    }
+    E->R.status = status; E->R.n_iters = n_iters; E->R.attempt = attempt;
+    E->R.pool.assign(pool.begin(), pool.begin() + pool_used);
+    E->cls = cls;
+    rc = E->R.build(n, n_paths);
+    if(rc != 0) { fprintf(stderr, "emu: record parse failed rc=%d\n", rc); delete E; return ALD_ERR_STATE; }
+    *out = E;
+    return ALD_OK;
+}
+
+int emu_result_export(const emu_result *E, int64_t *total_paths, int64_t *total_path_vertices, int32_t *status, int32_t *path_offset,
+                      double *weight, double *abd, double *conf, double *reads, int32_t *length, int32_t *count, char *strand,
+                      int64_t *pv_offset, int32_t *path_vertices)
+{
+    return export_results(E->R, E->n, total_paths, total_path_vertices, status, path_offset, weight, abd, conf, reads, length, count, strand, pv_offset, path_vertices);
+}
+int emu_result_iters(const emu_result *E, int32_t *iters, int32_t *cls) { for(int g = 0; g < E->n; g++) { iters[g] = E->R.n_iters[g]; cls[g] = E->cls[g]; } return 0; }
+int emu_result_trace(const emu_result *E, int32_t graph, int32_t *n_events, int32_t *codes3, double *values, int32_t cap)
+{
+    if(E->trace_cap <= 0) { *n_events = 0; return 0; }
+    int n = E->trace_n[graph]; *n_events = n;
+    if(!codes3) return 0;
+    for(int i = 0; i < n && i < cap && i < E->trace_cap; i++) { size_t o = (size_t)graph * E->trace_cap + i; codes3[3 * i] = E->trace_codes[3 * o]; codes3[3 * i + 1] = E->trace_codes[3 * o + 1]; codes3[3 * i + 2] = E->trace_codes[3 * o + 2]; values[i] = E->trace_vals[o]; }
+    return 0;
+}
+void emu_result_free(emu_result *E) { delete E; }
+
+} // extern "C"
