@@ -1,0 +1,375 @@
+// ald_abi.cpp -- implementation of the C ABI (include/aletsch_decomp.h) on the HIP runtime.
+//
+// Host side of the drop-in boundary: stages graphs into ONE pinned wire buffer, moves it to HBM with a single
+// copy, launches the per-size-class persistent kernels (decomp_class.hip) on the batch's stream, and parses the
+// packed path records that come back.  There is NO CPU compute path here: without a HIP device every compute
+// entry point fails with ALD_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include "host_pack.h"
+#include <mutex>
+#include <string>
+
+using namespace ald;
+
+extern "C" {
+int ald_launch_c0(const KernelArgs *, int, hipStream_t); int ald_launch_c1(const KernelArgs *, int, hipStream_t); int ald_launch_c2(const KernelArgs *, int, hipStream_t);
+int ald_launch_c3(const KernelArgs *, int, hipStream_t); int ald_launch_c4(const KernelArgs *, int, hipStream_t);
+int ald_occupancy_c0(); int ald_occupancy_c1(); int ald_occupancy_c2(); int ald_occupancy_c3(); int ald_occupancy_c4();
+}
+
+namespace {
+
+thread_local std::string g_err;
+int set_err(int code, const std::string &s) { g_err = s; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if(e_ != hipSuccess) return set_err(ALD_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while(0)
+
+typedef int (*launch_fn)(const KernelArgs *, int, hipStream_t);
+typedef int (*occ_fn)();
+const launch_fn k_launch[ALD_NUM_CLASSES] = {ald_launch_c0, ald_launch_c1, ald_launch_c2, ald_launch_c3, ald_launch_c4};
+const occ_fn k_occ[ALD_NUM_CLASSES] = {ald_occupancy_c0, ald_occupancy_c1, ald_occupancy_c2, ald_occupancy_c3, ald_occupancy_c4};
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) { if(bytes <= cap) return 0; if(p) hipFree(p); p = nullptr; cap = 0; size_t want = bytes + bytes / 4 + 256; if(hipMalloc(&p, want) != hipSuccess) return -1; cap = want; return 0; }
+    void release() { if(p) hipFree(p); p = nullptr; cap = 0; }
+};
+struct PinBuf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) { if(bytes <= cap) return 0; if(p) hipHostFree(p); p = nullptr; cap = 0; size_t want = bytes + bytes / 4 + 256; if(hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return -1; cap = want; return 0; }
+    void release() { if(p) hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+} // namespace
+
+struct ald_batch {
+    int device = 0; int n_cus = 0;
+    Params prm;
+    HostBatch hb;
+    HostBatch::Section sec[HostBatch::S_COUNT];
+    uint64_t in_bytes = 0;
+    hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    PinBuf pin_in, pin_out;
+    DevBuf d_in, d_status, d_npaths, d_niters, d_pool, d_poolused, d_trace_n, d_trace_codes, d_trace_vals, d_work, d_counter, d_args;
+    DevBuf d_slabs[ALD_NUM_CLASSES];
+    int blocks[ALD_NUM_CLASSES] = {0, 0, 0, 0, 0};
+    int occ[ALD_NUM_CLASSES] = {-1, -1, -1, -1, -1};
+    uint64_t pool_cap_words = 0;
+    int trace_cap = 0;
+    bool uploaded = false, ran = false, downloaded = false;
+    double kernel_ms = -1;
+    // per-graph scheduling state
+    std::vector<int32_t> cls, attempt, status, n_paths, n_iters;
+    std::vector<int32_t> trace_n, trace_codes; std::vector<double> trace_vals;
+    HostResults res;
+    int passes = 0;
+};
+
+namespace {
+
+int occupancy_for(ald_batch *b, int c)
+{
+    if(b->occ[c] < 0) { int o = k_occ[c](); if(o < 1) o = 1; if(o > 32) o = 32; b->occ[c] = o; }
+    return b->occ[c];
+}
+
+// launch one pass: every class that has work gets its own persistent grid on the batch stream
+int launch_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], int pass)
+{
+    const int n = b->hb.n();
+    size_t tot = 0; for(int c = 0; c < ALD_NUM_CLASSES; c++) tot += work[c].size();
+    if(tot == 0) return ALD_OK;
+    if(b->d_work.ensure(4 * (size_t)n + 64)) return set_err(ALD_ERR_NOMEM, "work list");
+    if(b->d_counter.ensure(4 * ALD_NUM_CLASSES * 64)) return set_err(ALD_ERR_NOMEM, "counters");
+    if(b->d_args.ensure(sizeof(KernelArgs) * ALD_NUM_CLASSES)) return set_err(ALD_ERR_NOMEM, "kernel args");
+    HIPCHK(hipMemsetAsync(b->d_counter.p, 0, 4 * ALD_NUM_CLASSES * 64, b->stream));
+    size_t woff = 0;
+    std::vector<KernelArgs> args(ALD_NUM_CLASSES);
+    std::vector<int32_t> flat(tot);
+    int nblk[ALD_NUM_CLASSES];
+    for(int c = 0; c < ALD_NUM_CLASSES; c++) {
+        nblk[c] = 0;
+        if(work[c].empty()) continue;
+        ClassInfo ci = class_info(c);
+        int per_cu = occupancy_for(b, c);
+        int want = b->n_cus * per_cu;
+        if((size_t)want > work[c].size()) want = (int)work[c].size();
+        if(want < 1) want = 1;
+        if(b->d_slabs[c].ensure((size_t)want * ci.slab_bytes)) return set_err(ALD_ERR_NOMEM, "class slab");
+        nblk[c] = want;
+        memcpy(flat.data() + woff, work[c].data(), 4 * work[c].size());
+        KernelArgs &A = args[c]; memset(&A, 0, sizeof(A));
+        A.in = b->hb.make_batch_in((uint8_t*)b->d_in.p, b->sec);
+        A.out.status = (int32_t*)b->d_status.p; A.out.n_paths = (int32_t*)b->d_npaths.p; A.out.n_iters = (int32_t*)b->d_niters.p;
+        A.out.pool_used = (unsigned long long*)b->d_poolused.p; A.out.pool = (uint32_t*)b->d_pool.p; A.out.pool_cap = b->pool_cap_words;
+        A.out.trace_cap = b->trace_cap; A.out.trace_n = (int32_t*)b->d_trace_n.p; A.out.trace_codes = (int32_t*)b->d_trace_codes.p; A.out.trace_vals = (double*)b->d_trace_vals.p;
+        A.prm = b->prm;
+        A.work = (const int32_t*)b->d_work.p + woff; A.n_work = (int32_t)work[c].size(); A.attempt = pass;
+        A.counter = (int32_t*)b->d_counter.p + 64 * c;
+        A.slabs = (uint8_t*)b->d_slabs[c].p; A.slab_stride = ci.slab_bytes;
+        woff += work[c].size();
+    }
+    HIPCHK(hipMemcpyAsync(b->d_work.p, flat.data(), 4 * tot, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_args.p, args.data(), sizeof(KernelArgs) * ALD_NUM_CLASSES, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));          // flat / args are stack-lifetime host buffers
+    HIPCHK(hipEventRecord(b->ev0, b->stream));
+    for(int c = ALD_NUM_CLASSES - 1; c >= 0; c--) {   // big graphs first: the long poles start early
+        if(nblk[c] == 0) continue;
+        b->blocks[c] = nblk[c];
+        if(k_launch[c]((const KernelArgs*)b->d_args.p + c, nblk[c], b->stream) != 0) return set_err(ALD_ERR_HIP, "kernel launch failed");
+    }
+    HIPCHK(hipEventRecord(b->ev1, b->stream));
+    return ALD_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *ald_last_error(void) { return g_err.c_str(); }
+const char *ald_version(void) { return "aletsch_amd-decomp 0.1 (gfx950)"; }
+
+int ald_default_params(ald_params *p)
+{
+    if(!p) return ALD_ERR_INVALID;
+    const double r[8] = {0.30, 0.00, 1.10, 1.10, 0.75, 0.30, 0.00, 1.00};     // util/parameters.cc:85-92
+    for(int i = 0; i < 8; i++) p->max_decompose_error_ratio[i] = r[i];
+    p->min_guaranteed_edge_weight = 0.01; p->min_transcript_coverage = 2.0; p->max_num_exons = 10000; p->reserved = 0;
+    return ALD_OK;
+}
+
+int ald_batch_create(const ald_params *p, int device, ald_batch **out)
+{
+    if(!out) return ALD_ERR_INVALID;
+    int ndev = 0;
+    if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(ALD_ERR_NO_DEVICE, "no HIP device visible: the decomposition path has no CPU fallback");
+    if(device < 0 || device >= ndev) return set_err(ALD_ERR_INVALID, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    ald_batch *b = new ald_batch();
+    b->device = device; b->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    params_from_abi(p, b->prm);
+    if(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { delete b; return set_err(ALD_ERR_HIP, "stream/event creation failed"); }
+    *out = b;
+    return ALD_OK;
+}
+
+int ald_batch_destroy(ald_batch *b)
+{
+    if(!b) return ALD_OK;
+    hipSetDevice(b->device);
+    if(b->stream) hipStreamSynchronize(b->stream);
+    b->pin_in.release(); b->pin_out.release();
+    DevBuf *bufs[] = {&b->d_in, &b->d_status, &b->d_npaths, &b->d_niters, &b->d_pool, &b->d_poolused, &b->d_trace_n, &b->d_trace_codes, &b->d_trace_vals, &b->d_work, &b->d_counter, &b->d_args};
+    for(DevBuf *d : bufs) d->release();
+    for(int c = 0; c < ALD_NUM_CLASSES; c++) b->d_slabs[c].release();
+    if(b->ev0) hipEventDestroy(b->ev0);
+    if(b->ev1) hipEventDestroy(b->ev1);
+    if(b->stream) hipStreamDestroy(b->stream);
+    delete b;
+    return ALD_OK;
+}
+
+int ald_batch_clear(ald_batch *b)
+{
+    if(!b) return ALD_ERR_INVALID;
+    b->hb.clear(); b->res.clear(); b->uploaded = b->ran = b->downloaded = false; b->kernel_ms = -1;
+    return ALD_OK;
+}
+
+int ald_batch_add_graph(ald_batch *b, const ald_graph_view *g)
+{
+    if(!b || !g) return ALD_ERR_INVALID;
+    b->uploaded = b->ran = b->downloaded = false;
+    int rc = b->hb.add_graph(*g);
+    if(rc != ALD_OK) return set_err(rc, b->hb.err);
+    return ALD_OK;
+}
+
+int ald_batch_add_packed(ald_batch *b, int32_t n, const int32_t *g_nv, const int32_t *g_ne, const int32_t *g_np,
+                         const int32_t *vertex_offset, const int32_t *edge_target, const double *edge_weight, const uint8_t *edge_strand, const double *edge_abd,
+                         const int32_t *edge_sample_offset, const int32_t *sample_id, const double *sample_abd,
+                         const double *vertex_weight, const int32_t *vertex_lpos, const int32_t *vertex_rpos, const int32_t *vertex_type,
+                         const int32_t *phasing_offset, const int32_t *phasing_vertex, const int32_t *phasing_count, const char *graph_strand)
+{
+    if(!b || n < 0 || !g_nv || !g_ne) return ALD_ERR_INVALID;
+    b->uploaded = b->ran = b->downloaded = false;
+    int rc = b->hb.add_packed(n, g_nv, g_ne, g_np, vertex_offset, edge_target, edge_weight, edge_strand, edge_abd, edge_sample_offset, sample_id, sample_abd,
+                              vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand);
+    if(rc != ALD_OK) return set_err(rc, b->hb.err);
+    return ALD_OK;
+}
+
+int ald_batch_num_graphs(const ald_batch *b) { return b ? b->hb.n() : 0; }
+
+int ald_batch_enable_trace(ald_batch *b, int32_t max_events_per_graph)
+{
+    if(!b || max_events_per_graph < 0) return ALD_ERR_INVALID;
+    b->trace_cap = max_events_per_graph; b->uploaded = false;
+    return ALD_OK;
+}
+
+int ald_batch_upload(ald_batch *b)
+{
+    if(!b) return ALD_ERR_INVALID;
+    HIPCHK(hipSetDevice(b->device));
+    const int n = b->hb.n();
+    b->in_bytes = b->hb.layout(b->sec);
+    if(b->pin_in.ensure(b->in_bytes)) return set_err(ALD_ERR_NOMEM, "pinned input buffer");
+    if(b->d_in.ensure(b->in_bytes)) return set_err(ALD_ERR_NOMEM, "device input buffer");
+    b->hb.pack_into((uint8_t*)b->pin_in.p, b->sec);
+    HIPCHK(hipMemcpyAsync(b->d_in.p, b->pin_in.p, b->in_bytes, hipMemcpyHostToDevice, b->stream));    // ONE coalesced H2D copy
+    // outputs
+    uint64_t pool = 0; for(int g = 0; g < n; g++) pool += 16ull * b->hb.g_ne[g] + 256;
+    b->pool_cap_words = pool;
+    if(b->d_status.ensure(4 * (size_t)n + 4) || b->d_npaths.ensure(4 * (size_t)n + 4) || b->d_niters.ensure(4 * (size_t)n + 4) || b->d_pool.ensure(4 * pool + 64) || b->d_poolused.ensure(64))
+        return set_err(ALD_ERR_NOMEM, "device output buffers");
+    if(b->trace_cap > 0) {
+        if(b->d_trace_n.ensure(4 * (size_t)n + 4) || b->d_trace_codes.ensure(12ull * n * b->trace_cap + 4) || b->d_trace_vals.ensure(8ull * n * b->trace_cap + 8)) return set_err(ALD_ERR_NOMEM, "trace buffers");
+        HIPCHK(hipMemsetAsync(b->d_trace_n.p, 0, 4 * (size_t)n + 4, b->stream));
+    }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->uploaded = true; b->ran = false; b->downloaded = false;
+    return ALD_OK;
+}
+
+int ald_batch_run(ald_batch *b)
+{
+    if(!b) return ALD_ERR_INVALID;
+    if(!b->uploaded) return set_err(ALD_ERR_STATE, "ald_batch_run before ald_batch_upload");
+    HIPCHK(hipSetDevice(b->device));
+    const int n = b->hb.n();
+    HIPCHK(hipMemsetAsync(b->d_poolused.p, 0, 64, b->stream));
+    HIPCHK(hipMemsetAsync(b->d_status.p, 0, 4 * (size_t)n + 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->d_npaths.p, 0, 4 * (size_t)n + 4, b->stream));
+    b->cls.assign(n, -1); b->attempt.assign(n, 0); b->status.assign(n, 0);
+    std::vector<int32_t> work[ALD_NUM_CLASSES];
+    for(int g = 0; g < n; g++) {
+        int64_t ns = b->hb.off_s[g + 1] - b->hb.off_s[g], npv = b->hb.off_pv[g + 1] - b->hb.off_pv[g];
+        int c = pick_class(b->hb.g_nv[g], b->hb.g_ne[g], ns, npv);
+        b->cls[g] = c;
+        if(c >= 0) work[c].push_back(g);
+    }
+    b->passes = 0; b->kernel_ms = 0;
+    int rc = launch_pass(b, work, 0);
+    if(rc != ALD_OK) return rc;
+    b->ran = true; b->downloaded = false;
+    return ALD_OK;
+}
+
+int ald_batch_sync(ald_batch *b)
+{
+    if(!b) return ALD_ERR_INVALID;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return ALD_OK;
+}
+
+int ald_batch_download(ald_batch *b)
+{
+    if(!b) return ALD_ERR_INVALID;
+    if(!b->ran) return set_err(ALD_ERR_STATE, "ald_batch_download before ald_batch_run");
+    HIPCHK(hipSetDevice(b->device));
+    const int n = b->hb.n();
+    b->n_paths.assign(n, 0); b->n_iters.assign(n, 0);
+    std::vector<int32_t> st(n);
+    for(int pass = 0; pass <= ALD_NUM_CLASSES; pass++) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        float ms = 0; if(hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->kernel_ms += ms;
+        b->passes++;
+        if(n > 0) HIPCHK(hipMemcpy(st.data(), b->d_status.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+        // graphs whose working set overflowed their class are retried one class up (records carry the pass number)
+        std::vector<int32_t> work[ALD_NUM_CLASSES]; bool any = false;
+        for(int g = 0; g < n; g++) {
+            if(b->cls[g] < 0) { b->status[g] = ALD_ST_CAPACITY; continue; }
+            if(b->attempt[g] != pass) continue;                 // not part of this pass
+            b->status[g] = st[g];
+            if(st[g] == ALD_ST_CAPACITY && b->cls[g] + 1 < ALD_NUM_CLASSES) { b->cls[g]++; b->attempt[g] = pass + 1; work[b->cls[g]].push_back(g); any = true; }
+        }
+        if(!any) break;
+        int rc = launch_pass(b, work, pass + 1);
+        if(rc != ALD_OK) return rc;
+    }
+    unsigned long long used = 0;
+    HIPCHK(hipMemcpy(&used, b->d_poolused.p, 8, hipMemcpyDeviceToHost));
+    if(used > b->pool_cap_words) used = b->pool_cap_words;
+    b->res.clear();
+    b->res.pool.resize(used);
+    if(n > 0) {
+        HIPCHK(hipMemcpy(b->n_paths.data(), b->d_npaths.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(b->n_iters.data(), b->d_niters.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    }
+    if(used) HIPCHK(hipMemcpy(b->res.pool.data(), b->d_pool.p, 4 * used, hipMemcpyDeviceToHost));
+    b->res.status = b->status; b->res.n_iters = b->n_iters; b->res.attempt = b->attempt;
+    int rc = b->res.build(n, b->n_paths);
+    if(rc != 0) return set_err(ALD_ERR_STATE, "path record stream is inconsistent (rc=" + std::to_string(rc) + ")");
+    if(b->trace_cap > 0 && n > 0) {
+        b->trace_n.resize(n); b->trace_codes.resize(3ull * n * b->trace_cap); b->trace_vals.resize((size_t)n * b->trace_cap);
+        HIPCHK(hipMemcpy(b->trace_n.data(), b->d_trace_n.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(b->trace_codes.data(), b->d_trace_codes.p, 12ull * n * b->trace_cap, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(b->trace_vals.data(), b->d_trace_vals.p, 8ull * n * b->trace_cap, hipMemcpyDeviceToHost));
+    }
+    b->downloaded = true;
+    return ALD_OK;
+}
+
+double ald_batch_last_kernel_ms(const ald_batch *b) { return b ? b->kernel_ms : -1; }
+
+int ald_batch_algorithmic_bytes(const ald_batch *b, int64_t *in_bytes, int64_t *out_bytes)
+{
+    if(!b) return ALD_ERR_INVALID;
+    if(in_bytes) *in_bytes = b->hb.algorithmic_in_bytes();
+    if(out_bytes) *out_bytes = b->downloaded ? b->res.out_bytes : 0;
+    return ALD_OK;
+}
+
+int ald_batch_get_result(const ald_batch *b, int32_t graph, ald_result_view *out)
+{
+    if(!b || !out || !b->downloaded || graph < 0 || graph >= b->hb.n()) return ALD_ERR_INVALID;
+    out->status = b->res.status[graph]; out->num_paths = (int32_t)(b->res.path_begin[graph + 1] - b->res.path_begin[graph]);
+    out->num_iterations = b->res.n_iters[graph]; out->reserved = 0;
+    return ALD_OK;
+}
+
+int ald_batch_get_path(const ald_batch *b, int32_t graph, int32_t path, ald_path_view *out)
+{
+    if(!b || !out || !b->downloaded || graph < 0 || graph >= b->hb.n()) return ALD_ERR_INVALID;
+    int64_t i = b->res.path_begin[graph] + path;
+    if(path < 0 || i >= b->res.path_begin[graph + 1]) return ALD_ERR_INVALID;
+    const PathRec &p = b->res.paths[i];
+    out->num_vertices = p.nv; out->vertices = (const int32_t*)b->res.vertices(p);
+    out->weight = p.weight; out->abd = p.abd; out->conf = p.conf; out->reads = p.reads; out->length = p.length; out->count = p.count; out->strand = p.strand;
+    return ALD_OK;
+}
+
+int ald_batch_export(const ald_batch *b, int64_t *total_paths, int64_t *total_path_vertices, int32_t *status, int32_t *path_offset,
+                     double *weight, double *abd, double *conf, double *reads, int32_t *length, int32_t *count, char *strand,
+                     int64_t *pv_offset, int32_t *path_vertices)
+{
+    if(!b || !b->downloaded) return set_err(ALD_ERR_STATE, "ald_batch_export before ald_batch_download");
+    return export_results(b->res, b->hb.n(), total_paths, total_path_vertices, status, path_offset, weight, abd, conf, reads, length, count, strand, pv_offset, path_vertices);
+}
+
+int ald_batch_get_trace(const ald_batch *b, int32_t graph, int32_t *n_events, const int32_t **codes, const double **values)
+{
+    if(!b || !n_events || !b->downloaded || graph < 0 || graph >= b->hb.n()) return ALD_ERR_INVALID;
+    if(b->trace_cap <= 0) { *n_events = 0; return ALD_OK; }
+    *n_events = b->trace_n[graph] < b->trace_cap ? b->trace_n[graph] : b->trace_cap;
+    if(codes) *codes = b->trace_codes.data() + 3ull * graph * b->trace_cap;
+    if(values) *values = b->trace_vals.data() + (size_t)graph * b->trace_cap;
+    return ALD_OK;
+}
+
+/* diagnostics used by bench.py / DESIGN.md: class sizes, occupancy and the grid of the last run */
+int ald_batch_class_info(ald_batch *b, int32_t cls, int32_t *maxv, int32_t *maxe, int32_t *blocks_per_cu, int32_t *blocks_last_run, int64_t *slab_bytes, int32_t *n_graphs)
+{
+    if(!b || cls < 0 || cls >= ALD_NUM_CLASSES) return ALD_ERR_INVALID;
+    ClassInfo ci = class_info(cls);
+    if(maxv) *maxv = ci.maxv; if(maxe) *maxe = ci.maxe; if(slab_bytes) *slab_bytes = (int64_t)ci.slab_bytes;
+    if(blocks_per_cu) { hipSetDevice(b->device); *blocks_per_cu = occupancy_for(b, cls); }
+    if(blocks_last_run) *blocks_last_run = b->blocks[cls];
+    if(n_graphs) { int k = 0; for(int c : b->cls) if(c == cls) k++; *n_graphs = k; }
+    return ALD_OK;
+}
+
+} // extern "C"

@@ -7,8 +7,11 @@
 #include "decomp_device.h"
 
 #define ALD_KERNEL_NAME ALD_CAT(ald_decomp_kernel_c, ALD_CLASS_ID)
+#ifndef ALD_WAVES_PER_EU
+#define ALD_WAVES_PER_EU 4      /* register budget: 512 / 4 = 128 VGPRs per lane (MI355X_MICROARCH.md, Register files) */
+#endif
 
-extern "C" __global__ void __launch_bounds__(64) ALD_KERNEL_NAME(const ald::KernelArgs *A)
+extern "C" __global__ void __launch_bounds__(64, ALD_WAVES_PER_EU) ALD_KERNEL_NAME(const ald::KernelArgs *A)
 {
     ALD_CLASS_NS::wave_main((ALD_GLOBAL const ald::KernelArgs*)A, (int)blockIdx.x);
 }

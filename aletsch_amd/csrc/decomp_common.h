@@ -22,6 +22,9 @@
   static inline int      atomic_add_i32(int *p, int v) { int o = *p; *p += v; return o; }
   static inline int      ffs64(uint64_t m) { return __builtin_ffsll((long long)m) - 1; }
   }
+#elif !defined(__HIP__)
+  // plain host C++ translation unit (ald_abi.cpp, synth.cpp): only the shared structs are needed
+  #define ALD_GLOBAL
 #else
   #include <hip/hip_runtime.h>
   #define ALD_FN  static __device__ __attribute__((noinline))

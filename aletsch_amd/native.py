@@ -1,0 +1,208 @@
+"""ctypes bindings of the C ABI (include/aletsch_decomp.h).
+
+``DecompBatch`` mirrors the call shape the reference uses for one graph --
+``scallop sx(gx, hx, cfg); sx.assemble(); sx.paths`` (meta/assembler.cc:1110-1121, scallop/scallop.h:31-51) --
+lifted to a batch: ``add`` graphs, ``upload``, ``run``, ``download``, read ``paths``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .packed import PackedGraphs, DecompResult, export_via
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class DecompError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"aletsch_decomp error {code}: {msg}")
+        self.code = code
+
+
+class AldParams(C.Structure):
+    _fields_ = [("max_decompose_error_ratio", C.c_double * 8), ("min_guaranteed_edge_weight", C.c_double),
+                ("min_transcript_coverage", C.c_double), ("max_num_exons", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SynthSpec(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_graphs", C.c_int32), ("v_min", C.c_int32), ("v_max", C.c_int32),
+                ("edges_per_vertex", C.c_int32), ("fixed_edges", C.c_int32), ("weight_mode", C.c_int32),
+                ("n_samples", C.c_int32), ("phasing_per_graph", C.c_int32), ("strand_mode", C.c_int32),
+                ("layout_mode", C.c_int32)]
+
+
+class _ResultView(C.Structure):
+    _fields_ = [("status", C.c_int32), ("num_paths", C.c_int32), ("num_iterations", C.c_int32), ("reserved", C.c_int32)]
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "lib", "libaletsch_decomp.so")
+
+
+def load_library():
+    """Load the in-tree HIP library; fail loudly if it has not been built (no fallback exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise DecompError(-100, f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(hipcc --offload-arch=gfx950); there is no CPU fallback for the decomposition path")
+    lib = C.CDLL(path)
+    lib.ald_last_error.restype = C.c_char_p
+    lib.ald_version.restype = C.c_char_p
+    lib.ald_batch_last_kernel_ms.restype = C.c_double
+    lib.ald_batch_last_kernel_ms.argtypes = [C.c_void_p]
+    for name in ("ald_batch_destroy", "ald_batch_clear", "ald_batch_upload", "ald_batch_run", "ald_batch_sync",
+                 "ald_batch_download", "ald_batch_num_graphs"):
+        getattr(lib, name).argtypes = [C.c_void_p]
+    lib.ald_batch_enable_trace.argtypes = [C.c_void_p, C.c_int32]
+    _LIB = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise DecompError(rc, (load_library().ald_last_error() or b"").decode())
+
+
+def default_params() -> AldParams:
+    p = AldParams()
+    _check(load_library().ald_default_params(C.byref(p)))
+    return p
+
+
+def synth(**kw) -> PackedGraphs:
+    """Deterministic synthetic batch (SURVEY.md 8d generator; csrc/synth.cpp)."""
+    lib = load_library()
+    spec = SynthSpec(**kw)
+    t = [C.c_int64() for _ in range(5)]
+    _check(lib.ald_synth_sizes(C.byref(spec), *[C.byref(x) for x in t]))
+    tv, te, ts, tp, tpv = [x.value for x in t]
+    n = spec.n_graphs
+    pg = PackedGraphs(
+        g_nv=np.zeros(n, np.int32), g_ne=np.zeros(n, np.int32), g_np=np.zeros(n, np.int32),
+        vertex_offset=np.zeros(tv + n, np.int32), edge_target=np.zeros(te, np.int32), edge_weight=np.zeros(te),
+        edge_strand=np.zeros(te, np.uint8), edge_abd=np.zeros(te), edge_sample_offset=np.zeros(te + n, np.int32),
+        sample_id=np.zeros(ts, np.int32), sample_abd=np.zeros(ts), vertex_weight=np.zeros(tv),
+        vertex_lpos=np.zeros(tv, np.int32), vertex_rpos=np.zeros(tv, np.int32), vertex_type=np.zeros(tv, np.int32),
+        phasing_offset=np.zeros(tp + n, np.int32), phasing_vertex=np.zeros(tpv, np.int32),
+        phasing_count=np.zeros(tp, np.int32), graph_strand=np.zeros(n, np.int8))
+    a = pg.c_args()
+    _check(lib.ald_synth_fill(C.byref(spec), *a[1:]))
+    return pg
+
+
+class DecompBatch:
+    """One batch of splice graphs on one MI355X (one HIP stream)."""
+
+    def __init__(self, device: int = 0, params: Optional[AldParams] = None, trace_events: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        _check(self._lib.ald_batch_create(C.byref(params) if params is not None else None, C.c_int(device), C.byref(self._h)))
+        if trace_events:
+            _check(self._lib.ald_batch_enable_trace(self._h, trace_events))
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            self._lib.ald_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def n(self) -> int:
+        return int(self._lib.ald_batch_num_graphs(self._h))
+
+    def clear(self):
+        _check(self._lib.ald_batch_clear(self._h))
+
+    def add(self, pg: PackedGraphs):
+        _check(self._lib.ald_batch_add_packed(self._h, *pg.c_args()))
+
+    def upload(self):
+        _check(self._lib.ald_batch_upload(self._h))
+
+    def run(self):
+        _check(self._lib.ald_batch_run(self._h))
+
+    def sync(self):
+        _check(self._lib.ald_batch_sync(self._h))
+
+    def download(self):
+        _check(self._lib.ald_batch_download(self._h))
+
+    def kernel_ms(self) -> float:
+        return float(self._lib.ald_batch_last_kernel_ms(self._h))
+
+    def algorithmic_bytes(self):
+        a = C.c_int64(); b = C.c_int64()
+        _check(self._lib.ald_batch_algorithmic_bytes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def result(self) -> DecompResult:
+        return export_via(self._lib.ald_batch_export, self._h, self.n)
+
+    def iterations(self) -> np.ndarray:
+        out = np.zeros(self.n, np.int32); rv = _ResultView()
+        for g in range(self.n):
+            _check(self._lib.ald_batch_get_result(self._h, g, C.byref(rv)))
+            out[g] = rv.num_iterations
+        return out
+
+    def trace(self, g: int):
+        n = C.c_int32(); codes = C.POINTER(C.c_int32)(); vals = C.POINTER(C.c_double)()
+        _check(self._lib.ald_batch_get_trace(self._h, g, C.byref(n), C.byref(codes), C.byref(vals)))
+        return [(codes[3 * i], codes[3 * i + 1], codes[3 * i + 2], vals[i]) for i in range(n.value)]
+
+    def class_info(self, cls: int):
+        v = [C.c_int32() for _ in range(4)]; sb = C.c_int64(); ng = C.c_int32()
+        _check(self._lib.ald_batch_class_info(self._h, cls, C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), C.byref(v[3]), C.byref(sb), C.byref(ng)))
+        return dict(maxv=v[0].value, maxe=v[1].value, blocks_per_cu=v[2].value, blocks_last_run=v[3].value, slab_bytes=sb.value, n_graphs=ng.value)
+
+
+def decompose(pg: PackedGraphs, device: int = 0, params: Optional[AldParams] = None) -> DecompResult:
+    """Convenience: stage, upload, run, download one batch."""
+    with DecompBatch(device, params) as b:
+        b.add(pg); b.upload(); b.run(); b.download()
+        return b.result()
+
+
+def subsetsum_batch(instances, device: int = 0):
+    """instances: list of (source [(value,label)...], target [(value,label)...]).  Returns list of
+    (error, S labels, T labels) or None for an instance the reference would assert on (scallop/subsetsum.cc)."""
+    lib = load_library()
+    n = len(instances)
+    ns = np.array([len(s) for s, _ in instances], np.int32); nt = np.array([len(t) for _, t in instances], np.int32)
+    sv = np.array([v for s, _ in instances for v, _l in s], np.int32); sl = np.array([l for s, _ in instances for _v, l in s], np.int32)
+    tv = np.array([v for _, t in instances for v, _l in t], np.int32); tl = np.array([l for _, t in instances for _v, l in t], np.int32)
+    err = np.zeros(n); ons = np.zeros(n, np.int32); ont = np.zeros(n, np.int32); os_ = np.zeros(64 * n, np.int32); ot = np.zeros(64 * n, np.int32)
+
+    def p(a, t):
+        return a.ctypes.data_as(C.POINTER(t))
+    _check(lib.ald_subsetsum_batch(C.c_int(device), C.c_int32(n), p(ns, C.c_int32), p(nt, C.c_int32), p(sv, C.c_int32), p(sl, C.c_int32),
+                                   p(tv, C.c_int32), p(tl, C.c_int32), p(err, C.c_double), p(ons, C.c_int32), p(ont, C.c_int32),
+                                   p(os_, C.c_int32), p(ot, C.c_int32)))
+    out = []
+    for i in range(n):
+        if ons[i] < 0:
+            out.append(None)
+        else:
+            out.append((float(err[i]), os_[64 * i:64 * i + ons[i]].tolist(), ot[64 * i:64 * i + ont[i]].tolist()))
+    return out

@@ -1,0 +1,144 @@
+"""Test-side helpers.  This module (with bench.py's cpu_baseline leg and smoke()) is the only place that loads
+anything under oracle/ or the single-lane emulation; the product package never does."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from aletsch_amd.packed import PackedGraphs, DecompResult, export_via
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE = None
+_EMU = None
+
+
+def _ensure(path: str, make_dir: str):
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", os.path.join(ROOT, make_dir), "-j8"], check=True, stdout=subprocess.DEVNULL)
+    return path
+
+
+def oracle_lib():
+    global _ORACLE
+    if _ORACLE is None:
+        _ORACLE = C.CDLL(_ensure(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle"))
+        _ORACLE.ora_result_seconds.restype = C.c_double
+        _ORACLE.ora_result_seconds.argtypes = [C.c_void_p]
+        _ORACLE.ora_result_free.argtypes = [C.c_void_p]
+    return _ORACLE
+
+
+def emu_lib():
+    global _EMU
+    if _EMU is None:
+        _EMU = C.CDLL(_ensure(os.path.join(ROOT, "tests", "_build", "libkernel_emu.so"), "tests/kernel_emu"))
+        _EMU.emu_result_free.argtypes = [C.c_void_p]
+    return _EMU
+
+
+def oracle_run(pg: PackedGraphs, threads: int = 1, trace: bool = False, params=None):
+    """-> (DecompResult, stats[n,6], seconds, traces or None)"""
+    O = oracle_lib()
+    h = C.c_void_p()
+    rc = O.ora_run_packed(*pg.c_args(), C.byref(params) if params is not None else None, C.c_int32(threads), C.c_int32(1 if trace else 0), C.byref(h))
+    assert rc == 0
+    r = export_via(O.ora_result_export, h, pg.n)
+    st = np.zeros((pg.n, 6), np.int32)
+    O.ora_result_stats(h, st.ctypes.data_as(C.POINTER(C.c_int32)))
+    sec = O.ora_result_seconds(h)
+    traces = None
+    if trace:
+        traces = []
+        for g in range(pg.n):
+            n = C.c_int32()
+            O.ora_result_trace(h, g, C.byref(n), None, None, 0)
+            codes = np.zeros(3 * max(n.value, 1), np.int32); vals = np.zeros(max(n.value, 1))
+            O.ora_result_trace(h, g, C.byref(n), codes.ctypes.data_as(C.POINTER(C.c_int32)), vals.ctypes.data_as(C.POINTER(C.c_double)), n.value)
+            traces.append([(int(codes[3 * i]), int(codes[3 * i + 1]), int(codes[3 * i + 2]), float(vals[i])) for i in range(n.value)])
+    O.ora_result_free(h)
+    return r, st, sec, traces
+
+
+def oracle_transcripts(pg: PackedGraphs):
+    """coverage + exon lists per path (scallop.cc:3250-3266, essential.cc:719-748) from the oracle."""
+    O = oracle_lib()
+    h = C.c_void_p()
+    assert O.ora_run_packed(*pg.c_args(), None, C.c_int32(1), C.c_int32(0), C.byref(h)) == 0
+    r = export_via(O.ora_result_export, h, pg.n)
+    te = C.c_int64()
+    O.ora_result_export_transcripts(h, C.byref(te), None, None, None)
+    P = len(r.weight)
+    cov = np.zeros(P); eo = np.zeros(P + 1, np.int64); lr = np.zeros(2 * max(te.value, 1), np.int32)
+    O.ora_result_export_transcripts(h, C.byref(te), cov.ctypes.data_as(C.POINTER(C.c_double)), eo.ctypes.data_as(C.POINTER(C.c_int64)), lr.ctypes.data_as(C.POINTER(C.c_int32)))
+    O.ora_result_free(h)
+    return r, cov, eo, lr[:2 * te.value].reshape(-1, 2)
+
+
+def emu_run(pg: PackedGraphs, trace_cap: int = 0, force_class: int = 0, params=None):
+    """single-lane emulation of the HIP engine -> (DecompResult, iterations[n], class[n])"""
+    E = emu_lib()
+    h = C.c_void_p()
+    rc = E.emu_run_packed(*pg.c_args(), C.byref(params) if params is not None else None, C.c_int32(trace_cap), C.c_int32(force_class), C.byref(h))
+    assert rc == 0, rc
+    r = export_via(E.emu_result_export, h, pg.n)
+    it = np.zeros(pg.n, np.int32); cl = np.zeros(pg.n, np.int32)
+    E.emu_result_iters(h, it.ctypes.data_as(C.POINTER(C.c_int32)), cl.ctypes.data_as(C.POINTER(C.c_int32)))
+    E.emu_result_free(h)
+    return r, it, cl
+
+
+def compare_results(want: DecompResult, got: DecompResult, n: int, tol: float = 0.0, conf_tol: float = 0.0):
+    """Per graph: same status, same number of paths, identical vertex lists in identical order, exact length /
+    count / strand; weight / abd / conf / reads bit-identical when tol == 0, else |d| <= tol * max(1, |x|)
+    (north_star allows 1e-4).  conf = exp(sum of log(...)) goes through libm log/exp, which differ by an ulp between
+    glibc and the device math library: conf_tol is its own relative tolerance (GPU tests use 1e-9).
+    Returns the list of mismatches."""
+    bad = []
+    if not np.array_equal(want.status[:n], got.status[:n]):
+        for g in np.nonzero(want.status[:n] != got.status[:n])[0][:5]:
+            bad.append((int(g), "status", int(want.status[g]), int(got.status[g])))
+        return bad
+    if not np.array_equal(want.path_offset, got.path_offset):
+        d = np.nonzero(np.diff(want.path_offset) != np.diff(got.path_offset))[0]
+        for g in d[:5]:
+            bad.append((int(g), "npaths", int(want.path_offset[g + 1] - want.path_offset[g]), int(got.path_offset[g + 1] - got.path_offset[g])))
+        return bad
+    if not np.array_equal(want.pv_offset, got.pv_offset) or not np.array_equal(want.path_vertices, got.path_vertices):
+        for g in range(n):
+            if want.paths_of(g) != got.paths_of(g) and [p["v"] for p in want.paths_of(g)] != [p["v"] for p in got.paths_of(g)]:
+                bad.append((g, "vertices")); break
+        return bad
+    for name in ("length", "count", "strand"):
+        if not np.array_equal(getattr(want, name), getattr(got, name)):
+            bad.append((-1, name))
+    for name in ("weight", "abd", "conf", "reads"):
+        a, b = getattr(want, name), getattr(got, name)
+        t = max(tol, conf_tol) if name == "conf" else tol
+        if t == 0.0:
+            ok = np.array_equal(a, b)
+        else:
+            ok = bool(np.all(np.abs(a - b) <= t * np.maximum(1.0, np.abs(a))))
+        if not ok:
+            i = int(np.argmax(np.abs(a - b)))
+            g = int(np.searchsorted(want.path_offset, i, side="right") - 1)
+            bad.append((g, name, float(a[i]), float(b[i])))
+    return bad
+
+
+# the synthetic configurations used across the parity tests (name -> ald_synth_spec fields)
+PARITY_CONFIGS = {
+    "cfg1_32v96e": dict(seed=1001, n_graphs=100, v_min=32, v_max=32, fixed_edges=96),
+    "cfg2_64v256e": dict(seed=1002, n_graphs=120, v_min=64, v_max=64, fixed_edges=256),
+    "tiny_8v16e": dict(seed=5, n_graphs=200, v_min=8, v_max=8, fixed_edges=16),
+    "minimal_3v": dict(seed=6, n_graphs=50, v_min=3, v_max=5, edges_per_vertex=2),
+    "cfg3_mixed": dict(seed=1003, n_graphs=40, v_min=8, v_max=300, edges_per_vertex=4),
+    "int_weights": dict(seed=11, n_graphs=150, v_min=10, v_max=60, edges_per_vertex=3, weight_mode=1),
+    "flow_weights": dict(seed=12, n_graphs=150, v_min=10, v_max=60, edges_per_vertex=3, weight_mode=2),
+    "multi_sample": dict(seed=13, n_graphs=150, v_min=10, v_max=60, edges_per_vertex=3, n_samples=5),
+    "stranded": dict(seed=14, n_graphs=150, v_min=10, v_max=60, edges_per_vertex=3, strand_mode=1, layout_mode=1),
+    "phasing": dict(seed=15, n_graphs=150, v_min=10, v_max=60, edges_per_vertex=3, phasing_per_graph=12, weight_mode=2),
+    "everything": dict(seed=16, n_graphs=150, v_min=6, v_max=100, edges_per_vertex=3, phasing_per_graph=20, weight_mode=1, n_samples=4, strand_mode=1, layout_mode=1),
+}
