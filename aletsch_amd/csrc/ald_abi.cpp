@@ -62,9 +62,22 @@ struct ald_batch {
     std::vector<int32_t> trace_n, trace_codes; std::vector<double> trace_vals;
     HostResults res;
     int passes = 0;
+    bool indexed = false;
 };
 
 namespace {
+
+// per-graph index over the raw record stream (consumer-side work, done once on first access)
+int ensure_index(const ald_batch *cb)
+{
+    ald_batch *b = const_cast<ald_batch*>(cb);
+    if(!b->downloaded) return set_err(ALD_ERR_STATE, "results requested before ald_batch_download");
+    if(b->indexed) return ALD_OK;
+    int rc = b->res.build(b->hb.n(), b->n_paths);
+    if(rc != 0) return set_err(ALD_ERR_STATE, "path record stream is inconsistent (rc=" + std::to_string(rc) + ")");
+    b->indexed = true;
+    return ALD_OK;
+}
 
 int occupancy_for(ald_batch *b, int c)
 {
@@ -126,6 +139,7 @@ int launch_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], 
 extern "C" {
 
 const char *ald_last_error(void) { return g_err.c_str(); }
+void ald_internal_set_error(const char *s) { g_err = s ? s : ""; }   /* used by the other translation units of the library */
 const char *ald_version(void) { return "aletsch_amd-decomp 0.1 (gfx950)"; }
 
 int ald_default_params(ald_params *p)
@@ -301,8 +315,7 @@ int ald_batch_download(ald_batch *b)
     }
     if(used) HIPCHK(hipMemcpy(b->res.pool.data(), b->d_pool.p, 4 * used, hipMemcpyDeviceToHost));
     b->res.status = b->status; b->res.n_iters = b->n_iters; b->res.attempt = b->attempt;
-    int rc = b->res.build(n, b->n_paths);
-    if(rc != 0) return set_err(ALD_ERR_STATE, "path record stream is inconsistent (rc=" + std::to_string(rc) + ")");
+    b->indexed = false;
     if(b->trace_cap > 0 && n > 0) {
         b->trace_n.resize(n); b->trace_codes.resize(3ull * n * b->trace_cap); b->trace_vals.resize((size_t)n * b->trace_cap);
         HIPCHK(hipMemcpy(b->trace_n.data(), b->d_trace_n.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
@@ -319,13 +332,14 @@ int ald_batch_algorithmic_bytes(const ald_batch *b, int64_t *in_bytes, int64_t *
 {
     if(!b) return ALD_ERR_INVALID;
     if(in_bytes) *in_bytes = b->hb.algorithmic_in_bytes();
-    if(out_bytes) *out_bytes = b->downloaded ? b->res.out_bytes : 0;
+    if(out_bytes) { *out_bytes = 0; if(b->downloaded && ensure_index(b) == ALD_OK) *out_bytes = b->res.out_bytes; }
     return ALD_OK;
 }
 
 int ald_batch_get_result(const ald_batch *b, int32_t graph, ald_result_view *out)
 {
     if(!b || !out || !b->downloaded || graph < 0 || graph >= b->hb.n()) return ALD_ERR_INVALID;
+    { int rc = ensure_index(b); if(rc != ALD_OK) return rc; }
     out->status = b->res.status[graph]; out->num_paths = (int32_t)(b->res.path_begin[graph + 1] - b->res.path_begin[graph]);
     out->num_iterations = b->res.n_iters[graph]; out->reserved = 0;
     return ALD_OK;
@@ -334,6 +348,7 @@ int ald_batch_get_result(const ald_batch *b, int32_t graph, ald_result_view *out
 int ald_batch_get_path(const ald_batch *b, int32_t graph, int32_t path, ald_path_view *out)
 {
     if(!b || !out || !b->downloaded || graph < 0 || graph >= b->hb.n()) return ALD_ERR_INVALID;
+    { int rc = ensure_index(b); if(rc != ALD_OK) return rc; }
     int64_t i = b->res.path_begin[graph] + path;
     if(path < 0 || i >= b->res.path_begin[graph + 1]) return ALD_ERR_INVALID;
     const PathRec &p = b->res.paths[i];
@@ -347,6 +362,7 @@ int ald_batch_export(const ald_batch *b, int64_t *total_paths, int64_t *total_pa
                      int64_t *pv_offset, int32_t *path_vertices)
 {
     if(!b || !b->downloaded) return set_err(ALD_ERR_STATE, "ald_batch_export before ald_batch_download");
+    { int rc = ensure_index(b); if(rc != ALD_OK) return rc; }
     return export_results(b->res, b->hb.n(), total_paths, total_path_vertices, status, path_offset, weight, abd, conf, reads, length, count, strand, pv_offset, path_vertices);
 }
 
@@ -357,6 +373,14 @@ int ald_batch_get_trace(const ald_batch *b, int32_t graph, int32_t *n_events, co
     *n_events = b->trace_n[graph] < b->trace_cap ? b->trace_n[graph] : b->trace_cap;
     if(codes) *codes = b->trace_codes.data() + 3ull * graph * b->trace_cap;
     if(values) *values = b->trace_vals.data() + (size_t)graph * b->trace_cap;
+    return ALD_OK;
+}
+
+/* raw packed record stream of the last download (what ranks exchange over RCCL in the multi-GPU gather) */
+int ald_batch_raw_records(const ald_batch *b, const uint32_t **words, int64_t *n_words)
+{
+    if(!b || !b->downloaded || !words || !n_words) return ALD_ERR_INVALID;
+    *words = b->res.pool.data(); *n_words = (int64_t)b->res.pool.size();
     return ALD_OK;
 }
 

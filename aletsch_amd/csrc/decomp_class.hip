@@ -18,6 +18,7 @@ extern "C" __global__ void __launch_bounds__(64, ALD_WAVES_PER_EU) ALD_KERNEL_NA
 
 extern "C" int ALD_CAT(ald_launch_c, ALD_CLASS_ID)(const ald::KernelArgs *dA, int blocks, hipStream_t stream)
 {
+    (void)hipGetLastError();                       // drop any stale sticky error of this thread before judging the launch
     hipLaunchKernelGGL(ALD_KERNEL_NAME, dim3(blocks), dim3(64), 0, stream, dA);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -570,8 +570,18 @@ ALD_FN void decompose_vertex_extend(int root, int n)
     // scallop.cc:1976-1985 resolve_single_trivial_vertex(k, jump_ratio) on the new vertices: a no-op unless jump_ratio > 1
     double jump = PRM.max_ratio[7];
     if(jump > 1.0) {
-        // evx lives in the work area that the nested decomposition reuses: walk the new vertex range instead (ev1 then ev2 order == ascending k)
-        for(int k = m; k < nn; k++) { resolve_single_trivial_vertex(k, jump); if(H.status) return; }
+        // the reference walks ev1 then ev2, each a std::map keyed by edge id.  The nested decompositions reuse the work area, so
+        // the visiting order is parked first in [3/8, 1/2) of wi, which no routine touches.
+        ALD_GLOBAL int32_t *order = C.wi + 3 * (C.w_cap / 8); int no = 0;
+        for(int part = 0; part < 2; part++) {
+            int lo = part == 0 ? 0 : nin, hi = part == 0 ? nin : nloc; int first = no;
+            for(int i = lo; i < hi; i++) if(evx[i] >= 0) {
+                int k = evx[i]; uint32_t id = H.eid[loc_e[i]]; int j = no - 1;
+                while(j >= first && H.eid[mdeg[j]] > id) { order[j + 1] = order[j]; mdeg[j + 1] = mdeg[j]; j--; }      // mdeg is free now: reuse it for the sort keys' edges
+                order[j + 1] = k; mdeg[j + 1] = loc_e[i]; no++;
+            }
+        }
+        for(int q = 0; q < no; q++) { resolve_single_trivial_vertex(order[q], jump); if(H.status) return; }
     }
 }
 
@@ -727,7 +737,7 @@ ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
         }
         if(hit < 0 || stopped) break;
         if(lane == 0) {
-            trace(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, hit, type, hit_r);
+            trace(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, hit, mode == 1 ? type : 0, hit_r);
             decompose_trivial_vertex(hit);
             hs_refresh_flags();
         }
@@ -981,33 +991,36 @@ ALD_FN bool sweep_unsplittable(int type, int degree, double max_ratio)
     int vend = H.nv - 1;
     bool flag = false;
     int root = -1; double ratio = max_ratio; int best_np = 0;      // meaningful on lane 0 only
-    for(int base = 0; base < vend; base += ALD_WAVE) {
-        int i0 = base + lane;
-        uint64_t m = wballot(i0 >= 1 && i0 < vend && H.nz[i0] && H.in_deg[i0] >= 2 && H.out_deg[i0] >= 2);
-        while(m) {
-            int l = ffs64(m); m &= m - 1; int i = base + l;
-            int act = 0;
-            if(lane == 0) {
-                // re-check: an earlier decomposition in this sweep may have changed the vertex
-                if(H.in_deg[i] >= 2 && H.out_deg[i] >= 2) {
-                    if(router_run(i, type, degree) && H.ro_type == type && H.ro_degree <= degree) {
-                        double rr = H.ro_ratio;
-                        if(rr < 0.01) {
-                            trace(OP_UNSPLIT_NOW, i, type, rr);
-                            decompose_vertex_extend(i, H.ro_npairs);
-                            act = 1;
-                        } else if(!(rr > ratio)) {
-                            root = i; ratio = rr; best_np = H.ro_npairs;
-                            save_pairs(best_np);
-                        }
-                    }
+    // The sweep is sequential in the reference: a decomposition (and, for jump_ratio > 1, the trivial decompositions nested in
+    // it) can make a LATER vertex newly eligible, so the next candidate is looked up again after every action.
+    int cur = 1;
+    while(cur < vend) {
+        int i = -1;
+        for(int base = (cur / ALD_WAVE) * ALD_WAVE; base < vend && i < 0; base += ALD_WAVE) {
+            int i0 = base + lane;
+            uint64_t m = wballot(i0 >= cur && i0 < vend && H.nz[i0] && H.in_deg[i0] >= 2 && H.out_deg[i0] >= 2);
+            if(m) i = base + ffs64(m);
+        }
+        if(i < 0) break;
+        int act = 0;
+        if(lane == 0) {
+            if(router_run(i, type, degree) && H.ro_type == type && H.ro_degree <= degree) {
+                double rr = H.ro_ratio;
+                if(rr < 0.01) {
+                    trace(OP_UNSPLIT_NOW, i, type, rr);
+                    decompose_vertex_extend(i, H.ro_npairs);
+                    act = 1;
+                } else if(!(rr > ratio)) {
+                    root = i; ratio = rr; best_np = H.ro_npairs;
+                    save_pairs(best_np);
                 }
             }
-            wsync();
-            act = wshfl(act, 0);
-            if(H.status) return true;
-            if(act) flag = true;
         }
+        wsync();
+        act = wshfl(act, 0);
+        if(H.status) return true;
+        if(act) flag = true;
+        cur = i + 1;
     }
     if(flag) return true;
     root = wshfl(root, 0);

@@ -10,12 +10,13 @@
 // KAT-checked kernel (tests/test_subsetsum.py: reference KAT subsetsum.cc:263-282 + oracle/_ref/ref_subsetsum).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string>
 #include "../../include/aletsch_decomp.h"
 
 namespace {
 
 constexpr int SS_MAXN = 32;       // items per side
-constexpr int SS_MAXS = 1000;     // sums 0..999 (ubound <= 999)
+constexpr int SS_MAXS = 1040;     // sums: the common bound is 1000, plus up to one unit per item bumped from 0 to 1 (subsetsum.cc:48-55)
 
 struct SSLds {
     uint8_t t[2][SS_MAXN + 1][SS_MAXS];     // back-pointer + 1 (0 = unreachable, k+1 = table value k)
@@ -131,6 +132,9 @@ __global__ void __launch_bounds__(64) subsetsum_kernel(int32_t n_inst, const int
 
 } // namespace
 
+extern "C" void ald_internal_set_error(const char *);
+#define SSCHK(x) do { hipError_t e_ = (x); if(e_ != hipSuccess) { ald_internal_set_error((std::string(#x) + ": " + hipGetErrorString(e_)).c_str()); ok = false; } } while(0)
+
 extern "C" int ald_subsetsum_batch(int device, int32_t n, const int32_t *ns, const int32_t *nt,
                                    const int32_t *src_val, const int32_t *src_lab, const int32_t *tgt_val, const int32_t *tgt_lab,
                                    double *err, int32_t *out_ns, int32_t *out_nt, int32_t *out_s, int32_t *out_t)
@@ -159,10 +163,12 @@ extern "C" int ald_subsetsum_batch(int device, int32_t n, const int32_t *ns, con
            && (T == 0 || (hipMemcpy(D + o_tv, tgt_val, 4 * T, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(D + o_tl, tgt_lab, 4 * T, hipMemcpyHostToDevice) == hipSuccess));
     if(ok) {
         int blocks = n < 2048 ? n : 2048;
+        (void)hipGetLastError();
         hipLaunchKernelGGL(subsetsum_kernel, dim3(blocks), dim3(64), 0, 0, n, (const int32_t*)(D + o_ns), (const int32_t*)(D + o_nt), (const int64_t*)(D + o_os), (const int64_t*)(D + o_ot),
                            (const int32_t*)(D + o_sv), (const int32_t*)(D + o_sl), (const int32_t*)(D + o_tv), (const int32_t*)(D + o_tl),
                            (double*)(D + o_err), (int32_t*)(D + o_ons), (int32_t*)(D + o_ont), (int32_t*)(D + o_outs), (int32_t*)(D + o_outt), (int32_t*)(D + o_st));
-        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+        SSCHK(hipGetLastError());
+        if(ok) SSCHK(hipDeviceSynchronize());
     }
     if(ok) {
         int32_t *st = new int32_t[n];

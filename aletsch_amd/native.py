@@ -156,6 +156,14 @@ class DecompBatch:
         _check(self._lib.ald_batch_algorithmic_bytes(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def raw_records(self) -> np.ndarray:
+        """Packed path-record stream of the last download (uint32 words; copy)."""
+        w = C.POINTER(C.c_uint32)(); n = C.c_int64()
+        _check(self._lib.ald_batch_raw_records(self._h, C.byref(w), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, np.uint32)
+        return np.ctypeslib.as_array(w, shape=(n.value,)).copy()
+
     def result(self) -> DecompResult:
         return export_via(self._lib.ald_batch_export, self._h, self.n)
 

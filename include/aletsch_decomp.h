@@ -148,6 +148,14 @@ int  ald_batch_export(const ald_batch *b, int64_t *total_paths, int64_t *total_p
                       int32_t *length, int32_t *count, char *strand,
                       int64_t *pv_offset, int32_t *path_vertices);
 
+/* raw packed path-record stream of the last download: 4-byte words, record = [graph, path index, #vertices, length, count,
+ * strand | attempt<<8, weight f64, abd f64, conf f64, reads f64, vertices..., pad to even].  This is what ranks exchange
+ * over RCCL for the final transcript gather (bench.py --gpus N). */
+int  ald_batch_raw_records(const ald_batch *b, const uint32_t **words, int64_t *n_words);
+/* diagnostics: size class `cls` (0..4): capacities, resident workgroups per CU, grid of the last run, graphs assigned */
+int  ald_batch_class_info(ald_batch *b, int32_t cls, int32_t *maxv, int32_t *maxe, int32_t *blocks_per_cu, int32_t *blocks_last_run,
+                          int64_t *slab_bytes, int32_t *n_graphs);
+
 /* optional per-graph operation trace (debug builds of the parity tests): rule id, vertex/edge, ratio */
 int  ald_batch_enable_trace(ald_batch *b, int32_t max_events_per_graph);
 int  ald_batch_get_trace(const ald_batch *b, int32_t graph, int32_t *n_events,

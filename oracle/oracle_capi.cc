@@ -198,6 +198,52 @@ int ora_result_trace(const ora_result *R, int32_t graph, int32_t *n_events, int3
     return 0;
 }
 
+/* Graph-layer script runner: the same edit/dump language as oracle/ref_drivers/ref_graph_main.cc, executed on the oracle's
+ * creation-ordered containers, so that the dump can be diffed against the reference-built oracle/_ref/ref_graph. */
+int ora_graph_script(const char *script, char *out, int32_t cap)
+{
+    std::string o; char buf[64];
+    ora::Graph dg; ora::UGraph ug; bool directed = true;
+    std::vector<int> h;   // handle -> edge id (or -1)
+    const char *p = script;
+    auto next_int = [&](int &v) { while(*p == ' ' || *p == '\n') p++; char *e; v = (int)strtol(p, &e, 10); p = e; };
+    while(*p) {
+        while(*p == ' ' || *p == '\n') p++;
+        if(!*p) break;
+        char op = *p++;
+        if(op == 'D') { int n; next_int(n); dg = ora::Graph(); directed = true; h.clear(); for(int i = 0; i < n; i++) dg.add_vertex(); }
+        else if(op == 'U') { int n; next_int(n); ug = ora::UGraph(); directed = false; h.clear(); for(int i = 0; i < n; i++) ug.add_vertex(); }
+        else if(op == 'a') { int s, t; next_int(s); next_int(t); h.push_back(directed ? dg.add_edge(s, t) : ug.add_edge(s, t)); }
+        else if(op == 'r') { int k; next_int(k); if(directed) dg.remove_edge(h[k]); else ug.remove_edge(h[k]); h[k] = -1; }
+        else if(op == 'm') { int k, x, y; next_int(k); next_int(x); next_int(y); dg.move_edge(h[k], x, y); }
+        else if(op == 'c') { int v; next_int(v);
+            if(directed) { std::vector<int> es = dg.in_edges(v); for(int e : dg.out_edges(v)) es.push_back(e); for(int e : es) { dg.remove_edge(e); } for(auto &x : h) if(x >= 0 && !dg.alive(x)) x = -1; }
+            else { std::vector<int> es; for(auto &k : ug.so[v]) es.push_back(std::get<2>(k)); ug.clear_vertex(v); for(auto &x : h) for(int e : es) if(x == e) x = -1; } }
+        else if(op == 'q') {
+            // handles are creation-numbered, and so are the oracle's edge ids: handle == id
+            int n = directed ? dg.num_vertices() : ug.num_vertices();
+            for(int v = 0; v < n; v++) {
+                if(directed) { snprintf(buf, sizeof buf, "in %d:", v); o += buf; for(int e : dg.in_edges(v)) { snprintf(buf, sizeof buf, " %d", e); o += buf; } o += "\n"; }
+                snprintf(buf, sizeof buf, "out %d:", v); o += buf;
+                if(directed) { for(int e : dg.out_edges(v)) { snprintf(buf, sizeof buf, " %d", e); o += buf; } }
+                else { for(auto &k : ug.so[v]) { snprintf(buf, sizeof buf, " %d", std::get<2>(k)); o += buf; } }
+                o += "\n";
+            }
+            o += "edges:"; for(int e : (directed ? dg.se : ug.se)) { snprintf(buf, sizeof buf, " %d", e); o += buf; } o += "\n";
+            if(directed) {
+                o += "topo:"; for(int x : dg.topological_sort()) { snprintf(buf, sizeof buf, " %d", x); o += buf; } o += "\n";
+                for(int s = 0; s < n; s++) for(int t = 0; t < n; t++) { if(s == t) continue; int e = dg.edge(s, t); if(e >= 0) { snprintf(buf, sizeof buf, "edge %d %d: %d\n", s, t, e); o += buf; } }
+            } else {
+                for(auto &cc : ug.compute_connected_components()) { o += "cc:"; for(int x : cc) { snprintf(buf, sizeof buf, " %d", x); o += buf; } o += "\n"; }
+            }
+            o += "end\n";
+        }
+    }
+    if((int)o.size() + 1 > cap) return -1;
+    memcpy(out, o.c_str(), o.size() + 1);
+    return (int)o.size();
+}
+
 /* subset-sum restatement (oracle/subsetsum_oracle.hpp), one instance */
 int ora_subsetsum(int32_t ns, int32_t nt, const int32_t *src_val, const int32_t *src_lab, const int32_t *tgt_val, const int32_t *tgt_lab,
                   double *err, int32_t *out_ns, int32_t *out_nt, int32_t *out_s, int32_t *out_t)

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Regenerates the committed fixtures under tests/golden/.
+
+  ref_graph.json      scripts + dumps produced by oracle/_ref/ref_graph  (the REFERENCE's graph/*.cc, built from
+                      /root/reference by oracle/Makefile)            -> pins the oracle's container orders
+  ref_subsetsum.json  instances + answers produced by oracle/_ref/ref_subsetsum (the REFERENCE's subsetsum.cc)
+                      -> pins the subset-sum restatement and the HIP subset-sum kernel
+  oracle_paths.npz    small synthetic batches + the oracle's own decomposition (regression fixture: scallop / router /
+                      hyper_set have no reference-authored vectors; "parity unpinned")
+
+Needs /root/reference (for the two _ref binaries); run from the repo root:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def graph_script(rng, directed, n, ops):
+    s = [("D" if directed else "U") + " %d" % n]; live = []; h = 0
+    for _ in range(ops):
+        r = rng.random()
+        if r < 0.55 or not live:
+            a, b = rng.randrange(n), rng.randrange(n)
+            if a == b:
+                continue
+            if a > b:
+                a, b = b, a                       # forward edges: the splice graphs are DAGs
+            s.append("a %d %d" % (a, b)); live.append(h); h += 1
+        elif r < 0.70:
+            k = rng.choice(live); live.remove(k); s.append("r %d" % k)
+        elif r < 0.85 and directed:
+            k = rng.choice(live); a, b = rng.randrange(n), rng.randrange(n)
+            if a < b:
+                s.append("m %d %d %d" % (k, a, b))
+        else:
+            s.append("q")
+    s.append("q")
+    return "\n".join(s) + "\n"
+
+
+def main():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
+    rng = random.Random(20250211)
+    # ---- graph layer ----
+    cases = []
+    for t in range(24):
+        sc = graph_script(rng, t % 3 != 2, 5 + t % 4, 40 + 5 * t)
+        out = subprocess.run([os.path.join(ROOT, "oracle/_ref/ref_graph")], input=sc, capture_output=True, text=True, check=True).stdout
+        cases.append({"script": sc, "dump": out})
+    json.dump(cases, open(os.path.join(HERE, "ref_graph.json"), "w"), indent=0)
+    # ---- subset sum: the reference's own KAT first (subsetsum.cc:263-282), then random instances ----
+    inst = [([(10, 1), (20, 2), (39, 3)], [(29, 1), (54, 2)])]
+    for t in range(200):
+        ns, nt = rng.randint(1, 12), rng.randint(1, 12)
+        hi = rng.choice([20, 100, 1000, 5000])
+        inst.append(([(rng.randint(1, hi), i) for i in range(ns)], [(rng.randint(1, hi), 100 + i) for i in range(nt)]))
+    ans = []
+    for s, t in inst:               # one process per instance: the reference asserts (aborts) when no cross pair exists
+        txt = "1\n%d %d\n" % (len(s), len(t)) + " ".join("%d %d" % p for p in s) + "\n" + " ".join("%d %d" % p for p in t) + "\n"
+        r = subprocess.run([os.path.join(ROOT, "oracle/_ref/ref_subsetsum")], input=txt, capture_output=True, text=True)
+        if r.returncode != 0 or not r.stdout.strip():
+            ans.append(None); continue
+        f = r.stdout.split(); e = float(f[0]); k = int(f[1]); ss = [int(x) for x in f[2:2 + k]]; m = int(f[2 + k]); tt = [int(x) for x in f[3 + k:3 + k + m]]
+        ans.append({"e": e, "s": ss, "t": tt})
+    json.dump({"instances": [{"s": s, "t": t} for s, t in inst], "answers": ans}, open(os.path.join(HERE, "ref_subsetsum.json"), "w"))
+    # ---- oracle regression fixture ----
+    import aletsch_amd as A
+    import common
+    from dataclasses import fields
+    from aletsch_amd.packed import PackedGraphs
+    blob = {}
+    for name in ("cfg1_32v96e", "tiny_8v16e", "everything"):
+        kw = dict(common.PARITY_CONFIGS[name]); kw["n_graphs"] = 12
+        pg = A.synth(**kw)
+        r = common.oracle_run(pg)[0]
+        for f in fields(PackedGraphs):
+            blob[f"{name}/in/{f.name}"] = getattr(pg, f.name)
+        for k in ("status", "path_offset", "weight", "abd", "conf", "reads", "length", "count", "strand", "pv_offset", "path_vertices"):
+            blob[f"{name}/out/{k}"] = getattr(r, k)
+    np.savez_compressed(os.path.join(HERE, "oracle_paths.npz"), **blob)
+    print("golden fixtures written:", len(cases), "graph scripts,", len(ans), "subset-sum instances")
+
+
+if __name__ == "__main__":
+    main()

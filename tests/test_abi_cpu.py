@@ -1,0 +1,71 @@
+"""CPU tier: the C-ABI library loads, exports every symbol include/aletsch_decomp.h declares, and refuses to compute
+without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import aletsch_amd as A
+import common
+
+
+def _declared_symbols():
+    txt = open(os.path.join(common.ROOT, "include", "aletsch_decomp.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ald_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = A.load_library()
+    names = _declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/aletsch_decomp.h but not exported"
+
+
+def test_version_and_defaults():
+    lib = A.load_library()
+    assert b"gfx950" in lib.ald_version()
+    p = A.default_params()
+    assert list(p.max_decompose_error_ratio) == [0.30, 0.0, 1.10, 1.10, 0.75, 0.30, 0.0, 1.00]      # util/parameters.cc:85-92
+    assert p.min_guaranteed_edge_weight == 0.01 and p.min_transcript_coverage == 2.0 and p.max_num_exons == 10000
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    pg = A.synth(seed=1, n_graphs=2, v_min=8, v_max=8, fixed_edges=16)
+    with pytest.raises(A.DecompError) as e:
+        A.decompose(pg)
+    assert e.value.code == -2                                        # ALD_ERR_NO_DEVICE
+    assert A.load_library().ald_subsetsum_batch(0, 0, None, None, None, None, None, None, None, None, None, None, None) == -2
+
+
+def test_product_package_never_touches_the_oracle():
+    """the product path must not import / load anything under oracle/ or the emulation"""
+    pkg = os.path.join(common.ROOT, "aletsch_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")) or f == "Makefile":
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "liboracle" not in txt and "kernel_emu" not in txt.replace("tests/kernel_emu", "") or f in ("decomp_device.h", "decomp_common.h", "host_pack.h"), (dp, f)
+                assert "scallop_oracle" not in txt, (dp, f)
+    out = os.popen(f"nm -D {A.library_path()}").read()
+    assert "ora_" not in out and "emu_run" not in out
+
+
+def test_synth_is_deterministic_and_well_formed():
+    import numpy as np
+    a = A.synth(seed=1002, n_graphs=50, v_min=64, v_max=64, fixed_edges=256)
+    b = A.synth(seed=1002, n_graphs=50, v_min=64, v_max=64, fixed_edges=256)
+    assert all(np.array_equal(getattr(a, f), getattr(b, f)) for f in ("edge_target", "edge_weight", "vertex_offset", "vertex_lpos"))
+    assert (a.g_nv == 64).all() and (a.g_ne == 256).all()
+    o = a.graph_slices()
+    for g in range(a.n):
+        vo = a.vertex_offset[o["vo"][g]:o["vo"][g] + 65]; t = a.edge_target[o["e"][g]:o["e"][g] + 256]
+        src = np.repeat(np.arange(64), np.diff(vo))
+        assert (t > src).all() and not ((src == 0) & (t == 63)).any()
+        indeg = np.bincount(t, minlength=64); outdeg = np.diff(vo)
+        assert (indeg[1:63] >= 1).all() and (outdeg[1:63] >= 1).all()

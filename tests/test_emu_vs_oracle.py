@@ -1,0 +1,110 @@
+"""CPU tier: the array-based engine that the HIP kernels are compiled from (aletsch_amd/csrc/decomp_device.h), run as a
+single-lane emulation, against the container-based oracle -- two independent statements of the reference algorithm.
+Bit-exact on every field.  (The GPU tier repeats this through the C ABI on a real MI355X.)"""
+import numpy as np
+import pytest
+
+import aletsch_amd as A
+import common
+
+
+@pytest.mark.parametrize("name", list(common.PARITY_CONFIGS))
+def test_engine_matches_oracle(name):
+    kw = dict(common.PARITY_CONFIGS[name]); kw["n_graphs"] = min(kw["n_graphs"], 60)
+    pg = A.synth(**kw)
+    want, st, _, _ = common.oracle_run(pg)
+    got, it, cl = common.emu_run(pg)
+    assert not common.compare_results(want, got, pg.n)
+    assert np.array_equal(it, st[:, 3])
+
+
+def test_engine_op_trace_matches_oracle():
+    """rule id / vertex or edge id / ratio of every firing, in order -- the sharpest parity check available"""
+    pg = A.synth(**dict(common.PARITY_CONFIGS["everything"], n_graphs=25))
+    _, _, _, traces = common.oracle_run(pg, trace=True)
+    import ctypes as C
+    E = common.emu_lib(); h = C.c_void_p()
+    assert E.emu_run_packed(*pg.c_args(), None, C.c_int32(4096), C.c_int32(0), C.byref(h)) == 0
+    for g in range(pg.n):
+        n = C.c_int32(); E.emu_result_trace(h, g, C.byref(n), None, None, 0)
+        codes = np.zeros(3 * max(1, n.value), np.int32); vals = np.zeros(max(1, n.value))
+        E.emu_result_trace(h, g, C.byref(n), codes.ctypes.data_as(C.POINTER(C.c_int32)), vals.ctypes.data_as(C.POINTER(C.c_double)), n.value)
+        mine = [(int(codes[3 * i]), int(codes[3 * i + 1]), int(codes[3 * i + 2]), float(vals[i])) for i in range(n.value)]
+        assert mine == traces[g], f"graph {g}: first divergence at {next((i for i, (a, b) in enumerate(zip(mine, traces[g])) if a != b), min(len(mine), len(traces[g])))}"
+    E.emu_result_free(h)
+
+
+def test_capacity_retry_moves_up_a_class():
+    """forcing every graph into a class that is too small must end with identical results after the automatic retry"""
+    pg = A.synth(seed=77, n_graphs=20, v_min=40, v_max=60, edges_per_vertex=4)
+    want = common.oracle_run(pg)[0]
+    got, _, cl = common.emu_run(pg, force_class=0)
+    assert not common.compare_results(want, got, pg.n)
+    assert (cl >= 1).all()
+
+
+def test_nondefault_parameters():
+    """jump_ratio > 1.02 exercises resolve_trivial_vertex_fast and the early `break` of resolve_trivial_vertex"""
+    p = A.default_params()
+    p.max_decompose_error_ratio[7] = 1.5; p.max_decompose_error_ratio[0] = 0.2; p.min_transcript_coverage = 5.0
+    pg = A.synth(seed=31, n_graphs=60, v_min=10, v_max=70, edges_per_vertex=3, phasing_per_graph=8, weight_mode=1)
+    want, st, _, _ = common.oracle_run(pg, params=p)
+    got, it, _ = common.emu_run(pg, params=p)
+    assert not common.compare_results(want, got, pg.n)
+    assert np.array_equal(it, st[:, 3])
+
+
+def test_edge_cases_and_invariant_classes():
+    from aletsch_amd.packed import PackedGraphs
+    graphs = [
+        # empty graph: source + sink only
+        dict(V=2, edges=[], vw=[0, 0], lpos=[0, 0], rpos=[0, 0]),
+        # a single chain
+        dict(V=4, edges=[(0, 1, 5.0), (1, 2, 5.0), (2, 3, 5.0)], vw=[0, 10, 10, 0], lpos=[0, 100, 300, 400], rpos=[0, 200, 400, 400]),
+        # isolated internal vertex + below-coverage path (nothing reported)
+        dict(V=4, edges=[(0, 1, 1.0), (1, 3, 1.0)], vw=[0, 1, 1, 0], lpos=[0, 100, 300, 400], rpos=[0, 200, 400, 400]),
+        # broken vertex (no out-edge) -> resolve_broken_vertex
+        dict(V=5, edges=[(0, 1, 9.0), (1, 2, 4.0), (1, 3, 5.0), (3, 4, 5.0)], vw=[0, 3, 3, 3, 0], lpos=[0, 10, 30, 50, 60], rpos=[0, 20, 40, 60, 60]),
+        # edge without sample support: the reference asserts in merge_adjacent_equal_edges (count > 0)
+        dict(V=4, edges=[(0, 1, 5.0, 0, {}), (1, 2, 5.0), (2, 3, 5.0)], vw=[0, 10, 10, 0], lpos=[0, 100, 300, 400], rpos=[0, 200, 400, 400]),
+        # disjoint sample sets on the two sides of a vertex: empty intersection (count becomes 0 downstream)
+        dict(V=5, edges=[(0, 1, 6.0, 0, {1: 6.0}), (1, 2, 6.0, 0, {2: 6.0}), (2, 3, 6.0, 0, {1: 6.0}), (3, 4, 6.0, 0, {1: 6.0})], vw=[0, 1, 1, 1, 0], lpos=[0, 10, 30, 50, 60], rpos=[0, 20, 40, 60, 60]),
+        # EMPTY_VERTEX (-9) on a path: collected but not reported (scallop.cc:2788-2794)
+        dict(V=4, edges=[(0, 1, 5.0), (1, 2, 5.0), (2, 3, 5.0)], vw=[0, 10, 10, 0], lpos=[0, 100, 300, 400], rpos=[0, 200, 400, 400], vtype=[-1, -9, -1, -1]),
+        # mixed strands meeting at one vertex
+        dict(V=6, edges=[(0, 1, 8.0, 1), (0, 2, 6.0, 2), (1, 3, 8.0, 1), (2, 3, 6.0, 2), (3, 4, 7.0, 1), (3, 5, 7.0, 2), (4, 5, 7.0, 1)], vw=[0, 1, 1, 1, 1, 0],
+             lpos=[0, 10, 30, 50, 70, 80], rpos=[0, 20, 40, 60, 80, 80]),
+    ]
+    pg = PackedGraphs.from_graphs(graphs)
+    want = common.oracle_run(pg)[0]
+    got, _, _ = common.emu_run(pg)
+    assert not common.compare_results(want, got, pg.n)
+    assert want.status[0] == 0 and want.path_offset[1] == 0           # empty graph: no paths, no failure
+    assert want.path_offset[2] - want.path_offset[1] == 1              # chain: one path
+    assert want.status[4] >= 100                                       # assert class reported, not a crash
+    assert want.path_offset[7] - want.path_offset[6] == 0              # EMPTY_VERTEX path dropped
+
+
+def test_staging_normalises_unsorted_input():
+    """rows not sorted by target, sample lists not ascending, duplicate / unsorted phasing lists: staging must put them into
+    the canonical order (edge id = CSR position after a stable sort by target; hyper_set::add_node_list semantics)"""
+    import copy
+    from aletsch_amd.packed import PackedGraphs
+    a = A.synth(seed=5, n_graphs=10, v_min=12, v_max=20, edges_per_vertex=3, n_samples=3, phasing_per_graph=6, weight_mode=1)
+    b = copy.deepcopy(a)
+    o = b.graph_slices()
+    for g in range(b.n):
+        V = int(b.g_nv[g]); vo = b.vertex_offset[o["vo"][g]:o["vo"][g] + V + 1]
+        for s in range(V):
+            lo, hi = int(o["e"][g] + vo[s]), int(o["e"][g] + vo[s + 1])
+            if hi - lo >= 2:                  # reverse the row: distinct targets, so the stable sort restores it
+                eso = b.edge_sample_offset[o["eo"][g]:o["eo"][g] + int(b.g_ne[g]) + 1]
+                if len(set(np.diff(eso[vo[s]:vo[s + 1] + 1]).tolist())) == 1:      # equal support sizes: the sample slices can stay where they are
+                    for arr in (b.edge_target, b.edge_weight, b.edge_strand, b.edge_abd):
+                        arr[lo:hi] = arr[lo:hi][::-1].copy()
+                    k = int(np.diff(eso[vo[s]:vo[s + 1] + 1])[0]); so = int(o["s"][g]) + int(eso[vo[s]])
+                    for arr in (b.sample_id, b.sample_abd):
+                        blk = arr[so:so + k * (hi - lo)].reshape(hi - lo, k)[::-1].copy(); arr[so:so + k * (hi - lo)] = blk.reshape(-1)
+    ra, _, _ = common.emu_run(a)
+    rb, _, _ = common.emu_run(b)
+    assert not common.compare_results(ra, rb, a.n)

@@ -27,3 +27,100 @@ def test_iteration_counts_match_oracle():
         b.add(pg); b.upload(); b.run(); b.download()
         it = b.iterations()
     assert np.array_equal(it, st[:, 3])
+
+
+def test_op_trace_matches_oracle_on_gpu():
+    pg = A.synth(**dict(common.PARITY_CONFIGS["everything"], n_graphs=40))
+    _, _, _, traces = common.oracle_run(pg, trace=True)
+    with A.DecompBatch(0, trace_events=4096) as b:
+        b.add(pg); b.upload(); b.run(); b.download()
+        for g in range(pg.n):
+            mine = [(c, a, bb, v) for c, a, bb, v in b.trace(g)]
+            assert mine == traces[g], f"graph {g} diverges from the oracle's op trace"
+
+
+def test_nondefault_parameters_on_gpu():
+    p = A.default_params()
+    p.max_decompose_error_ratio[7] = 1.5; p.max_decompose_error_ratio[0] = 0.2; p.min_transcript_coverage = 5.0
+    pg = A.synth(seed=31, n_graphs=200, v_min=10, v_max=70, edges_per_vertex=3, phasing_per_graph=8, weight_mode=1)
+    want = common.oracle_run(pg, params=p)[0]
+    got = A.decompose(pg, 0, p)
+    assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
+
+
+def test_edge_cases_on_gpu():
+    from aletsch_amd.packed import PackedGraphs
+    graphs = [
+        dict(V=2, edges=[], vw=[0, 0], lpos=[0, 0], rpos=[0, 0]),
+        dict(V=4, edges=[(0, 1, 5.0), (1, 2, 5.0), (2, 3, 5.0)], vw=[0, 10, 10, 0], lpos=[0, 100, 300, 400], rpos=[0, 200, 400, 400]),
+        dict(V=4, edges=[(0, 1, 1.0), (1, 3, 1.0)], vw=[0, 1, 1, 0], lpos=[0, 100, 300, 400], rpos=[0, 200, 400, 400]),
+        dict(V=5, edges=[(0, 1, 9.0), (1, 2, 4.0), (1, 3, 5.0), (3, 4, 5.0)], vw=[0, 3, 3, 3, 0], lpos=[0, 10, 30, 50, 60], rpos=[0, 20, 40, 60, 60]),
+        dict(V=4, edges=[(0, 1, 5.0, 0, {}), (1, 2, 5.0), (2, 3, 5.0)], vw=[0, 10, 10, 0], lpos=[0, 100, 300, 400], rpos=[0, 200, 400, 400]),
+        dict(V=5, edges=[(0, 1, 6.0, 0, {1: 6.0}), (1, 2, 6.0, 0, {2: 6.0}), (2, 3, 6.0, 0, {1: 6.0}), (3, 4, 6.0, 0, {1: 6.0})], vw=[0, 1, 1, 1, 0], lpos=[0, 10, 30, 50, 60], rpos=[0, 20, 40, 60, 60]),
+        dict(V=4, edges=[(0, 1, 5.0), (1, 2, 5.0), (2, 3, 5.0)], vw=[0, 10, 10, 0], lpos=[0, 100, 300, 400], rpos=[0, 200, 400, 400], vtype=[-1, -9, -1, -1]),
+        dict(V=6, edges=[(0, 1, 8.0, 1), (0, 2, 6.0, 2), (1, 3, 8.0, 1), (2, 3, 6.0, 2), (3, 4, 7.0, 1), (3, 5, 7.0, 2), (4, 5, 7.0, 1)], vw=[0, 1, 1, 1, 1, 0],
+             lpos=[0, 10, 30, 50, 70, 80], rpos=[0, 20, 40, 60, 80, 80]),
+    ]
+    pg = PackedGraphs.from_graphs(graphs)
+    want = common.oracle_run(pg)[0]
+    got = A.decompose(pg, 0)
+    assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
+    # an empty batch is legal
+    with A.DecompBatch(0) as b:
+        b.upload(); b.run(); b.download()
+        assert len(b.result().status) == 0
+
+
+def test_subsetsum_kernel_matches_reference_golden():
+    """HIP subset-sum DP against the answers of the reference's own subsetsum.cc (tests/golden/ref_subsetsum.json),
+    first instance = the reference's KAT (subsetsum.cc:263-282)"""
+    import json, os
+    d = json.load(open(os.path.join(common.ROOT, "tests", "golden", "ref_subsetsum.json")))
+    inst = [([tuple(x) for x in i["s"]], [tuple(x) for x in i["t"]]) for i in d["instances"]]
+    got = A.subsetsum_batch(inst, 0)
+    for g, ans in zip(got, d["answers"]):
+        if ans is None:
+            assert g is None
+        else:
+            assert g is not None and g[0] == ans["e"] and g[1] == ans["s"] and g[2] == ans["t"]
+    assert got[0][1] == [3, 1] and got[0][2] == [2]
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] at full size (100k x 64v/256e): size-independent properties of the decomposition"""
+    n = 100000
+    pg = A.synth(seed=1002, n_graphs=n, v_min=64, v_max=64, fixed_edges=256)
+    with A.DecompBatch(0) as b:
+        b.add(pg); b.upload(); b.run(); b.download()
+        r1 = b.result(); raw1 = b.raw_records()
+        b.run(); b.download()
+        r2 = b.result()
+    assert (r1.status == 0).all()
+    # idempotent / deterministic: a second run of the same resident batch gives the same answer
+    assert not common.compare_results(r1, r2, n)
+    # every path runs source -> sink along edges of the ORIGINAL graph, vertices strictly ascending
+    src = np.repeat(np.tile(np.arange(64), n), np.diff(pg.vertex_offset.reshape(n, 65), axis=1).reshape(-1))
+    key = (np.repeat(np.arange(n, dtype=np.int64), 256) * 64 + src) * 64 + pg.edge_target
+    keys = np.sort(key)
+    gid = np.repeat(np.arange(n, dtype=np.int64), np.diff(r1.path_offset))
+    pv = r1.path_vertices.astype(np.int64); po = r1.pv_offset
+    first = pv[po[:-1]]; last = pv[po[1:] - 1]
+    assert (first == 0).all() and (last == 63).all()
+    a = np.delete(pv, po[1:] - 1); bnext = np.delete(pv, po[:-1])                # consecutive pairs inside each path
+    pg_of_pair = np.repeat(gid, np.diff(po) - 1)
+    assert (bnext > a).all()
+    k = (pg_of_pair * 64 + a) * 64 + bnext
+    idx = np.searchsorted(keys, k)
+    assert (keys[np.minimum(idx, len(keys) - 1)] == k).all()
+    # weights are positive, above the reporting threshold only for greedy paths; lengths = 200 * internal vertices
+    assert (r1.weight > 0).all()
+    assert np.array_equal(r1.length, 200 * (np.diff(po) - 2))
+    # sharding invariance: the first 1000 graphs decomposed alone give the same paths (graphs are independent)
+    sub = A.decompose(pg.select(np.arange(1000)), 0)
+    lim = int(r1.path_offset[1000])
+    assert np.array_equal(sub.path_offset, r1.path_offset[:1001]) and np.array_equal(sub.weight, r1.weight[:lim])
+    assert np.array_equal(sub.path_vertices, r1.path_vertices[: int(r1.pv_offset[lim])])
+    # oracle parity on a sample of the full-size batch
+    want = common.oracle_run(pg.select(np.arange(0, 300)))[0]
+    got = A.decompose(pg.select(np.arange(0, 300)), 0)
+    assert not common.compare_results(want, got, 300, conf_tol=1e-9)
