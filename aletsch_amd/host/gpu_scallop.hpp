@@ -1,0 +1,176 @@
+// gpu_scallop.hpp -- C++ host adapter over the C ABI (include/aletsch_decomp.h) with the reference's call surface.
+//
+// The reference decomposes one graph with (meta/assembler.cc:1110-1121, scallop/scallop.h:31-51):
+//
+//     scallop sx(gx, hx, pa, false);     // ctor: splice_graph&, hyper_set&, const parameters&, bool random_ordering
+//     sx.assemble();                     // int, always 0
+//     for(transcript &t : sx.trsts) ...  // public: vector<path> paths; vector<transcript> trsts;
+//
+// aletsch::gpu_scallop keeps exactly that two-call shape (single graph = a batch of one), and
+// aletsch::gpu_scallop_batch lifts it to many graphs per launch, which is where the MI355X pays off: the dispatch
+// loops (meta/incubator.cc:609-637, meta/assembler.cc:296-347,370) enqueue (graph, phasing set) pairs, flush() runs
+// them in one batch, and result(i) hands back what `sx.paths` would have held for graph i.
+//
+// The adapter is a template over the reference's own types so that it compiles INSIDE the reference tree with its
+// headers (splice_graph.h, hyper_set.h, parameters.h, path.h) and needs none of them here.  Duck-typed members used:
+//   SpliceGraph: num_vertices(), edges() -> pair<edge_iterator,edge_iterator> over edge_descriptor (with ->source(),
+//                ->target()), get_edge_weight(e), get_edge_info(e) {.strand,.count,.abd,.samples,.spAbd},
+//                get_vertex_weight(v), get_vertex_info(v) {.lpos,.rpos,.type}, .strand
+//   HyperSet:    .nodes  (map<vector<int>, int>: vertex lists -> count, after the ctor + filter_nodes)
+//   Parameters:  .max_decompose_error_ratio[8], .min_guaranteed_edge_weight, .min_transcript_coverage, .max_num_exons
+//   Path:        .v, .junc, .length, .abd, .weight, .conf, .reads, .strand, .count      (rnacore/path.h)
+//
+// Canonical edge order: the reference's order is raw-pointer order; the adapter defines it as
+// (source, target, position in gr.edges()), which is the order each vertex's out-edge set iterates in.
+// The consumed-input contract is relaxed: gx / hx are left untouched (the reference empties them; its callers never read
+// them again: assembler.cc:346-355).
+#pragma once
+#include "../../include/aletsch_decomp.h"
+#include <vector>
+#include <map>
+#include <algorithm>
+#include <stdexcept>
+#include <string>
+#include <cstdint>
+#include <type_traits>
+
+namespace aletsch {
+
+struct staged_graph {                       // owning arrays behind one ald_graph_view
+    std::vector<int32_t> vertex_offset, edge_target, edge_sample_offset, sample_id, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count;
+    std::vector<double> edge_weight, edge_abd, sample_abd, vertex_weight; std::vector<uint8_t> edge_strand; char strand = '.';
+    ald_graph_view view() const {
+        ald_graph_view g{};
+        g.num_vertices = (int32_t)vertex_weight.size(); g.num_edges = (int32_t)edge_target.size();
+        g.vertex_offset = vertex_offset.data(); g.edge_target = edge_target.data(); g.edge_weight = edge_weight.data(); g.edge_strand = edge_strand.data(); g.edge_abd = edge_abd.data();
+        g.edge_sample_offset = edge_sample_offset.data(); g.sample_id = sample_id.data(); g.sample_abd = sample_abd.data();
+        g.vertex_weight = vertex_weight.data(); g.vertex_lpos = vertex_lpos.data(); g.vertex_rpos = vertex_rpos.data(); g.vertex_type = vertex_type.data();
+        g.num_phasing = (int32_t)phasing_count.size(); g.phasing_offset = phasing_offset.data(); g.phasing_vertex = phasing_vertex.data(); g.phasing_count = phasing_count.data();
+        g.strand = strand;
+        return g;
+    }
+};
+
+template<class SpliceGraph, class HyperSet>
+staged_graph stage_graph(SpliceGraph &gr, const HyperSet &hs)
+{
+    staged_graph s;
+    const int V = (int)gr.num_vertices();
+    typedef typename std::decay<decltype(*gr.edges().first)>::type edge_t;     // edge_descriptor
+    struct E { int src, dst, ord; edge_t e; };
+    std::vector<E> es;
+    { auto pe = gr.edges(); int k = 0; for(auto it = pe.first; it != pe.second; ++it, ++k) es.push_back(E{(*it)->source(), (*it)->target(), k, *it}); }
+    std::stable_sort(es.begin(), es.end(), [](const E &a, const E &b) { return a.src != b.src ? a.src < b.src : (a.dst != b.dst ? a.dst < b.dst : a.ord < b.ord); });
+    s.vertex_offset.assign(V + 1, 0);
+    for(const E &x : es) s.vertex_offset[x.src + 1]++;
+    for(int i = 0; i < V; i++) s.vertex_offset[i + 1] += s.vertex_offset[i];
+    s.edge_sample_offset.push_back(0);
+    for(const E &x : es) {
+        const auto &ei = gr.get_edge_info(x.e);
+        s.edge_target.push_back(x.dst); s.edge_weight.push_back(gr.get_edge_weight(x.e)); s.edge_strand.push_back((uint8_t)ei.strand); s.edge_abd.push_back(ei.abd);
+        // edge_info.count is the number of supporting samples (meta/assembler.cc:202-231); an edge whose count disagrees with
+        // its sample set cannot be expressed on the wire and is rejected rather than silently changed
+        if((int)ei.samples.size() != ei.count) throw std::invalid_argument("edge_info.count != |edge_info.samples|");
+        for(int sp : ei.samples) { s.sample_id.push_back(sp); auto f = ei.spAbd.find(sp); s.sample_abd.push_back(f == ei.spAbd.end() ? 0.0 : f->second); }
+        s.edge_sample_offset.push_back((int32_t)s.sample_id.size());
+    }
+    for(int i = 0; i < V; i++) { const auto &vi = gr.get_vertex_info(i); s.vertex_weight.push_back(gr.get_vertex_weight(i)); s.vertex_lpos.push_back(vi.lpos); s.vertex_rpos.push_back(vi.rpos); s.vertex_type.push_back(vi.type); }
+    s.phasing_offset.push_back(0);
+    for(const auto &kv : hs.nodes) { for(int x : kv.first) s.phasing_vertex.push_back(x); s.phasing_offset.push_back((int32_t)s.phasing_vertex.size()); s.phasing_count.push_back(kv.second); }
+    s.strand = gr.strand;
+    return s;
+}
+
+template<class Parameters>
+ald_params stage_params(const Parameters &cfg)
+{
+    ald_params p;
+    for(int i = 0; i < 8; i++) p.max_decompose_error_ratio[i] = cfg.max_decompose_error_ratio[i];
+    p.min_guaranteed_edge_weight = cfg.min_guaranteed_edge_weight; p.min_transcript_coverage = cfg.min_transcript_coverage;
+    p.max_num_exons = cfg.max_num_exons; p.reserved = 0;
+    return p;
+}
+
+// what scallop::collect_path fills (scallop.cc:2797-2822), including the junction list derived from the ORIGINAL coordinates
+template<class Path>
+Path make_path(const ald_path_view &pv, const std::vector<int32_t> &lpos, const std::vector<int32_t> &rpos)
+{
+    Path p;
+    p.v.assign(pv.vertices, pv.vertices + pv.num_vertices);
+    p.length = pv.length; p.weight = pv.weight; p.abd = pv.abd; p.conf = pv.conf; p.reads = pv.reads; p.count = pv.count; p.strand = pv.strand;
+    p.junc.clear();
+    for(int i = 2; i + 1 < pv.num_vertices; i++) if(lpos[p.v[i]] != rpos[p.v[i - 1]]) p.junc.push_back(std::make_pair(p.v[i - 1], p.v[i]));
+    return p;
+}
+
+class gpu_error : public std::runtime_error {
+public:
+    int code;
+    gpu_error(int c, const char *what) : std::runtime_error(std::string("aletsch_decomp: ") + what + " (" + std::to_string(c) + "): " + ald_last_error()), code(c) {}
+};
+
+// many graphs per launch
+template<class SpliceGraph, class HyperSet, class Parameters, class Path>
+class gpu_scallop_batch {
+public:
+    explicit gpu_scallop_batch(const Parameters &cfg, int device = 0) {
+        ald_params p = stage_params(cfg);
+        int rc = ald_batch_create(&p, device, &b_);
+        if(rc != ALD_OK) throw gpu_error(rc, "ald_batch_create");
+    }
+    ~gpu_scallop_batch() { if(b_) ald_batch_destroy(b_); }
+    gpu_scallop_batch(const gpu_scallop_batch &) = delete;
+    gpu_scallop_batch &operator=(const gpu_scallop_batch &) = delete;
+
+    // returns the index under which the graph's result will be available after flush()
+    int enqueue(SpliceGraph &gr, const HyperSet &hs) {
+        staged_graph s = stage_graph(gr, hs);
+        ald_graph_view g = s.view();
+        int rc = ald_batch_add_graph(b_, &g);
+        if(rc != ALD_OK) throw gpu_error(rc, "ald_batch_add_graph");
+        lpos_.push_back(std::move(s.vertex_lpos)); rpos_.push_back(std::move(s.vertex_rpos));
+        return (int)lpos_.size() - 1;
+    }
+    void flush() {
+        int rc;
+        if((rc = ald_batch_upload(b_)) != ALD_OK) throw gpu_error(rc, "ald_batch_upload");
+        if((rc = ald_batch_run(b_)) != ALD_OK) throw gpu_error(rc, "ald_batch_run");
+        if((rc = ald_batch_download(b_)) != ALD_OK) throw gpu_error(rc, "ald_batch_download");
+    }
+    // per-graph status word (ALD_ST_*): the reference would have aborted on an assert where this is >= ALD_ST_INVARIANT
+    int status(int i) const { ald_result_view r; if(ald_batch_get_result(b_, i, &r) != ALD_OK) return -1; return r.status; }
+    std::vector<Path> paths(int i) const {
+        ald_result_view r;
+        int rc = ald_batch_get_result(b_, i, &r);
+        if(rc != ALD_OK) throw gpu_error(rc, "ald_batch_get_result");
+        std::vector<Path> out;
+        for(int k = 0; k < r.num_paths; k++) { ald_path_view pv; ald_batch_get_path(b_, i, k, &pv); out.push_back(make_path<Path>(pv, lpos_[i], rpos_[i])); }
+        return out;
+    }
+    void clear() { ald_batch_clear(b_); lpos_.clear(); rpos_.clear(); }
+private:
+    ald_batch *b_ = nullptr;
+    std::vector<std::vector<int32_t>> lpos_, rpos_;
+};
+
+// the reference's single-graph shape: ctor + assemble() + .paths
+template<class SpliceGraph, class HyperSet, class Parameters, class Path>
+class gpu_scallop {
+public:
+    gpu_scallop(SpliceGraph &gr, HyperSet &hs, const Parameters &cfg, bool random_ordering = false, int device = 0)
+        : gr_(gr), hs_(hs), batch_(cfg, device) { if(random_ordering) throw std::invalid_argument("random_ordering is not supported (always false in the reference: assembler.cc:1110)"); }
+    int assemble() {
+        int i = batch_.enqueue(gr_, hs_);
+        batch_.flush();
+        status = batch_.status(i);
+        paths = batch_.paths(i);
+        return 0;
+    }
+    std::vector<Path> paths;               // scallop::paths
+    int status = 0;                        // ALD_ST_*: >= 100 where the reference would have asserted
+private:
+    SpliceGraph &gr_; HyperSet &hs_;
+    gpu_scallop_batch<SpliceGraph, HyperSet, Parameters, Path> batch_;
+};
+
+} // namespace aletsch

@@ -125,7 +125,12 @@ def main():
                          "bytes_per_graph": (in_b + out_b) / args.graphs, "kernel_graphs_per_s": args.graphs / (k_ms / 1e3)},
         }
         if args.cpu_sample > 0:
-            cores = os.cpu_count() or 1
+            # the GPU box gives each GPU a share of the host (16 cores per GPU): use the cores this process may actually run on
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
+            cores = max(1, min(cores, 16 * max(1, world)))
             sample = pg.select(np.arange(min(args.cpu_sample, pg.n)))
             v, cpu_sec, wall = cpu_baseline(sample, cores)
             line["cpu_baseline"] = {"value": v, "unit": "bundles/s", "cores": cores, "kind": "port",
