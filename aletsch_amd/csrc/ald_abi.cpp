@@ -8,6 +8,8 @@
 #include "host_pack.h"
 #include <mutex>
 #include <string>
+#include <cstdlib>
+#include <cstdio>
 
 using namespace ald;
 
@@ -104,6 +106,7 @@ int launch_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], 
         if(work[c].empty()) continue;
         ClassInfo ci = class_info(c);
         int per_cu = occupancy_for(b, c);
+        if(const char *ov = getenv("ALD_WG_PER_CU")) { int k = atoi(ov); if(k >= 1 && k < per_cu) per_cu = k; }     // tuning knob: cap the persistent grid
         int want = b->n_cus * per_cu;
         if((size_t)want > work[c].size()) want = (int)work[c].size();
         if(want < 1) want = 1;
@@ -298,6 +301,7 @@ int ald_batch_download(ald_batch *b)
             if(b->cls[g] < 0) { b->status[g] = ALD_ST_CAPACITY; continue; }
             if(b->attempt[g] != pass) continue;                 // not part of this pass
             b->status[g] = st[g];
+            if(st[g] == ALD_ST_CAPACITY && getenv("ALD_DEBUG_RETRY")) fprintf(stderr, "[ald] graph %d (V=%d E=%d) overflowed class %d in pass %d\n", g, b->hb.g_nv[g], b->hb.g_ne[g], b->cls[g], pass);
             if(st[g] == ALD_ST_CAPACITY && b->cls[g] + 1 < ALD_NUM_CLASSES) { b->cls[g]++; b->attempt[g] = pass + 1; work[b->cls[g]].push_back(g); any = true; }
         }
         if(!any) break;

@@ -21,6 +21,7 @@
   static inline unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
   static inline int      atomic_add_i32(int *p, int v) { int o = *p; *p += v; return o; }
   static inline int      ffs64(uint64_t m) { return __builtin_ffsll((long long)m) - 1; }
+  template<class T> static inline T uni(T v) { return v; }
   }
 #elif !defined(__HIP__)
   // plain host C++ translation unit (ald_abi.cpp, synth.cpp): only the shared structs are needed
@@ -43,6 +44,17 @@
   __device__ __forceinline__ unsigned long long atomic_add_u64(ALD_GLOBAL unsigned long long *p, unsigned long long v) { return atomicAdd((unsigned long long*)p, v); }
   __device__ __forceinline__ int      atomic_add_i32(ALD_GLOBAL int *p, int v) { return atomicAdd((int*)p, v); }
   __device__ __forceinline__ int      ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
+  // uni(): "this value is the same in every active lane".  The scalar routines run with only lane 0 active, but the compiler
+  // cannot know that a loaded value is wave-uniform; routing it through v_readfirstlane tells it, so loop control, address math
+  // and branches on it use SGPRs / scalar branches instead of VALU compares and exec-mask save/restore sequences.
+  __device__ __forceinline__ int      uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+  __device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+  __device__ __forceinline__ unsigned short uni(unsigned short v) { return (unsigned short)__builtin_amdgcn_readfirstlane((int)v); }
+  __device__ __forceinline__ unsigned char uni(unsigned char v) { return (unsigned char)__builtin_amdgcn_readfirstlane((int)v); }
+  __device__ __forceinline__ bool     uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+  __device__ __forceinline__ unsigned long long uni(unsigned long long v) { unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)); return ((unsigned long long)hi << 32) | lo; }
+  __device__ __forceinline__ unsigned long uni(unsigned long v) { return (unsigned long)uni((unsigned long long)v); }
+  __device__ __forceinline__ double   uni(double v) { return __longlong_as_double((long long)uni((unsigned long long)__double_as_longlong(v))); }
   }
 #endif
 
@@ -89,7 +101,7 @@ struct KernelArgs {                               // lives in device memory; eve
 #define ALD_NUM_CLASSES 5
 template<int ID> struct ClassDims;
 template<> struct ClassDims<0> { enum { MAXV = 64,   MAXE = 160,  NW = 1 }; };
-template<> struct ClassDims<1> { enum { MAXV = 128,  MAXE = 320,  NW = 1 }; };
+template<> struct ClassDims<1> { enum { MAXV = 128,  MAXE = 288,  NW = 1 }; };
 template<> struct ClassDims<2> { enum { MAXV = 256,  MAXE = 640,  NW = 2 }; };
 template<> struct ClassDims<3> { enum { MAXV = 512,  MAXE = 1280, NW = 4 }; };
 template<> struct ClassDims<4> { enum { MAXV = 1024, MAXE = 2560, NW = 8 }; };
@@ -115,7 +127,9 @@ struct ColdLayoutT {
     static constexpr uint64_t o_estrand = al(o_ecount + 4ull * MAXE);
     static constexpr uint64_t o_spoff = al(o_estrand + 1ull * MAXE);
     static constexpr uint64_t o_splen = al(o_spoff + 4ull * MAXE);
-    static constexpr uint64_t o_mask = al(o_splen + 4ull * MAXE);
+    static constexpr uint64_t o_s0id = al(o_splen + 4ull * MAXE);      // first supporting sample inline (single-sample edges never touch the pool)
+    static constexpr uint64_t o_s0abd = al(o_s0id + 4ull * MAXE);
+    static constexpr uint64_t o_mask = al(o_s0abd + 8ull * MAXE);
     static constexpr uint64_t o_spid = al(o_mask + 8ull * MAXE * NW);
     static constexpr uint64_t o_spabd = al(o_spid + 4ull * SP_CAP);
     static constexpr uint64_t o_hl = al(o_spabd + 8ull * SP_CAP);

@@ -32,17 +32,17 @@ enum { MAXV = ClassDims<ALD_CLASS_ID>::MAXV, MAXE = ClassDims<ALD_CLASS_ID>::MAX
 typedef uint16_t IDX;
 static constexpr IDX NIL = (IDX)0xFFFF;
 typedef ColdLayoutT<MAXV, MAXE, NW> CL;
+enum { LP = 16, ARENA_I = 160, ARENA_D = 64, SCR_I = 4 * LP + ARENA_I, SCR_D = 2 * LP + ARENA_D };   // LDS scratch geometry (ints / doubles)
 
 // ---------------------------------------------------------------------------------------------
 // hot state: ONE instance per workgroup (= per wavefront)
 // ---------------------------------------------------------------------------------------------
 struct Hot {
     double   ew[MAXE];                          // splice_graph::ewrt
-    uint32_t eid[MAXE];                         // creation id == scallop edge index
-    IDX      es[MAXE], et[MAXE];                // endpoints; es == NIL  <=> slot dead
-    IDX      inx[MAXE], onx[MAXE];              // next edge in target's in-list / source's out-list (sorted)
+    uint16_t eid[MAXE];                         // creation id == scallop edge index (ids >= 65535 -> the graph moves up a class)
+    struct alignas(8) Link { IDX es, et, inx, onx; };      // endpoints (es == NIL <=> slot dead) + next edge in the target's in-list / the source's
+    Link     lk[MAXE];                          // out-list (both sorted); one 8-byte word so that a list step is ONE LDS round trip
     IDX      in_head[MAXV], out_head[MAXV], in_deg[MAXV], out_deg[MAXV];
-    IDX      uidx[MAXE];                        // scratch: edge slot -> router / decomposition local index
     uint8_t  nz[MAXV];                          // scallop::nonzeroset membership
     uint8_t  hflag[MAXE];                       // HF_* (phasing occupancy / extend flags / protect)
     // wave-uniform context
@@ -54,6 +54,19 @@ struct Hot {
     int32_t  nv, next_id, slot_hw, free_head, free_cnt, pend_head, status, any_strand, hs_dirty, n_paths, n_iters, n_trace;
     uint32_t sp_used, hl_used; int32_t hl_n;
     int32_t  s_next;
+    // parameters cached once per wave (saves a dependent HBM/L2 round per use)
+    double   p_min_w, p_min_cov, p_ratio[8]; int32_t p_max_exons, p_trace_cap;
+    // small-case scratch: the pe2w pair area (+ a parked copy) and the router / decomposition arenas live here whenever the
+    // vertex at hand is small (the common case); larger cases use the slab's work arrays
+    int32_t  pw_lds, park_lds;
+    // the sink keeps ONE physical index (V0-1) for the whole run: the reference re-numbers it to stay last whenever
+    // decompose_vertex_extend appends vertices (exchange_sink, scallop.cc:2198-2215); here order comparisons map it to +inf
+    // instead.  Physical order of all other vertices == the reference's index order.
+    int32_t  sinkp, special_linked;
+    int32_t  scr_i[SCR_I]; double scr_d[SCR_D];
+#ifdef ALD_PROF
+    unsigned long long prof[32];
+#endif
 };
 
 #ifdef ALD_EMU
@@ -67,6 +80,7 @@ __shared__ Hot g_H;
 struct Cold {
     ALD_GLOBAL double *vw; ALD_GLOBAL int32_t *lpos, *rpos, *vtype, *v2v;
     ALD_GLOBAL double *med, *eabd, *econf; ALD_GLOBAL int32_t *mei, *ecount; ALD_GLOBAL uint8_t *estrand; ALD_GLOBAL uint32_t *sp_off, *sp_len;
+    ALD_GLOBAL int32_t *s0id; ALD_GLOBAL double *s0abd;     // copy of the first (smallest-id) supporting sample
     ALD_GLOBAL uint64_t *mask;                  // [MAXE*NW] bitmask over ORIGINAL vertices (scallop::mev as a set)
     ALD_GLOBAL int32_t *sp_id; ALD_GLOBAL double *sp_abd;
     ALD_GLOBAL int32_t *hl, *hl_off, *hl_len, *hl_capk, *hl_cnt;   // phasing lists (hyper_set::edges / ecnts); elements are edge SLOTS or -1
@@ -81,7 +95,7 @@ ALD_INL Cold cold_view()
     C.vtype = (ALD_GLOBAL int32_t*)(b + CL::o_vtype); C.v2v = (ALD_GLOBAL int32_t*)(b + CL::o_v2v);
     C.med = (ALD_GLOBAL double*)(b + CL::o_med); C.eabd = (ALD_GLOBAL double*)(b + CL::o_eabd); C.econf = (ALD_GLOBAL double*)(b + CL::o_econf);
     C.mei = (ALD_GLOBAL int32_t*)(b + CL::o_mei); C.ecount = (ALD_GLOBAL int32_t*)(b + CL::o_ecount); C.estrand = (ALD_GLOBAL uint8_t*)(b + CL::o_estrand);
-    C.sp_off = (ALD_GLOBAL uint32_t*)(b + CL::o_spoff); C.sp_len = (ALD_GLOBAL uint32_t*)(b + CL::o_splen); C.mask = (ALD_GLOBAL uint64_t*)(b + CL::o_mask);
+    C.sp_off = (ALD_GLOBAL uint32_t*)(b + CL::o_spoff); C.sp_len = (ALD_GLOBAL uint32_t*)(b + CL::o_splen); C.s0id = (ALD_GLOBAL int32_t*)(b + CL::o_s0id); C.s0abd = (ALD_GLOBAL double*)(b + CL::o_s0abd); C.mask = (ALD_GLOBAL uint64_t*)(b + CL::o_mask);
     C.sp_id = (ALD_GLOBAL int32_t*)(b + CL::o_spid); C.sp_abd = (ALD_GLOBAL double*)(b + CL::o_spabd);
     C.hl = (ALD_GLOBAL int32_t*)(b + CL::o_hl); C.hl_off = (ALD_GLOBAL int32_t*)(b + CL::o_hloff); C.hl_len = (ALD_GLOBAL int32_t*)(b + CL::o_hllen);
     C.hl_capk = (ALD_GLOBAL int32_t*)(b + CL::o_hlcapk); C.hl_cnt = (ALD_GLOBAL int32_t*)(b + CL::o_hlcnt);
@@ -89,72 +103,111 @@ ALD_INL Cold cold_view()
     return C;
 }
 #define COLD const Cold C = cold_view()
-#define PRM (H.args->prm)
+
+// Diagnostic build only (-DALD_PROF): per-phase cycle sums, emitted as trace events 100+k at the end of each graph.
+// The product build compiles none of this (no stamp executes in the measured kernel).
+#if defined(ALD_PROF) && !defined(ALD_EMU)
+  #define PROF_DECL unsigned long long prof_t_ = __builtin_readcyclecounter()
+  #define PROF_ADD(k) do { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) H.prof[k] += t1_ - prof_t_; prof_t_ = t1_; } while(0)
+  #define PROF_RESET() (prof_t_ = __builtin_readcyclecounter())
+#else
+  #define PROF_DECL do {} while(0)
+  #define PROF_ADD(k) do {} while(0)
+  #define PROF_RESET() do {} while(0)
+#endif
+enum { PF_LOAD = 0, PF_BROKEN, PF_TRIV_EVAL, PF_TRIV_MUT, PF_SMALL_EVAL, PF_SMALL_MUT, PF_UNSPLIT, PF_COLLECT0, PF_G_BALANCE, PF_G_DP, PF_G_SPLITMERGE, PF_G_COLLECT, PF_FINISH,
+       PF_T_BALANCE, PF_T_PAIRS, PF_T_SETUP, PF_T_MERGE_LOAD, PF_T_MERGE_ADD, PF_T_MERGE_ISECT, PF_T_MERGE_MASK, PF_T_MERGE_SUMS, PF_T_MERGE_KILL, PF_T_HS, PF_T_TAIL, PF_COUNT };
 
 // ---------------------------------------------------------------- small helpers
 ALD_INL void fail(int st) { if(H.status == 0) H.status = st; }
 ALD_FN void trace(int code, int a, int b, double v)
 {
     H.n_iters++;
-    ALD_GLOBAL const KernelArgs *A = H.args;
-    int cap = A->out.trace_cap;
+    int cap = H.p_trace_cap;
     if(cap <= 0) return;
+    ALD_GLOBAL const KernelArgs *A = H.args;
     int k = H.n_trace++;
     if(k < cap) { int64_t o = (int64_t)H.g * cap + k; A->out.trace_codes[3 * o] = code; A->out.trace_codes[3 * o + 1] = a; A->out.trace_codes[3 * o + 2] = b; A->out.trace_vals[o] = v; }
 }
-ALD_INL bool tracing() { return H.args->out.trace_cap > 0; }
+ALD_INL bool tracing() { return H.p_trace_cap > 0; }
+// u_*: the same accessors for the scalar (lane-0) routines, with the result marked wave-uniform (see uni() in decomp_common.h)
+ALD_INL int u_first_in(int v) { IDX h = uni(H.in_head[v]); return h == NIL ? -1 : (int)h; }
+ALD_INL int u_first_out(int v) { IDX h = uni(H.out_head[v]); return h == NIL ? -1 : (int)h; }
+ALD_INL int u_next_in(int e) { IDX h = uni(H.lk[e].inx); return h == NIL ? -1 : (int)h; }
+ALD_INL int u_next_out(int e) { IDX h = uni(H.lk[e].onx); return h == NIL ? -1 : (int)h; }
 ALD_INL int first_in(int v) { return H.in_head[v] == NIL ? -1 : (int)H.in_head[v]; }
 ALD_INL int first_out(int v) { return H.out_head[v] == NIL ? -1 : (int)H.out_head[v]; }
-ALD_INL int next_in(int e) { return H.inx[e] == NIL ? -1 : (int)H.inx[e]; }
-ALD_INL int next_out(int e) { return H.onx[e] == NIL ? -1 : (int)H.onx[e]; }
+ALD_INL int next_in(int e) { return H.lk[e].inx == NIL ? -1 : (int)H.lk[e].inx; }
+ALD_INL int next_out(int e) { return H.lk[e].onx == NIL ? -1 : (int)H.lk[e].onx; }
 ALD_INL double in_weights(int v) { double w = 0; for(int e = first_in(v); e >= 0; e = next_in(e)) w += H.ew[e]; return w; }    // splice_graph.cc:187-198
 ALD_INL double out_weights(int v) { double w = 0; for(int e = first_out(v); e >= 0; e = next_out(e)) w += H.ew[e]; return w; } // splice_graph.cc:174-185
 
 // ---------------------------------------------------------------- sorted adjacency lists (scalar code)
 // in-list of v ordered by (source, id); out-list ordered by (target, id): graph/edge_base.h:35-45
+// out(source 0) and in(sink) grow to dozens of entries and are never iterated by the rule cascade: until the final collect /
+// greedy phase (materialize_special) edges are only counted there, not linked.
+ALD_INL uint32_t tkey(uint32_t p) { return (int)p == H.sinkp ? 0xFFFFu : p; }      // the sink sorts after every other vertex
+ALD_INL int vlog(int p) { return p < H.V0 - 1 ? p : (p == H.sinkp ? H.nv - 1 : p - 1); }   // physical -> reference index (traces)
+ALD_INL uint64_t lkw(int e) { return uni(*(const uint64_t*)&H.lk[e]); }            // es | et << 16 | inx << 32 | onx << 48
+ALD_INL int lk_next(uint32_t f) { return f == 0xFFFFu ? -1 : (int)f; }
 ALD_FN void link_in(int v, int e)
 {
-    uint32_t ks = H.es[e], kid = H.eid[e];
-    int prev = -1, cur = first_in(v);
-    while(cur >= 0) { uint32_t cs = H.es[cur]; if(cs > ks || (cs == ks && H.eid[cur] > kid)) break; prev = cur; cur = next_in(cur); }
-    H.inx[e] = cur < 0 ? NIL : (IDX)cur;
-    if(prev < 0) H.in_head[v] = (IDX)e; else H.inx[prev] = (IDX)e;
+    v = uni(v); e = uni(e);
+    if(v == uni(H.sinkp) && !uni(H.special_linked)) { H.in_deg[v]++; return; }
+    uint32_t ks = uni(H.lk[e].es), kid = uni(H.eid[e]);
+    int prev = -1, cur = u_first_in(v);
+    while(cur >= 0) { uint64_t w = lkw(cur); uint32_t cs = (uint32_t)(w & 0xFFFF); if(cs > ks || (cs == ks && uni(H.eid[cur]) > kid)) break; prev = cur; cur = lk_next((uint32_t)((w >> 32) & 0xFFFF)); }
+    H.lk[e].inx = cur < 0 ? NIL : (IDX)cur;
+    if(prev < 0) H.in_head[v] = (IDX)e; else H.lk[prev].inx = (IDX)e;
     H.in_deg[v]++;
 }
 ALD_FN void link_out(int v, int e)
 {
-    uint32_t kt = H.et[e], kid = H.eid[e];
-    int prev = -1, cur = first_out(v);
-    while(cur >= 0) { uint32_t ct = H.et[cur]; if(ct > kt || (ct == kt && H.eid[cur] > kid)) break; prev = cur; cur = next_out(cur); }
-    H.onx[e] = cur < 0 ? NIL : (IDX)cur;
-    if(prev < 0) H.out_head[v] = (IDX)e; else H.onx[prev] = (IDX)e;
+    v = uni(v); e = uni(e);
+    if(v == 0 && !uni(H.special_linked)) { H.out_deg[v]++; return; }
+    const uint32_t sk = (uint32_t)uni(H.sinkp);
+    uint32_t kt = uni(H.lk[e].et), kid = uni(H.eid[e]);
+    if(kt == sk) kt = 0xFFFFu;
+    int prev = -1, cur = u_first_out(v);
+    while(cur >= 0) { uint64_t w = lkw(cur); uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu; if(ct > kt || (ct == kt && uni(H.eid[cur]) > kid)) break; prev = cur; cur = lk_next((uint32_t)(w >> 48)); }
+    H.lk[e].onx = cur < 0 ? NIL : (IDX)cur;
+    if(prev < 0) H.out_head[v] = (IDX)e; else H.lk[prev].onx = (IDX)e;
     H.out_deg[v]++;
 }
 ALD_FN void unlink_in(int v, int e)
 {
-    int prev = -1, cur = first_in(v), guard = MAXE;
-    while(cur >= 0 && cur != e && guard-- > 0) { prev = cur; cur = next_in(cur); }
+    v = uni(v); e = uni(e);
+    if(v == uni(H.sinkp) && !uni(H.special_linked)) { H.in_deg[v]--; return; }
+    int prev = -1, cur = u_first_in(v), guard = MAXE;
+    while(cur >= 0 && cur != e && guard-- > 0) { prev = cur; cur = u_next_in(cur); }
     if(cur != e) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }       // cannot happen on a consistent state; never walk off a list
-    if(prev < 0) H.in_head[v] = H.inx[e]; else H.inx[prev] = H.inx[e];
+    IDX nx = uni(H.lk[e].inx);
+    if(prev < 0) H.in_head[v] = nx; else H.lk[prev].inx = nx;
     H.in_deg[v]--;
 }
 ALD_FN void unlink_out(int v, int e)
 {
-    int prev = -1, cur = first_out(v), guard = MAXE;
-    while(cur >= 0 && cur != e && guard-- > 0) { prev = cur; cur = next_out(cur); }
+    v = uni(v); e = uni(e);
+    if(v == 0 && !uni(H.special_linked)) { H.out_deg[v]--; return; }
+    int prev = -1, cur = u_first_out(v), guard = MAXE;
+    while(cur >= 0 && cur != e && guard-- > 0) { prev = cur; cur = u_next_out(cur); }
     if(cur != e) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
-    if(prev < 0) H.out_head[v] = H.onx[e]; else H.onx[prev] = H.onx[e];
+    IDX nx = uni(H.lk[e].onx);
+    if(prev < 0) H.out_head[v] = nx; else H.lk[prev].onx = nx;
     H.out_deg[v]--;
 }
-ALD_INL int free_slots() { return H.free_cnt + (MAXE - H.slot_hw); }
+ALD_INL int free_slots() { return uni(H.free_cnt) + (MAXE - uni(H.slot_hw)); }
 // directed_graph::add_edge (directed_graph.cc:38-48) + i2e.push_back: the new id is the largest
 ALD_FN int add_edge(int s, int t)
 {
-    int e;
-    if(H.free_head >= 0) { e = H.free_head; H.free_head = H.onx[e] == NIL ? -1 : (int)H.onx[e]; H.free_cnt--; }
-    else if(H.slot_hw < MAXE) e = H.slot_hw++;
+    s = uni(s); t = uni(t);
+    int e; int fh = uni(H.free_head), hw = uni(H.slot_hw);
+    if(fh >= 0) { e = fh; IDX nx = uni(H.lk[e].onx); H.free_head = nx == NIL ? -1 : (int)nx; H.free_cnt--; }
+    else if(hw < MAXE) { e = hw; H.slot_hw = hw + 1; }
     else { fail(ALD_ST_CAPACITY); return -1; }
-    H.es[e] = (IDX)s; H.et[e] = (IDX)t; H.eid[e] = (uint32_t)H.next_id++; H.hflag[e] = 0; H.ew[e] = 0;
+    int id = uni(H.next_id); H.next_id = id + 1;
+    if(id >= 0xFFFF) { fail(ALD_ST_CAPACITY); return -1; }
+    H.lk[e].es = (IDX)s; H.lk[e].et = (IDX)t; H.eid[e] = (uint16_t)id; H.hflag[e] = 0; H.ew[e] = 0;
     link_out(s, e); link_in(t, e);
     return e;
 }
@@ -162,20 +215,22 @@ ALD_FN int add_edge(int s, int t)
 // until the compound operation has called hs_remove on it; all others are recycled at once.
 ALD_FN void kill_edge(int e)
 {
-    unlink_out(H.es[e], e); unlink_in(H.et[e], e);
-    H.es[e] = NIL;
-    if(H.hflag[e] & HF_PROT) { H.onx[e] = H.pend_head < 0 ? NIL : (IDX)H.pend_head; H.pend_head = e; }
-    else { H.onx[e] = H.free_head < 0 ? NIL : (IDX)H.free_head; H.free_head = e; H.free_cnt++; }
+    e = uni(e);
+    unlink_out(uni(H.lk[e].es), e); unlink_in(uni(H.lk[e].et), e);
+    H.lk[e].es = NIL;
+    if(uni(H.hflag[e]) & HF_PROT) { int ph = uni(H.pend_head); H.lk[e].onx = ph < 0 ? NIL : (IDX)ph; H.pend_head = e; }
+    else { int fh = uni(H.free_head); H.lk[e].onx = fh < 0 ? NIL : (IDX)fh; H.free_head = e; H.free_cnt++; }
 }
 ALD_FN void flush_pending()
 {
     int guard = MAXE;
-    while(H.pend_head >= 0 && guard-- > 0) { int e = H.pend_head; H.pend_head = H.onx[e] == NIL ? -1 : (int)H.onx[e]; H.hflag[e] = 0; H.onx[e] = H.free_head < 0 ? NIL : (IDX)H.free_head; H.free_head = e; H.free_cnt++; }
+    while(uni(H.pend_head) >= 0 && guard-- > 0) { int e = uni(H.pend_head); IDX nx = uni(H.lk[e].onx); H.pend_head = nx == NIL ? -1 : (int)nx; H.hflag[e] = 0; int fh = uni(H.free_head); H.lk[e].onx = fh < 0 ? NIL : (IDX)fh; H.free_head = e; H.free_cnt++; }
 }
 ALD_FN void move_edge(int e, int x, int y)      // directed_graph.cc:180-194
 {
-    unlink_out(H.es[e], e); unlink_in(H.et[e], e);
-    H.es[e] = (IDX)x; H.et[e] = (IDX)y;
+    e = uni(e); x = uni(x); y = uni(y);
+    unlink_out(uni(H.lk[e].es), e); unlink_in(uni(H.lk[e].et), e);
+    H.lk[e].es = (IDX)x; H.lk[e].et = (IDX)y;
     link_out(x, e); link_in(y, e);
 }
 
@@ -200,31 +255,44 @@ ALD_INL void borrow_edge_strand(const Cold &C, int e1, int e2) { int s2 = C.estr
 ALD_FN bool intersect_samples(int e1, int e2, int z)
 {
     COLD;
-    uint32_t o1 = C.sp_off[e1], n1 = C.sp_len[e1], o2 = C.sp_off[e2], n2 = C.sp_len[e2];
+    uint32_t n1 = uni(C.sp_len[e1]), n2 = uni(C.sp_len[e2]);
+    if(n1 == 1 && n2 == 1) {                     // single-sample edges: everything needed is inline, no pool round trip
+        int a = uni(C.s0id[e1]), b = uni(C.s0id[e2]); double x = uni(C.s0abd[e1]), y = uni(C.s0abd[e2]);
+        if(a == b) {
+            uint32_t o = H.sp_used;
+            if(o + 1 > C.sp_cap) { fail(ALD_ST_CAPACITY); return false; }
+            double c = (y < x) ? y : x;
+            C.sp_id[o] = a; C.sp_abd[o] = c; H.sp_used = o + 1;
+            C.sp_off[z] = o; C.sp_len[z] = 1; C.ecount[z] = 1; C.eabd[z] = 0.0 + c; C.s0id[z] = a; C.s0abd[z] = c;
+        } else { C.sp_off[z] = H.sp_used; C.sp_len[z] = 0; C.ecount[z] = 0; C.eabd[z] = 0; C.s0id[z] = 0; C.s0abd[z] = 0; }
+        return true;
+    }
+    uint32_t o1 = uni(C.sp_off[e1]), o2 = uni(C.sp_off[e2]);
     uint32_t need = n1 < n2 ? n1 : n2;
     uint32_t o = H.sp_used;
     if(o + need > C.sp_cap) { fail(ALD_ST_CAPACITY); return false; }
     uint32_t i = 0, j = 0, k = 0; double abd = 0;
     while(i < n1 && j < n2) {
-        int a = C.sp_id[o1 + i], b = C.sp_id[o2 + j];
+        int a = uni(C.sp_id[o1 + i]), b = uni(C.sp_id[o2 + j]);
         if(a < b) i++; else if(b < a) j++;
-        else { double x = C.sp_abd[o1 + i], y = C.sp_abd[o2 + j]; double c = (y < x) ? y : x;     // std::min(x, y)
+        else { double x = uni(C.sp_abd[o1 + i]), y = uni(C.sp_abd[o2 + j]); double c = (y < x) ? y : x;     // std::min(x, y)
                C.sp_id[o + k] = a; C.sp_abd[o + k] = c; abd += c; k++; i++; j++; }
     }
     H.sp_used = o + k;
     C.sp_off[z] = o; C.sp_len[z] = k; C.ecount[z] = (int32_t)k; C.eabd[z] = abd;
+    if(k > 0) { C.s0id[z] = uni(C.sp_id[o]); C.s0abd[z] = uni(C.sp_abd[o]); } else { C.s0id[z] = 0; C.s0abd[z] = 0; }
     return true;
 }
 // router.cc:1035-1038: sum over common samples of 0.99*min + 0.01*max
 ALD_FN double common_abd(int e1, int e2)
 {
     COLD;
-    uint32_t o1 = C.sp_off[e1], n1 = C.sp_len[e1], o2 = C.sp_off[e2], n2 = C.sp_len[e2];
+    uint32_t o1 = uni(C.sp_off[e1]), n1 = uni(C.sp_len[e1]), o2 = uni(C.sp_off[e2]), n2 = uni(C.sp_len[e2]);
     uint32_t i = 0, j = 0; double c = 0;
     while(i < n1 && j < n2) {
-        int a = C.sp_id[o1 + i], b = C.sp_id[o2 + j];
+        int a = uni(C.sp_id[o1 + i]), b = uni(C.sp_id[o2 + j]);
         if(a < b) i++; else if(b < a) j++;
-        else { double x = C.sp_abd[o1 + i], y = C.sp_abd[o2 + j]; double mn = (y < x) ? y : x, mx = (x < y) ? y : x; c += 0.99 * mn + 0.01 * mx; i++; j++; }
+        else { double x = uni(C.sp_abd[o1 + i]), y = uni(C.sp_abd[o2 + j]); double mn = (y < x) ? y : x, mx = (x < y) ? y : x; c += 0.99 * mn + 0.01 * mx; i++; j++; }
     }
     return c;
 }
@@ -239,7 +307,7 @@ ALD_FN void hs_refresh_flags()                  // per-slot OCC / LEXT / REXT: h
     for(int e = 0; e < H.slot_hw; e++) H.hflag[e] &= (uint8_t)HF_PROT;
     int nl = H.hl_n;
     for(int k = 0; k < nl; k++) {
-        ALD_GLOBAL int32_t *v = C.hl + C.hl_off[k]; int n = C.hl_len[k];
+        ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]);
         for(int i = 0; i < n; i++) {
             int e = v[i]; if(e < 0) continue;
             uint8_t f = HF_OCC;
@@ -254,20 +322,20 @@ ALD_FN void hs_remove(int e)                    // hyper_set.cc:787-818
 {
     int nl = H.hl_n; if(nl == 0) return;
     COLD;
-    for(int k = 0; k < nl; k++) { ALD_GLOBAL int32_t *v = C.hl + C.hl_off[k]; int n = C.hl_len[k]; for(int i = 0; i < n; i++) if(v[i] == e) { v[i] = -1; H.hs_dirty = 1; } }
+    for(int k = 0; k < nl; k++) { ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]); for(int i = 0; i < n; i++) if(v[i] == e) { v[i] = -1; H.hs_dirty = 1; } }
 }
 ALD_FN void hs_replace1(int x, int e)           // hyper_set.cc:609-615 -> 626-675 with |v| == 1
 {
     int nl = H.hl_n; if(nl == 0) return;
     COLD;
-    for(int k = 0; k < nl; k++) { ALD_GLOBAL int32_t *v = C.hl + C.hl_off[k]; int n = C.hl_len[k]; for(int i = 0; i < n; i++) if(v[i] == x) { v[i] = e; H.hs_dirty = 1; } }
+    for(int k = 0; k < nl; k++) { ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]); for(int i = 0; i < n; i++) if(v[i] == x) { v[i] = e; H.hs_dirty = 1; } }
 }
 ALD_FN void hs_replace2(int x, int y, int e)    // hyper_set.cc:617-624 -> 626-675 with |v| == 2
 {
     int nl = H.hl_n; if(nl == 0) return;
     COLD;
     for(int k = 0; k < nl; k++) {
-        ALD_GLOBAL int32_t *v = C.hl + C.hl_off[k]; int n = C.hl_len[k]; int w = 0;
+        ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]); int w = 0;
         // matches of a 2-pattern with x != y cannot overlap; replace (x,y) by e left to right
         for(int i = 0; i < n; i++) {
             if(i + 1 < n && v[i] == x && v[i + 1] == y) { v[w++] = e; i++; H.hs_dirty = 1; }
@@ -281,11 +349,11 @@ ALD_FN void hs_insert_between(int x, int y, int e)   // hyper_set.cc:865-902
     int nl = H.hl_n; if(nl == 0) return;
     COLD;
     for(int k = 0; k < nl; k++) {
-        int n = C.hl_len[k]; ALD_GLOBAL int32_t *v = C.hl + C.hl_off[k];
+        int n = uni(C.hl_len[k]); ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]);
         int cnt = 0;
         for(int i = 0; i + 1 < n; i++) if(v[i] == x && v[i + 1] == y) cnt++;
         if(cnt == 0) continue;
-        if(n + cnt > C.hl_capk[k]) {             // relocate the list to the end of the pool with slack
+        if(n + cnt > uni(C.hl_capk[k])) {             // relocate the list to the end of the pool with slack
             uint32_t ncap = (uint32_t)(n + cnt) * 2u + 4u, o = H.hl_used;
             if(o + ncap > C.hl_cap) { fail(ALD_ST_CAPACITY); return; }
             for(int i = 0; i < n; i++) C.hl[o + i] = v[i];
@@ -307,7 +375,7 @@ ALD_FN bool hs_dominate(int e, int side)
     int nl = H.hl_n;
     ALD_GLOBAL int32_t *x1 = C.wi, *x2 = C.wi + C.w_cap / 4; int n1 = 0, n2 = 0; const int cap = C.w_cap / 8;
     for(int k = 0; k < nl; k++) {
-        ALD_GLOBAL int32_t *v = C.hl + C.hl_off[k]; int n = C.hl_len[k];
+        ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]);
         if(side == 2) {
             for(int i = 0; i + 1 < n; i++) {
                 if(v[i] != e) continue;
@@ -334,87 +402,126 @@ ALD_FN bool hs_dominate(int e, int side)
 // scallop::split_edge (scallop.cc:2433-2484)
 ALD_FN int split_edge(int ei, double w)
 {
-    if(!(w >= PRM.min_w - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
-    double ww = H.ew[ei];
+    if(!(w >= H.p_min_w - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
+    double ww = uni(H.ew[ei]);
     if(fabs(ww - w) <= kSMIN) return ei;
-    int s = H.es[ei], t = H.et[ei];
+    int s = uni(H.lk[ei].es), t = uni(H.lk[ei].et);
     int p2 = add_edge(s, t);
     if(p2 < 0) return -1;
     COLD;
     double www = ww - w;
-    double mw = PRM.min_w;
+    double mw = H.p_min_w;
     if(www <= mw) www = mw;
     H.ew[ei] = www; H.ew[p2] = w;
-    C.estrand[p2] = C.estrand[ei]; C.ecount[p2] = C.ecount[ei]; C.eabd[p2] = C.eabd[ei]; C.econf[p2] = C.econf[ei];
-    C.sp_off[p2] = C.sp_off[ei]; C.sp_len[p2] = C.sp_len[ei];            // immutable support lists are shared
-    for(int k = 0; k < NW; k++) C.mask[(int64_t)p2 * NW + k] = C.mask[(int64_t)ei * NW + k];
-    C.mei[p2] = C.mei[ei]; C.med[p2] = C.med[ei] * w / ww;
+    C.estrand[p2] = uni(C.estrand[ei]); C.ecount[p2] = uni(C.ecount[ei]); C.eabd[p2] = uni(C.eabd[ei]); C.econf[p2] = uni(C.econf[ei]);
+    C.sp_off[p2] = uni(C.sp_off[ei]); C.sp_len[p2] = uni(C.sp_len[ei]); C.s0id[p2] = uni(C.s0id[ei]); C.s0abd[p2] = uni(C.s0abd[ei]);   // immutable support lists are shared
+    for(int k = 0; k < NW; k++) C.mask[(int64_t)p2 * NW + k] = uni(C.mask[(int64_t)ei * NW + k]);
+    C.mei[p2] = uni(C.mei[ei]); C.med[p2] = uni(C.med[ei]) * w / ww;
     return p2;
 }
-// scallop::merge_adjacent_equal_edges (scallop.cc:2242-2378)
-ALD_FN int merge_adjacent_equal_edges(int x, int y)
-{
-    if(x < 0 || y < 0) return -1;
-    int xs = H.es[x], xt = H.et[x], ys = H.es[y], yt = H.et[y];
-    if(xt != ys && yt != xs) return -1;
-    if(yt == xs) { int t = x; x = y; y = t; xs = H.es[x]; xt = H.et[x]; ys = H.es[y]; yt = H.et[y]; }
-    int n = add_edge(xs, yt);
-    if(n < 0) return -1;
-    COLD;
-    double wx0 = H.ew[x], wy0 = H.ew[y];
-    if(!(fabs(wx0 - wy0) <= kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_MERGE_EQUAL); return -1; }
-    H.ew[n] = wx0 * 0.5 + wy0 * 0.5;
-    if(!(C.ecount[x] > 0 && C.ecount[y] > 0)) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return -1; }
-    if(!intersect_samples(x, y, n)) return -1;
-    C.econf[n] = C.econf[x] + C.econf[y];
-    C.estrand[n] = 0; borrow_edge_strand(C, n, x); borrow_edge_strand(C, n, y);
-    int ov = C.v2v[xt];
-    for(int k = 0; k < NW; k++) C.mask[(int64_t)n * NW + k] = C.mask[(int64_t)x * NW + k] | C.mask[(int64_t)y * NW + k];
-    if(ov >= 0) C.mask[(int64_t)n * NW + (ov >> 6)] |= (1ull << (ov & 63));
-    double sum1 = in_weights(xt), sum2 = out_weights(xt);
-    double sum = (sum1 + sum2) * 0.5;
-    double r1 = C.vw[xt] * (wx0 + wy0) * 0.5 / sum;
-    double r2 = C.vw[xt] - r1;
-    C.vw[xt] = r2;
-    int mi = C.rpos[xt] - C.lpos[xt] + C.mei[x] + C.mei[y];
-    double md = mi * r1 + C.med[x] + C.med[y];
-    C.med[n] = md; C.mei[n] = mi;
-    kill_edge(x); kill_edge(y);
-    if(H.in_deg[xt] == 0 && H.out_deg[xt] == 0) H.nz[xt] = 0;
-    return n;
-}
-// scallop::merge_adjacent_edges(x, y, ww) (scallop.cc:2394-2416)
+// scallop::merge_adjacent_edges(x, y, ww) (scallop.cc:2394-2416) = split_edge(x, ww) + split_edge(y, ww) (scallop.cc:2433-2484)
+// + merge_adjacent_equal_edges (scallop.cc:2242-2378), fused: the two split pieces live only between the split and the merge in
+// the reference, so they are never materialised here -- their creation ids are consumed, their weights take part in the vertex
+// sums at the position their (endpoint, id) keys would have had, and everything else is computed from the originals' state.
 ALD_FN int merge_adjacent_edges(int x, int y, double ww)
 {
-    if(!(ww >= PRM.min_w - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
-    if(H.et[x] != H.es[y]) { int t = x; x = y; y = t; }
-    int x1 = split_edge(x, ww); if(x1 < 0) return -1;
-    int y1 = split_edge(y, ww); if(y1 < 0) return -1;
-    return merge_adjacent_equal_edges(x1, y1);
+    const double mw = H.p_min_w;
+    if(!(ww >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
+    if(x < 0 || y < 0) return -1;
+    if(H.lk[x].et != uni(H.lk[y].es)) { int t = x; x = y; y = t; }
+    const int xs = uni(H.lk[x].es), xt = uni(H.lk[x].et), yt = uni(H.lk[y].et);
+    if((int)uni(H.lk[y].es) != xt) return -1;
+    PROF_DECL;
+    COLD;
+    const double wx = uni(H.ew[x]), wy = uni(H.ew[y]);
+    const bool sx = !(fabs(wx - ww) <= kSMIN), sy = !(fabs(wy - ww) <= kSMIN);     // does split_edge cut a piece off?
+    // cold state of the originals (one round of independent loads)
+    const double medx = uni(C.med[x]), medy = uni(C.med[y]), cx = uni(C.econf[x]), cy = uni(C.econf[y]), vwt = uni(C.vw[xt]);
+    const int meix = uni(C.mei[x]), meiy = uni(C.mei[y]), cntx = uni(C.ecount[x]), cnty = uni(C.ecount[y]), lt = uni(C.lpos[xt]), rt = uni(C.rpos[xt]), ov = uni(C.v2v[xt]);
+    const int stx = uni(C.estrand[x]), sty = uni(C.estrand[y]);
+    // split_edge(x, ww), split_edge(y, ww): a piece of weight ww gets the next id, the original keeps max(w - ww, min_w)
+    if(uni(H.next_id) >= 0xFFF0) { fail(ALD_ST_CAPACITY); return -1; }
+    if(sx) { H.next_id++; double r = wx - ww; if(r <= mw) r = mw; H.ew[x] = r; }
+    if(sy) { H.next_id++; double r = wy - ww; if(r <= mw) r = mw; H.ew[y] = r; }
+    const double wx0 = sx ? ww : wx, wy0 = sy ? ww : wy;                 // weights of the two pieces being merged
+    const double medx1 = sx ? medx * ww / wx : medx, medy1 = sy ? medy * ww / wy : medy;
+    // merge_adjacent_equal_edges(piece x, piece y)
+    PROF_ADD(PF_T_MERGE_LOAD);
+    int n = add_edge(xs, yt);
+    PROF_ADD(PF_T_MERGE_ADD);
+    if(n < 0) return -1;
+    if(!(fabs(wx0 - wy0) <= kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_MERGE_EQUAL); return -1; }
+    H.ew[n] = wx0 * 0.5 + wy0 * 0.5;
+    if(!(cntx > 0 && cnty > 0)) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return -1; }
+    if(!intersect_samples(x, y, n)) return -1;
+    PROF_ADD(PF_T_MERGE_ISECT);
+    C.econf[n] = cx + cy;
+    C.estrand[n] = (uint8_t)(sty != 0 ? sty : stx);                     // borrow_edge_strand(n, x) then (n, y): a non-zero strand of y wins
+    for(int k = 0; k < NW; k++) C.mask[(int64_t)n * NW + k] = uni(C.mask[(int64_t)x * NW + k]) | uni(C.mask[(int64_t)y * NW + k]);
+    if(ov >= 0) C.mask[(int64_t)n * NW + (ov >> 6)] |= (1ull << (ov & 63));
+    // get_in_weights(xt) / get_out_weights(xt) while both pieces are still attached: a piece sorts behind every edge with the
+    // same far endpoint (its id is the newest), before the first edge with a larger one
+    PROF_ADD(PF_T_MERGE_MASK);
+    double sum1 = 0, sum2 = 0;
+    { bool ins = !sx; for(int e = u_first_in(xt); e >= 0; e = u_next_in(e)) { if(!ins && (int)uni(H.lk[e].es) > xs) { sum1 += ww; ins = true; } sum1 += uni(H.ew[e]); } if(!ins) sum1 += ww; }
+    { bool ins = !sy; for(int e = u_first_out(xt); e >= 0; e = u_next_out(e)) { if(!ins && tkey(H.lk[e].et) > tkey(yt)) { sum2 += ww; ins = true; } sum2 += uni(H.ew[e]); } if(!ins) sum2 += ww; }
+    const double sum = (sum1 + sum2) * 0.5;
+    const double r1 = vwt * (wx0 + wy0) * 0.5 / sum;
+    C.vw[xt] = vwt - r1;
+    const int mi = rt - lt + meix + meiy;
+    C.med[n] = mi * r1 + medx1 + medy1; C.mei[n] = mi;
+    // the pieces disappear; an edge that was not cut IS the piece
+    PROF_ADD(PF_T_MERGE_SUMS);
+    if(!sx) kill_edge(x);
+    if(!sy) kill_edge(y);
+    if(H.in_deg[xt] == 0 && uni(H.out_deg[xt]) == 0) H.nz[xt] = 0;
+    PROF_ADD(PF_T_MERGE_KILL);
+    return n;
 }
 // scallop::balance_vertex (scallop.cc:2486-2576)
 ALD_FN void balance_vertex(int v)
 {
-    if(H.in_deg[v] == 0 || H.out_deg[v] == 0) return;
-    const double mw = PRM.min_w;
+    if(H.in_deg[v] == 0 || uni(H.out_deg[v]) == 0) return;
+    const double mw = H.p_min_w;
     double w1 = 0, w2 = 0;
-    for(int e = first_in(v); e >= 0; e = next_in(e)) { double w = H.ew[e]; if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w1 += w; }
-    for(int e = first_out(v); e >= 0; e = next_out(e)) { double w = H.ew[e]; if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w2 += w; }
+    for(int e = u_first_in(v); e >= 0; e = u_next_in(e)) { double w = uni(H.ew[e]); if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w1 += w; }
+    for(int e = u_first_out(v); e >= 0; e = u_next_out(e)) { double w = uni(H.ew[e]); if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w2 += w; }
     double ww = sqrt(w1 * w2);
     double r1 = ww / w1, r2 = ww / w2;
     double m1 = 0, m2 = 0;
-    for(int e = first_in(v); e >= 0; e = next_in(e)) { double wy = H.ew[e] * r1; if(wy < mw) { m1 += mw - wy; wy = mw; } H.ew[e] = wy; }
-    for(int e = first_out(v); e >= 0; e = next_out(e)) { double wy = H.ew[e] * r2; if(wy < mw) { m2 += mw - wy; wy = mw; } H.ew[e] = wy; }
-    if(m1 > m2) { int e = first_out(v); H.ew[e] = H.ew[e] + m1 - m2; }
-    else if(m1 < m2) { int e = first_in(v); H.ew[e] = H.ew[e] + m2 - m1; }
+    for(int e = u_first_in(v); e >= 0; e = u_next_in(e)) { double wy = uni(H.ew[e]) * r1; if(wy < mw) { m1 += mw - wy; wy = mw; } H.ew[e] = wy; }
+    for(int e = u_first_out(v); e >= 0; e = u_next_out(e)) { double wy = uni(H.ew[e]) * r2; if(wy < mw) { m2 += mw - wy; wy = mw; } H.ew[e] = wy; }
+    if(m1 > m2) { int e = u_first_out(v); H.ew[e] = uni(H.ew[e]) + m1 - m2; }
+    else if(m1 < m2) { int e = u_first_in(v); H.ew[e] = uni(H.ew[e]) + m2 - m1; }
 }
 
-// pe2w as a sorted array in the work area: keys (id1,id2) ascending == std::map<PI,double> order (router.h:23)
-// pair arrays live in the upper halves of wi / wd
-#define PW_E1(C) ((C).wi + Cold::w_cap / 2)
-#define PW_E2(C) ((C).wi + Cold::w_cap / 2 + Cold::w_cap / 4)
-#define PW_W(C)  ((C).wd + Cold::w_cap / 2)
-static constexpr int PW_CAP = Cold::w_cap / 4;
+// pe2w as a sorted array: keys (id1,id2) ascending == std::map<PI,double> order (router.h:23).  The pairs of a small vertex
+// (<= LP pairs) live in the LDS scratch, larger sets in the upper halves of the slab's work arrays.  A second area parks the best
+// candidate of an unsplittable sweep while the sweep goes on.
+// A pair entry packs (edge slot | local index << 16): the local index is the edge's position among the root's in-edges followed
+// by its out-edges (adjacency order), which every consumer needs and which would otherwise cost a per-slot lookup table in LDS.
+struct Pairs { int32_t *a, *b; double *w; int cap; };
+#define PSLOT(x) ((int)((x) & 0xFFFF))
+#define PLOC(x)  ((int)(((uint32_t)(x)) >> 16))
+#define PMAKE(slot, loc) ((int32_t)((uint32_t)(slot) | ((uint32_t)(loc) << 16)))
+static constexpr int PW_CAP = Cold::w_cap / 8;       // pairs per area in the slab (current / parked)
+ALD_INL Pairs pairs_at(bool lds, bool parked)
+{
+    Pairs p;
+    if(lds) { int o = parked ? 2 * LP : 0; p.a = (int32_t*)H.scr_i + o; p.b = p.a + LP; p.w = (double*)H.scr_d + (parked ? LP : 0); p.cap = LP; }
+    else { COLD; int o = parked ? PW_CAP : 0; p.a = (int32_t*)(C.wi + Cold::w_cap / 2) + o; p.b = (int32_t*)(C.wi + Cold::w_cap / 2 + Cold::w_cap / 4) + o; p.w = (double*)(C.wd + Cold::w_cap / 2) + o; p.cap = PW_CAP; }
+    return p;
+}
+ALD_INL Pairs pairs_cur() { return pairs_at(H.pw_lds != 0, false); }
+// scalar arenas for the router / the decompositions: LDS when the vertex is small, else the lower half of the slab's work arrays
+struct Arena { int32_t *i; double *d; int cap_i, cap_d; };
+ALD_INL Arena arena_at(bool lds)
+{
+    Arena a;
+    if(lds) { a.i = (int32_t*)H.scr_i + 4 * LP; a.d = (double*)H.scr_d + 2 * LP; a.cap_i = ARENA_I; a.cap_d = ARENA_D; }
+    else { COLD; a.i = (int32_t*)C.wi; a.d = (double*)C.wd; a.cap_i = Cold::w_cap / 2; a.cap_d = Cold::w_cap / 2; }
+    return a;
+}
 ALD_INL bool pair_less(int a1, int a2, int b1, int b2)
 {
     uint32_t x1 = H.eid[a1], y1 = H.eid[b1];
@@ -423,61 +530,75 @@ ALD_INL bool pair_less(int a1, int a2, int b1, int b2)
 }
 ALD_FN void sort_pairs(int n)                   // insertion sort by (id(e1), id(e2)); keys are unique
 {
-    COLD;
-    ALD_GLOBAL int32_t *a = PW_E1(C), *b = PW_E2(C); ALD_GLOBAL double *w = PW_W(C);
+    Pairs P = pairs_cur();
     for(int i = 1; i < n; i++) {
-        int x = a[i], y = b[i]; double z = w[i]; int j = i - 1;
-        while(j >= 0 && pair_less(x, y, a[j], b[j])) { a[j + 1] = a[j]; b[j + 1] = b[j]; w[j + 1] = w[j]; j--; }
-        a[j + 1] = x; b[j + 1] = y; w[j + 1] = z;
+        int x = P.a[i], y = P.b[i]; double z = P.w[i]; int j = i - 1;
+        while(j >= 0 && pair_less(PSLOT(x), PSLOT(y), PSLOT(P.a[j]), PSLOT(P.b[j]))) { P.a[j + 1] = P.a[j]; P.b[j + 1] = P.b[j]; P.w[j + 1] = P.w[j]; j--; }
+        P.a[j + 1] = x; P.b[j + 1] = y; P.w[j + 1] = z;
     }
 }
 
 // scallop::decompose_vertex_replace (scallop.cc:2009-2142), pe2w = n sorted pairs in the work area
 ALD_FN void decompose_vertex_replace(int root, int n)
 {
-    COLD;
-    ALD_GLOBAL int32_t *a = PW_E1(C), *b = PW_E2(C); ALD_GLOBAL double *w = PW_W(C);
-    ALD_GLOBAL double *md = C.wd;                 // per-edge sum of its pe2w entries, in pe2w order
-    int nloc = 0; ALD_GLOBAL int32_t *loc_e = C.wi;
-    for(int e = first_in(root); e >= 0; e = next_in(e)) { H.uidx[e] = (IDX)nloc; loc_e[nloc] = e; md[nloc] = 0; nloc++; }
-    for(int e = first_out(root); e >= 0; e = next_out(e)) { H.uidx[e] = (IDX)nloc; loc_e[nloc] = e; md[nloc] = 0; nloc++; }
-    ALD_GLOBAL int32_t *mdeg = C.wi + C.w_cap / 4;     // [nloc] pe2w degree m[e]
+    PROF_DECL;
+    const Pairs P = pairs_cur();
+    int32_t *a = P.a, *b = P.b; double *w = P.w;
+    const int deg = (int)uni(H.in_deg[root]) + (int)uni(H.out_deg[root]);
+    const Arena AR = arena_at(2 * deg <= ARENA_I && deg <= ARENA_D);
+    if(2 * deg > AR.cap_i || deg > AR.cap_d) { fail(ALD_ST_CAPACITY); return; }
+    double *md = AR.d;                            // per-edge sum of its pe2w entries, in pe2w order
+    int nloc = 0; int32_t *loc_e = AR.i;
+    for(int e = u_first_in(root); e >= 0; e = u_next_in(e)) { loc_e[nloc] = e; md[nloc] = 0; nloc++; }
+    for(int e = u_first_out(root); e >= 0; e = u_next_out(e)) { loc_e[nloc] = e; md[nloc] = 0; nloc++; }
+    int32_t *mdeg = AR.i + deg;                   // [nloc] pe2w degree m[e]
     for(int i = 0; i < nloc; i++) mdeg[i] = 0;
-    const double mw = PRM.min_w;
+    const double mw = H.p_min_w;
     for(int i = 0; i < n; i++) {
         if(!(w[i] >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
-        int u1 = H.uidx[a[i]], u2 = H.uidx[b[i]];
+        int u1 = PLOC(a[i]), u2 = PLOC(b[i]);
         if(mdeg[u1] == 0) md[u1] = w[i]; else md[u1] += w[i];
         if(mdeg[u2] == 0) md[u2] = w[i]; else md[u2] += w[i];
         mdeg[u1]++; mdeg[u2]++;
     }
     for(int i = 0; i < nloc; i++) { if(mdeg[i] == 0) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; } H.ew[loc_e[i]] = md[i]; H.hflag[loc_e[i]] |= HF_PROT; }
+    PROF_ADD(PF_T_SETUP);
     for(int i = 0; i < n; i++) {
-        int e1 = a[i], e2 = b[i];
-        int m1 = mdeg[H.uidx[e1]], m2 = mdeg[H.uidx[e2]];
-        if(free_slots() < 3) { fail(ALD_ST_CAPACITY); return; }
+        int e1 = PSLOT(a[i]), e2 = PSLOT(b[i]);
+        int m1 = mdeg[PLOC(a[i])], m2 = mdeg[PLOC(b[i])];
+        if(free_slots() < 1) { fail(ALD_ST_CAPACITY); return; }
+        PROF_RESET();
         int e = merge_adjacent_edges(e1, e2, w[i]);
+        PROF_RESET();
         if(e < 0 || H.status) { if(!H.status) fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
         hs_replace2(e1, e2, e);
         if(m1 == 1) hs_replace1(e1, e);
         if(m2 == 1) hs_replace1(e2, e);
+        PROF_ADD(PF_T_HS);
     }
     for(int i = 0; i < nloc; i++) hs_remove(loc_e[i]);
     flush_pending();
-    if(H.in_deg[root] != 0 || H.out_deg[root] != 0) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }
+    PROF_ADD(PF_T_TAIL);
+    if(H.in_deg[root] != 0 || uni(H.out_deg[root]) != 0) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }
     H.nz[root] = 0;
 }
 // scallop::decompose_trivial_vertex (scallop.cc:2144-2167)
 ALD_FN void decompose_trivial_vertex(int x)
 {
+    PROF_DECL;
     balance_vertex(x);
+    PROF_ADD(PF_T_BALANCE);
     if(H.status) return;
-    COLD;
-    ALD_GLOBAL int32_t *a = PW_E1(C), *b = PW_E2(C); ALD_GLOBAL double *w = PW_W(C); int n = 0;
-    if((int)H.in_deg[x] * (int)H.out_deg[x] > PW_CAP || (int)H.in_deg[x] + (int)H.out_deg[x] > C.w_cap / 4) { fail(ALD_ST_CAPACITY); return; }
-    for(int e1 = first_in(x); e1 >= 0; e1 = next_in(e1)) { double w1 = H.ew[e1];
-        for(int e2 = first_out(x); e2 >= 0; e2 = next_out(e2)) { double w2 = H.ew[e2]; a[n] = e1; b[n] = e2; w[n] = w1 <= w2 ? w1 : w2; n++; } }
+    const int np = (int)uni(H.in_deg[x]) * (int)uni(H.out_deg[x]);
+    H.pw_lds = (np <= LP) ? 1 : 0;
+    const Pairs P = pairs_cur();
+    int32_t *a = P.a, *b = P.b; double *w = P.w; int n = 0;
+    if(np > P.cap) { fail(ALD_ST_CAPACITY); return; }
+    const int nin = uni(H.in_deg[x]); int ui = 0;
+    for(int e1 = u_first_in(x); e1 >= 0; e1 = u_next_in(e1), ui++) { double w1 = uni(H.ew[e1]); int uj = nin;
+        for(int e2 = u_first_out(x); e2 >= 0; e2 = u_next_out(e2), uj++) { double w2 = uni(H.ew[e2]); a[n] = PMAKE(e1, ui); b[n] = PMAKE(e2, uj); w[n] = w1 <= w2 ? w1 : w2; n++; } }
     sort_pairs(n);
+    PROF_ADD(PF_T_PAIRS);
     decompose_vertex_replace(x, n);
 }
 
@@ -487,73 +608,71 @@ ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio);
 ALD_FN void decompose_vertex_extend(int root, int n)
 {
     COLD;
-    ALD_GLOBAL int32_t *a = PW_E1(C), *b = PW_E2(C); ALD_GLOBAL double *w = PW_W(C);
-    int nloc = 0; ALD_GLOBAL int32_t *loc_e = C.wi;
-    if((int)H.in_deg[root] + (int)H.out_deg[root] > C.w_cap / 8) { fail(ALD_ST_CAPACITY); return; }
-    for(int e = first_in(root); e >= 0; e = next_in(e)) { H.uidx[e] = (IDX)nloc; loc_e[nloc++] = e; }
+    const Pairs P = pairs_cur();
+    int32_t *a = P.a, *b = P.b; double *w = P.w;
+    const int deg = (int)uni(H.in_deg[root]) + (int)uni(H.out_deg[root]);
+    // the visiting order of the nested decompositions (jump_ratio > 1 only) must survive them: it always lives in the slab
+    const Arena AR = arena_at(3 * deg <= ARENA_I && deg <= ARENA_D && !(H.p_ratio[7] > 1.0));
+    if(4 * deg > AR.cap_i || deg > AR.cap_d || deg > C.w_cap / 16) { fail(ALD_ST_CAPACITY); return; }
+    int nloc = 0; int32_t *loc_e = AR.i;
+    for(int e = u_first_in(root); e >= 0; e = u_next_in(e)) { loc_e[nloc++] = e; }
     int nin = nloc;
-    for(int e = first_out(root); e >= 0; e = next_out(e)) { H.uidx[e] = (IDX)nloc; loc_e[nloc++] = e; }
-    ALD_GLOBAL int32_t *mdeg = C.wi + C.w_cap / 8;   // [nloc]
-    ALD_GLOBAL int32_t *evx = C.wi + C.w_cap / 4;    // [nloc] new vertex of the edge (ev1 / ev2), or -1
-    ALD_GLOBAL double *mweight = C.wd;               // [nloc]
+    for(int e = u_first_out(root); e >= 0; e = u_next_out(e)) { loc_e[nloc++] = e; }
+    int32_t *mdeg = AR.i + deg;                   // [nloc]
+    int32_t *evx = AR.i + 2 * deg;                // [nloc] new vertex of the edge (ev1 / ev2), or -1
+    double *mweight = AR.d;                       // [nloc]
     for(int i = 0; i < nloc; i++) { mdeg[i] = 0; evx[i] = -1; mweight[i] = 0; }
-    const double mw = PRM.min_w;
+    const double mw = H.p_min_w;
     double total_weight = 0;
     for(int i = 0; i < n; i++) {
         if(!(w[i] >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
-        int u1 = H.uidx[a[i]], u2 = H.uidx[b[i]];
+        int u1 = PLOC(a[i]), u2 = PLOC(b[i]);
         total_weight += w[i];
         if(mdeg[u1] == 0) mweight[u1] = w[i]; else mweight[u1] += w[i];
         if(mdeg[u2] == 0) mweight[u2] = w[i]; else mweight[u2] += w[i];
         mdeg[u1]++; mdeg[u2]++;
     }
-    int rlen = C.rpos[root] - C.lpos[root];
-    double vertex_weight = C.vw[root] * rlen;
+    int rlen = uni(C.rpos[root]) - uni(C.lpos[root]);
+    double vertex_weight = uni(C.vw[root]) * rlen;
     for(int i = 0; i < nloc; i++) mweight[i] = mweight[i] / total_weight * vertex_weight;
-    int m = H.nv - 1, nn = m;
+    // new vertices (scallop.cc:1753-1806) are appended at the end of the physical index space; the reference gives them the
+    // indices m.. and moves the sink behind them -- same relative order, no edge has to move here
+    int m = H.nv, nn = m;
     for(int i = 0; i < nloc; i++) { if(mdeg[i] == 0) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; } if(mdeg[i] >= 2) evx[i] = nn++; }
     int newedges = 0;
-    for(int i = 0; i < n; i++) { int u1 = H.uidx[a[i]], u2 = H.uidx[b[i]]; if(mdeg[u1] == 1 && mdeg[u2] == 1) evx[u1] = nn++; else if(mdeg[u1] >= 2 && mdeg[u2] >= 2) newedges++; }
-    if(nn + 1 > MAXV || free_slots() < newedges) { fail(ALD_ST_CAPACITY); return; }
-    // add vertices and exchange sink (scallop.cc:1793-1806, 2198-2215)
-    for(int i = m + 1; i <= nn; i++) { H.in_head[i] = NIL; H.out_head[i] = NIL; H.in_deg[i] = 0; H.out_deg[i] = 0; H.nz[i] = 0; C.vw[i] = 0; C.lpos[i] = 0; C.rpos[i] = 0; C.vtype[i] = -1; C.v2v[i] = -1; }
-    for(int i = m; i < nn; i++) H.nz[i] = 1;
-    H.nv = nn + 1;
-    if(m != nn) {
-        C.v2v[nn] = C.v2v[m]; C.lpos[nn] = C.lpos[m]; C.rpos[nn] = C.rpos[m]; C.vtype[nn] = C.vtype[m];
-        int guard = MAXE;
-        while(first_in(m) >= 0 && guard-- > 0) { int e = first_in(m); move_edge(e, H.es[e], nn); }
-        for(int i = m; i < nn; i++) C.v2v[i] = -1;
-    }
+    for(int i = 0; i < n; i++) { int u1 = PLOC(a[i]), u2 = PLOC(b[i]); if(mdeg[u1] == 1 && mdeg[u2] == 1) evx[u1] = nn++; else if(mdeg[u1] >= 2 && mdeg[u2] >= 2) newedges++; }
+    if(nn > MAXV || free_slots() < newedges) { fail(ALD_ST_CAPACITY); return; }
+    for(int i = m; i < nn; i++) { H.in_head[i] = NIL; H.out_head[i] = NIL; H.in_deg[i] = 0; H.out_deg[i] = 0; H.nz[i] = 1; C.vw[i] = 0; C.lpos[i] = 0; C.rpos[i] = 0; C.vtype[i] = -1; C.v2v[i] = -1; }
+    H.nv = nn;
     for(int i = 0; i < nin; i++) {               // ev1: detach in-edges onto their new vertex
         int k = evx[i]; if(k < 0) continue; int e = loc_e[i];
-        int p = C.rpos[H.es[e]];
-        move_edge(e, H.es[e], k); C.lpos[k] = p; C.rpos[k] = p; C.vtype[k] = -1; C.vw[k] = 0; C.v2v[k] = -2;
+        int p = uni(C.rpos[uni(H.lk[e].es)]);
+        move_edge(e, uni(H.lk[e].es), k); C.lpos[k] = p; C.rpos[k] = p; C.vtype[k] = -1; C.vw[k] = 0; C.v2v[k] = -2;
     }
     for(int i = nin; i < nloc; i++) {            // ev2
         int k = evx[i]; if(k < 0) continue; int e = loc_e[i];
-        int p = C.lpos[H.et[e]];
-        move_edge(e, k, H.et[e]); C.lpos[k] = p; C.rpos[k] = p; C.vtype[k] = -1; C.vw[k] = 0; C.v2v[k] = -2;
+        int p = uni(C.lpos[uni(H.lk[e].et)]);
+        move_edge(e, k, uni(H.lk[e].et)); C.lpos[k] = p; C.rpos[k] = p; C.vtype[k] = -1; C.vw[k] = 0; C.v2v[k] = -2;
     }
-    int rv = C.v2v[root];
+    int rv = uni(C.v2v[root]);
     for(int i = 0; i < n; i++) {
-        int e1 = a[i], e2 = b[i]; int u1 = H.uidx[e1], u2 = H.uidx[e2]; double ww = w[i];
+        int e1 = PSLOT(a[i]), e2 = PSLOT(b[i]); int u1 = PLOC(a[i]), u2 = PLOC(b[i]); double ww = w[i];
         if(mdeg[u1] == 1 && mdeg[u2] >= 2) {
             borrow_edge_strand(C, e1, e2);
-            move_edge(e1, H.es[e1], evx[u2]);
+            move_edge(e1, uni(H.lk[e1].es), evx[u2]);
             if(rv >= 0) C.mask[(int64_t)e1 * NW + (rv >> 6)] |= (1ull << (rv & 63));
             C.med[e1] += mweight[u1]; C.mei[e1] += rlen;
         } else if(mdeg[u2] == 1) {
             if(evx[u1] < 0) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
             borrow_edge_strand(C, e2, e1);
-            move_edge(e2, evx[u1], H.et[e2]);
+            move_edge(e2, evx[u1], uni(H.lk[e2].et));
             if(rv >= 0) C.mask[(int64_t)e2 * NW + (rv >> 6)] |= (1ull << (rv & 63));
             C.med[e2] += mweight[u2]; C.mei[e2] += rlen;
         } else {
             int z = add_edge(evx[u1], evx[u2]);
             if(z < 0) return;
             H.ew[z] = ww;
-            if(!(C.ecount[e1] > 0 && C.ecount[e2] > 0)) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
+            if(!(C.ecount[e1] > 0 && uni(C.ecount[e2]) > 0)) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
             if(!intersect_samples(e1, e2, z)) return;
             if(C.ecount[z] <= 0) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
             C.econf[z] = 0; C.estrand[z] = 0;
@@ -565,19 +684,19 @@ ALD_FN void decompose_vertex_extend(int root, int n)
             if(H.status) return;
         }
     }
-    if(H.in_deg[root] != 0 || H.out_deg[root] != 0) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }
+    if(H.in_deg[root] != 0 || uni(H.out_deg[root]) != 0) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }
     H.nz[root] = 0;
     // scallop.cc:1976-1985 resolve_single_trivial_vertex(k, jump_ratio) on the new vertices: a no-op unless jump_ratio > 1
-    double jump = PRM.max_ratio[7];
+    double jump = H.p_ratio[7];
     if(jump > 1.0) {
         // the reference walks ev1 then ev2, each a std::map keyed by edge id.  The nested decompositions reuse the work area, so
         // the visiting order is parked first in [3/8, 1/2) of wi, which no routine touches.
-        ALD_GLOBAL int32_t *order = C.wi + 3 * (C.w_cap / 8); int no = 0;
+        int32_t *order = (int32_t*)(C.wi + 3 * (C.w_cap / 8)); int no = 0;     // slab region [3/8, 1/2) of wi: untouched by every routine
         for(int part = 0; part < 2; part++) {
             int lo = part == 0 ? 0 : nin, hi = part == 0 ? nin : nloc; int first = no;
             for(int i = lo; i < hi; i++) if(evx[i] >= 0) {
-                int k = evx[i]; uint32_t id = H.eid[loc_e[i]]; int j = no - 1;
-                while(j >= first && H.eid[mdeg[j]] > id) { order[j + 1] = order[j]; mdeg[j + 1] = mdeg[j]; j--; }      // mdeg is free now: reuse it for the sort keys' edges
+                int k = evx[i]; uint32_t id = uni(H.eid[loc_e[i]]); int j = no - 1;
+                while(j >= first && uni(H.eid[mdeg[j]]) > id) { order[j + 1] = order[j]; mdeg[j + 1] = mdeg[j]; j--; }      // mdeg is free now: reuse it for the sort keys' edges
                 order[j + 1] = k; mdeg[j + 1] = loc_e[i]; no++;
             }
         }
@@ -592,17 +711,17 @@ ALD_INL int classify_trivial_fastpath(int x, bool fast)
     int d1 = H.in_deg[x], d2 = H.out_deg[x];
     if(d1 != 1 && d2 != 1) return -1;
     int e1 = first_in(x), e2 = first_out(x);
-    if(d1 == 1) { int s = H.es[e1]; if(H.out_deg[s] == 1) return 1; if(fast) { if(!(H.hflag[e1] & HF_OCC)) return 1; return -2; } }
-    if(d2 == 1) { int t = H.et[e2]; if(H.in_deg[t] == 1) return 1; if(fast) { if(!(H.hflag[e2] & HF_OCC)) return 1; return -2; } }
+    if(d1 == 1) { int s = H.lk[e1].es; if(H.out_deg[s] == 1) return 1; if(fast) { if(!(H.hflag[e1] & HF_OCC)) return 1; return -2; } }
+    if(d2 == 1) { int t = H.lk[e2].et; if(H.in_deg[t] == 1) return 1; if(fast) { if(!(H.hflag[e2] & HF_OCC)) return 1; return -2; } }
     return 2;
 }
 ALD_FN int classify_trivial_vertex(int x, bool fast)     // scalar version with the dominate queries
 {
-    int d1 = H.in_deg[x], d2 = H.out_deg[x];
+    int d1 = uni(H.in_deg[x]), d2 = uni(H.out_deg[x]);
     if(d1 != 1 && d2 != 1) return -1;
-    int e1 = first_in(x), e2 = first_out(x);
-    if(d1 == 1) { int s = H.es[e1]; if(H.out_deg[s] == 1) return 1; if(fast && hs_dominate(e1, 1)) return 1; }
-    if(d2 == 1) { int t = H.et[e2]; if(H.in_deg[t] == 1) return 1; if(fast && hs_dominate(e2, 2)) return 1; }
+    int e1 = u_first_in(x), e2 = u_first_out(x);
+    if(d1 == 1) { int s = uni(H.lk[e1].es); if(H.out_deg[s] == 1) return 1; if(fast && hs_dominate(e1, 1)) return 1; }
+    if(d2 == 1) { int t = uni(H.lk[e2].et); if(H.in_deg[t] == 1) return 1; if(fast && hs_dominate(e2, 2)) return 1; }
     return 2;
 }
 ALD_INL double compute_balance_ratio(int v, bool &ok)    // scallop.cc:2578-2602
@@ -621,7 +740,7 @@ ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio)
     bool ok; double r = compute_balance_ratio(i, ok);
     if(!ok) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return false; }
     if(r >= jump_ratio) return false;
-    trace(OP_TRIVIAL_FAST, i, 0, r);
+    trace(OP_TRIVIAL_FAST, vlog(i), 0, r);
     decompose_trivial_vertex(i);
     return true;
 }
@@ -637,7 +756,7 @@ ALD_INL int eval_smallest(int i, double &r)
     if(!(sum1 >= kSMIN) || !(sum2 >= kSMIN)) return -3;          // reference assert(sum1 >= SMIN)
     double r1 = min1 / sum1, r2 = min2 / sum2;
     int e; if(r1 < r2) { r = r1; e = e1; } else { r = r2; e = e2; }
-    int s = H.es[e], t = H.et[e];
+    int s = H.lk[e].es, t = H.lk[e].et;
     if(H.out_deg[s] <= 1) return -1;
     if(H.in_deg[t] <= 1) return -1;
     uint8_t f = H.hflag[e];
@@ -657,10 +776,10 @@ ALD_INL int eval_smallest(int i, double &r)
 ALD_FN bool resolve_broken_vertex()
 {
     const int lane = lane_id();
-    int vend = H.nv - 1; int x = -1;
+    int vend = H.nv; int x = -1;
     for(int base = 0; base < vend && x < 0; base += ALD_WAVE) {
         int i = base + lane;
-        bool p = (i >= 1 && i < vend) && H.nz[i] && !(H.in_deg[i] >= 1 && H.out_deg[i] >= 1);
+        bool p = (i >= 1 && i < vend && i != H.sinkp) && H.nz[i] && !(H.in_deg[i] >= 1 && H.out_deg[i] >= 1);
         uint64_t m = wballot(p);
         if(m) x = base + ffs64(m);
     }
@@ -668,7 +787,7 @@ ALD_FN bool resolve_broken_vertex()
     if(lane == 0) {
         if(H.in_deg[x] + H.out_deg[x] == 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);      // assert(ve.size() >= 1)
         else {
-            trace(OP_BROKEN, x, H.in_deg[x] + H.out_deg[x], 0);
+            trace(OP_BROKEN, vlog(x), H.in_deg[x] + H.out_deg[x], 0);
             int guard = MAXE;
             while(first_in(x) >= 0 && guard-- > 0) { int e = first_in(x); kill_edge(e); hs_remove(e); }
             while(first_out(x) >= 0 && guard-- > 0) { int e = first_out(x); kill_edge(e); hs_remove(e); }
@@ -686,11 +805,12 @@ ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
     const int lane = lane_id();
     const bool fast = (mode == 1);
     const double now_thr = (mode == 1) ? 1.02 : jump_ratio;
-    int vend = H.nv - 1;                       // snapshot of nonzeroset: vertices created later are not visited
+    int vend = H.nv;                           // snapshot of nonzeroset: vertices created later are not visited (the sink is never in it: nz == 0)
     bool flag = false;
     double best_r = DBL_MAX; int best_v = -1;  // running (ratio, root) of the sequential loop
     bool stopped = false;
     int start = 1;
+    PROF_DECL;
     if(lane == 0) hs_refresh_flags();
     wsync();
     while(start < vend) {
@@ -735,13 +855,15 @@ ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
             }
             if(now) { hit = base + ffs64(now); hit_r = wshfl(r, ffs64(now)); }
         }
+        PROF_ADD(PF_TRIV_EVAL);
         if(hit < 0 || stopped) break;
         if(lane == 0) {
-            trace(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, hit, mode == 1 ? type : 0, hit_r);
+            trace(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, vlog(hit), mode == 1 ? type : 0, hit_r);
             decompose_trivial_vertex(hit);
             hs_refresh_flags();
         }
         wsync();
+        PROF_ADD(PF_TRIV_MUT);
         flag = true;
         if(H.status) return true;
         start = hit + 1;
@@ -750,10 +872,11 @@ ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
     if(mode == 0) return false;
     if(best_v < 0) return false;
     if(lane == 0) {
-        trace(OP_TRIVIAL_BEST, best_v, type, best_r);
+        trace(OP_TRIVIAL_BEST, vlog(best_v), type, best_r);
         decompose_trivial_vertex(best_v);
     }
     wsync();
+    PROF_ADD(PF_TRIV_MUT);
     return true;
 }
 
@@ -761,10 +884,11 @@ ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
 ALD_FN bool sweep_smallest(double max_ratio)
 {
     const int lane = lane_id();
-    int vend = H.nv - 1;
+    int vend = H.nv;
     bool flag = false;
     double best_r = max_ratio; int best_e = -1, best_v = -1;
     int start = 1;
+    PROF_DECL;
     if(lane == 0) hs_refresh_flags();
     wsync();
     while(start < vend) {
@@ -787,22 +911,25 @@ ALD_FN bool sweep_smallest(double max_ratio)
             if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = ee; }   // if(ratio < r) continue;
             if(now) { int l = ffs64(now); hit = base + l; hit_e = wshfl(e, l); hit_r = wshfl(r, l); }
         }
+        PROF_ADD(PF_SMALL_EVAL);
         if(hit < 0) break;
         if(lane == 0) {
-            trace(OP_SMALL_NOW, (int)H.eid[hit_e], hit, hit_r);
+            trace(OP_SMALL_NOW, (int)H.eid[hit_e], vlog(hit), hit_r);
             kill_edge(hit_e); hs_remove(hit_e); hs_refresh_flags();
         }
         wsync();
+        PROF_ADD(PF_SMALL_MUT);
         flag = true;
         start = hit + 1;
     }
     if(flag) return true;
     if(best_e < 0) return false;
     if(lane == 0) {
-        trace(OP_SMALLEST, (int)H.eid[best_e], best_v, best_r);
+        trace(OP_SMALLEST, (int)H.eid[best_e], vlog(best_v), best_r);
         kill_edge(best_e); hs_remove(best_e);
     }
     wsync();
+    PROF_ADD(PF_SMALL_MUT);
     return true;
 }
 
@@ -812,25 +939,31 @@ ALD_FN bool router_run(int root, int want_type, int max_degree)
 {
     COLD;
     // ---- build_indices (router.cc:225-248)
-    int nin = H.in_deg[root], nout = H.out_deg[root], n = nin + nout;
-    const int cap = C.w_cap / 2;
-    if(n > cap / 8) { fail(ALD_ST_CAPACITY); return false; }
-    ALD_GLOBAL int32_t *u2e = C.wi;
-    { int k = 0; for(int e = first_in(root); e >= 0; e = next_in(e)) { H.uidx[e] = (IDX)k; u2e[k++] = e; }
-      for(int e = first_out(root); e >= 0; e = next_out(e)) { H.uidx[e] = (IDX)k; u2e[k++] = e; } }
+    int nin = uni(H.in_deg[root]), nout = uni(H.out_deg[root]), n = nin + nout;
+    // small vertices (the common case) keep every router array in the LDS scratch; larger ones use the slab
+    const int route_bound = (H.hl_n == 0) ? 0 : nin * nout;          // routes only come from phasing lists
+    const bool small = (route_bound + n <= LP) && (5 * n + 3 * (route_bound + n) <= ARENA_I) && (3 * n + route_bound + n <= ARENA_D);
+    H.pw_lds = small ? 1 : 0;
+    const Arena AR = arena_at(small);
+    const Pairs PW = pairs_cur();
+    const int cap = AR.cap_i;
+    if(5 * n > cap) { fail(ALD_ST_CAPACITY); return false; }
+    int32_t *u2e = AR.i;
+    { int k = 0; for(int e = u_first_in(root); e >= 0; e = u_next_in(e)) { u2e[k++] = e; }
+      for(int e = u_first_out(root); e >= 0; e = u_next_out(e)) { u2e[k++] = e; } }
     if(mixed_strand_vertex(root)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }     // router.cc:71-76
     // ---- routes from the phasing lists (hyper_set::get_routes, hyper_set.cc:553-571), gathered in the pair area
-    const int half = PW_CAP / 2;               // the upper half of the pair area may hold a parked candidate (save_pairs)
+    const int half = PW.cap;
     int nr = 0;
-    ALD_GLOBAL int32_t *ra = PW_E1(C), *rb = PW_E2(C); ALD_GLOBAL double *rc = PW_W(C);
+    int32_t *ra = PW.a, *rb = PW.b; double *rc = PW.w;
     {
         int nl = H.hl_n;
         for(int k = 0; k < nl; k++) {
-            ALD_GLOBAL int32_t *v = C.hl + C.hl_off[k]; int len = C.hl_len[k]; int c = C.hl_cnt[k];
+            ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int len = uni(C.hl_len[k]); int c = uni(C.hl_cnt[k]);
             for(int i = 0; i + 1 < len; i++) {
                 int x = v[i], y = v[i + 1];
                 if(x < 0 || y < 0) continue;
-                if(H.es[x] == NIL || (int)H.et[x] != root) continue;
+                if(H.lk[x].es == NIL || (int)uni(H.lk[x].et) != root) continue;
                 int f = -1;
                 for(int j = 0; j < nr; j++) if(ra[j] == x && rb[j] == y) { f = j; break; }
                 if(f >= 0) rc[f] += c;
@@ -842,39 +975,48 @@ ALD_FN bool router_run(int root, int want_type, int max_degree)
     // ---- arena (sized now that the number of routes is known)
     int maxue = nr + n;                        // + one edge per isolated node
     int o = n;
-    ALD_GLOBAL int32_t *udeg = C.wi + o; o += n;
-    ALD_GLOBAL int32_t *comp = C.wi + o; o += n;
-    ALD_GLOBAL int32_t *queue = C.wi + o; o += n;
-    ALD_GLOBAL int32_t *iso = C.wi + o; o += n;          // isolated flag -> econf pending
-    ALD_GLOBAL int32_t *us = C.wi + o; o += maxue;
-    ALD_GLOBAL int32_t *ut = C.wi + o; o += maxue;
-    ALD_GLOBAL int32_t *ualive = C.wi + o; o += maxue;
-    if(o > cap || 2 * n + maxue > cap) { fail(ALD_ST_CAPACITY); return false; }
-    ALD_GLOBAL double *vw = C.wd, *uw = C.wd + n, *econf = C.wd + n + maxue;
+    int32_t *udeg = AR.i + o; o += n;
+    int32_t *comp = AR.i + o; o += n;
+    int32_t *queue = AR.i + o; o += n;
+    int32_t *iso = AR.i + o; o += n;          // isolated flag -> econf pending
+    int32_t *us = AR.i + o; o += maxue;
+    int32_t *ut = AR.i + o; o += maxue;
+    int32_t *ualive = AR.i + o; o += maxue;
+    if(o > cap || 3 * n + maxue > AR.cap_d) { fail(ALD_ST_CAPACITY); return false; }
+    double *vw = AR.d, *uw = AR.d + n, *econf = AR.d + n + maxue;
     // ---- build_bipartite_graph (router.cc:250-325)
     int nue = 0;
     for(int i = 0; i < n; i++) { udeg[i] = 0; iso[i] = 0; }
     for(int j = 0; j < nr; j++) {
         int y = rb[j];
-        if(H.es[y] == NIL || (int)H.es[y] != root) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }   // assert(e2u.find(e2) != end)
-        int s = H.uidx[ra[j]], t = H.uidx[y];
+        if(H.lk[y].es == NIL || (int)uni(H.lk[y].es) != root) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }   // assert(e2u.find(e2) != end)
+        int s = -1, t = -1;                       // local indices by search (routes exist only with phasing paths)
+        for(int q = 0; q < nin; q++) if(u2e[q] == ra[j]) { s = q; break; }
+        for(int q = nin; q < n; q++) if(u2e[q] == y) { t = q; break; }
+        if(s < 0 || t < 0) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
         us[nue] = s; ut[nue] = t; uw[nue] = rc[j]; ualive[nue] = 1; udeg[s]++; udeg[t]++; nue++;
     }
-    // isolated vertices attach to the best partner by shared sample abundance (router.cc:1010-1129)
+    // isolated vertices attach to the best partner by shared sample abundance (router.cc:1010-1129).
+    // Per-node support is fetched once (one round of independent loads); single-sample pairs are then pure arithmetic.
+    int32_t *ncnt = comp, *nsid = queue;         // comp / queue are not needed before classify: reuse them as (count, first sample id)
+    double *nabd = AR.d + 2 * n + maxue;         // [n] abundance of the first sample
+    for(int v = 0; v < n; v++) { int e = u2e[v]; ncnt[v] = (int32_t)uni(C.sp_len[e]); nsid[v] = uni(C.s0id[e]); nabd[v] = uni(C.s0abd[e]); }
+    for(int v = 0; v < n; v++) iso[v] = (C.ecount[u2e[v]] == 0) ? 2 : 0;      // 2 = "Warning!(count = 0)": not in left / right
+#define ALD_COMMON(l, r) ((ncnt[l] == 1 && ncnt[r] == 1) ? ((nsid[l] == nsid[r]) ? (0.0 + (0.99 * ((nabd[r] < nabd[l]) ? nabd[r] : nabd[l]) + 0.01 * ((nabd[l] < nabd[r]) ? nabd[r] : nabd[l]))) : 0.0) : common_abd(u2e[l], u2e[r]))
     for(int v = 0; v < nin; v++) {
-        if(C.ecount[u2e[v]] == 0) continue;       // "Warning!(count = 0)": not in `left`
+        if(iso[v] == 2) continue;
         if(udeg[v] != 0) continue;
         int partner = -1; double max_abd = 0.0, sum_abd = 0.0;
-        for(int r = nin; r < n; r++) { if(C.ecount[u2e[r]] == 0) continue; double c = common_abd(u2e[v], u2e[r]); sum_abd += c; if(c > max_abd) { max_abd = c; partner = r; } }
+        for(int r = nin; r < n; r++) { if(iso[r] == 2) continue; double c = ALD_COMMON(v, r); sum_abd += c; if(c > max_abd) { max_abd = c; partner = r; } }
         if(partner < 0) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
         us[nue] = v; ut[nue] = partner; uw[nue] = max_abd; ualive[nue] = 1; udeg[v]++; udeg[partner]++; nue++;
         iso[v] = 1; econf[v] = log(max_abd / sum_abd);
     }
     for(int v = nin; v < n; v++) {
-        if(C.ecount[u2e[v]] == 0) continue;
+        if(iso[v] == 2) continue;
         if(udeg[v] != 0) continue;
         int partner = -1; double max_abd = 0.0, sum_abd = 0.0;
-        for(int l = 0; l < nin; l++) { if(C.ecount[u2e[l]] == 0) continue; double c = common_abd(u2e[l], u2e[v]); sum_abd += c; if(c > max_abd) { max_abd = c; partner = l; } }
+        for(int l = 0; l < nin; l++) { if(iso[l] == 2) continue; double c = ALD_COMMON(l, v); sum_abd += c; if(c > max_abd) { max_abd = c; partner = l; } }
         if(partner < 0) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
         us[nue] = partner; ut[nue] = v; uw[nue] = max_abd; ualive[nue] = 1; udeg[v]++; udeg[partner]++; nue++;
         iso[v] = 1; econf[v] = log(max_abd / sum_abd);
@@ -911,13 +1053,13 @@ ALD_FN bool router_run(int root, int want_type, int max_degree)
     for(int i = 0; i < n; i++) vw[i] = 0;
     for(int c = 0; c < ncomp; c++) {
         double sum1 = 0, sum2 = 0;
-        for(int i = 0; i < n; i++) { if(comp[i] != c) continue; double wgt = H.ew[u2e[i]]; if(i < nin) sum1 += wgt; else sum2 += wgt; vw[i] = wgt; }
+        for(int i = 0; i < n; i++) { if(comp[i] != c) continue; double wgt = uni(H.ew[u2e[i]]); if(i < nin) sum1 += wgt; else sum2 += wgt; vw[i] = wgt; }
         double r1 = sqrt(sum2 / sum1), r2 = sqrt(sum1 / sum2);
         for(int i = 0; i < n; i++) { if(comp[i] != c) continue; if(i < nin) vw[i] *= r1; else vw[i] *= r2; }
     }
     double weight_sum = 0;
     for(int i = 0; i < n; i++) weight_sum += vw[i];
-    ALD_GLOBAL int32_t *pa = PW_E1(C), *pb = PW_E2(C); ALD_GLOBAL double *pwt = PW_W(C); int np = 0;
+    int32_t *pa = PW.a, *pb = PW.b; double *pwt = PW.w; int np = 0;
     int live = nue;
     int guard = 4 * (nue + n) + 8;
     while(guard-- > 0) {
@@ -934,7 +1076,7 @@ ALD_FN bool router_run(int root, int want_type, int max_degree)
             else if(udeg[t] == 1 && vw[t] <= vw[s]) { x = t; y = s; }
             if(x < 0) continue;
             if(np >= half) { fail(ALD_ST_CAPACITY); return false; }
-            pa[np] = u2e[s]; pb[np] = u2e[t]; pwt[np] = vw[x]; np++;
+            pa[np] = PMAKE(u2e[s], s); pb[np] = PMAKE(u2e[t], t); pwt[np] = vw[x]; np++;
             for(int q = 0; q < nue; q++) if(ualive[q] && (us[q] == x || ut[q] == x)) { ualive[q] = 0; udeg[us[q]]--; udeg[ut[q]]--; live--; }   // clear_vertex
             vw[y] -= vw[x]; vw[x] = -1; b = true;
         }
@@ -950,7 +1092,7 @@ ALD_FN bool router_run(int root, int want_type, int max_degree)
             if(!ualive[k]) continue; int y = (us[k] == x) ? ut[k] : ((ut[k] == x) ? us[k] : -1); if(y != t) continue;
             double wgt = vw[x] * uw[k] / sum;
             if(np >= half) { fail(ALD_ST_CAPACITY); return false; }
-            if(x < t) { pa[np] = u2e[x]; pb[np] = u2e[t]; } else { pa[np] = u2e[t]; pb[np] = u2e[x]; }
+            if(x < t) { pa[np] = PMAKE(u2e[x], x); pb[np] = PMAKE(u2e[t], t); } else { pa[np] = PMAKE(u2e[t], t); pb[np] = PMAKE(u2e[x], x); }
             pwt[np] = wgt; np++;
             vw[t] -= wgt;
         }
@@ -961,34 +1103,34 @@ ALD_FN bool router_run(int root, int want_type, int max_degree)
     double weight_remain = 0;
     for(int i = 0; i < n; i++) { if(vw[i] <= 0) continue; weight_remain += vw[i]; }
     H.ro_ratio = weight_remain / weight_sum;
-    for(int i = 0; i < n; i++) if(iso[i]) C.econf[u2e[i]] += econf[i];     // router.cc:849-855: side effect of every build()
+    for(int i = 0; i < n; i++) if(iso[i] == 1) C.econf[u2e[i]] += econf[i];     // router.cc:849-855: side effect of every build()
     sort_pairs(np);
-    const double mw = PRM.min_w;
+    const double mw = H.p_min_w;
     for(int i = 0; i < np; i++) if(pwt[i] < mw) pwt[i] = mw;                // router.cc:217-220
     H.ro_npairs = np;
     return true;
 }
-// the pair area holds PW_CAP pairs; the upper half parks the best candidate while a sweep goes on
+// park / un-park the best candidate's pe2w while an unsplittable sweep goes on
 ALD_FN void save_pairs(int n)
 {
-    COLD;
-    const int h = PW_CAP / 2;
-    if(n > h) { fail(ALD_ST_CAPACITY); return; }
-    ALD_GLOBAL int32_t *a = PW_E1(C), *b = PW_E2(C); ALD_GLOBAL double *w = PW_W(C);
-    for(int i = 0; i < n; i++) { a[h + i] = a[i]; b[h + i] = b[i]; w[h + i] = w[i]; }
+    const bool lds = H.pw_lds != 0;
+    const Pairs S = pairs_at(lds, false), D = pairs_at(lds, true);
+    if(n > D.cap) { fail(ALD_ST_CAPACITY); return; }
+    for(int i = 0; i < n; i++) { D.a[i] = S.a[i]; D.b[i] = S.b[i]; D.w[i] = S.w[i]; }
+    H.park_lds = lds ? 1 : 0;
 }
 ALD_FN void restore_pairs(int n)
 {
-    COLD;
-    const int h = PW_CAP / 2;
-    ALD_GLOBAL int32_t *a = PW_E1(C), *b = PW_E2(C); ALD_GLOBAL double *w = PW_W(C);
-    for(int i = 0; i < n; i++) { a[i] = a[h + i]; b[i] = b[h + i]; w[i] = w[h + i]; }
+    const bool lds = H.park_lds != 0;
+    H.pw_lds = lds ? 1 : 0;
+    const Pairs S = pairs_at(lds, true), D = pairs_at(lds, false);
+    for(int i = 0; i < n; i++) { D.a[i] = S.a[i]; D.b[i] = S.b[i]; D.w[i] = S.w[i]; }
 }
 // scallop::resolve_unsplittable_vertex (scallop.cc:1004-1060)
 ALD_FN bool sweep_unsplittable(int type, int degree, double max_ratio)
 {
     const int lane = lane_id();
-    int vend = H.nv - 1;
+    int vend = H.nv;
     bool flag = false;
     int root = -1; double ratio = max_ratio; int best_np = 0;      // meaningful on lane 0 only
     // The sweep is sequential in the reference: a decomposition (and, for jump_ratio > 1, the trivial decompositions nested in
@@ -1007,7 +1149,7 @@ ALD_FN bool sweep_unsplittable(int type, int degree, double max_ratio)
             if(router_run(i, type, degree) && H.ro_type == type && H.ro_degree <= degree) {
                 double rr = H.ro_ratio;
                 if(rr < 0.01) {
-                    trace(OP_UNSPLIT_NOW, i, type, rr);
+                    trace(OP_UNSPLIT_NOW, vlog(i), type, rr);
                     decompose_vertex_extend(i, H.ro_npairs);
                     act = 1;
                 } else if(!(rr > ratio)) {
@@ -1027,7 +1169,7 @@ ALD_FN bool sweep_unsplittable(int type, int degree, double max_ratio)
     if(root < 0) return false;
     if(lane == 0) {
         restore_pairs(best_np);
-        trace(OP_UNSPLIT_BEST, root, type, ratio);
+        trace(OP_UNSPLIT_BEST, vlog(root), type, ratio);
         decompose_vertex_extend(root, best_np);
     }
     wsync();
@@ -1040,11 +1182,11 @@ ALD_FN void collect_path(int e)
 {
     COLD;
     ALD_GLOBAL const KernelArgs *A = H.args;
-    int n = C.v2v[H.nv - 1];
+    int n = H.V0 - 1;                           // v2v[sink]: the sink's original index
     int cnt = 0, mi = 0; bool empty = false;
-    for(int k = 0; k < NW; k++) { uint64_t mk = C.mask[(int64_t)e * NW + k]; while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; cnt++; mi += C.rpos[x] - C.lpos[x]; if(C.vtype[x] == K_EMPTY_VERTEX) empty = true; } }
+    for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.mask[(int64_t)e * NW + k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; cnt++; mi += uni(C.rpos[x]) - uni(C.lpos[x]); if(C.vtype[x] == K_EMPTY_VERTEX) empty = true; } }
     if(C.mei[e] != mi || cnt == 0) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
-    if(C.vtype[0] == K_EMPTY_VERTEX || C.vtype[n] == K_EMPTY_VERTEX) empty = true;
+    if(C.vtype[0] == K_EMPTY_VERTEX || uni(C.vtype[n]) == K_EMPTY_VERTEX) empty = true;
     if(!empty) {
         int nvp = cnt + 2;
         unsigned long long words = (unsigned long long)(REC_HDR_WORDS + nvp + ((REC_HDR_WORDS + nvp) & 1));
@@ -1055,54 +1197,70 @@ ALD_FN void collect_path(int e)
         if(C.estrand[e] == 1) st = '+';
         if(C.estrand[e] == 2) st = '-';
         if(st == '.') st = H.gstrand;
-        r[0] = (uint32_t)H.g; r[1] = (uint32_t)H.n_paths; r[2] = (uint32_t)nvp; r[3] = (uint32_t)mi; r[4] = (uint32_t)C.ecount[e]; r[5] = (uint32_t)st | ((uint32_t)(A->attempt & 0xFF) << 8);
+        r[0] = (uint32_t)H.g; r[1] = (uint32_t)H.n_paths; r[2] = (uint32_t)nvp; r[3] = (uint32_t)mi; r[4] = (uint32_t)uni(C.ecount[e]); r[5] = (uint32_t)st | ((uint32_t)(A->attempt & 0xFF) << 8);
         ALD_GLOBAL double *d = (ALD_GLOBAL double*)(r + 6);
-        d[0] = H.ew[e]; d[1] = C.eabd[e]; d[2] = exp(C.econf[e]); d[3] = C.med[e];
+        d[0] = uni(H.ew[e]); d[1] = uni(C.eabd[e]); d[2] = exp(C.econf[e]); d[3] = uni(C.med[e]);
         ALD_GLOBAL uint32_t *pv = r + REC_HDR_WORDS; int w = 0;
         pv[w++] = 0;
-        for(int k = 0; k < NW; k++) { uint64_t mk = C.mask[(int64_t)e * NW + k]; while(mk) { int b = ffs64(mk); mk &= mk - 1; pv[w++] = (uint32_t)(k * 64 + b); } }
+        for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.mask[(int64_t)e * NW + k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; pv[w++] = (uint32_t)(k * 64 + b); } }
         pv[w++] = (uint32_t)n;
         if((REC_HDR_WORDS + nvp) & 1) pv[w] = 0;
-        if(tracing()) { int save = H.n_iters; trace(OP_COLLECT, (int)H.eid[e], nvp, H.ew[e]); H.n_iters = save; }
+        if(tracing()) { int save = H.n_iters; trace(OP_COLLECT, (int)uni(H.eid[e]), nvp, uni(H.ew[e])); H.n_iters = save; }
         H.n_paths++;
     }
     H.hflag[e] = 0;
     kill_edge(e);
 }
+// Before the final phase walks out(0) / in(sink): link every live edge of those two lists (sorted insertion).
+ALD_FN void materialize_special()
+{
+    if(H.special_linked) return;
+    H.special_linked = 1;
+    const int sinkp = H.sinkp;
+    H.out_head[0] = NIL; H.in_head[sinkp] = NIL; H.out_deg[0] = 0; H.in_deg[sinkp] = 0;
+    for(int e = 0; e < H.slot_hw; e++) {
+        if(H.lk[e].es == NIL) continue;
+        if((int)uni(H.lk[e].es) == 0) link_out(0, e);
+        if((int)uni(H.lk[e].et) == sinkp) link_in(sinkp, e);
+    }
+}
 // scallop::collect_existing_st_paths (scallop.cc:2742-2752): ascending edge index == ascending creation id
 ALD_FN void collect_existing_st_paths()
 {
-    int sink = H.nv - 1;
-    // the source's out-list is ordered by (target, id): the edges to the sink are its tail, already ascending in id
-    int e = first_out(0); int guard = MAXE;
-    while(e >= 0 && guard-- > 0) { int nx = next_out(e); if((int)H.et[e] == sink) { collect_path(e); if(H.status) return; } e = nx; }
+    int sink = H.sinkp;
+    // the source's out-list is ordered by (target, id) with the sink last: the edges to the sink are its tail, ascending in id
+    int e = u_first_out(0); int guard = MAXE;
+    while(e >= 0 && guard-- > 0) { int nx = u_next_out(e); if((int)uni(H.lk[e].et) == sink) { collect_path(e); if(H.status) return; } e = nx; }
 }
 // splice_graph::compute_maximum_path_w (splice_graph.cc:819-885) + directed_graph::topological_sort (directed_graph.cc:420-451)
-// path edges -> PW_E1 area, length -> H.tmp0
+// path edges -> upper half of wi, length -> H.tmp0
 ALD_FN double compute_maximum_path()
 {
     COLD;
     int n = H.nv;
     ALD_GLOBAL int32_t *vd = C.wi, *q = C.wi + n, *back = C.wi + 2 * n; ALD_GLOBAL double *table = C.wd;
-    ALD_GLOBAL int32_t *path = PW_E1(C);
+    ALD_GLOBAL int32_t *path = C.wi + Cold::w_cap / 2;
     int qt = 0;
-    for(int i = 0; i < n; i++) { int d = H.in_deg[i]; vd[i] = d; if(d == 0) q[qt++] = i; table[i] = -1; back[i] = -1; }
+    const int sinkp = H.sinkp;
+    // queue seeded in the reference's index order: physical order with the sink last
+    for(int i = 0; i < n; i++) { int d = uni(H.in_deg[i]); vd[i] = d; if(d == 0 && i != sinkp) q[qt++] = i; table[i] = -1; back[i] = -1; }
+    if(vd[sinkp] == 0) q[qt++] = sinkp;
     int k = 0;
-    while(k < qt) { int x = q[k++]; for(int e = first_out(x); e >= 0; e = next_out(e)) { int t = H.et[e]; if(--vd[t] == 0) q[qt++] = t; } }
+    while(k < qt) { int x = q[k++]; for(int e = u_first_out(x); e >= 0; e = u_next_out(e)) { int t = uni(H.lk[e].et); if(--vd[t] == 0) q[qt++] = t; } }
     H.tmp0 = 0;
     if(qt != n) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return -1; }
     int ssi = -1, tti = -1;
-    for(int i = 0; i < n; i++) { if(q[i] == 0) ssi = i; if(q[i] == n - 1) tti = i; }
+    for(int i = 0; i < n; i++) { if(q[i] == 0) ssi = i; if(q[i] == sinkp) tti = i; }
     table[0] = DBL_MAX;
     for(int ii = ssi + 1; ii <= tti; ii++) {
         int i = q[ii];
-        if(H.in_deg[i] + H.out_deg[i] == 0) continue;
+        if(H.in_deg[i] + uni(H.out_deg[i]) == 0) continue;
         double max_abd = 0; int max_edge = -1;
-        for(int e = first_in(i); e >= 0; e = next_in(e)) {
-            int s = H.es[e];
+        for(int e = u_first_in(i); e >= 0; e = u_next_in(e)) {
+            int s = uni(H.lk[e].es);
             double ts = table[s];
             if(ts <= -1) continue;
-            double xw = H.ew[e];
+            double xw = uni(H.ew[e]);
             double ww = xw < ts ? xw : ts;
             if(ww >= max_abd) { max_abd = ww; max_edge = e; }
         }
@@ -1110,11 +1268,11 @@ ALD_FN double compute_maximum_path()
         back[i] = max_edge; table[i] = max_abd;
     }
     int plen = 0;
-    int x = n - 1;
-    while(plen < n) { int e = back[x]; if(e < 0) break; path[plen++] = e; x = H.es[e]; }
+    int x = sinkp;
+    while(plen < n) { int e = back[x]; if(e < 0) break; path[plen++] = e; x = uni(H.lk[e].es); }
     for(int i = 0; i < plen / 2; i++) { int t = path[i]; path[i] = path[plen - 1 - i]; path[plen - 1 - i] = t; }
     H.tmp0 = plen;
-    return table[n - 1];
+    return table[sinkp];
 }
 // scallop::greedy_decompose (scallop.cc:2874-2897) + split_merge_path (scallop.cc:2230-2240)
 ALD_FN void greedy_decompose()
@@ -1123,30 +1281,33 @@ ALD_FN void greedy_decompose()
     bool any = false;
     for(int i = 0; i < H.nv && !any; i++) if(H.out_deg[i]) any = true;
     if(!any) return;
-    for(int rep = 0; rep < 2; rep++) for(int i = 1; i < H.nv - 1; i++) { balance_vertex(i); if(H.status) return; }
-    if(3 * H.nv > C.w_cap / 2 || H.nv > PW_CAP) { fail(ALD_ST_CAPACITY); return; }
-    ALD_GLOBAL int32_t *path = PW_E1(C);
-    const double min_cov = PRM.min_cov;
+    PROF_DECL;
+    for(int rep = 0; rep < 2; rep++) for(int i = 1; i < H.nv; i++) { if(i == H.sinkp) continue; balance_vertex(i); if(H.status) return; }
+    PROF_ADD(PF_G_BALANCE);
+    if(3 * H.nv > C.w_cap / 2) { fail(ALD_ST_CAPACITY); return; }
+    ALD_GLOBAL int32_t *path = C.wi + Cold::w_cap / 2;
+    const double min_cov = H.p_min_cov;
     int guard = 4 * MAXE;
     while(guard-- > 0) {
         double w = compute_maximum_path();
         int plen = H.tmp0;
+        PROF_ADD(PF_G_DP);
         if(H.status) return;
         if(w < 0) break;
         if(w <= min_cov) break;
         if(tracing()) { int save = H.n_iters; trace(OP_GREEDY, plen, 0, w); H.n_iters = save; }
         if(plen == 0) break;
-        if(free_slots() < 3) { fail(ALD_ST_CAPACITY); return; }
+        if(free_slots() < 2) { fail(ALD_ST_CAPACITY); return; }
         int ee = split_edge(path[0], w);
         for(int i = 1; i < plen && ee >= 0 && !H.status; i++) {
-            if(free_slots() < 3) { fail(ALD_ST_CAPACITY); return; }
-            int x = split_edge(path[i], w);
-            if(x < 0) { ee = -1; break; }
-            ee = merge_adjacent_equal_edges(ee, x);
+            if(free_slots() < 2) { fail(ALD_ST_CAPACITY); return; }
+            ee = merge_adjacent_edges(ee, path[i], w);     // split(path[i]) + merge with the (already equal) running edge
         }
         if(H.status) return;
         if(ee < 0) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
+        PROF_ADD(PF_G_SPLITMERGE);
         collect_path(ee);
+        PROF_ADD(PF_G_COLLECT);
         if(H.status) return;
     }
 }
@@ -1162,6 +1323,7 @@ ALD_FN bool load_graph()
     int64_t ov = A->in.off_v[g], ovo = ov + g, oe = A->in.off_e[g], oeo = oe + g, os = A->in.off_s[g], op = A->in.off_p[g], opo = op + g, opv = A->in.off_pv[g];
     if(lane == 0) {
         H.V0 = V; H.gstrand = (int)(unsigned char)A->in.graph_strand[g];
+        H.sinkp = V - 1; H.special_linked = 0;
         H.nv = V; H.next_id = E; H.slot_hw = E; H.free_head = -1; H.free_cnt = 0; H.pend_head = -1; H.status = 0; H.any_strand = 0; H.hs_dirty = 1;
         H.n_paths = 0; H.n_iters = 0; H.n_trace = 0; H.sp_used = 0; H.hl_used = 0; H.hl_n = 0;
     }
@@ -1172,21 +1334,23 @@ ALD_FN bool load_graph()
     ALD_GLOBAL const int32_t *vo = A->in.vertex_offset + ovo, *io = A->in.in_offset + ovo, *ie = A->in.in_edge + oe;
     for(int i = lane; i < V; i += ALD_WAVE) {
         int o0 = vo[i], o1 = vo[i + 1], i0 = io[i], i1 = io[i + 1];
-        H.out_head[i] = o1 > o0 ? (IDX)o0 : NIL; H.out_deg[i] = (IDX)(o1 - o0);
-        H.in_head[i] = i1 > i0 ? (IDX)ie[i0] : NIL; H.in_deg[i] = (IDX)(i1 - i0);
+        // out(0) and in(sink) are counted, not linked (see link_in / link_out)
+        H.out_head[i] = (o1 > o0 && i != 0) ? (IDX)o0 : NIL; H.out_deg[i] = (IDX)(o1 - o0);
+        H.in_head[i] = (i1 > i0 && i != V - 1) ? (IDX)ie[i0] : NIL; H.in_deg[i] = (IDX)(i1 - i0);
         H.nz[i] = (i >= 1 && i < V - 1 && (o1 - o0) + (i1 - i0) > 0) ? 1 : 0;
-        for(int k = o0; k < o1; k++) { H.es[k] = (IDX)i; H.onx[k] = (k + 1 < o1) ? (IDX)(k + 1) : NIL; }
-        for(int k = i0; k < i1; k++) { H.inx[ie[k]] = (k + 1 < i1) ? (IDX)ie[k + 1] : NIL; }
+        for(int k = o0; k < o1; k++) { H.lk[k].es = (IDX)i; H.lk[k].onx = (k + 1 < o1) ? (IDX)(k + 1) : NIL; }
+        for(int k = i0; k < i1; k++) { H.lk[ie[k]].inx = (k + 1 < i1) ? (IDX)ie[k + 1] : NIL; }
         C.vw[i] = A->in.vertex_weight[ov + i]; C.lpos[i] = A->in.vertex_lpos[ov + i]; C.rpos[i] = A->in.vertex_rpos[ov + i];
         C.vtype[i] = A->in.vertex_type[ov + i]; C.v2v[i] = i;
     }
     bool strand = false;
     ALD_GLOBAL const int32_t *so = A->in.edge_sample_offset + oeo;
     for(int k = lane; k < E; k += ALD_WAVE) {
-        H.et[k] = (IDX)A->in.edge_target[oe + k]; H.ew[k] = A->in.edge_weight[oe + k]; H.eid[k] = (uint32_t)k; H.hflag[k] = 0;
+        H.lk[k].et = (IDX)A->in.edge_target[oe + k]; H.ew[k] = A->in.edge_weight[oe + k]; H.eid[k] = (uint16_t)k; H.hflag[k] = 0;
         uint8_t st = A->in.edge_strand[oe + k]; C.estrand[k] = st; if(st) strand = true;
         C.med[k] = 0; C.mei[k] = 0; C.econf[k] = 0; C.eabd[k] = A->in.edge_abd[oe + k];
         C.sp_off[k] = (uint32_t)so[k]; C.sp_len[k] = (uint32_t)(so[k + 1] - so[k]); C.ecount[k] = so[k + 1] - so[k];
+        if(so[k + 1] > so[k]) { C.s0id[k] = A->in.sample_id[os + so[k]]; C.s0abd[k] = A->in.sample_abd[os + so[k]]; } else { C.s0id[k] = 0; C.s0abd[k] = 0; }
         for(int q = 0; q < NW; q++) C.mask[(int64_t)k * NW + q] = 0;
     }
     for(int64_t k = lane; k < ns; k += ALD_WAVE) { C.sp_id[k] = A->in.sample_id[os + k]; C.sp_abd[k] = A->in.sample_abd[os + k]; }
@@ -1208,7 +1372,8 @@ ALD_FN bool load_graph()
                 int s = A->in.phasing_vertex[opv + a + k], t = A->in.phasing_vertex[opv + a + k + 1];
                 if(!(s < t) || s < 0 || t >= V) { H.status = ALD_ST_INVARIANT + ALD_INV_OTHER; ok = false; break; }
                 int best = -1;
-                for(int e = first_out(s); e >= 0; e = next_out(e)) { int tt = H.et[e]; if(tt == t) best = e; else if(tt > t) break; }
+                if(s == 0) { for(int e = vo[0]; e < vo[1]; e++) { int tt = H.lk[e].et; if(tt == t) best = e; else if(tt > t) break; } }      // row 0 is not linked: scan the CSR row
+                else for(int e = first_out(s); e >= 0; e = next_out(e)) { int tt = H.lk[e].et; if(tt == t) best = e; else if(tt > t) break; }
                 if(best < 0) ok = false; else C.hl[used + k] = best;
             }
             if(!ok || len - 1 < 2) continue;
@@ -1225,6 +1390,9 @@ ALD_FN void finish_graph()
     if(lane_id() == 0) {
         ALD_GLOBAL const KernelArgs *A = H.args; const int g = H.g;
         A->out.status[g] = H.status; A->out.n_paths[g] = (H.status == 0 || H.status == ALD_ST_SKIPPED_LARGE) ? H.n_paths : 0; A->out.n_iters[g] = H.n_iters;
+#ifdef ALD_PROF
+        if(H.p_trace_cap > 0) for(int k = 0; k < PF_COUNT; k++) { int q = H.n_trace++; if(q < A->out.trace_cap) { int64_t o = (int64_t)g * A->out.trace_cap + q; A->out.trace_codes[3 * o] = 100 + k; A->out.trace_codes[3 * o + 1] = 0; A->out.trace_codes[3 * o + 2] = 0; A->out.trace_vals[o] = (double)H.prof[k]; } }
+#endif
         if(A->out.trace_cap > 0) A->out.trace_n[g] = H.n_trace;
     }
     wsync();
@@ -1233,31 +1401,51 @@ ALD_FN void finish_graph()
 // ---------------------------------------------------------------- scallop::assemble (scallop.cc:38-188)
 ALD_FN void run_graph()
 {
+    PROF_DECL;
+#ifdef ALD_PROF
+    if(lane_id() == 0) for(int k = 0; k < 32; k++) H.prof[k] = 0;
+    wsync();
+#endif
     if(!load_graph()) { finish_graph(); return; }
+    PROF_ADD(PF_LOAD);
     bool skipped = false;
-    const double r_triv = PRM.max_ratio[7], r_small = PRM.max_ratio[0], r_single = PRM.max_ratio[5], r_pure = PRM.max_ratio[4];
-    const int max_exons = PRM.max_num_exons;
+    const double r_triv = H.p_ratio[7], r_small = H.p_ratio[0], r_single = H.p_ratio[5], r_pure = H.p_ratio[4];
+    const int max_exons = H.p_max_exons;
     int guard = 64 * MAXE;                     // every successful rule consumes an edge or a vertex; far above any real count
     while(guard-- > 0) {
         if(H.nv > max_exons) { skipped = true; break; }
         if(H.status) break;
-        if(resolve_broken_vertex()) continue;
+        PROF_RESET();
+        bool brk = resolve_broken_vertex();
+        PROF_ADD(PF_BROKEN);
+        if(brk) continue;
         if(r_triv > 1.0) { if(sweep_trivial(0, 1, r_triv)) continue; }     // resolve_trivial_vertex_fast: a no-op for jump_ratio <= 1 (r >= 1 always)
         if(sweep_trivial(1, 1, r_triv)) continue;
         if(sweep_smallest(r_small)) continue;
+        PROF_RESET();
+        bool un = sweep_unsplittable(T_UNSPLITTABLE_SINGLE, 1, 0.01) || sweep_unsplittable(T_SPLITTABLE_PURE, 1, 0.01)
+               || sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, r_single) || sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, r_pure)
+               || sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, DBL_MAX) || sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, DBL_MAX);
+        PROF_ADD(PF_UNSPLIT);
+        if(un) continue;
+#if 0
         if(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, 1, 0.01)) continue;
         if(sweep_unsplittable(T_SPLITTABLE_PURE, 1, 0.01)) continue;
         if(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, r_single)) continue;
         if(sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, r_pure)) continue;
         if(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, DBL_MAX)) continue;
         if(sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, DBL_MAX)) continue;
+#endif
         if(sweep_trivial(1, 2, r_triv)) continue;
         break;
     }
     if(lane_id() == 0 && H.status == 0) {
         if(guard <= 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);
         else {
+            PROF_RESET();
+            materialize_special();
             collect_existing_st_paths();
+            PROF_ADD(PF_COLLECT0);
             if(H.status == 0) greedy_decompose();
             if(H.status == 0 && skipped) H.status = ALD_ST_SKIPPED_LARGE;
         }
@@ -1269,7 +1457,12 @@ ALD_FN void run_graph()
 // one wave's whole life: pull graphs of this size class from the shared counter until the class is drained
 ALD_INL void wave_main(ALD_GLOBAL const KernelArgs *A, int block)
 {
-    if(lane_id() == 0) { H.args = A; H.cold = A->slabs + (uint64_t)block * A->slab_stride; }
+    if(lane_id() == 0) {
+        H.args = A; H.cold = A->slabs + (uint64_t)block * A->slab_stride;
+        for(int k = 0; k < 8; k++) H.p_ratio[k] = A->prm.max_ratio[k];
+        H.p_min_w = A->prm.min_w; H.p_min_cov = A->prm.min_cov; H.p_max_exons = A->prm.max_num_exons; H.p_trace_cap = A->out.trace_cap;
+        H.pw_lds = 0; H.park_lds = 0;
+    }
     wsync();
     while(true) {
         if(lane_id() == 0) H.s_next = atomic_add_i32(A->counter, 1);
@@ -1285,5 +1478,4 @@ ALD_INL void wave_main(ALD_GLOBAL const KernelArgs *A, int block)
 
 #undef H
 #undef COLD
-#undef PRM
 } // namespace ALD_CLASS_NS

@@ -41,7 +41,8 @@ class _ResultView(C.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "lib", "libaletsch_decomp.so")
+    # ALETSCH_DECOMP_LIB selects a diagnostic build of the same HIP library (e.g. the -DALD_PROF variant); never a fallback
+    return os.environ.get("ALETSCH_DECOMP_LIB") or os.path.join(_HERE, "lib", "libaletsch_decomp.so")
 
 
 def load_library():

@@ -1,0 +1,18 @@
+import os, sys, numpy as np
+os.environ["ALETSCH_DECOMP_LIB"] = "/root/repo/aletsch_amd/lib/libaletsch_decomp_prof.so"
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import aletsch_amd as A
+names = ["load","broken","triv_eval","triv_mut","small_eval","small_mut","unsplit","collect0","g_balance","g_dp","g_splitmerge","g_collect","finish","T_balance","T_pairs","T_setup","M_load","M_add","M_isect","M_mask","M_sums","M_kill","T_hs","T_tail"]
+for n in (20000,):
+    pg = A.synth(seed=1002, n_graphs=n, v_min=64, v_max=64, fixed_edges=256)
+    with A.DecompBatch(0, trace_events=600) as b:
+        b.add(pg); b.upload(); b.run(); b.download()
+        tot = np.zeros(len(names)); cnt = 0
+        for g in range(0, n, max(1, n // 200)):
+            ev = b.trace(g)
+            for c, a, bb, v in ev:
+                if c >= 100: tot[c - 100] += v
+            cnt += 1
+        tot /= cnt
+        print(f"n={n} kernel_ms={b.kernel_ms():.2f}  mean cycles/graph = {tot.sum():.0f}")
+        for k, nm in enumerate(names): print(f"   {nm:14s} {tot[k]:12.0f}  {100*tot[k]/tot.sum():5.1f}%")
