@@ -50,6 +50,8 @@ struct ald_batch {
     HostBatch::Section sec[HostBatch::S_COUNT];
     uint64_t in_bytes = 0;
     hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t cstream[ALD_NUM_CLASSES] = {nullptr, nullptr, nullptr, nullptr, nullptr};    // one stream per size class: the classes run concurrently
+    hipEvent_t cdone[ALD_NUM_CLASSES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     PinBuf pin_in, pin_out;
     DevBuf d_in, d_status, d_npaths, d_niters, d_pool, d_poolused, d_trace_n, d_trace_codes, d_trace_vals, d_work, d_counter, d_args;
     DevBuf d_slabs[ALD_NUM_CLASSES];
@@ -127,11 +129,16 @@ int launch_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], 
     HIPCHK(hipMemcpyAsync(b->d_work.p, flat.data(), 4 * tot, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->d_args.p, args.data(), sizeof(KernelArgs) * ALD_NUM_CLASSES, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));          // flat / args are stack-lifetime host buffers
+    // fork: every class with work launches on its own stream behind ev0, the batch stream joins them all before ev1
+    // (big graphs first: the long poles start early and the small classes fill the LDS they leave free)
     HIPCHK(hipEventRecord(b->ev0, b->stream));
-    for(int c = ALD_NUM_CLASSES - 1; c >= 0; c--) {   // big graphs first: the long poles start early
+    for(int c = ALD_NUM_CLASSES - 1; c >= 0; c--) {
         if(nblk[c] == 0) continue;
         b->blocks[c] = nblk[c];
-        if(k_launch[c]((const KernelArgs*)b->d_args.p + c, nblk[c], b->stream) != 0) return set_err(ALD_ERR_HIP, "kernel launch failed");
+        HIPCHK(hipStreamWaitEvent(b->cstream[c], b->ev0, 0));
+        if(k_launch[c]((const KernelArgs*)b->d_args.p + c, nblk[c], b->cstream[c]) != 0) return set_err(ALD_ERR_HIP, "kernel launch failed");
+        HIPCHK(hipEventRecord(b->cdone[c], b->cstream[c]));
+        HIPCHK(hipStreamWaitEvent(b->stream, b->cdone[c], 0));
     }
     HIPCHK(hipEventRecord(b->ev1, b->stream));
     return ALD_OK;
@@ -166,7 +173,9 @@ int ald_batch_create(const ald_params *p, int device, ald_batch **out)
     ald_batch *b = new ald_batch();
     b->device = device; b->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     params_from_abi(p, b->prm);
-    if(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { delete b; return set_err(ALD_ERR_HIP, "stream/event creation failed"); }
+    bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev1) == hipSuccess;
+    for(int c = 0; c < ALD_NUM_CLASSES && ok; c++) ok = hipStreamCreateWithFlags(&b->cstream[c], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&b->cdone[c], hipEventDisableTiming) == hipSuccess;
+    if(!ok) { ald_batch_destroy(b); return set_err(ALD_ERR_HIP, "stream/event creation failed"); }
     *out = b;
     return ALD_OK;
 }
@@ -180,6 +189,7 @@ int ald_batch_destroy(ald_batch *b)
     DevBuf *bufs[] = {&b->d_in, &b->d_status, &b->d_npaths, &b->d_niters, &b->d_pool, &b->d_poolused, &b->d_trace_n, &b->d_trace_codes, &b->d_trace_vals, &b->d_work, &b->d_counter, &b->d_args};
     for(DevBuf *d : bufs) d->release();
     for(int c = 0; c < ALD_NUM_CLASSES; c++) b->d_slabs[c].release();
+    for(int c = 0; c < ALD_NUM_CLASSES; c++) { if(b->cstream[c]) { hipStreamSynchronize(b->cstream[c]); hipStreamDestroy(b->cstream[c]); } if(b->cdone[c]) hipEventDestroy(b->cdone[c]); }
     if(b->ev0) hipEventDestroy(b->ev0);
     if(b->ev1) hipEventDestroy(b->ev1);
     if(b->stream) hipStreamDestroy(b->stream);
@@ -267,6 +277,10 @@ int ald_batch_run(ald_batch *b)
         b->cls[g] = c;
         if(c >= 0) work[c].push_back(g);
     }
+    // longest-processing-time-first inside a class: the persistent waves pull graphs in list order, so the big graphs of a
+    // class start early and the tail of the launch is made of small ones
+    for(int c = 0; c < ALD_NUM_CLASSES; c++)
+        std::stable_sort(work[c].begin(), work[c].end(), [&](int32_t x, int32_t y) { return b->hb.g_ne[x] > b->hb.g_ne[y]; });
     b->passes = 0; b->kernel_ms = 0;
     int rc = launch_pass(b, work, 0);
     if(rc != ALD_OK) return rc;
