@@ -10,13 +10,16 @@
 #include <string>
 #include <cstdlib>
 #include <cstdio>
+#include <cmath>
 
 using namespace ald;
 
 extern "C" {
 int ald_launch_c0(const KernelArgs *, int, hipStream_t); int ald_launch_c1(const KernelArgs *, int, hipStream_t); int ald_launch_c2(const KernelArgs *, int, hipStream_t);
-int ald_launch_c3(const KernelArgs *, int, hipStream_t); int ald_launch_c4(const KernelArgs *, int, hipStream_t);
-int ald_occupancy_c0(); int ald_occupancy_c1(); int ald_occupancy_c2(); int ald_occupancy_c3(); int ald_occupancy_c4();
+int ald_launch_c3(const KernelArgs *, int, hipStream_t); int ald_launch_c4(const KernelArgs *, int, hipStream_t); int ald_launch_c5(const KernelArgs *, int, hipStream_t);
+int ald_occupancy_c0(); int ald_occupancy_c1(); int ald_occupancy_c2(); int ald_occupancy_c3(); int ald_occupancy_c4(); int ald_occupancy_c5();
+unsigned long long ald_hot_slab_bytes_c0(); unsigned long long ald_hot_slab_bytes_c1(); unsigned long long ald_hot_slab_bytes_c2();
+unsigned long long ald_hot_slab_bytes_c3(); unsigned long long ald_hot_slab_bytes_c4(); unsigned long long ald_hot_slab_bytes_c5();
 }
 
 namespace {
@@ -27,8 +30,10 @@ int set_err(int code, const std::string &s) { g_err = s; return code; }
 
 typedef int (*launch_fn)(const KernelArgs *, int, hipStream_t);
 typedef int (*occ_fn)();
-const launch_fn k_launch[ALD_NUM_CLASSES] = {ald_launch_c0, ald_launch_c1, ald_launch_c2, ald_launch_c3, ald_launch_c4};
-const occ_fn k_occ[ALD_NUM_CLASSES] = {ald_occupancy_c0, ald_occupancy_c1, ald_occupancy_c2, ald_occupancy_c3, ald_occupancy_c4};
+typedef unsigned long long (*hot_fn)();
+const launch_fn k_launch[ALD_NUM_CLASSES] = {ald_launch_c0, ald_launch_c1, ald_launch_c2, ald_launch_c3, ald_launch_c4, ald_launch_c5};
+const occ_fn k_occ[ALD_NUM_CLASSES] = {ald_occupancy_c0, ald_occupancy_c1, ald_occupancy_c2, ald_occupancy_c3, ald_occupancy_c4, ald_occupancy_c5};
+const hot_fn k_hot[ALD_NUM_CLASSES] = {ald_hot_slab_bytes_c0, ald_hot_slab_bytes_c1, ald_hot_slab_bytes_c2, ald_hot_slab_bytes_c3, ald_hot_slab_bytes_c4, ald_hot_slab_bytes_c5};
 
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
@@ -50,13 +55,13 @@ struct ald_batch {
     HostBatch::Section sec[HostBatch::S_COUNT];
     uint64_t in_bytes = 0;
     hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipStream_t cstream[ALD_NUM_CLASSES] = {nullptr, nullptr, nullptr, nullptr, nullptr};    // one stream per size class: the classes run concurrently
-    hipEvent_t cdone[ALD_NUM_CLASSES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t cstream[ALD_NUM_CLASSES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};    // one stream per size class: the classes run concurrently
+    hipEvent_t cdone[ALD_NUM_CLASSES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     PinBuf pin_in, pin_out;
     DevBuf d_in, d_status, d_npaths, d_niters, d_pool, d_poolused, d_trace_n, d_trace_codes, d_trace_vals, d_work, d_counter, d_args;
     DevBuf d_slabs[ALD_NUM_CLASSES];
-    int blocks[ALD_NUM_CLASSES] = {0, 0, 0, 0, 0};
-    int occ[ALD_NUM_CLASSES] = {-1, -1, -1, -1, -1};
+    int blocks[ALD_NUM_CLASSES] = {0, 0, 0, 0, 0, 0};
+    int occ[ALD_NUM_CLASSES] = {-1, -1, -1, -1, -1, -1};
     uint64_t pool_cap_words = 0;
     int trace_cap = 0;
     bool uploaded = false, ran = false, downloaded = false;
@@ -110,9 +115,11 @@ int launch_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], 
         int per_cu = occupancy_for(b, c);
         if(const char *ov = getenv("ALD_WG_PER_CU")) { int k = atoi(ov); if(k >= 1 && k < per_cu) per_cu = k; }     // tuning knob: cap the persistent grid
         int want = b->n_cus * per_cu;
+        const uint64_t stride = ci.slab_bytes + k_hot[c]();           // catch-all class: hot state + cold state per wave
+        if(c >= ALD_FIRST_GLOBAL_CLASS && want > b->n_cus) want = b->n_cus;      // ~13 MB per wave: one wave per CU is plenty
         if((size_t)want > work[c].size()) want = (int)work[c].size();
         if(want < 1) want = 1;
-        if(b->d_slabs[c].ensure((size_t)want * ci.slab_bytes)) return set_err(ALD_ERR_NOMEM, "class slab");
+        if(b->d_slabs[c].ensure((size_t)want * stride)) return set_err(ALD_ERR_NOMEM, "class slab");
         nblk[c] = want;
         memcpy(flat.data() + woff, work[c].data(), 4 * work[c].size());
         KernelArgs &A = args[c]; memset(&A, 0, sizeof(A));
@@ -123,7 +130,7 @@ int launch_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], 
         A.prm = b->prm;
         A.work = (const int32_t*)b->d_work.p + woff; A.n_work = (int32_t)work[c].size(); A.attempt = pass;
         A.counter = (int32_t*)b->d_counter.p + 64 * c;
-        A.slabs = (uint8_t*)b->d_slabs[c].p; A.slab_stride = ci.slab_bytes;
+        A.slabs = (uint8_t*)b->d_slabs[c].p; A.slab_stride = stride;
         woff += work[c].size();
     }
     HIPCHK(hipMemcpyAsync(b->d_work.p, flat.data(), 4 * tot, hipMemcpyHostToDevice, b->stream));
@@ -391,6 +398,51 @@ int ald_batch_get_trace(const ald_batch *b, int32_t graph, int32_t *n_events, co
     *n_events = b->trace_n[graph] < b->trace_cap ? b->trace_n[graph] : b->trace_cap;
     if(codes) *codes = b->trace_codes.data() + 3ull * graph * b->trace_cap;
     if(values) *values = b->trace_vals.data() + (size_t)graph * b->trace_cap;
+    return ALD_OK;
+}
+
+/* scallop::build_transcripts / build_transcript (scallop.cc:3250-3266, essential.cc:719-748): exon join + coverage, host side */
+static void join_exons(const ald_batch *b, int32_t graph, const PathRec &p, std::vector<int32_t> &ex)
+{
+    const int64_t ov = b->hb.off_v[graph];
+    const uint32_t *v = b->res.vertices(p);
+    ex.clear();
+    for(int k = 1; k + 1 < p.nv; k++) {
+        int32_t l = b->hb.vertex_lpos[ov + v[k]], r = b->hb.vertex_rpos[ov + v[k]];
+        if(l >= r) continue;                                  // empty interval: vanishes in the interval map
+        if(!ex.empty() && ex.back() == l) ex.back() = r;      // touching intervals with the same value join
+        else { ex.push_back(l); ex.push_back(r); }
+    }
+}
+
+int ald_batch_get_transcript(const ald_batch *b, int32_t graph, int32_t path, ald_transcript_view *out)
+{
+    if(!b || !out || !b->downloaded || graph < 0 || graph >= b->hb.n()) return ALD_ERR_INVALID;
+    { int rc = ensure_index(b); if(rc != ALD_OK) return rc; }
+    int64_t i = b->res.path_begin[graph] + path;
+    if(path < 0 || i >= b->res.path_begin[graph + 1]) return ALD_ERR_INVALID;
+    static thread_local std::vector<int32_t> ex;
+    const PathRec &p = b->res.paths[i];
+    join_exons(b, graph, p, ex);
+    out->num_exons = (int32_t)(ex.size() / 2); out->exons = ex.data();
+    out->coverage = log(1.0 + p.weight); out->conf = p.conf; out->abd = p.abd; out->count1 = p.count; out->strand = p.strand;
+    return ALD_OK;
+}
+
+int ald_batch_export_transcripts(const ald_batch *b, int64_t *total_exons, double *coverage, int64_t *exon_offset, int32_t *exon_lr)
+{
+    if(!b || !b->downloaded) return set_err(ALD_ERR_STATE, "ald_batch_export_transcripts before ald_batch_download");
+    { int rc = ensure_index(b); if(rc != ALD_OK) return rc; }
+    std::vector<int32_t> ex; int64_t te = 0, it = 0;
+    const int n = b->hb.n();
+    for(int g = 0; g < n; g++) for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++, it++) {
+        const PathRec &p = b->res.paths[i];
+        join_exons(b, g, p, ex);
+        if(coverage) { coverage[it] = log(1.0 + p.weight); exon_offset[it] = te; for(size_t k = 0; k < ex.size(); k++) exon_lr[2 * te + k] = ex[k]; }
+        te += (int64_t)(ex.size() / 2);
+    }
+    if(coverage) exon_offset[it] = te;
+    if(total_exons) *total_exons = te;
     return ALD_OK;
 }
 

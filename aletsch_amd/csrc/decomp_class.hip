@@ -23,6 +23,16 @@ extern "C" int ALD_CAT(ald_launch_c, ALD_CLASS_ID)(const ald::KernelArgs *dA, in
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// bytes of hot state that live in the wave's slab (0 for the LDS classes)
+extern "C" unsigned long long ALD_CAT(ald_hot_slab_bytes_c, ALD_CLASS_ID)()
+{
+#if ALD_CLASS_ID >= ALD_FIRST_GLOBAL_CLASS
+    return (sizeof(ALD_CLASS_NS::Hot) + 255) / 256 * 256;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int ALD_CAT(ald_occupancy_c, ALD_CLASS_ID)()
 {
     int nb = 0;

@@ -98,13 +98,15 @@ struct KernelArgs {                               // lives in device memory; eve
 };
 
 // ---- size classes ----
-#define ALD_NUM_CLASSES 5
+#define ALD_NUM_CLASSES 6
 template<int ID> struct ClassDims;
 template<> struct ClassDims<0> { enum { MAXV = 64,   MAXE = 160,  NW = 1 }; };
 template<> struct ClassDims<1> { enum { MAXV = 128,  MAXE = 288,  NW = 1 }; };
 template<> struct ClassDims<2> { enum { MAXV = 256,  MAXE = 640,  NW = 2 }; };
 template<> struct ClassDims<3> { enum { MAXV = 512,  MAXE = 1280, NW = 4 }; };
 template<> struct ClassDims<4> { enum { MAXV = 1024, MAXE = 2560, NW = 8 }; };
+template<> struct ClassDims<5> { enum { MAXV = 4096, MAXE = 16384, NW = 64 }; };   // catch-all: hot state in the wave's HBM slab, not LDS
+#define ALD_FIRST_GLOBAL_CLASS 5
 
 // per-wave HBM slab, laid out at compile time (so that cold pointers cost no registers)
 template<int MAXV, int MAXE, int NW>
@@ -148,7 +150,7 @@ static inline ClassInfo class_info(int c)
     switch(c) {
 #define ALD_CI(ID) case ID: { typedef ColdLayoutT<ClassDims<ID>::MAXV, ClassDims<ID>::MAXE, ClassDims<ID>::NW> L; \
         return ClassInfo{ClassDims<ID>::MAXV, ClassDims<ID>::MAXE, ClassDims<ID>::NW, L::SP_CAP, L::HL_CAP, L::total}; }
-    ALD_CI(0) ALD_CI(1) ALD_CI(2) ALD_CI(3) ALD_CI(4)
+    ALD_CI(0) ALD_CI(1) ALD_CI(2) ALD_CI(3) ALD_CI(4) ALD_CI(5)
 #undef ALD_CI
     }
     return ClassInfo{0, 0, 0, 0, 0, 0};

@@ -69,12 +69,18 @@ struct Hot {
 #endif
 };
 
-#ifdef ALD_EMU
+#if defined(ALD_EMU)
 static thread_local Hot g_H;
+#define H g_H
+#elif ALD_CLASS_ID >= ALD_FIRST_GLOBAL_CLASS
+// catch-all class: the working set does not fit LDS; the Hot struct is the first part of the wave's HBM slab
+__shared__ ALD_GLOBAL Hot *g_Hp;
+#define H (*g_Hp)
+#define ALD_HOT_IN_SLAB 1
 #else
 __shared__ Hot g_H;
-#endif
 #define H g_H
+#endif
 
 // cold state: typed views at compile-time offsets of the slab
 struct Cold {
@@ -1457,8 +1463,17 @@ ALD_FN void run_graph()
 // one wave's whole life: pull graphs of this size class from the shared counter until the class is drained
 ALD_INL void wave_main(ALD_GLOBAL const KernelArgs *A, int block)
 {
+#ifdef ALD_HOT_IN_SLAB
+    if(lane_id() == 0) g_Hp = (ALD_GLOBAL Hot*)(A->slabs + (uint64_t)block * A->slab_stride);
+    wsync();
+#endif
     if(lane_id() == 0) {
-        H.args = A; H.cold = A->slabs + (uint64_t)block * A->slab_stride;
+        H.args = A;
+#ifdef ALD_HOT_IN_SLAB
+        H.cold = A->slabs + (uint64_t)block * A->slab_stride + ((sizeof(Hot) + 255) / 256 * 256);
+#else
+        H.cold = A->slabs + (uint64_t)block * A->slab_stride;
+#endif
         for(int k = 0; k < 8; k++) H.p_ratio[k] = A->prm.max_ratio[k];
         H.p_min_w = A->prm.min_w; H.p_min_cov = A->prm.min_cov; H.p_max_exons = A->prm.max_num_exons; H.p_trace_cap = A->out.trace_cap;
         H.pw_lds = 0; H.park_lds = 0;

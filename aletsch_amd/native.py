@@ -168,6 +168,16 @@ class DecompBatch:
     def result(self) -> DecompResult:
         return export_via(self._lib.ald_batch_export, self._h, self.n)
 
+    def transcripts(self):
+        """(coverage[paths], exon_offset[paths+1], exons[n,2]): scallop::build_transcripts without the ML features."""
+        te = C.c_int64()
+        _check(self._lib.ald_batch_export_transcripts(self._h, C.byref(te), None, None, None))
+        P = len(self.result().weight)
+        cov = np.zeros(P); eo = np.zeros(P + 1, np.int64); lr = np.zeros(2 * max(te.value, 1), np.int32)
+        _check(self._lib.ald_batch_export_transcripts(self._h, C.byref(te), cov.ctypes.data_as(C.POINTER(C.c_double)),
+                                                      eo.ctypes.data_as(C.POINTER(C.c_int64)), lr.ctypes.data_as(C.POINTER(C.c_int32))))
+        return cov, eo, lr[:2 * te.value].reshape(-1, 2)
+
     def iterations(self) -> np.ndarray:
         out = np.zeros(self.n, np.int32); rv = _ResultView()
         for g in range(self.n):

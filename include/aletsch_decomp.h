@@ -148,6 +148,22 @@ int  ald_batch_export(const ald_batch *b, int64_t *total_paths, int64_t *total_p
                       int32_t *length, int32_t *count, char *strand,
                       int64_t *pv_offset, int32_t *path_vertices);
 
+/* ---- transcripts (replaces scallop::build_transcripts -> build_transcript, scallop.cc:3250-3266, rnacore/essential.cc:719-748) ----
+ * One transcript per path: exons = the path's internal vertices' [lpos, rpos) intervals with touching intervals joined (the
+ * reference's Boost.ICL join_interval_map), coverage = log(1 + path.weight).  The ML feature block of update_trst_features
+ * (scallop.cc:3268-3451) is NOT produced here. */
+typedef struct ald_transcript_view {
+    int32_t        num_exons;
+    const int32_t *exons;          /* 2 * num_exons values: l0, r0, l1, r1, ...; valid until the next call on this thread */
+    double         coverage;       /* transcript.coverage = cov2 = log(1 + weight) */
+    double         conf, abd;      /* transcript.conf / abd                         */
+    int32_t        count1;         /* transcript.count1 = path.count                */
+    char           strand;
+} ald_transcript_view;
+int  ald_batch_get_transcript(const ald_batch *b, int32_t graph, int32_t path, ald_transcript_view *out);
+/* bulk: coverage[total_paths], exon_offset[total_paths+1], exon_lr[2*total_exons]; pass NULL arrays to query *total_exons */
+int  ald_batch_export_transcripts(const ald_batch *b, int64_t *total_exons, double *coverage, int64_t *exon_offset, int32_t *exon_lr);
+
 /* raw packed path-record stream of the last download: 4-byte words, record = [graph, path index, #vertices, length, count,
  * strand | attempt<<8, weight f64, abd f64, conf f64, reads f64, vertices..., pad to even].  This is what ranks exchange
  * over RCCL for the final transcript gather (bench.py --gpus N). */

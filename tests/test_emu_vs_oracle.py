@@ -108,3 +108,13 @@ def test_staging_normalises_unsorted_input():
     ra, _, _ = common.emu_run(a)
     rb, _, _ = common.emu_run(b)
     assert not common.compare_results(ra, rb, a.n)
+
+
+def test_catch_all_class_large_graphs():
+    """graphs beyond the LDS classes (V > 512) run in the catch-all class whose hot state lives in the wave's slab"""
+    pg = A.synth(seed=99, n_graphs=2, v_min=700, v_max=900, edges_per_vertex=4)
+    want, st, _, _ = common.oracle_run(pg)
+    got, it, cl = common.emu_run(pg)
+    assert (cl == 5).all()
+    assert not common.compare_results(want, got, pg.n)
+    assert np.array_equal(it, st[:, 3])

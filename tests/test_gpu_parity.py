@@ -124,3 +124,31 @@ def test_full_size_properties():
     want = common.oracle_run(pg.select(np.arange(0, 300)))[0]
     got = A.decompose(pg.select(np.arange(0, 300)), 0)
     assert not common.compare_results(want, got, 300, conf_tol=1e-9)
+
+
+def test_transcripts_match_oracle():
+    """exon join + coverage = log(1 + weight) (scallop.cc:3250-3266, essential.cc:719-748) against the oracle's build_transcripts;
+    layout_mode=1 makes ~30% of consecutive vertices touch, so joins do happen"""
+    pg = A.synth(seed=44, n_graphs=120, v_min=8, v_max=80, edges_per_vertex=3, layout_mode=1, weight_mode=2, phasing_per_graph=4)
+    _, cov_o, eo_o, lr_o = common.oracle_transcripts(pg)
+    with A.DecompBatch(0) as b:
+        b.add(pg); b.upload(); b.run(); b.download()
+        cov, eo, lr = b.transcripts()
+        r = b.result()
+    assert np.array_equal(eo, eo_o) and np.array_equal(lr, lr_o)
+    assert np.array_equal(cov, cov_o)                       # host libm on both sides, bit-identical weights
+    assert (np.diff(eo) < np.diff(r.pv_offset) - 2).any()   # at least one path had touching exons joined
+
+
+def test_catch_all_class_on_gpu():
+    """V > 512: hot state in HBM (class 5); mixed with small graphs in the same batch (concurrent class streams)"""
+    big = A.synth(seed=99, n_graphs=3, v_min=900, v_max=1400, edges_per_vertex=4)
+    small = A.synth(seed=98, n_graphs=40, v_min=8, v_max=120, edges_per_vertex=3)
+    from aletsch_amd.packed import PackedGraphs
+    pg = PackedGraphs.concat([small, big])
+    want = common.oracle_run(pg)[0]
+    with A.DecompBatch(0) as b:
+        b.add(pg); b.upload(); b.run(); b.download()
+        got = b.result()
+        assert b.class_info(5)["n_graphs"] == 3
+    assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
