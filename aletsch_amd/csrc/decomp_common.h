@@ -116,23 +116,14 @@ struct ColdLayoutT {
     static constexpr uint32_t HL_CAP = 8u * MAXE;        // phasing-list pool (ints)
     static constexpr int32_t  HL_MAXLISTS = MAXE;
     static constexpr int32_t  W_CAP = 8 * MAXE;          // scalar work arrays (ints / doubles)
-    static constexpr uint64_t o_vw = 0;
-    static constexpr uint64_t o_lpos = al(o_vw + 8ull * MAXV);
-    static constexpr uint64_t o_rpos = al(o_lpos + 4ull * MAXV);
-    static constexpr uint64_t o_vtype = al(o_rpos + 4ull * MAXV);
-    static constexpr uint64_t o_v2v = al(o_vtype + 4ull * MAXV);
-    static constexpr uint64_t o_med = al(o_v2v + 4ull * MAXV);
-    static constexpr uint64_t o_eabd = al(o_med + 8ull * MAXE);
-    static constexpr uint64_t o_econf = al(o_eabd + 8ull * MAXE);
-    static constexpr uint64_t o_mei = al(o_econf + 8ull * MAXE);
-    static constexpr uint64_t o_ecount = al(o_mei + 4ull * MAXE);
-    static constexpr uint64_t o_estrand = al(o_ecount + 4ull * MAXE);
-    static constexpr uint64_t o_spoff = al(o_estrand + 1ull * MAXE);
-    static constexpr uint64_t o_splen = al(o_spoff + 4ull * MAXE);
-    static constexpr uint64_t o_s0id = al(o_splen + 4ull * MAXE);      // first supporting sample inline (single-sample edges never touch the pool)
-    static constexpr uint64_t o_s0abd = al(o_s0id + 4ull * MAXE);
-    static constexpr uint64_t o_mask = al(o_s0abd + 8ull * MAXE);
-    static constexpr uint64_t o_spid = al(o_mask + 8ull * MAXE * NW);
+    // per-vertex and per-edge-slot cold state are arrays of records (ColdVertex / ColdEdge in decomp_device.h): one merge
+    // touches the two or three records involved, i.e. two or three cache lines, instead of one line per field
+    static constexpr uint64_t VX_BYTES = 24;                                        // vw f64, lpos, rpos, vtype, v2v i32
+    static constexpr uint64_t ED_BYTES = (56 + 8ull * NW + 63) / 64 * 64;          // 4 f64 + mask[NW] + 5 i32 + strand, padded to whole lines
+    static constexpr uint64_t o_vx = 0;
+    static constexpr uint64_t o_ed = (o_vx + VX_BYTES * MAXV + 63) / 64 * 64;
+    static constexpr uint64_t o_mask = o_ed;                                        // (name kept for the next offset)
+    static constexpr uint64_t o_spid = al(o_ed + ED_BYTES * MAXE);
     static constexpr uint64_t o_spabd = al(o_spid + 4ull * SP_CAP);
     static constexpr uint64_t o_hl = al(o_spabd + 8ull * SP_CAP);
     static constexpr uint64_t o_hloff = al(o_hl + 4ull * HL_CAP);

@@ -17,6 +17,10 @@
 //                                   the algorithm on a CPU-only box.  Never part of the product library.
 #pragma once
 #include "decomp_common.h"
+#ifdef ALD_EMU
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 #ifndef ALD_CLASS_ID
 #error "compile with -DALD_CLASS_ID=<0..4> (one translation unit per size class)"
@@ -83,11 +87,18 @@ __shared__ Hot g_H;
 #endif
 
 // cold state: typed views at compile-time offsets of the slab
+struct ColdVertex { double vw; int32_t lpos, rpos, vtype, v2v; };                 // splice_graph::vwrt / vertex_info + scallop::v2v
+struct alignas(64) ColdEdge {
+    double   med, eabd, econf, s0abd;            // scallop::med, edge_info.abd / confidence, abundance of the first supporting sample
+    uint64_t mask[NW];                           // scallop::mev as a bitmask over ORIGINAL vertices
+    int32_t  mei, ecount, s0id;                  // scallop::mei, edge_info.count, id of the first (smallest-id) supporting sample
+    uint32_t sp_off, sp_len;                     // support list in the pool (edge_info.samples / spAbd)
+    uint8_t  estrand;                            // edge_info.strand
+};
+static_assert(sizeof(ColdVertex) == CL::VX_BYTES && sizeof(ColdEdge) == CL::ED_BYTES, "slab layout out of sync");
 struct Cold {
-    ALD_GLOBAL double *vw; ALD_GLOBAL int32_t *lpos, *rpos, *vtype, *v2v;
-    ALD_GLOBAL double *med, *eabd, *econf; ALD_GLOBAL int32_t *mei, *ecount; ALD_GLOBAL uint8_t *estrand; ALD_GLOBAL uint32_t *sp_off, *sp_len;
-    ALD_GLOBAL int32_t *s0id; ALD_GLOBAL double *s0abd;     // copy of the first (smallest-id) supporting sample
-    ALD_GLOBAL uint64_t *mask;                  // [MAXE*NW] bitmask over ORIGINAL vertices (scallop::mev as a set)
+    ALD_GLOBAL ColdVertex *vx;
+    ALD_GLOBAL ColdEdge *ed;
     ALD_GLOBAL int32_t *sp_id; ALD_GLOBAL double *sp_abd;
     ALD_GLOBAL int32_t *hl, *hl_off, *hl_len, *hl_capk, *hl_cnt;   // phasing lists (hyper_set::edges / ecnts); elements are edge SLOTS or -1
     ALD_GLOBAL int32_t *wi; ALD_GLOBAL double *wd;                 // scalar work arrays
@@ -97,11 +108,7 @@ struct Cold {
 ALD_INL Cold cold_view()
 {
     ALD_GLOBAL uint8_t *b = H.cold; Cold C;
-    C.vw = (ALD_GLOBAL double*)(b + CL::o_vw); C.lpos = (ALD_GLOBAL int32_t*)(b + CL::o_lpos); C.rpos = (ALD_GLOBAL int32_t*)(b + CL::o_rpos);
-    C.vtype = (ALD_GLOBAL int32_t*)(b + CL::o_vtype); C.v2v = (ALD_GLOBAL int32_t*)(b + CL::o_v2v);
-    C.med = (ALD_GLOBAL double*)(b + CL::o_med); C.eabd = (ALD_GLOBAL double*)(b + CL::o_eabd); C.econf = (ALD_GLOBAL double*)(b + CL::o_econf);
-    C.mei = (ALD_GLOBAL int32_t*)(b + CL::o_mei); C.ecount = (ALD_GLOBAL int32_t*)(b + CL::o_ecount); C.estrand = (ALD_GLOBAL uint8_t*)(b + CL::o_estrand);
-    C.sp_off = (ALD_GLOBAL uint32_t*)(b + CL::o_spoff); C.sp_len = (ALD_GLOBAL uint32_t*)(b + CL::o_splen); C.s0id = (ALD_GLOBAL int32_t*)(b + CL::o_s0id); C.s0abd = (ALD_GLOBAL double*)(b + CL::o_s0abd); C.mask = (ALD_GLOBAL uint64_t*)(b + CL::o_mask);
+    C.vx = (ALD_GLOBAL ColdVertex*)(b + CL::o_vx); C.ed = (ALD_GLOBAL ColdEdge*)(b + CL::o_ed);
     C.sp_id = (ALD_GLOBAL int32_t*)(b + CL::o_spid); C.sp_abd = (ALD_GLOBAL double*)(b + CL::o_spabd);
     C.hl = (ALD_GLOBAL int32_t*)(b + CL::o_hl); C.hl_off = (ALD_GLOBAL int32_t*)(b + CL::o_hloff); C.hl_len = (ALD_GLOBAL int32_t*)(b + CL::o_hllen);
     C.hl_capk = (ALD_GLOBAL int32_t*)(b + CL::o_hlcapk); C.hl_cnt = (ALD_GLOBAL int32_t*)(b + CL::o_hlcnt);
@@ -125,7 +132,14 @@ enum { PF_LOAD = 0, PF_BROKEN, PF_TRIV_EVAL, PF_TRIV_MUT, PF_SMALL_EVAL, PF_SMAL
        PF_T_BALANCE, PF_T_PAIRS, PF_T_SETUP, PF_T_MERGE_LOAD, PF_T_MERGE_ADD, PF_T_MERGE_ISECT, PF_T_MERGE_MASK, PF_T_MERGE_SUMS, PF_T_MERGE_KILL, PF_T_HS, PF_T_TAIL, PF_COUNT };
 
 // ---------------------------------------------------------------- small helpers
-ALD_INL void fail(int st) { if(H.status == 0) H.status = st; }
+ALD_INL void fail_(int st, int line)
+{
+#ifdef ALD_EMU
+    if(H.status == 0 && getenv("ALD_EMU_VERBOSE")) fprintf(stderr, "[emu] graph %d: status %d raised at decomp_device.h:%d\n", H.g, st, line);
+#endif
+    if(H.status == 0) H.status = st;
+}
+#define fail(st) fail_((st), __LINE__)
 ALD_FN void trace(int code, int a, int b, double v)
 {
     H.n_iters++;
@@ -245,8 +259,8 @@ ALD_INL void strand_degree(int v, int vs[6])
 {
     COLD;
     for(int k = 0; k < 6; k++) vs[k] = 0;
-    for(int e = first_in(v); e >= 0; e = next_in(e)) vs[C.estrand[e]]++;
-    for(int e = first_out(v); e >= 0; e = next_out(e)) vs[C.estrand[e] + 3]++;
+    for(int e = first_in(v); e >= 0; e = next_in(e)) vs[C.ed[e].estrand]++;
+    for(int e = first_out(v); e >= 0; e = next_out(e)) vs[C.ed[e].estrand + 3]++;
 }
 ALD_INL bool mixed_strand_vertex(int v)
 {
@@ -254,26 +268,26 @@ ALD_INL bool mixed_strand_vertex(int v)
     int vs[6]; strand_degree(v, vs);
     return (vs[1] + vs[4] >= 1) && (vs[2] + vs[5] >= 1);
 }
-ALD_INL void borrow_edge_strand(const Cold &C, int e1, int e2) { int s2 = C.estrand[e2]; if(s2 == 0) return; C.estrand[e1] = (uint8_t)s2; }   // scallop.cc:1997-2007
+ALD_INL void borrow_edge_strand(const Cold &C, int e1, int e2) { int s2 = C.ed[e2].estrand; if(s2 == 0) return; C.ed[e1].estrand = (uint8_t)s2; }   // scallop.cc:1997-2007
 
 // ---------------------------------------------------------------- sample support (edge_info.samples / spAbd)
 // intersection with per-sample min, abd = sum in ascending sample order (scallop.cc:2300-2318, 1915-1933)
 ALD_FN bool intersect_samples(int e1, int e2, int z)
 {
     COLD;
-    uint32_t n1 = uni(C.sp_len[e1]), n2 = uni(C.sp_len[e2]);
+    uint32_t n1 = uni(C.ed[e1].sp_len), n2 = uni(C.ed[e2].sp_len);
     if(n1 == 1 && n2 == 1) {                     // single-sample edges: everything needed is inline, no pool round trip
-        int a = uni(C.s0id[e1]), b = uni(C.s0id[e2]); double x = uni(C.s0abd[e1]), y = uni(C.s0abd[e2]);
+        int a = uni(C.ed[e1].s0id), b = uni(C.ed[e2].s0id); double x = uni(C.ed[e1].s0abd), y = uni(C.ed[e2].s0abd);
         if(a == b) {
             uint32_t o = H.sp_used;
             if(o + 1 > C.sp_cap) { fail(ALD_ST_CAPACITY); return false; }
             double c = (y < x) ? y : x;
             C.sp_id[o] = a; C.sp_abd[o] = c; H.sp_used = o + 1;
-            C.sp_off[z] = o; C.sp_len[z] = 1; C.ecount[z] = 1; C.eabd[z] = 0.0 + c; C.s0id[z] = a; C.s0abd[z] = c;
-        } else { C.sp_off[z] = H.sp_used; C.sp_len[z] = 0; C.ecount[z] = 0; C.eabd[z] = 0; C.s0id[z] = 0; C.s0abd[z] = 0; }
+            C.ed[z].sp_off = o; C.ed[z].sp_len = 1; C.ed[z].ecount = 1; C.ed[z].eabd = 0.0 + c; C.ed[z].s0id = a; C.ed[z].s0abd = c;
+        } else { C.ed[z].sp_off = H.sp_used; C.ed[z].sp_len = 0; C.ed[z].ecount = 0; C.ed[z].eabd = 0; C.ed[z].s0id = 0; C.ed[z].s0abd = 0; }
         return true;
     }
-    uint32_t o1 = uni(C.sp_off[e1]), o2 = uni(C.sp_off[e2]);
+    uint32_t o1 = uni(C.ed[e1].sp_off), o2 = uni(C.ed[e2].sp_off);
     uint32_t need = n1 < n2 ? n1 : n2;
     uint32_t o = H.sp_used;
     if(o + need > C.sp_cap) { fail(ALD_ST_CAPACITY); return false; }
@@ -285,15 +299,15 @@ ALD_FN bool intersect_samples(int e1, int e2, int z)
                C.sp_id[o + k] = a; C.sp_abd[o + k] = c; abd += c; k++; i++; j++; }
     }
     H.sp_used = o + k;
-    C.sp_off[z] = o; C.sp_len[z] = k; C.ecount[z] = (int32_t)k; C.eabd[z] = abd;
-    if(k > 0) { C.s0id[z] = uni(C.sp_id[o]); C.s0abd[z] = uni(C.sp_abd[o]); } else { C.s0id[z] = 0; C.s0abd[z] = 0; }
+    C.ed[z].sp_off = o; C.ed[z].sp_len = k; C.ed[z].ecount = (int32_t)k; C.ed[z].eabd = abd;
+    if(k > 0) { C.ed[z].s0id = uni(C.sp_id[o]); C.ed[z].s0abd = uni(C.sp_abd[o]); } else { C.ed[z].s0id = 0; C.ed[z].s0abd = 0; }
     return true;
 }
 // router.cc:1035-1038: sum over common samples of 0.99*min + 0.01*max
 ALD_FN double common_abd(int e1, int e2)
 {
     COLD;
-    uint32_t o1 = uni(C.sp_off[e1]), n1 = uni(C.sp_len[e1]), o2 = uni(C.sp_off[e2]), n2 = uni(C.sp_len[e2]);
+    uint32_t o1 = uni(C.ed[e1].sp_off), n1 = uni(C.ed[e1].sp_len), o2 = uni(C.ed[e2].sp_off), n2 = uni(C.ed[e2].sp_len);
     uint32_t i = 0, j = 0; double c = 0;
     while(i < n1 && j < n2) {
         int a = uni(C.sp_id[o1 + i]), b = uni(C.sp_id[o2 + j]);
@@ -419,10 +433,10 @@ ALD_FN int split_edge(int ei, double w)
     double mw = H.p_min_w;
     if(www <= mw) www = mw;
     H.ew[ei] = www; H.ew[p2] = w;
-    C.estrand[p2] = uni(C.estrand[ei]); C.ecount[p2] = uni(C.ecount[ei]); C.eabd[p2] = uni(C.eabd[ei]); C.econf[p2] = uni(C.econf[ei]);
-    C.sp_off[p2] = uni(C.sp_off[ei]); C.sp_len[p2] = uni(C.sp_len[ei]); C.s0id[p2] = uni(C.s0id[ei]); C.s0abd[p2] = uni(C.s0abd[ei]);   // immutable support lists are shared
-    for(int k = 0; k < NW; k++) C.mask[(int64_t)p2 * NW + k] = uni(C.mask[(int64_t)ei * NW + k]);
-    C.mei[p2] = uni(C.mei[ei]); C.med[p2] = uni(C.med[ei]) * w / ww;
+    C.ed[p2].estrand = uni(C.ed[ei].estrand); C.ed[p2].ecount = uni(C.ed[ei].ecount); C.ed[p2].eabd = uni(C.ed[ei].eabd); C.ed[p2].econf = uni(C.ed[ei].econf);
+    C.ed[p2].sp_off = uni(C.ed[ei].sp_off); C.ed[p2].sp_len = uni(C.ed[ei].sp_len); C.ed[p2].s0id = uni(C.ed[ei].s0id); C.ed[p2].s0abd = uni(C.ed[ei].s0abd);   // immutable support lists are shared
+    for(int k = 0; k < NW; k++) C.ed[p2].mask[k] = uni(C.ed[ei].mask[k]);
+    C.ed[p2].mei = uni(C.ed[ei].mei); C.ed[p2].med = uni(C.ed[ei].med) * w / ww;
     return p2;
 }
 // scallop::merge_adjacent_edges(x, y, ww) (scallop.cc:2394-2416) = split_edge(x, ww) + split_edge(y, ww) (scallop.cc:2433-2484)
@@ -442,9 +456,9 @@ ALD_FN int merge_adjacent_edges(int x, int y, double ww)
     const double wx = uni(H.ew[x]), wy = uni(H.ew[y]);
     const bool sx = !(fabs(wx - ww) <= kSMIN), sy = !(fabs(wy - ww) <= kSMIN);     // does split_edge cut a piece off?
     // cold state of the originals (one round of independent loads)
-    const double medx = uni(C.med[x]), medy = uni(C.med[y]), cx = uni(C.econf[x]), cy = uni(C.econf[y]), vwt = uni(C.vw[xt]);
-    const int meix = uni(C.mei[x]), meiy = uni(C.mei[y]), cntx = uni(C.ecount[x]), cnty = uni(C.ecount[y]), lt = uni(C.lpos[xt]), rt = uni(C.rpos[xt]), ov = uni(C.v2v[xt]);
-    const int stx = uni(C.estrand[x]), sty = uni(C.estrand[y]);
+    const double medx = uni(C.ed[x].med), medy = uni(C.ed[y].med), cx = uni(C.ed[x].econf), cy = uni(C.ed[y].econf), vwt = uni(C.vx[xt].vw);
+    const int meix = uni(C.ed[x].mei), meiy = uni(C.ed[y].mei), cntx = uni(C.ed[x].ecount), cnty = uni(C.ed[y].ecount), lt = uni(C.vx[xt].lpos), rt = uni(C.vx[xt].rpos), ov = uni(C.vx[xt].v2v);
+    const int stx = uni(C.ed[x].estrand), sty = uni(C.ed[y].estrand);
     // split_edge(x, ww), split_edge(y, ww): a piece of weight ww gets the next id, the original keeps max(w - ww, min_w)
     if(uni(H.next_id) >= 0xFFF0) { fail(ALD_ST_CAPACITY); return -1; }
     if(sx) { H.next_id++; double r = wx - ww; if(r <= mw) r = mw; H.ew[x] = r; }
@@ -461,10 +475,10 @@ ALD_FN int merge_adjacent_edges(int x, int y, double ww)
     if(!(cntx > 0 && cnty > 0)) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return -1; }
     if(!intersect_samples(x, y, n)) return -1;
     PROF_ADD(PF_T_MERGE_ISECT);
-    C.econf[n] = cx + cy;
-    C.estrand[n] = (uint8_t)(sty != 0 ? sty : stx);                     // borrow_edge_strand(n, x) then (n, y): a non-zero strand of y wins
-    for(int k = 0; k < NW; k++) C.mask[(int64_t)n * NW + k] = uni(C.mask[(int64_t)x * NW + k]) | uni(C.mask[(int64_t)y * NW + k]);
-    if(ov >= 0) C.mask[(int64_t)n * NW + (ov >> 6)] |= (1ull << (ov & 63));
+    C.ed[n].econf = cx + cy;
+    C.ed[n].estrand = (uint8_t)(sty != 0 ? sty : stx);                     // borrow_edge_strand(n, x) then (n, y): a non-zero strand of y wins
+    for(int k = 0; k < NW; k++) C.ed[n].mask[k] = uni(C.ed[x].mask[k]) | uni(C.ed[y].mask[k]);
+    if(ov >= 0) C.ed[n].mask[(ov >> 6)] |= (1ull << (ov & 63));
     // get_in_weights(xt) / get_out_weights(xt) while both pieces are still attached: a piece sorts behind every edge with the
     // same far endpoint (its id is the newest), before the first edge with a larger one
     PROF_ADD(PF_T_MERGE_MASK);
@@ -473,9 +487,9 @@ ALD_FN int merge_adjacent_edges(int x, int y, double ww)
     { bool ins = !sy; for(int e = u_first_out(xt); e >= 0; e = u_next_out(e)) { if(!ins && tkey(H.lk[e].et) > tkey(yt)) { sum2 += ww; ins = true; } sum2 += uni(H.ew[e]); } if(!ins) sum2 += ww; }
     const double sum = (sum1 + sum2) * 0.5;
     const double r1 = vwt * (wx0 + wy0) * 0.5 / sum;
-    C.vw[xt] = vwt - r1;
+    C.vx[xt].vw = vwt - r1;
     const int mi = rt - lt + meix + meiy;
-    C.med[n] = mi * r1 + medx1 + medy1; C.mei[n] = mi;
+    C.ed[n].med = mi * r1 + medx1 + medy1; C.ed[n].mei = mi;
     // the pieces disappear; an edge that was not cut IS the piece
     PROF_ADD(PF_T_MERGE_SUMS);
     if(!sx) kill_edge(x);
@@ -573,6 +587,10 @@ ALD_FN void decompose_vertex_replace(int root, int n)
         int e1 = PSLOT(a[i]), e2 = PSLOT(b[i]);
         int m1 = mdeg[PLOC(a[i])], m2 = mdeg[PLOC(b[i])];
         if(free_slots() < 1) { fail(ALD_ST_CAPACITY); return; }
+        // an edge that takes part in this pair only has every phasing occurrence replaced right below (hs_replace1), so the
+        // final hs.remove on it is a no-op in the reference: its slot need not stay parked until the end of the decomposition
+        if(m1 == 1) H.hflag[e1] &= (uint8_t)~HF_PROT;
+        if(m2 == 1) H.hflag[e2] &= (uint8_t)~HF_PROT;
         PROF_RESET();
         int e = merge_adjacent_edges(e1, e2, w[i]);
         PROF_RESET();
@@ -582,7 +600,7 @@ ALD_FN void decompose_vertex_replace(int root, int n)
         if(m2 == 1) hs_replace1(e2, e);
         PROF_ADD(PF_T_HS);
     }
-    for(int i = 0; i < nloc; i++) hs_remove(loc_e[i]);
+    for(int i = 0; i < nloc; i++) if(mdeg[i] >= 2) hs_remove(loc_e[i]);      // single-pair edges were fully replaced above (their slots may already be reused)
     flush_pending();
     PROF_ADD(PF_T_TAIL);
     if(H.in_deg[root] != 0 || uni(H.out_deg[root]) != 0) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }
@@ -638,8 +656,8 @@ ALD_FN void decompose_vertex_extend(int root, int n)
         if(mdeg[u2] == 0) mweight[u2] = w[i]; else mweight[u2] += w[i];
         mdeg[u1]++; mdeg[u2]++;
     }
-    int rlen = uni(C.rpos[root]) - uni(C.lpos[root]);
-    double vertex_weight = uni(C.vw[root]) * rlen;
+    int rlen = uni(C.vx[root].rpos) - uni(C.vx[root].lpos);
+    double vertex_weight = uni(C.vx[root].vw) * rlen;
     for(int i = 0; i < nloc; i++) mweight[i] = mweight[i] / total_weight * vertex_weight;
     // new vertices (scallop.cc:1753-1806) are appended at the end of the physical index space; the reference gives them the
     // indices m.. and moves the sink behind them -- same relative order, no edge has to move here
@@ -648,43 +666,43 @@ ALD_FN void decompose_vertex_extend(int root, int n)
     int newedges = 0;
     for(int i = 0; i < n; i++) { int u1 = PLOC(a[i]), u2 = PLOC(b[i]); if(mdeg[u1] == 1 && mdeg[u2] == 1) evx[u1] = nn++; else if(mdeg[u1] >= 2 && mdeg[u2] >= 2) newedges++; }
     if(nn > MAXV || free_slots() < newedges) { fail(ALD_ST_CAPACITY); return; }
-    for(int i = m; i < nn; i++) { H.in_head[i] = NIL; H.out_head[i] = NIL; H.in_deg[i] = 0; H.out_deg[i] = 0; H.nz[i] = 1; C.vw[i] = 0; C.lpos[i] = 0; C.rpos[i] = 0; C.vtype[i] = -1; C.v2v[i] = -1; }
+    for(int i = m; i < nn; i++) { H.in_head[i] = NIL; H.out_head[i] = NIL; H.in_deg[i] = 0; H.out_deg[i] = 0; H.nz[i] = 1; C.vx[i].vw = 0; C.vx[i].lpos = 0; C.vx[i].rpos = 0; C.vx[i].vtype = -1; C.vx[i].v2v = -1; }
     H.nv = nn;
     for(int i = 0; i < nin; i++) {               // ev1: detach in-edges onto their new vertex
         int k = evx[i]; if(k < 0) continue; int e = loc_e[i];
-        int p = uni(C.rpos[uni(H.lk[e].es)]);
-        move_edge(e, uni(H.lk[e].es), k); C.lpos[k] = p; C.rpos[k] = p; C.vtype[k] = -1; C.vw[k] = 0; C.v2v[k] = -2;
+        int p = uni(C.vx[uni(H.lk[e].es)].rpos);
+        move_edge(e, uni(H.lk[e].es), k); C.vx[k].lpos = p; C.vx[k].rpos = p; C.vx[k].vtype = -1; C.vx[k].vw = 0; C.vx[k].v2v = -2;
     }
     for(int i = nin; i < nloc; i++) {            // ev2
         int k = evx[i]; if(k < 0) continue; int e = loc_e[i];
-        int p = uni(C.lpos[uni(H.lk[e].et)]);
-        move_edge(e, k, uni(H.lk[e].et)); C.lpos[k] = p; C.rpos[k] = p; C.vtype[k] = -1; C.vw[k] = 0; C.v2v[k] = -2;
+        int p = uni(C.vx[uni(H.lk[e].et)].lpos);
+        move_edge(e, k, uni(H.lk[e].et)); C.vx[k].lpos = p; C.vx[k].rpos = p; C.vx[k].vtype = -1; C.vx[k].vw = 0; C.vx[k].v2v = -2;
     }
-    int rv = uni(C.v2v[root]);
+    int rv = uni(C.vx[root].v2v);
     for(int i = 0; i < n; i++) {
         int e1 = PSLOT(a[i]), e2 = PSLOT(b[i]); int u1 = PLOC(a[i]), u2 = PLOC(b[i]); double ww = w[i];
         if(mdeg[u1] == 1 && mdeg[u2] >= 2) {
             borrow_edge_strand(C, e1, e2);
             move_edge(e1, uni(H.lk[e1].es), evx[u2]);
-            if(rv >= 0) C.mask[(int64_t)e1 * NW + (rv >> 6)] |= (1ull << (rv & 63));
-            C.med[e1] += mweight[u1]; C.mei[e1] += rlen;
+            if(rv >= 0) C.ed[e1].mask[(rv >> 6)] |= (1ull << (rv & 63));
+            C.ed[e1].med += mweight[u1]; C.ed[e1].mei += rlen;
         } else if(mdeg[u2] == 1) {
             if(evx[u1] < 0) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
             borrow_edge_strand(C, e2, e1);
             move_edge(e2, evx[u1], uni(H.lk[e2].et));
-            if(rv >= 0) C.mask[(int64_t)e2 * NW + (rv >> 6)] |= (1ull << (rv & 63));
-            C.med[e2] += mweight[u2]; C.mei[e2] += rlen;
+            if(rv >= 0) C.ed[e2].mask[(rv >> 6)] |= (1ull << (rv & 63));
+            C.ed[e2].med += mweight[u2]; C.ed[e2].mei += rlen;
         } else {
             int z = add_edge(evx[u1], evx[u2]);
             if(z < 0) return;
             H.ew[z] = ww;
-            if(!(C.ecount[e1] > 0 && uni(C.ecount[e2]) > 0)) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
+            if(!(C.ed[e1].ecount > 0 && uni(C.ed[e2].ecount) > 0)) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
             if(!intersect_samples(e1, e2, z)) return;
-            if(C.ecount[z] <= 0) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
-            C.econf[z] = 0; C.estrand[z] = 0;
-            for(int k = 0; k < NW; k++) C.mask[(int64_t)z * NW + k] = 0;
-            if(rv >= 0) C.mask[(int64_t)z * NW + (rv >> 6)] |= (1ull << (rv & 63));
-            C.med[z] = ww / total_weight * vertex_weight; C.mei[z] = rlen;
+            if(C.ed[z].ecount <= 0) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
+            C.ed[z].econf = 0; C.ed[z].estrand = 0;
+            for(int k = 0; k < NW; k++) C.ed[z].mask[k] = 0;
+            if(rv >= 0) C.ed[z].mask[(rv >> 6)] |= (1ull << (rv & 63));
+            C.ed[z].med = ww / total_weight * vertex_weight; C.ed[z].mei = rlen;
             borrow_edge_strand(C, z, e1); borrow_edge_strand(C, z, e2);
             hs_insert_between(e1, e2, z);
             if(H.status) return;
@@ -771,7 +789,7 @@ ALD_INL int eval_smallest(int i, double &r)
     if(s == i && (f & HF_LEXT)) return -1;
     if(H.any_strand) {
         COLD;
-        int z = C.estrand[e];
+        int z = C.ed[e].estrand;
         if(z >= 1) { int vs[6]; strand_degree(i, vs); if(s == i && vs[0] + vs[z] <= 1) return -1; if(t == i && vs[3] + vs[z + 3] <= 1) return -1; }
     }
     return e;
@@ -1006,8 +1024,8 @@ ALD_FN bool router_run(int root, int want_type, int max_degree)
     // Per-node support is fetched once (one round of independent loads); single-sample pairs are then pure arithmetic.
     int32_t *ncnt = comp, *nsid = queue;         // comp / queue are not needed before classify: reuse them as (count, first sample id)
     double *nabd = AR.d + 2 * n + maxue;         // [n] abundance of the first sample
-    for(int v = 0; v < n; v++) { int e = u2e[v]; ncnt[v] = (int32_t)uni(C.sp_len[e]); nsid[v] = uni(C.s0id[e]); nabd[v] = uni(C.s0abd[e]); }
-    for(int v = 0; v < n; v++) iso[v] = (C.ecount[u2e[v]] == 0) ? 2 : 0;      // 2 = "Warning!(count = 0)": not in left / right
+    for(int v = 0; v < n; v++) { int e = u2e[v]; ncnt[v] = (int32_t)uni(C.ed[e].sp_len); nsid[v] = uni(C.ed[e].s0id); nabd[v] = uni(C.ed[e].s0abd); }
+    for(int v = 0; v < n; v++) iso[v] = (C.ed[u2e[v]].ecount == 0) ? 2 : 0;      // 2 = "Warning!(count = 0)": not in left / right
 #define ALD_COMMON(l, r) ((ncnt[l] == 1 && ncnt[r] == 1) ? ((nsid[l] == nsid[r]) ? (0.0 + (0.99 * ((nabd[r] < nabd[l]) ? nabd[r] : nabd[l]) + 0.01 * ((nabd[l] < nabd[r]) ? nabd[r] : nabd[l]))) : 0.0) : common_abd(u2e[l], u2e[r]))
     for(int v = 0; v < nin; v++) {
         if(iso[v] == 2) continue;
@@ -1109,7 +1127,7 @@ ALD_FN bool router_run(int root, int want_type, int max_degree)
     double weight_remain = 0;
     for(int i = 0; i < n; i++) { if(vw[i] <= 0) continue; weight_remain += vw[i]; }
     H.ro_ratio = weight_remain / weight_sum;
-    for(int i = 0; i < n; i++) if(iso[i] == 1) C.econf[u2e[i]] += econf[i];     // router.cc:849-855: side effect of every build()
+    for(int i = 0; i < n; i++) if(iso[i] == 1) C.ed[u2e[i]].econf += econf[i];     // router.cc:849-855: side effect of every build()
     sort_pairs(np);
     const double mw = H.p_min_w;
     for(int i = 0; i < np; i++) if(pwt[i] < mw) pwt[i] = mw;                // router.cc:217-220
@@ -1190,9 +1208,9 @@ ALD_FN void collect_path(int e)
     ALD_GLOBAL const KernelArgs *A = H.args;
     int n = H.V0 - 1;                           // v2v[sink]: the sink's original index
     int cnt = 0, mi = 0; bool empty = false;
-    for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.mask[(int64_t)e * NW + k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; cnt++; mi += uni(C.rpos[x]) - uni(C.lpos[x]); if(C.vtype[x] == K_EMPTY_VERTEX) empty = true; } }
-    if(C.mei[e] != mi || cnt == 0) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
-    if(C.vtype[0] == K_EMPTY_VERTEX || uni(C.vtype[n]) == K_EMPTY_VERTEX) empty = true;
+    for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.ed[e].mask[k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; cnt++; mi += uni(C.vx[x].rpos) - uni(C.vx[x].lpos); if(C.vx[x].vtype == K_EMPTY_VERTEX) empty = true; } }
+    if(C.ed[e].mei != mi || cnt == 0) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
+    if(C.vx[0].vtype == K_EMPTY_VERTEX || uni(C.vx[n].vtype) == K_EMPTY_VERTEX) empty = true;
     if(!empty) {
         int nvp = cnt + 2;
         unsigned long long words = (unsigned long long)(REC_HDR_WORDS + nvp + ((REC_HDR_WORDS + nvp) & 1));
@@ -1200,15 +1218,15 @@ ALD_FN void collect_path(int e)
         if(o + words > A->out.pool_cap) { fail(ALD_ST_CAPACITY); return; }
         ALD_GLOBAL uint32_t *r = A->out.pool + o;
         int st = '.';
-        if(C.estrand[e] == 1) st = '+';
-        if(C.estrand[e] == 2) st = '-';
+        if(C.ed[e].estrand == 1) st = '+';
+        if(C.ed[e].estrand == 2) st = '-';
         if(st == '.') st = H.gstrand;
-        r[0] = (uint32_t)H.g; r[1] = (uint32_t)H.n_paths; r[2] = (uint32_t)nvp; r[3] = (uint32_t)mi; r[4] = (uint32_t)uni(C.ecount[e]); r[5] = (uint32_t)st | ((uint32_t)(A->attempt & 0xFF) << 8);
+        r[0] = (uint32_t)H.g; r[1] = (uint32_t)H.n_paths; r[2] = (uint32_t)nvp; r[3] = (uint32_t)mi; r[4] = (uint32_t)uni(C.ed[e].ecount); r[5] = (uint32_t)st | ((uint32_t)(A->attempt & 0xFF) << 8);
         ALD_GLOBAL double *d = (ALD_GLOBAL double*)(r + 6);
-        d[0] = uni(H.ew[e]); d[1] = uni(C.eabd[e]); d[2] = exp(C.econf[e]); d[3] = uni(C.med[e]);
+        d[0] = uni(H.ew[e]); d[1] = uni(C.ed[e].eabd); d[2] = exp(C.ed[e].econf); d[3] = uni(C.ed[e].med);
         ALD_GLOBAL uint32_t *pv = r + REC_HDR_WORDS; int w = 0;
         pv[w++] = 0;
-        for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.mask[(int64_t)e * NW + k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; pv[w++] = (uint32_t)(k * 64 + b); } }
+        for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.ed[e].mask[k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; pv[w++] = (uint32_t)(k * 64 + b); } }
         pv[w++] = (uint32_t)n;
         if((REC_HDR_WORDS + nvp) & 1) pv[w] = 0;
         if(tracing()) { int save = H.n_iters; trace(OP_COLLECT, (int)uni(H.eid[e]), nvp, uni(H.ew[e])); H.n_iters = save; }
@@ -1346,18 +1364,18 @@ ALD_FN bool load_graph()
         H.nz[i] = (i >= 1 && i < V - 1 && (o1 - o0) + (i1 - i0) > 0) ? 1 : 0;
         for(int k = o0; k < o1; k++) { H.lk[k].es = (IDX)i; H.lk[k].onx = (k + 1 < o1) ? (IDX)(k + 1) : NIL; }
         for(int k = i0; k < i1; k++) { H.lk[ie[k]].inx = (k + 1 < i1) ? (IDX)ie[k + 1] : NIL; }
-        C.vw[i] = A->in.vertex_weight[ov + i]; C.lpos[i] = A->in.vertex_lpos[ov + i]; C.rpos[i] = A->in.vertex_rpos[ov + i];
-        C.vtype[i] = A->in.vertex_type[ov + i]; C.v2v[i] = i;
+        C.vx[i].vw = A->in.vertex_weight[ov + i]; C.vx[i].lpos = A->in.vertex_lpos[ov + i]; C.vx[i].rpos = A->in.vertex_rpos[ov + i];
+        C.vx[i].vtype = A->in.vertex_type[ov + i]; C.vx[i].v2v = i;
     }
     bool strand = false;
     ALD_GLOBAL const int32_t *so = A->in.edge_sample_offset + oeo;
     for(int k = lane; k < E; k += ALD_WAVE) {
         H.lk[k].et = (IDX)A->in.edge_target[oe + k]; H.ew[k] = A->in.edge_weight[oe + k]; H.eid[k] = (uint16_t)k; H.hflag[k] = 0;
-        uint8_t st = A->in.edge_strand[oe + k]; C.estrand[k] = st; if(st) strand = true;
-        C.med[k] = 0; C.mei[k] = 0; C.econf[k] = 0; C.eabd[k] = A->in.edge_abd[oe + k];
-        C.sp_off[k] = (uint32_t)so[k]; C.sp_len[k] = (uint32_t)(so[k + 1] - so[k]); C.ecount[k] = so[k + 1] - so[k];
-        if(so[k + 1] > so[k]) { C.s0id[k] = A->in.sample_id[os + so[k]]; C.s0abd[k] = A->in.sample_abd[os + so[k]]; } else { C.s0id[k] = 0; C.s0abd[k] = 0; }
-        for(int q = 0; q < NW; q++) C.mask[(int64_t)k * NW + q] = 0;
+        uint8_t st = A->in.edge_strand[oe + k]; C.ed[k].estrand = st; if(st) strand = true;
+        C.ed[k].med = 0; C.ed[k].mei = 0; C.ed[k].econf = 0; C.ed[k].eabd = A->in.edge_abd[oe + k];
+        C.ed[k].sp_off = (uint32_t)so[k]; C.ed[k].sp_len = (uint32_t)(so[k + 1] - so[k]); C.ed[k].ecount = so[k + 1] - so[k];
+        if(so[k + 1] > so[k]) { C.ed[k].s0id = A->in.sample_id[os + so[k]]; C.ed[k].s0abd = A->in.sample_abd[os + so[k]]; } else { C.ed[k].s0id = 0; C.ed[k].s0abd = 0; }
+        for(int q = 0; q < NW; q++) C.ed[k].mask[q] = 0;
     }
     for(int64_t k = lane; k < ns; k += ALD_WAVE) { C.sp_id[k] = A->in.sample_id[os + k]; C.sp_abd[k] = A->in.sample_abd[os + k]; }
     uint64_t sb = wballot(strand);
