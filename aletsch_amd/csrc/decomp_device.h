@@ -272,47 +272,45 @@ ALD_INL void borrow_edge_strand(const Cold &C, int e1, int e2) { int s2 = C.ed[e
 
 // ---------------------------------------------------------------- sample support (edge_info.samples / spAbd)
 // intersection with per-sample min, abd = sum in ascending sample order (scallop.cc:2300-2318, 1915-1933)
+// Support lists: a list of ONE sample lives inline in the edge record (s0id / s0abd) and never touches the pool; longer lists
+// live in the pool at [sp_off, sp_off + sp_len).
 ALD_FN bool intersect_samples(int e1, int e2, int z)
 {
     COLD;
-    uint32_t n1 = uni(C.ed[e1].sp_len), n2 = uni(C.ed[e2].sp_len);
-    if(n1 == 1 && n2 == 1) {                     // single-sample edges: everything needed is inline, no pool round trip
+    const uint32_t n1 = uni(C.ed[e1].sp_len), n2 = uni(C.ed[e2].sp_len);
+    if(n1 == 1 && n2 == 1) {                     // single-sample edges: everything is inline, no pool traffic at all
         int a = uni(C.ed[e1].s0id), b = uni(C.ed[e2].s0id); double x = uni(C.ed[e1].s0abd), y = uni(C.ed[e2].s0abd);
-        if(a == b) {
-            uint32_t o = H.sp_used;
-            if(o + 1 > C.sp_cap) { fail(ALD_ST_CAPACITY); return false; }
-            double c = (y < x) ? y : x;
-            C.sp_id[o] = a; C.sp_abd[o] = c; H.sp_used = o + 1;
-            C.ed[z].sp_off = o; C.ed[z].sp_len = 1; C.ed[z].ecount = 1; C.ed[z].eabd = 0.0 + c; C.ed[z].s0id = a; C.ed[z].s0abd = c;
-        } else { C.ed[z].sp_off = H.sp_used; C.ed[z].sp_len = 0; C.ed[z].ecount = 0; C.ed[z].eabd = 0; C.ed[z].s0id = 0; C.ed[z].s0abd = 0; }
+        if(a == b) { double c = (y < x) ? y : x; C.ed[z].sp_off = 0; C.ed[z].sp_len = 1; C.ed[z].ecount = 1; C.ed[z].eabd = 0.0 + c; C.ed[z].s0id = a; C.ed[z].s0abd = c; }
+        else { C.ed[z].sp_off = 0; C.ed[z].sp_len = 0; C.ed[z].ecount = 0; C.ed[z].eabd = 0; C.ed[z].s0id = 0; C.ed[z].s0abd = 0; }
         return true;
     }
-    uint32_t o1 = uni(C.ed[e1].sp_off), o2 = uni(C.ed[e2].sp_off);
-    uint32_t need = n1 < n2 ? n1 : n2;
-    uint32_t o = H.sp_used;
+    const uint32_t o1 = uni(C.ed[e1].sp_off), o2 = uni(C.ed[e2].sp_off);
+    const int i1 = uni(C.ed[e1].s0id), i2 = uni(C.ed[e2].s0id); const double a1 = uni(C.ed[e1].s0abd), a2 = uni(C.ed[e2].s0abd);
+    const uint32_t need = n1 < n2 ? n1 : n2;
+    const uint32_t o = H.sp_used;
     if(o + need > C.sp_cap) { fail(ALD_ST_CAPACITY); return false; }
-    uint32_t i = 0, j = 0, k = 0; double abd = 0;
+    uint32_t i = 0, j = 0, k = 0; double abd = 0; int first_id = 0; double first_abd = 0;
     while(i < n1 && j < n2) {
-        int a = uni(C.sp_id[o1 + i]), b = uni(C.sp_id[o2 + j]);
+        int a = n1 == 1 ? i1 : uni(C.sp_id[o1 + i]), b = n2 == 1 ? i2 : uni(C.sp_id[o2 + j]);
         if(a < b) i++; else if(b < a) j++;
-        else { double x = uni(C.sp_abd[o1 + i]), y = uni(C.sp_abd[o2 + j]); double c = (y < x) ? y : x;     // std::min(x, y)
-               C.sp_id[o + k] = a; C.sp_abd[o + k] = c; abd += c; k++; i++; j++; }
+        else { double x = n1 == 1 ? a1 : uni(C.sp_abd[o1 + i]), y = n2 == 1 ? a2 : uni(C.sp_abd[o2 + j]); double c = (y < x) ? y : x;     // std::min(x, y)
+               C.sp_id[o + k] = a; C.sp_abd[o + k] = c; abd += c; if(k == 0) { first_id = a; first_abd = c; } k++; i++; j++; }
     }
-    H.sp_used = o + k;
-    C.ed[z].sp_off = o; C.ed[z].sp_len = k; C.ed[z].ecount = (int32_t)k; C.ed[z].eabd = abd;
-    if(k > 0) { C.ed[z].s0id = uni(C.sp_id[o]); C.ed[z].s0abd = uni(C.sp_abd[o]); } else { C.ed[z].s0id = 0; C.ed[z].s0abd = 0; }
+    C.ed[z].sp_len = k; C.ed[z].ecount = (int32_t)k; C.ed[z].eabd = abd; C.ed[z].s0id = first_id; C.ed[z].s0abd = first_abd;
+    if(k >= 2) { C.ed[z].sp_off = o; H.sp_used = o + k; } else C.ed[z].sp_off = 0;      // a single survivor stays inline
     return true;
 }
 // router.cc:1035-1038: sum over common samples of 0.99*min + 0.01*max
 ALD_FN double common_abd(int e1, int e2)
 {
     COLD;
-    uint32_t o1 = uni(C.ed[e1].sp_off), n1 = uni(C.ed[e1].sp_len), o2 = uni(C.ed[e2].sp_off), n2 = uni(C.ed[e2].sp_len);
+    const uint32_t o1 = uni(C.ed[e1].sp_off), n1 = uni(C.ed[e1].sp_len), o2 = uni(C.ed[e2].sp_off), n2 = uni(C.ed[e2].sp_len);
+    const int i1 = uni(C.ed[e1].s0id), i2 = uni(C.ed[e2].s0id); const double a1 = uni(C.ed[e1].s0abd), a2 = uni(C.ed[e2].s0abd);
     uint32_t i = 0, j = 0; double c = 0;
     while(i < n1 && j < n2) {
-        int a = uni(C.sp_id[o1 + i]), b = uni(C.sp_id[o2 + j]);
+        int a = n1 == 1 ? i1 : uni(C.sp_id[o1 + i]), b = n2 == 1 ? i2 : uni(C.sp_id[o2 + j]);
         if(a < b) i++; else if(b < a) j++;
-        else { double x = uni(C.sp_abd[o1 + i]), y = uni(C.sp_abd[o2 + j]); double mn = (y < x) ? y : x, mx = (x < y) ? y : x; c += 0.99 * mn + 0.01 * mx; i++; j++; }
+        else { double x = n1 == 1 ? a1 : uni(C.sp_abd[o1 + i]), y = n2 == 1 ? a2 : uni(C.sp_abd[o2 + j]); double mn = (y < x) ? y : x, mx = (x < y) ? y : x; c += 0.99 * mn + 0.01 * mx; i++; j++; }
     }
     return c;
 }
