@@ -8,7 +8,7 @@ There is no CPU compute fallback: without a HIP device every compute call raises
 """
 from .packed import PackedGraphs, DecompResult
 from .native import (DecompBatch, DecompError, default_params, load_library, library_path, synth,
-                     subsetsum_batch, decompose, SynthSpec, AldParams)
+                     subsetsum_batch, decompose, SynthSpec, AldParams, TranscriptSink)
 
 __all__ = ["PackedGraphs", "DecompResult", "DecompBatch", "DecompError", "default_params", "load_library",
-           "library_path", "synth", "subsetsum_batch", "decompose", "SynthSpec", "AldParams"]
+           "library_path", "synth", "subsetsum_batch", "decompose", "SynthSpec", "AldParams", "TranscriptSink"]

@@ -6,6 +6,7 @@
 // entry point fails with ALD_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include "host_pack.h"
+#include "../host/transcript_sink.hpp"
 #include <mutex>
 #include <string>
 #include <cstdlib>
@@ -443,6 +444,81 @@ int ald_batch_export_transcripts(const ald_batch *b, int64_t *total_exons, doubl
     }
     if(coverage) exon_offset[it] = te;
     if(total_exons) *total_exons = te;
+    return ALD_OK;
+}
+
+/* ---- result sink: transcript_set restated (aletsch_amd/host/transcript_sink.hpp) ---- */
+struct ald_tset { aletsch::transcript_sink sink; explicit ald_tset(double ov) : sink(ov) {} };
+
+int ald_tset_create(double single_exon_overlap, ald_tset **out) { if(!out) return ALD_ERR_INVALID; *out = new ald_tset(single_exon_overlap); return ALD_OK; }
+int ald_tset_destroy(ald_tset *t) { delete t; return ALD_OK; }
+
+int ald_tset_add(ald_tset *t, int32_t n_groups, const int64_t *group_offset, const int32_t *group_sid,
+                 const char *strand, const double *coverage, const double *conf, const double *abd, const int32_t *count1,
+                 const int64_t *tid, const int64_t *exon_offset, const int32_t *exon_lr, int32_t skip_single_exon)
+{
+    if(!t || n_groups < 0 || (n_groups > 0 && (!group_offset || !group_sid || !strand || !coverage || !conf || !abd || !count1 || !tid || !exon_offset || !exon_lr))) return ALD_ERR_INVALID;
+    for(int g = 0; g < n_groups; g++) {
+        aletsch::transcript_sink ts(t->sink.single_exon_overlap());
+        for(int64_t i = group_offset[g]; i < group_offset[g + 1]; i++) {
+            aletsch::sink_transcript x;
+            x.strand = strand[i]; x.coverage = coverage[i]; x.cov2 = coverage[i]; x.conf = conf[i]; x.abd = abd[i]; x.count1 = count1[i]; x.count2 = 1; x.tid = tid[i];
+            for(int64_t k = exon_offset[i]; k < exon_offset[i + 1]; k++) x.exons.push_back(std::make_pair(exon_lr[2 * k], exon_lr[2 * k + 1]));
+            if(x.exons.size() <= 1 && skip_single_exon) continue;           // assembler.cc:1117
+            ts.add(x, 1, group_sid[g]);                                      // assembler.cc:1120
+        }
+        t->sink.add(ts);                                                     // assembler.cc:1130
+    }
+    return ALD_OK;
+}
+
+int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int64_t tid_base, int32_t skip_single_exon)
+{
+    if(!t || !b || !b->downloaded) return ALD_ERR_INVALID;
+    { int rc = ensure_index(b); if(rc != ALD_OK) return rc; }
+    std::vector<int32_t> ex;
+    const int n = b->hb.n();
+    for(int g = 0; g < n; g++) {
+        aletsch::transcript_sink ts(t->sink.single_exon_overlap());
+        for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++) {
+            const PathRec &p = b->res.paths[i];
+            join_exons(b, g, p, ex);
+            aletsch::sink_transcript x;
+            x.strand = p.strand; x.coverage = log(1.0 + p.weight); x.cov2 = x.coverage; x.conf = p.conf; x.abd = p.abd; x.count1 = p.count; x.count2 = 1;
+            x.tid = tid_base + (((int64_t)g << 20) | (int64_t)(i - b->res.path_begin[g]));
+            for(size_t k = 0; k + 1 < ex.size(); k += 2) x.exons.push_back(std::make_pair(ex[k], ex[k + 1]));
+            if(x.exons.size() <= 1 && skip_single_exon) continue;
+            ts.add(x, 1, sid ? sid[g] : -1);
+        }
+        t->sink.add(ts);
+    }
+    return ALD_OK;
+}
+
+int ald_tset_size(const ald_tset *t, int64_t *n_items, int64_t *n_exons, int64_t *n_samples)
+{
+    if(!t) return ALD_ERR_INVALID;
+    int64_t a = 0, e = 0, s = 0;
+    for(auto &x : t->sink.mt) for(auto &z : x.second) { a++; e += (int64_t)z.trst.exons.size(); s += (int64_t)z.samples.size(); }
+    if(n_items) *n_items = a; if(n_exons) *n_exons = e; if(n_samples) *n_samples = s;
+    return ALD_OK;
+}
+
+int ald_tset_export(const ald_tset *t, uint64_t *hash, int32_t *count, char *strand, double *coverage, double *cov2, double *conf, double *abd,
+                    int32_t *count1, int32_t *count2, int64_t *tid, int64_t *exon_offset, int32_t *exon_lr,
+                    int64_t *sample_offset, int32_t *sample_sid, double *sample_cov2, double *sample_conf, double *sample_abd, int32_t *sample_count1)
+{
+    if(!t || !hash || !count || !strand || !coverage || !cov2 || !conf || !abd || !count1 || !count2 || !tid || !exon_offset || !exon_lr || !sample_offset || !sample_sid || !sample_cov2 || !sample_conf || !sample_abd || !sample_count1) return ALD_ERR_INVALID;
+    int64_t i = 0, e = 0, s = 0;
+    for(auto &x : t->sink.mt) for(auto &z : x.second) {
+        const aletsch::sink_transcript &r = z.trst;
+        hash[i] = (uint64_t)x.first; count[i] = z.count; strand[i] = r.strand; coverage[i] = r.coverage; cov2[i] = r.cov2; conf[i] = r.conf; abd[i] = r.abd;
+        count1[i] = r.count1; count2[i] = r.count2; tid[i] = r.tid; exon_offset[i] = e; sample_offset[i] = s;
+        for(auto &q : r.exons) { exon_lr[2 * e] = q.first; exon_lr[2 * e + 1] = q.second; e++; }
+        for(auto &q : z.samples) { sample_sid[s] = q.first; sample_cov2[s] = q.second.cov2; sample_conf[s] = q.second.conf; sample_abd[s] = q.second.abd; sample_count1[s] = q.second.count1; s++; }
+        i++;
+    }
+    exon_offset[i] = e; sample_offset[i] = s;
     return ALD_OK;
 }
 

@@ -63,6 +63,12 @@ def load_library():
                  "ald_batch_download", "ald_batch_num_graphs"):
         getattr(lib, name).argtypes = [C.c_void_p]
     lib.ald_batch_enable_trace.argtypes = [C.c_void_p, C.c_int32]
+    lib.ald_tset_destroy.argtypes = [C.c_void_p]
+    lib.ald_tset_create.argtypes = [C.c_double, C.POINTER(C.c_void_p)]
+    lib.ald_tset_add.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 10 + [C.c_int32]
+    lib.ald_tset_add_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+    lib.ald_tset_size.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 3
+    lib.ald_tset_export.argtypes = [C.c_void_p] * 19
     _LIB = lib
     return lib
 
@@ -194,6 +200,66 @@ class DecompBatch:
         v = [C.c_int32() for _ in range(4)]; sb = C.c_int64(); ng = C.c_int32()
         _check(self._lib.ald_batch_class_info(self._h, cls, C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), C.byref(v[3]), C.byref(sb), C.byref(ng)))
         return dict(maxv=v[0].value, maxe=v[1].value, blocks_per_cu=v[2].value, blocks_last_run=v[3].value, slab_bytes=sb.value, n_graphs=ng.value)
+
+
+class TranscriptSink:
+    """The result sink (transcript_set::add / trans_item::merge, rnacore/transcript_set.cc:38-175) behind ald_tset_*."""
+
+    def __init__(self, single_exon_overlap: float = 0.8):
+        self._lib = load_library(); self._h = C.c_void_p()
+        _check(self._lib.ald_tset_create(C.c_double(single_exon_overlap), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.ald_tset_destroy(self._h); self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_groups(self, groups, skip_single_exon: bool = False):
+        """groups: list of (sid, [ (strand, coverage, conf, abd, count1, tid, [(l, r), ...]), ... ]) -- one group per graph."""
+        go = [0]; sid = []; st = []; cov = []; conf = []; abd = []; c1 = []; tid = []; eo = [0]; lr = []
+        for s, ts in groups:
+            sid.append(s)
+            for t in ts:
+                st.append(ord(t[0])); cov.append(t[1]); conf.append(t[2]); abd.append(t[3]); c1.append(t[4]); tid.append(t[5])
+                for l, r in t[6]:
+                    lr += [l, r]
+                eo.append(len(lr) // 2)
+            go.append(len(st))
+        a = lambda x, dt: np.ascontiguousarray(np.array(x, dt) if len(x) else np.zeros(1, dt))
+        go, sid, st, cov, conf, abd, c1, tid, eo, lr = (a(go, np.int64), a(sid, np.int32), a(st, np.int8), a(cov, np.float64), a(conf, np.float64),
+                                                        a(abd, np.float64), a(c1, np.int32), a(tid, np.int64), a(eo, np.int64), a(lr, np.int32))
+        _check(self._lib.ald_tset_add(self._h, C.c_int32(len(groups)), C.c_void_p(go.ctypes.data), C.c_void_p(sid.ctypes.data), C.c_void_p(st.ctypes.data),
+                                      C.c_void_p(cov.ctypes.data), C.c_void_p(conf.ctypes.data), C.c_void_p(abd.ctypes.data), C.c_void_p(c1.ctypes.data),
+                                      C.c_void_p(tid.ctypes.data), C.c_void_p(eo.ctypes.data), C.c_void_p(lr.ctypes.data), C.c_int32(int(skip_single_exon))))
+
+    def add_batch(self, batch: "DecompBatch", sid=None, tid_base: int = 0, skip_single_exon: bool = False):
+        """Every transcript of a downloaded batch, graph by graph (meta/assembler.cc:1105-1133)."""
+        sp = None
+        if sid is not None:
+            sid = np.ascontiguousarray(sid, np.int32); assert len(sid) == batch.n; sp = C.c_void_p(sid.ctypes.data)
+        _check(self._lib.ald_tset_add_batch(self._h, batch._h, sp, C.c_int64(tid_base), C.c_int32(int(skip_single_exon))))
+
+    def items(self):
+        """List of dicts in the reference's iteration order (bucket hash ascending, then bucket order)."""
+        n = C.c_int64(); ne = C.c_int64(); ns = C.c_int64()
+        _check(self._lib.ald_tset_size(self._h, C.byref(n), C.byref(ne), C.byref(ns)))
+        n, ne, ns = n.value, ne.value, ns.value
+        z = lambda k, dt: np.zeros(max(k, 1), dt)
+        h = z(n, np.uint64); cnt = z(n, np.int32); st = z(n, np.int8); cov = z(n, np.float64); cov2 = z(n, np.float64); conf = z(n, np.float64); abd = z(n, np.float64)
+        c1 = z(n, np.int32); c2 = z(n, np.int32); tid = z(n, np.int64); eo = z(n + 1, np.int64); lr = z(2 * ne, np.int32)
+        so = z(n + 1, np.int64); ssid = z(ns, np.int32); scov2 = z(ns, np.float64); sconf = z(ns, np.float64); sabd = z(ns, np.float64); sc1 = z(ns, np.int32)
+        _check(self._lib.ald_tset_export(self._h, *[C.c_void_p(x.ctypes.data) for x in (h, cnt, st, cov, cov2, conf, abd, c1, c2, tid, eo, lr, so, ssid, scov2, sconf, sabd, sc1)]))
+        out = []
+        for i in range(n):
+            out.append(dict(hash=int(h[i]), count=int(cnt[i]), strand=chr(st[i]), coverage=float(cov[i]), cov2=float(cov2[i]), conf=float(conf[i]), abd=float(abd[i]),
+                            count1=int(c1[i]), count2=int(c2[i]), tid=int(tid[i]), exons=[(int(lr[2 * k]), int(lr[2 * k + 1])) for k in range(eo[i], eo[i + 1])],
+                            samples=[dict(sid=int(ssid[k]), cov2=float(scov2[k]), conf=float(sconf[k]), abd=float(sabd[k]), count1=int(sc1[k])) for k in range(so[i], so[i + 1])]))
+        return out
 
 
 def decompose(pg: PackedGraphs, device: int = 0, params: Optional[AldParams] = None) -> DecompResult:

@@ -164,6 +164,26 @@ int  ald_batch_get_transcript(const ald_batch *b, int32_t graph, int32_t path, a
 /* bulk: coverage[total_paths], exon_offset[total_paths+1], exon_lr[2*total_exons]; pass NULL arrays to query *total_exons */
 int  ald_batch_export_transcripts(const ald_batch *b, int64_t *total_exons, double *coverage, int64_t *exon_offset, int32_t *exon_lr);
 
+/* ---- result sink (replaces transcript_set::add / trans_item::merge, rnacore/transcript_set.cc:38-175) ----
+ * Host-side: hash-bucketed merge of transcripts across graphs / samples, as assembler::assemble does with `ts` / `tm`
+ * (meta/assembler.cc:1105-1133).  Transcripts of one group (= one graph) first merge among themselves, then into the sink. */
+typedef struct ald_tset ald_tset;
+int  ald_tset_create(double single_exon_overlap, ald_tset **out);
+int  ald_tset_destroy(ald_tset *t);
+/* n transcripts, grouped: group_offset[n_groups+1] into the transcript arrays, group_sid[n_groups] = sample id of the group;
+ * exon_offset[n+1] into exon_lr (l, r pairs); tid[n] = caller-chosen transcript ids (the first inserted wins a merge) */
+int  ald_tset_add(ald_tset *t, int32_t n_groups, const int64_t *group_offset, const int32_t *group_sid,
+                  const char *strand, const double *coverage, const double *conf, const double *abd, const int32_t *count1,
+                  const int64_t *tid, const int64_t *exon_offset, const int32_t *exon_lr, int32_t skip_single_exon);
+/* every graph of a downloaded batch, ascending graph id; sid[graphs] gives each graph's sample id (NULL => -1);
+ * tid = tid_base + (graph << 20 | path index) */
+int  ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int64_t tid_base, int32_t skip_single_exon);
+int  ald_tset_size(const ald_tset *t, int64_t *n_items, int64_t *n_exons, int64_t *n_samples);
+/* items in the reference's iteration order (hash ascending, then bucket order) */
+int  ald_tset_export(const ald_tset *t, uint64_t *hash, int32_t *count, char *strand, double *coverage, double *cov2, double *conf, double *abd,
+                     int32_t *count1, int32_t *count2, int64_t *tid, int64_t *exon_offset, int32_t *exon_lr,
+                     int64_t *sample_offset, int32_t *sample_sid, double *sample_cov2, double *sample_conf, double *sample_abd, int32_t *sample_count1);
+
 /* raw packed path-record stream of the last download: 4-byte words, record = [graph, path index, #vertices, length, count,
  * strand | attempt<<8, weight f64, abd f64, conf f64, reads f64, vertices..., pad to even].  This is what ranks exchange
  * over RCCL for the final transcript gather (bench.py --gpus N). */

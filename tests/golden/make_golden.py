@@ -8,7 +8,10 @@
   oracle_paths.npz    small synthetic batches + the oracle's own decomposition (regression fixture: scallop / router /
                       hyper_set have no reference-authored vectors; "parity unpinned")
 
-Needs /root/reference (for the two _ref binaries); run from the repo root:  python tests/golden/make_golden.py
+  ref_tset.json       transcript groups + the merged set produced by oracle/_ref/ref_tset (the REFERENCE's
+                      rnacore/transcript_set.cc + gtf/transcript.cc)  -> pins the result sink (ald_tset_*)
+
+Needs /root/reference (for the _ref binaries); run from the repo root:  python tests/golden/make_golden.py
 """
 import json
 import os
@@ -46,6 +49,50 @@ def graph_script(rng, directed, n, ops):
     return "\n".join(s) + "\n"
 
 
+def tset_case(rng, n_groups, n_samples, n_chains):
+    """Transcript groups with plenty of shared intron chains, single-exon overlaps and both strands."""
+    chains = []
+    for _ in range(n_chains):
+        ne = rng.choice([1, 1, 2, 2, 3, 4, 6, 9]); x = rng.randrange(1000, 200000); ex = []
+        for _k in range(ne):
+            l = x + rng.randrange(20, 400); r = l + rng.randrange(30, 900); ex.append((l, r)); x = r
+        chains.append((rng.choice("+-."), ex))
+    groups = []; tid = 0
+    for g in range(n_groups):
+        sid = rng.randrange(n_samples); ts = []
+        for _ in range(rng.randint(0, 6)):
+            st, ex = chains[rng.randrange(n_chains)]; ex = list(ex)
+            if len(ex) == 1:
+                d = rng.choice([0, 0, 5, 40, 300, 2000]); ex[0] = (ex[0][0] + d, ex[0][1] + rng.choice([d, d + 3, 2 * d]))
+            else:
+                ex[0] = (ex[0][0] - rng.choice([0, 0, 7, 90]), ex[0][1]); ex[-1] = (ex[-1][0], ex[-1][1] + rng.choice([0, 0, 11, 250]))
+            if rng.random() < 0.1:
+                st = rng.choice("+-.")
+            ts.append((st, round(rng.uniform(0.1, 30), 3), round(rng.random(), 4), round(rng.uniform(0, 50), 2), rng.randint(1, 9), tid, ex)); tid += 1
+        groups.append((sid, ts))
+    return groups
+
+
+def tset_text(groups):
+    s = ["%d" % len(groups)]
+    for sid, ts in groups:
+        s.append("%d %d" % (sid, len(ts)))
+        for st, cov, conf, abd, c1, tid, ex in ts:
+            s.append("%s %r %r %r %d %d %s %d" % (st, cov, conf, abd, c1, len(ex), " ".join("%d %d" % e for e in ex), tid))
+    return "\n".join(s) + "\n"
+
+
+def tset_parse(out):
+    items = []
+    for line in out.splitlines():
+        a, b = line.split(" | "); f = a.split(); ne = int(f[9]); g = b.replace("{", "").replace("}", "").split(); ns = int(g[0])
+        items.append({"hash": int(f[0]), "count": int(f[1]), "coverage": float(f[2]), "cov2": float(f[3]), "conf": float(f[4]), "abd": float(f[5]),
+                      "count1": int(f[6]), "count2": int(f[7]), "tid": int(f[8]), "exons": [[int(f[10 + 2 * k]), int(f[11 + 2 * k])] for k in range(ne)],
+                      "samples": [{"sid": int(g[1 + 7 * k]), "coverage": float(g[2 + 7 * k]), "cov2": float(g[3 + 7 * k]), "conf": float(g[4 + 7 * k]),
+                                   "abd": float(g[5 + 7 * k]), "count1": int(g[6 + 7 * k]), "count2": int(g[7 + 7 * k])} for k in range(ns)]})
+    return items
+
+
 def main():
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
     rng = random.Random(20250211)
@@ -71,6 +118,13 @@ def main():
         f = r.stdout.split(); e = float(f[0]); k = int(f[1]); ss = [int(x) for x in f[2:2 + k]]; m = int(f[2 + k]); tt = [int(x) for x in f[3 + k:3 + k + m]]
         ans.append({"e": e, "s": ss, "t": tt})
     json.dump({"instances": [{"s": s, "t": t} for s, t in inst], "answers": ans}, open(os.path.join(HERE, "ref_subsetsum.json"), "w"))
+    # ---- result sink: the reference's transcript_set over random transcript groups ----
+    tcases = []
+    for t, (ng, nsmp, nch) in enumerate([(1, 1, 3), (6, 2, 4), (40, 3, 10), (120, 8, 25), (300, 20, 40), (60, 1, 6)]):
+        groups = tset_case(rng, ng, nsmp, nch)
+        out = subprocess.run([os.path.join(ROOT, "oracle/_ref/ref_tset")], input=tset_text(groups), capture_output=True, text=True, check=True).stdout
+        tcases.append({"groups": groups, "items": tset_parse(out)})
+    json.dump(tcases, open(os.path.join(HERE, "ref_tset.json"), "w"))
     # ---- oracle regression fixture ----
     import aletsch_amd as A
     import common

@@ -140,6 +140,27 @@ def test_transcripts_match_oracle():
     assert (np.diff(eo) < np.diff(r.pv_offset) - 2).any()   # at least one path had touching exons joined
 
 
+def test_batch_into_result_sink():
+    """ald_tset_add_batch (graph by graph, assembler.cc:1105-1133) == feeding the exported transcripts through ald_tset_add,
+    whose merge rules are pinned to the reference's transcript_set.cc by tests/test_tset_cpu.py"""
+    pg = A.synth(seed=45, n_graphs=200, v_min=8, v_max=40, edges_per_vertex=3, layout_mode=1, weight_mode=2, phasing_per_graph=2)
+    sid = (np.arange(pg.n) % 5).astype(np.int32)
+    with A.DecompBatch(0) as b:
+        b.add(pg); b.upload(); b.run(); b.download()
+        cov, eo, lr = b.transcripts(); r = b.result()
+        s = A.TranscriptSink(0.8); s.add_batch(b, sid, tid_base=0)
+    groups = []
+    for g in range(pg.n):
+        ts = []
+        for k, i in enumerate(range(r.path_offset[g], r.path_offset[g + 1])):
+            ts.append((chr(r.strand[i]), float(cov[i]), float(r.conf[i]), float(r.abd[i]), int(r.count[i]), (g << 20) | k, [tuple(map(int, e)) for e in lr[eo[i]:eo[i + 1]]]))
+        groups.append((int(sid[g]), ts))
+    t = A.TranscriptSink(0.8); t.add_groups(groups)
+    a, c = s.items(), t.items()
+    assert len(a) > 0 and a == c
+    assert sum(x["count"] for x in a) == len(cov)           # every transcript landed in exactly one item
+
+
 def test_catch_all_class_on_gpu():
     """V > 512: hot state in HBM (class 5); mixed with small graphs in the same batch (concurrent class streams)"""
     big = A.synth(seed=99, n_graphs=3, v_min=900, v_max=1400, edges_per_vertex=4)
