@@ -140,16 +140,15 @@ ALD_INL void fail_(int st, int line)
     if(H.status == 0) H.status = st;
 }
 #define fail(st) fail_((st), __LINE__)
-ALD_FN void trace(int code, int a, int b, double v)
+ALD_FN void trace_emit(int code, int a, int b, double v)
 {
-    H.n_iters++;
     int cap = H.p_trace_cap;
-    if(cap <= 0) return;
     ALD_GLOBAL const KernelArgs *A = H.args;
     int k = H.n_trace++;
     if(k < cap) { int64_t o = (int64_t)H.g * cap + k; A->out.trace_codes[3 * o] = code; A->out.trace_codes[3 * o + 1] = a; A->out.trace_codes[3 * o + 2] = b; A->out.trace_vals[o] = v; }
 }
 ALD_INL bool tracing() { return H.p_trace_cap > 0; }
+ALD_INL void trace(int code, int a, int b, double v) { H.n_iters++; if(H.p_trace_cap > 0) trace_emit(code, a, b, v); }
 // u_*: the same accessors for the scalar (lane-0) routines, with the result marked wave-uniform (see uni() in decomp_common.h)
 ALD_INL int u_first_in(int v) { IDX h = uni(H.in_head[v]); return h == NIL ? -1 : (int)h; }
 ALD_INL int u_first_out(int v) { IDX h = uni(H.out_head[v]); return h == NIL ? -1 : (int)h; }
@@ -170,7 +169,7 @@ ALD_INL uint32_t tkey(uint32_t p) { return (int)p == H.sinkp ? 0xFFFFu : p; }   
 ALD_INL int vlog(int p) { return p < H.V0 - 1 ? p : (p == H.sinkp ? H.nv - 1 : p - 1); }   // physical -> reference index (traces)
 ALD_INL uint64_t lkw(int e) { return uni(*(const uint64_t*)&H.lk[e]); }            // es | et << 16 | inx << 32 | onx << 48
 ALD_INL int lk_next(uint32_t f) { return f == 0xFFFFu ? -1 : (int)f; }
-ALD_FN void link_in(int v, int e)
+ALD_INL void link_in(int v, int e)
 {
     v = uni(v); e = uni(e);
     if(v == uni(H.sinkp) && !uni(H.special_linked)) { H.in_deg[v]++; return; }
@@ -181,7 +180,7 @@ ALD_FN void link_in(int v, int e)
     if(prev < 0) H.in_head[v] = (IDX)e; else H.lk[prev].inx = (IDX)e;
     H.in_deg[v]++;
 }
-ALD_FN void link_out(int v, int e)
+ALD_INL void link_out(int v, int e)
 {
     v = uni(v); e = uni(e);
     if(v == 0 && !uni(H.special_linked)) { H.out_deg[v]++; return; }
@@ -194,7 +193,7 @@ ALD_FN void link_out(int v, int e)
     if(prev < 0) H.out_head[v] = (IDX)e; else H.lk[prev].onx = (IDX)e;
     H.out_deg[v]++;
 }
-ALD_FN void unlink_in(int v, int e)
+ALD_INL void unlink_in(int v, int e)
 {
     v = uni(v); e = uni(e);
     if(v == uni(H.sinkp) && !uni(H.special_linked)) { H.in_deg[v]--; return; }
@@ -205,7 +204,7 @@ ALD_FN void unlink_in(int v, int e)
     if(prev < 0) H.in_head[v] = nx; else H.lk[prev].inx = nx;
     H.in_deg[v]--;
 }
-ALD_FN void unlink_out(int v, int e)
+ALD_INL void unlink_out(int v, int e)
 {
     v = uni(v); e = uni(e);
     if(v == 0 && !uni(H.special_linked)) { H.out_deg[v]--; return; }
@@ -336,21 +335,21 @@ ALD_FN void hs_refresh_flags()                  // per-slot OCC / LEXT / REXT: h
     }
     H.hs_dirty = 0;
 }
-ALD_FN void hs_remove(int e)                    // hyper_set.cc:787-818
+ALD_FN void hs_remove_lists(int e)              // hyper_set.cc:787-818
 {
-    int nl = H.hl_n; if(nl == 0) return;
+    int nl = H.hl_n;
     COLD;
     for(int k = 0; k < nl; k++) { ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]); for(int i = 0; i < n; i++) if(v[i] == e) { v[i] = -1; H.hs_dirty = 1; } }
 }
-ALD_FN void hs_replace1(int x, int e)           // hyper_set.cc:609-615 -> 626-675 with |v| == 1
+ALD_FN void hs_replace1_lists(int x, int e)     // hyper_set.cc:609-615 -> 626-675 with |v| == 1
 {
-    int nl = H.hl_n; if(nl == 0) return;
+    int nl = H.hl_n;
     COLD;
     for(int k = 0; k < nl; k++) { ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]); for(int i = 0; i < n; i++) if(v[i] == x) { v[i] = e; H.hs_dirty = 1; } }
 }
-ALD_FN void hs_replace2(int x, int y, int e)    // hyper_set.cc:617-624 -> 626-675 with |v| == 2
+ALD_FN void hs_replace2_lists(int x, int y, int e)   // hyper_set.cc:617-624 -> 626-675 with |v| == 2
 {
-    int nl = H.hl_n; if(nl == 0) return;
+    int nl = H.hl_n;
     COLD;
     for(int k = 0; k < nl; k++) {
         ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]); int w = 0;
@@ -362,9 +361,9 @@ ALD_FN void hs_replace2(int x, int y, int e)    // hyper_set.cc:617-624 -> 626-6
         C.hl_len[k] = w;
     }
 }
-ALD_FN void hs_insert_between(int x, int y, int e)   // hyper_set.cc:865-902
+ALD_FN void hs_insert_between_lists(int x, int y, int e)   // hyper_set.cc:865-902
 {
-    int nl = H.hl_n; if(nl == 0) return;
+    int nl = H.hl_n;
     COLD;
     for(int k = 0; k < nl; k++) {
         int n = uni(C.hl_len[k]); ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]);
@@ -386,6 +385,11 @@ ALD_FN void hs_insert_between(int x, int y, int e)   // hyper_set.cc:865-902
         C.hl_len[k] = n + cnt; H.hs_dirty = 1;
     }
 }
+// a graph without phasing lists (hl_n == 0) pays one LDS read per edit, not a call
+ALD_INL void hs_remove(int e) { if(uni(H.hl_n) != 0) hs_remove_lists(e); }
+ALD_INL void hs_replace1(int x, int e) { if(uni(H.hl_n) != 0) hs_replace1_lists(x, e); }
+ALD_INL void hs_replace2(int x, int y, int e) { if(uni(H.hl_n) != 0) hs_replace2_lists(x, y, e); }
+ALD_INL void hs_insert_between(int x, int y, int e) { if(uni(H.hl_n) != 0) hs_insert_between_lists(x, y, e); }
 // hyper_set.cc:1003-1042 (side == 2, left_dominate) and 1044-1082 (side == 1, right_dominate)
 ALD_FN bool hs_dominate(int e, int side)
 {

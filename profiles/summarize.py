@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 result databases (gpurun_out/<dir>/*_results.db) into the small summaries committed under profiles/.
+
+  python profiles/summarize.py stats  gpurun_out/prof_r1_d/d_results.db   profiles/r01/d_kernel_stats.csv
+  python profiles/summarize.py pmc    gpurun_out/pmc_fetch_r1_d/d_results.db gpurun_out/pmc_write_r1_d/d_results.db profiles/r01/d_pmc_traffic.json
+
+`pmc` writes per-launch HBM traffic of the dominant kernel, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section)
+prescribes: FETCH_SIZE and WRITE_SIZE are in KiB, collected in separate passes; on gfx950 FETCH_SIZE tallies 128-B requests
+at 64 B, so read bytes = 2 x FETCH_SIZE x 1024 (an upper bound for this kernel's narrow accesses, which the guide calls
+uncalibrated); WRITE_SIZE x 1024 is taken as is.  bench.py reads the JSON for `roofline.traffic`.
+"""
+import json
+import sqlite3
+import sys
+
+
+def stats(db, out):
+    c = sqlite3.connect(db)
+    q = ("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(grid_x), max(workgroup_x), max(lds_size), "
+         "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(scratch_size) from kernels group by name order by sum(duration) desc")
+    rows = list(c.execute(q)); tot = sum(r[2] for r in rows)
+    with open(out, "w") as f:
+        f.write("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs,Percentage,Grid,Workgroup,LDS,VGPR,AGPR,SGPR,Scratch\n")
+        for r in rows:
+            f.write('"%s",%d,%d,%.1f,%d,%d,%.4f,%d,%d,%d,%d,%d,%d,%d\n' % (r[0], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot, *r[6:]))
+    print(open(out).read())
+
+
+def per_launch(db, counter, kernel_prefix):
+    c = sqlite3.connect(db)
+    v = [r[0] for r in c.execute("select value from counters_collection where counter_name=? and kernel_name like ?", (counter, kernel_prefix + "%"))]
+    return v
+
+
+def pmc(fetch_db, write_db, out, kernel_prefix="ald_decomp_kernel"):
+    f = per_launch(fetch_db, "FETCH_SIZE", kernel_prefix); w = per_launch(write_db, "WRITE_SIZE", kernel_prefix)
+    fk = sum(f) / len(f); wk = sum(w) / len(w)
+    d = {"kernel": kernel_prefix, "launches": [len(f), len(w)], "FETCH_SIZE_KiB_per_launch": fk, "WRITE_SIZE_KiB_per_launch": wk,
+         "read_bytes_per_launch_corrected": 2 * fk * 1024, "write_bytes_per_launch": wk * 1024,
+         "traffic_bytes_per_launch": 2 * fk * 1024 + wk * 1024,
+         "note": "gfx950: FETCH_SIZE doubled per the microarch guide (upper bound for narrow accesses); separate --pmc passes"}
+    json.dump(d, open(out, "w"), indent=1); print(json.dumps(d, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
