@@ -36,7 +36,7 @@ enum { MAXV = ClassDims<ALD_CLASS_ID>::MAXV, MAXE = ClassDims<ALD_CLASS_ID>::MAX
 typedef uint16_t IDX;
 static constexpr IDX NIL = (IDX)0xFFFF;
 typedef ColdLayoutT<MAXV, MAXE, NW> CL;
-enum { LP = 16, ARENA_I = 160, ARENA_D = 64, SCR_I = 4 * LP + ARENA_I, SCR_D = 2 * LP + ARENA_D };   // LDS scratch geometry (ints / doubles)
+enum { LP = 16, ARENA_I = 96, ARENA_D = 48, SCR_I = 4 * LP + ARENA_I, SCR_D = 2 * LP + ARENA_D };   // LDS scratch geometry (ints / doubles)
 
 // ---------------------------------------------------------------------------------------------
 // hot state: ONE instance per workgroup (= per wavefront)
@@ -67,6 +67,8 @@ struct Hot {
     // decompose_vertex_extend appends vertices (exchange_sink, scallop.cc:2198-2215); here order comparisons map it to +inf
     // instead.  Physical order of all other vertices == the reference's index order.
     int32_t  sinkp, special_linked;
+    // state of the trivial-vertex sweep in flight (scan_trivial <-> sweep_trivial)
+    double   sw_best_r, sw_hit_r; int32_t sw_best_v, sw_hit, sw_vend, sw_dom_base; uint32_t sw_need_lo, sw_need_hi;
     int32_t  scr_i[SCR_I]; double scr_d[SCR_D];
 #ifdef ALD_PROF
     unsigned long long prof[32];
@@ -217,7 +219,7 @@ ALD_INL void unlink_out(int v, int e)
 }
 ALD_INL int free_slots() { return uni(H.free_cnt) + (MAXE - uni(H.slot_hw)); }
 // directed_graph::add_edge (directed_graph.cc:38-48) + i2e.push_back: the new id is the largest
-ALD_FN int add_edge(int s, int t)
+ALD_INL int add_edge_i(int s, int t)
 {
     s = uni(s); t = uni(t);
     int e; int fh = uni(H.free_head), hw = uni(H.slot_hw);
@@ -232,7 +234,7 @@ ALD_FN int add_edge(int s, int t)
 }
 // scallop::remove_edge (scallop.cc:2380-2392).  A slot that phasing lists may still name (HF_PROT) is parked
 // until the compound operation has called hs_remove on it; all others are recycled at once.
-ALD_FN void kill_edge(int e)
+ALD_INL void kill_edge_i(int e)
 {
     e = uni(e);
     unlink_out(uni(H.lk[e].es), e); unlink_in(uni(H.lk[e].et), e);
@@ -240,6 +242,8 @@ ALD_FN void kill_edge(int e)
     if(uni(H.hflag[e]) & HF_PROT) { int ph = uni(H.pend_head); H.lk[e].onx = ph < 0 ? NIL : (IDX)ph; H.pend_head = e; }
     else { int fh = uni(H.free_head); H.lk[e].onx = fh < 0 ? NIL : (IDX)fh; H.free_head = e; H.free_cnt++; }
 }
+ALD_FN int add_edge(int s, int t) { return add_edge_i(uni(s), uni(t)); }
+ALD_FN void kill_edge(int e) { kill_edge_i(uni(e)); }
 ALD_FN void flush_pending()
 {
     int guard = MAXE;
@@ -275,6 +279,7 @@ ALD_INL void borrow_edge_strand(const Cold &C, int e1, int e2) { int s2 = C.ed[e
 // live in the pool at [sp_off, sp_off + sp_len).
 ALD_FN bool intersect_samples(int e1, int e2, int z)
 {
+    e1 = uni(e1); e2 = uni(e2); z = uni(z);
     COLD;
     const uint32_t n1 = uni(C.ed[e1].sp_len), n2 = uni(C.ed[e2].sp_len);
     if(n1 == 1 && n2 == 1) {                     // single-sample edges: everything is inline, no pool traffic at all
@@ -302,6 +307,7 @@ ALD_FN bool intersect_samples(int e1, int e2, int z)
 // router.cc:1035-1038: sum over common samples of 0.99*min + 0.01*max
 ALD_FN double common_abd(int e1, int e2)
 {
+    e1 = uni(e1); e2 = uni(e2);
     COLD;
     const uint32_t o1 = uni(C.ed[e1].sp_off), n1 = uni(C.ed[e1].sp_len), o2 = uni(C.ed[e2].sp_off), n2 = uni(C.ed[e2].sp_len);
     const int i1 = uni(C.ed[e1].s0id), i2 = uni(C.ed[e2].s0id); const double a1 = uni(C.ed[e1].s0abd), a2 = uni(C.ed[e2].s0abd);
@@ -337,18 +343,21 @@ ALD_FN void hs_refresh_flags()                  // per-slot OCC / LEXT / REXT: h
 }
 ALD_FN void hs_remove_lists(int e)              // hyper_set.cc:787-818
 {
+    e = uni(e);
     int nl = H.hl_n;
     COLD;
     for(int k = 0; k < nl; k++) { ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]); for(int i = 0; i < n; i++) if(v[i] == e) { v[i] = -1; H.hs_dirty = 1; } }
 }
 ALD_FN void hs_replace1_lists(int x, int e)     // hyper_set.cc:609-615 -> 626-675 with |v| == 1
 {
+    x = uni(x); e = uni(e);
     int nl = H.hl_n;
     COLD;
     for(int k = 0; k < nl; k++) { ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]); for(int i = 0; i < n; i++) if(v[i] == x) { v[i] = e; H.hs_dirty = 1; } }
 }
 ALD_FN void hs_replace2_lists(int x, int y, int e)   // hyper_set.cc:617-624 -> 626-675 with |v| == 2
 {
+    x = uni(x); y = uni(y); e = uni(e);
     int nl = H.hl_n;
     COLD;
     for(int k = 0; k < nl; k++) {
@@ -363,6 +372,7 @@ ALD_FN void hs_replace2_lists(int x, int y, int e)   // hyper_set.cc:617-624 -> 
 }
 ALD_FN void hs_insert_between_lists(int x, int y, int e)   // hyper_set.cc:865-902
 {
+    x = uni(x); y = uni(y); e = uni(e);
     int nl = H.hl_n;
     COLD;
     for(int k = 0; k < nl; k++) {
@@ -393,6 +403,7 @@ ALD_INL void hs_insert_between(int x, int y, int e) { if(uni(H.hl_n) != 0) hs_in
 // hyper_set.cc:1003-1042 (side == 2, left_dominate) and 1044-1082 (side == 1, right_dominate)
 ALD_FN bool hs_dominate(int e, int side)
 {
+    e = uni(e); side = uni(side);
     COLD;
     int nl = H.hl_n;
     ALD_GLOBAL int32_t *x1 = C.wi, *x2 = C.wi + C.w_cap / 4; int n1 = 0, n2 = 0; const int cap = C.w_cap / 8;
@@ -424,6 +435,7 @@ ALD_FN bool hs_dominate(int e, int side)
 // scallop::split_edge (scallop.cc:2433-2484)
 ALD_FN int split_edge(int ei, double w)
 {
+    ei = uni(ei); w = uni(w);
     if(!(w >= H.p_min_w - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
     double ww = uni(H.ew[ei]);
     if(fabs(ww - w) <= kSMIN) return ei;
@@ -445,7 +457,7 @@ ALD_FN int split_edge(int ei, double w)
 // + merge_adjacent_equal_edges (scallop.cc:2242-2378), fused: the two split pieces live only between the split and the merge in
 // the reference, so they are never materialised here -- their creation ids are consumed, their weights take part in the vertex
 // sums at the position their (endpoint, id) keys would have had, and everything else is computed from the originals' state.
-ALD_FN int merge_adjacent_edges(int x, int y, double ww)
+ALD_INL int merge_adjacent_edges_i(int x, int y, double ww)
 {
     const double mw = H.p_min_w;
     if(!(ww >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
@@ -469,7 +481,7 @@ ALD_FN int merge_adjacent_edges(int x, int y, double ww)
     const double medx1 = sx ? medx * ww / wx : medx, medy1 = sy ? medy * ww / wy : medy;
     // merge_adjacent_equal_edges(piece x, piece y)
     PROF_ADD(PF_T_MERGE_LOAD);
-    int n = add_edge(xs, yt);
+    int n = add_edge_i(xs, yt);
     PROF_ADD(PF_T_MERGE_ADD);
     if(n < 0) return -1;
     if(!(fabs(wx0 - wy0) <= kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_MERGE_EQUAL); return -1; }
@@ -494,14 +506,15 @@ ALD_FN int merge_adjacent_edges(int x, int y, double ww)
     C.ed[n].med = mi * r1 + medx1 + medy1; C.ed[n].mei = mi;
     // the pieces disappear; an edge that was not cut IS the piece
     PROF_ADD(PF_T_MERGE_SUMS);
-    if(!sx) kill_edge(x);
-    if(!sy) kill_edge(y);
+    if(!sx) kill_edge_i(x);
+    if(!sy) kill_edge_i(y);
     if(H.in_deg[xt] == 0 && uni(H.out_deg[xt]) == 0) H.nz[xt] = 0;
     PROF_ADD(PF_T_MERGE_KILL);
     return n;
 }
+ALD_FN int merge_adjacent_edges(int x, int y, double ww) { return merge_adjacent_edges_i(uni(x), uni(y), uni(ww)); }     // out-of-line copy for the greedy phase
 // scallop::balance_vertex (scallop.cc:2486-2576)
-ALD_FN void balance_vertex(int v)
+ALD_INL void balance_vertex_i(int v)
 {
     if(H.in_deg[v] == 0 || uni(H.out_deg[v]) == 0) return;
     const double mw = H.p_min_w;
@@ -517,6 +530,7 @@ ALD_FN void balance_vertex(int v)
     else if(m1 < m2) { int e = u_first_in(v); H.ew[e] = uni(H.ew[e]) + m2 - m1; }
 }
 
+ALD_FN void balance_vertex(int v) { balance_vertex_i(uni(v)); }
 // pe2w as a sorted array: keys (id1,id2) ascending == std::map<PI,double> order (router.h:23).  The pairs of a small vertex
 // (<= LP pairs) live in the LDS scratch, larger sets in the upper halves of the slab's work arrays.  A second area parks the best
 // candidate of an unsplittable sweep while the sweep goes on.
@@ -550,7 +564,7 @@ ALD_INL bool pair_less(int a1, int a2, int b1, int b2)
     if(x1 != y1) return x1 < y1;
     return H.eid[a2] < H.eid[b2];
 }
-ALD_FN void sort_pairs(int n)                   // insertion sort by (id(e1), id(e2)); keys are unique
+ALD_INL void sort_pairs(int n)                   // insertion sort by (id(e1), id(e2)); keys are unique
 {
     Pairs P = pairs_cur();
     for(int i = 1; i < n; i++) {
@@ -561,7 +575,7 @@ ALD_FN void sort_pairs(int n)                   // insertion sort by (id(e1), id
 }
 
 // scallop::decompose_vertex_replace (scallop.cc:2009-2142), pe2w = n sorted pairs in the work area
-ALD_FN void decompose_vertex_replace(int root, int n)
+ALD_INL void decompose_vertex_replace(int root, int n)
 {
     PROF_DECL;
     const Pairs P = pairs_cur();
@@ -594,7 +608,7 @@ ALD_FN void decompose_vertex_replace(int root, int n)
         if(m1 == 1) H.hflag[e1] &= (uint8_t)~HF_PROT;
         if(m2 == 1) H.hflag[e2] &= (uint8_t)~HF_PROT;
         PROF_RESET();
-        int e = merge_adjacent_edges(e1, e2, w[i]);
+        int e = merge_adjacent_edges_i(e1, e2, w[i]);
         PROF_RESET();
         if(e < 0 || H.status) { if(!H.status) fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
         hs_replace2(e1, e2, e);
@@ -611,8 +625,9 @@ ALD_FN void decompose_vertex_replace(int root, int n)
 // scallop::decompose_trivial_vertex (scallop.cc:2144-2167)
 ALD_FN void decompose_trivial_vertex(int x)
 {
+    x = uni(x);
     PROF_DECL;
-    balance_vertex(x);
+    balance_vertex_i(x);
     PROF_ADD(PF_T_BALANCE);
     if(H.status) return;
     const int np = (int)uni(H.in_deg[x]) * (int)uni(H.out_deg[x]);
@@ -633,12 +648,13 @@ ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio);
 // scallop::decompose_vertex_extend (scallop.cc:1675-1986); pe2w = n sorted pairs in the work area
 ALD_FN void decompose_vertex_extend(int root, int n)
 {
+    root = uni(root); n = uni(n);
     COLD;
     const Pairs P = pairs_cur();
     int32_t *a = P.a, *b = P.b; double *w = P.w;
     const int deg = (int)uni(H.in_deg[root]) + (int)uni(H.out_deg[root]);
     // the visiting order of the nested decompositions (jump_ratio > 1 only) must survive them: it always lives in the slab
-    const Arena AR = arena_at(3 * deg <= ARENA_I && deg <= ARENA_D && !(H.p_ratio[7] > 1.0));
+    const Arena AR = arena_at(4 * deg <= ARENA_I && deg <= ARENA_D && !(H.p_ratio[7] > 1.0));
     if(4 * deg > AR.cap_i || deg > AR.cap_d || deg > C.w_cap / 16) { fail(ALD_ST_CAPACITY); return; }
     int nloc = 0; int32_t *loc_e = AR.i;
     for(int e = u_first_in(root); e >= 0; e = u_next_in(e)) { loc_e[nloc++] = e; }
@@ -743,6 +759,7 @@ ALD_INL int classify_trivial_fastpath(int x, bool fast)
 }
 ALD_FN int classify_trivial_vertex(int x, bool fast)     // scalar version with the dominate queries
 {
+    x = uni(x); fast = uni(fast);
     int d1 = uni(H.in_deg[x]), d2 = uni(H.out_deg[x]);
     if(d1 != 1 && d2 != 1) return -1;
     int e1 = u_first_in(x), e2 = u_first_out(x);
@@ -759,6 +776,7 @@ ALD_INL double compute_balance_ratio(int v, bool &ok)    // scallop.cc:2578-2602
 // scallop::resolve_single_trivial_vertex (scallop.cc:1236-1254), scalar
 ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio)
 {
+    i = uni(i); jump_ratio = uni(jump_ratio);
     if(H.in_deg[i] == 0 || H.out_deg[i] == 0) return false;
     if(H.in_deg[i] >= 2 && H.out_deg[i] >= 2) return false;
     if(mixed_strand_vertex(i)) return false;
@@ -826,80 +844,100 @@ ALD_FN bool resolve_broken_vertex()
 
 // generic trivial-vertex sweep: mode 0 = resolve_trivial_vertex_fast (scallop.cc:1256-1270: fast=false, type 1, r < jump)
 //                               mode 1 = resolve_trivial_vertex(type, fast=true, jump)  (scallop.cc:1180-1234)
-ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
+// The wave-parallel evaluation is a LEAF (scan_trivial: no calls, so no callee-saved registers go to scratch on the ~500 scans
+// a graph takes); what it carries from one scan of a sweep to the next -- the running (ratio, root) of the reference's
+// sequential loop -- lives in the LDS context, and the thin driver below only keeps `start` across the decomposition call.
+enum { SC_NONE = 0, SC_HIT = 1, SC_STOP = 2, SC_NEED = 3, SC_BAD = 4 };
+ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
 {
+    start = uni(start); mode = uni(mode); type = uni(type); jump_ratio = uni(jump_ratio);
     const int lane = lane_id();
     const bool fast = (mode == 1);
     const double now_thr = (mode == 1) ? 1.02 : jump_ratio;
-    int vend = H.nv;                           // snapshot of nonzeroset: vertices created later are not visited (the sink is never in it: nz == 0)
-    bool flag = false;
-    double best_r = DBL_MAX; int best_v = -1;  // running (ratio, root) of the sequential loop
-    bool stopped = false;
-    int start = 1;
-    PROF_DECL;
-    if(lane == 0) hs_refresh_flags();
-    wsync();
-    while(start < vend) {
-        int hit = -1; double hit_r = 0;
-        for(int base = (start / ALD_WAVE) * ALD_WAVE; base < vend && hit < 0; base += ALD_WAVE) {
-            int i = base + lane;
-            int cls = -9; double r = 0; bool bad = false;
-            if(i >= start && i < vend && H.nz[i] && H.in_deg[i] >= 1 && H.out_deg[i] >= 1 && !(H.in_deg[i] >= 2 && H.out_deg[i] >= 2) && !mixed_strand_vertex(i)) {
-                cls = classify_trivial_fastpath(i, fast);
-            }
-            // lanes that need a dominate query are served one at a time by lane 0 (rare: only edges on phasing paths)
-            uint64_t need = wballot(cls == -2);
-            while(need) {
-                int l = ffs64(need); need &= need - 1;
-                int res = 0;
-                if(lane == 0) res = classify_trivial_vertex(base + l, fast);
-                wsync();
-                res = wshfl(res, 0);
-                if(lane == l) cls = res;
-            }
-            bool cand = (cls == type);
-            if(cand) { bool ok; r = compute_balance_ratio(i, ok); if(!ok) bad = true; }
-            if(wballot(bad)) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); wsync(); return true; }
-            uint64_t now = wballot(cand && r < now_thr);
-            // scallop.cc:1222 `if(ratio < jump_ratio) break;`: the first candidate with 1.02 <= r < jump_ratio becomes the root and ends the sweep
-            uint64_t stp = (mode == 1) ? wballot(cand && !(r < now_thr) && r < jump_ratio) : 0ull;
-            if(stp && (!now || ffs64(stp) < ffs64(now))) {
-                int l = ffs64(stp); best_v = base + l; best_r = wshfl(r, l); stopped = true; break;
-            }
-            // sequential semantics: candidates before the first "now" vertex update (ratio, root); ties go to the LATER vertex
-            int lim = now ? ffs64(now) : ALD_WAVE;
-            if(mode == 1) {
-                bool mine = cand && lane < lim;
-                double rr = mine ? r : DBL_MAX; int vv = mine ? i : -1;
-                for(int off = ALD_WAVE / 2; off >= 1; off >>= 1) {
-                    double r2 = wshfl(rr, lane ^ off); int v2 = wshfl(vv, lane ^ off);
-                    bool take = (v2 >= 0) && (vv < 0 || r2 < rr || (r2 == rr && v2 > vv));
-                    if(take) { rr = r2; vv = v2; }
-                }
-                rr = wshfl(rr, 0); vv = wshfl(vv, 0);
-                if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; }      // if(ratio < r) continue;
-            }
-            if(now) { hit = base + ffs64(now); hit_r = wshfl(r, ffs64(now)); }
+    const int vend = H.sw_vend;                // snapshot of nonzeroset: vertices created later are not visited (the sink is never in it: nz == 0)
+    double best_r = H.sw_best_r; int best_v = H.sw_best_v;
+    const int dom_base = H.sw_dom_base;        // chunk whose dominate queries the driver has answered (scr_i[lane]), or -1
+    int code = SC_NONE, hit = -1; double hit_r = 0;
+    for(int base = (start / ALD_WAVE) * ALD_WAVE; base < vend; base += ALD_WAVE) {
+        int i = base + lane;
+        int cls = -9; double r = 0; bool bad = false;
+        if(i >= start && i < vend && H.nz[i] && H.in_deg[i] >= 1 && H.out_deg[i] >= 1 && !(H.in_deg[i] >= 2 && H.out_deg[i] >= 2) && !mixed_strand_vertex(i)) {
+            cls = classify_trivial_fastpath(i, fast);
         }
+        // lanes that need a dominate query (rare: only edges on phasing paths) are answered by the driver, one at a time on lane 0
+        if(cls == -2 && base == dom_base) cls = H.scr_i[lane];
+        uint64_t need = wballot(cls == -2);
+        if(need) { if(lane == 0) { H.sw_dom_base = base; H.sw_need_lo = (uint32_t)need; H.sw_need_hi = (uint32_t)(need >> 32); } code = SC_NEED; break; }
+        bool cand = (cls == type);
+        if(cand) { bool ok; r = compute_balance_ratio(i, ok); if(!ok) bad = true; }
+        if(wballot(bad)) { code = SC_BAD; break; }
+        uint64_t now = wballot(cand && r < now_thr);
+        // scallop.cc:1222 `if(ratio < jump_ratio) break;`: the first candidate with 1.02 <= r < jump_ratio becomes the root and ends the sweep
+        uint64_t stp = (mode == 1) ? wballot(cand && !(r < now_thr) && r < jump_ratio) : 0ull;
+        if(stp && (!now || ffs64(stp) < ffs64(now))) {
+            int l = ffs64(stp); best_v = base + l; best_r = wshfl(r, l); code = SC_STOP; break;
+        }
+        // sequential semantics: candidates before the first "now" vertex update (ratio, root); ties go to the LATER vertex
+        int lim = now ? ffs64(now) : ALD_WAVE;
+        if(mode == 1) {
+            bool mine = cand && lane < lim;
+            double rr = mine ? r : DBL_MAX; int vv = mine ? i : -1;
+            for(int off = ALD_WAVE / 2; off >= 1; off >>= 1) {
+                double r2 = wshfl(rr, lane ^ off); int v2 = wshfl(vv, lane ^ off);
+                bool take = (v2 >= 0) && (vv < 0 || r2 < rr || (r2 == rr && v2 > vv));
+                if(take) { rr = r2; vv = v2; }
+            }
+            rr = wshfl(rr, 0); vv = wshfl(vv, 0);
+            if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; }      // if(ratio < r) continue;
+        }
+        if(now) { hit = base + ffs64(now); hit_r = wshfl(r, ffs64(now)); code = SC_HIT; break; }
+    }
+    if(lane == 0) { H.sw_best_r = best_r; H.sw_best_v = best_v; H.sw_hit = hit; H.sw_hit_r = hit_r; }
+    wsync();
+    return code;
+}
+ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
+{
+    mode = uni(mode); type = uni(type); jump_ratio = uni(jump_ratio);
+    const int lane = lane_id();
+    PROF_DECL;
+    if(lane == 0) { hs_refresh_flags(); H.sw_vend = H.nv; H.sw_best_r = DBL_MAX; H.sw_best_v = -1; H.sw_dom_base = -1; }
+    wsync();
+    bool flag = false;
+    int start = 1;
+    while(start < uni(H.sw_vend)) {
+        int code = uni(scan_trivial(start, mode, type, jump_ratio));     // chunks before `start` hold no unvisited vertex
         PROF_ADD(PF_TRIV_EVAL);
-        if(hit < 0 || stopped) break;
+        if(code == SC_NEED) {
+            if(lane == 0) {
+                uint64_t need = (uint64_t)H.sw_need_lo | ((uint64_t)H.sw_need_hi << 32); const int base = H.sw_dom_base;
+                while(need) { int l = ffs64(need); need &= need - 1; H.scr_i[l] = classify_trivial_vertex(base + l, mode == 1); }
+            }
+            wsync();
+            if(uni(H.sw_dom_base) > start) start = uni(H.sw_dom_base);       // earlier chunks are done (no hit; their candidates are in sw_best_*)
+            continue;
+        }
+        if(code == SC_BAD) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); wsync(); return true; }
+        if(code != SC_HIT) break;
         if(lane == 0) {
-            trace(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, vlog(hit), mode == 1 ? type : 0, hit_r);
+            const int hit = H.sw_hit;
+            trace(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, vlog(hit), mode == 1 ? type : 0, H.sw_hit_r);
             decompose_trivial_vertex(hit);
             hs_refresh_flags();
+            H.sw_dom_base = -1;
         }
         wsync();
         PROF_ADD(PF_TRIV_MUT);
         flag = true;
         if(H.status) return true;
-        start = hit + 1;
+        start = uni(H.sw_hit) + 1;
     }
     if(flag) return true;
     if(mode == 0) return false;
-    if(best_v < 0) return false;
+    if(H.sw_best_v < 0) return false;
     if(lane == 0) {
-        trace(OP_TRIVIAL_BEST, vlog(best_v), type, best_r);
-        decompose_trivial_vertex(best_v);
+        trace(OP_TRIVIAL_BEST, vlog(H.sw_best_v), type, H.sw_best_r);
+        decompose_trivial_vertex(H.sw_best_v);
     }
     wsync();
     PROF_ADD(PF_TRIV_MUT);
@@ -909,6 +947,7 @@ ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
 // scallop::resolve_smallest_edges (scallop.cc:844-945)
 ALD_FN bool sweep_smallest(double max_ratio)
 {
+    max_ratio = uni(max_ratio);
     const int lane = lane_id();
     int vend = H.nv;
     bool flag = false;
@@ -963,6 +1002,7 @@ ALD_FN bool sweep_smallest(double max_ratio)
 // Results in H.ro_type / H.ro_degree / H.ro_ratio / H.ro_npairs; pe2w pairs (sorted, clamped) in the pair area.
 ALD_FN bool router_run(int root, int want_type, int max_degree)
 {
+    root = uni(root); want_type = uni(want_type); max_degree = uni(max_degree);
     COLD;
     // ---- build_indices (router.cc:225-248)
     int nin = uni(H.in_deg[root]), nout = uni(H.out_deg[root]), n = nin + nout;
@@ -1139,6 +1179,7 @@ ALD_FN bool router_run(int root, int want_type, int max_degree)
 // park / un-park the best candidate's pe2w while an unsplittable sweep goes on
 ALD_FN void save_pairs(int n)
 {
+    n = uni(n);
     const bool lds = H.pw_lds != 0;
     const Pairs S = pairs_at(lds, false), D = pairs_at(lds, true);
     if(n > D.cap) { fail(ALD_ST_CAPACITY); return; }
@@ -1147,6 +1188,7 @@ ALD_FN void save_pairs(int n)
 }
 ALD_FN void restore_pairs(int n)
 {
+    n = uni(n);
     const bool lds = H.park_lds != 0;
     H.pw_lds = lds ? 1 : 0;
     const Pairs S = pairs_at(lds, true), D = pairs_at(lds, false);
@@ -1155,6 +1197,7 @@ ALD_FN void restore_pairs(int n)
 // scallop::resolve_unsplittable_vertex (scallop.cc:1004-1060)
 ALD_FN bool sweep_unsplittable(int type, int degree, double max_ratio)
 {
+    type = uni(type); degree = uni(degree); max_ratio = uni(max_ratio);
     const int lane = lane_id();
     int vend = H.nv;
     bool flag = false;
@@ -1206,6 +1249,7 @@ ALD_FN bool sweep_unsplittable(int type, int degree, double max_ratio)
 // scallop::collect_path (scallop.cc:2766-2834), scalar on lane 0
 ALD_FN void collect_path(int e)
 {
+    e = uni(e);
     COLD;
     ALD_GLOBAL const KernelArgs *A = H.args;
     int n = H.V0 - 1;                           // v2v[sink]: the sink's original index
@@ -1432,26 +1476,26 @@ ALD_FN void run_graph()
     if(lane_id() == 0) for(int k = 0; k < 32; k++) H.prof[k] = 0;
     wsync();
 #endif
-    if(!load_graph()) { finish_graph(); return; }
+    if(!uni(load_graph())) { finish_graph(); return; }
     PROF_ADD(PF_LOAD);
     bool skipped = false;
-    const double r_triv = H.p_ratio[7], r_small = H.p_ratio[0], r_single = H.p_ratio[5], r_pure = H.p_ratio[4];
-    const int max_exons = H.p_max_exons;
+    const double r_triv = uni(H.p_ratio[7]), r_small = uni(H.p_ratio[0]), r_single = uni(H.p_ratio[5]), r_pure = uni(H.p_ratio[4]);
+    const int max_exons = uni(H.p_max_exons);
     int guard = 64 * MAXE;                     // every successful rule consumes an edge or a vertex; far above any real count
     while(guard-- > 0) {
-        if(H.nv > max_exons) { skipped = true; break; }
-        if(H.status) break;
+        if(uni(H.nv) > max_exons) { skipped = true; break; }
+        if(uni(H.status)) break;
         PROF_RESET();
-        bool brk = resolve_broken_vertex();
+        bool brk = uni(resolve_broken_vertex());
         PROF_ADD(PF_BROKEN);
         if(brk) continue;
-        if(r_triv > 1.0) { if(sweep_trivial(0, 1, r_triv)) continue; }     // resolve_trivial_vertex_fast: a no-op for jump_ratio <= 1 (r >= 1 always)
-        if(sweep_trivial(1, 1, r_triv)) continue;
-        if(sweep_smallest(r_small)) continue;
+        if(r_triv > 1.0) { if(uni(sweep_trivial(0, 1, r_triv))) continue; }     // resolve_trivial_vertex_fast: a no-op for jump_ratio <= 1 (r >= 1 always)
+        if(uni(sweep_trivial(1, 1, r_triv))) continue;
+        if(uni(sweep_smallest(r_small))) continue;
         PROF_RESET();
-        bool un = sweep_unsplittable(T_UNSPLITTABLE_SINGLE, 1, 0.01) || sweep_unsplittable(T_SPLITTABLE_PURE, 1, 0.01)
-               || sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, r_single) || sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, r_pure)
-               || sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, DBL_MAX) || sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, DBL_MAX);
+        bool un = uni(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, 1, 0.01)) || uni(sweep_unsplittable(T_SPLITTABLE_PURE, 1, 0.01))
+               || uni(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, r_single)) || uni(sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, r_pure))
+               || uni(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, DBL_MAX)) || uni(sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, DBL_MAX));
         PROF_ADD(PF_UNSPLIT);
         if(un) continue;
 #if 0
@@ -1462,7 +1506,7 @@ ALD_FN void run_graph()
         if(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, DBL_MAX)) continue;
         if(sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, DBL_MAX)) continue;
 #endif
-        if(sweep_trivial(1, 2, r_triv)) continue;
+        if(uni(sweep_trivial(1, 2, r_triv))) continue;
         break;
     }
     if(lane_id() == 0 && H.status == 0) {

@@ -10,7 +10,7 @@ import common
 
 @pytest.mark.parametrize("name", list(common.PARITY_CONFIGS))
 def test_engine_matches_oracle(name):
-    kw = dict(common.PARITY_CONFIGS[name]); kw["n_graphs"] = min(kw["n_graphs"], 60)
+    kw = dict(common.PARITY_CONFIGS[name])       # the full configuration, exactly what the GPU tier runs
     pg = A.synth(**kw)
     want, st, _, _ = common.oracle_run(pg)
     got, it, cl = common.emu_run(pg)
