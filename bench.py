@@ -107,6 +107,17 @@ def main():
     k_ms = float(np.mean(kms))
     info = batch.class_info(1)
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the figure comes from the committed
+    # summary of separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (profiles/summarize.py);
+    # it is only quoted when it was collected on this exact workload, else null
+    traffic = None; traffic_src = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if tj.get("graphs_per_gpu") == args.graphs and tj.get("vertices") == args.vertices and tj.get("edges") == args.edges:
+            traffic = tj["traffic_bytes_per_launch"]; traffic_src = tj.get("source")
+    except (OSError, ValueError, KeyError):
+        pass
+
     if rank == 0:
         total_graphs = args.graphs * world * args.steps
         value = total_graphs / elapsed
@@ -120,7 +131,7 @@ def main():
                        "graphs_per_gpu": args.graphs, "sharding": "independent graphs per rank, RCCL gather of path records to rank 0" if world > 1 else "single GPU",
                        "failed_graphs": n_bad, "paths_per_graph": float(len(res.weight)) / max(1, args.graphs),
                        "workgroups_per_cu": info["blocks_per_cu"], "grid": info["blocks_last_run"]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ald_decomp_kernel_c1", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": in_b + out_b,
                          "bytes_per_graph": (in_b + out_b) / args.graphs, "kernel_graphs_per_s": args.graphs / (k_ms / 1e3)},
         }
