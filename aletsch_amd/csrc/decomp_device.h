@@ -622,14 +622,11 @@ ALD_INL void decompose_vertex_replace(int root, int n)
     if(H.in_deg[root] != 0 || uni(H.out_deg[root]) != 0) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }
     H.nz[root] = 0;
 }
-// scallop::decompose_trivial_vertex (scallop.cc:2144-2167)
-ALD_FN void decompose_trivial_vertex(int x)
+// scallop::decompose_trivial_vertex (scallop.cc:2144-2167), general form: pe2w = in x out, then decompose_vertex_replace
+ALD_FN void decompose_trivial_generic(int x)
 {
     x = uni(x);
     PROF_DECL;
-    balance_vertex_i(x);
-    PROF_ADD(PF_T_BALANCE);
-    if(H.status) return;
     const int np = (int)uni(H.in_deg[x]) * (int)uni(H.out_deg[x]);
     H.pw_lds = (np <= LP) ? 1 : 0;
     const Pairs P = pairs_cur();
@@ -641,6 +638,107 @@ ALD_FN void decompose_trivial_vertex(int x)
     sort_pairs(n);
     PROF_ADD(PF_T_PAIRS);
     decompose_vertex_replace(x, n);
+}
+// The same decomposition for the shape every trivial vertex has -- ONE edge c on one side (A: the in-edge, else the out-edge)
+// and a fan of d edges on the other -- without the pair array: pe2w is {(c, f_j)} with weight min(w(c), w(f_j)), visited in
+// creation-id order of f_j (the sorted order of map<PI,double>, router.h:23).  What merge_adjacent_edges (scallop.cc:2394-2431)
+// does to such a pair is known in advance: the fan edge is never cut (its weight IS the pair weight), c is cut until the last
+// pair consumes it, and the merged edge differs from f_j only in one endpoint.  So the merged edge takes over f_j's slot (new id,
+// new endpoint, re-sorted into the two lists it belongs to), c's record and the vertex are read once, and the weight sums
+// around x are taken from the gathered fan in list order -- the same additions, in the same order, as the general form.
+enum { STAR_MAX = 32 };
+template<bool A> ALD_INL void decompose_trivial_star(int x)
+{
+    COLD;
+    PROF_DECL;
+    const double mw = H.p_min_w;
+    const int c = A ? u_first_in(x) : u_first_out(x);
+    int32_t *fe = (int32_t*)H.scr_i + 4 * LP;      // [n] fan edges in adjacency-list order, -1 once merged  (the arena part of the
+    int32_t *ord = fe + STAR_MAX;                   // [n] positions in fe, ascending creation id            LDS scratch: the parked
+    double *fw = (double*)H.scr_d + 2 * LP;         // [n] pe2w weight of (c, fan edge)                       pair area stays intact)
+    int n = 0; const double wc = uni(H.ew[c]);
+    for(int e = A ? u_first_out(x) : u_first_in(x); e >= 0; e = A ? u_next_out(e) : u_next_in(e)) {
+        double w2 = uni(H.ew[e]); fe[n] = e; fw[n] = A ? (wc <= w2 ? wc : w2) : (w2 <= wc ? w2 : wc); n++;
+    }
+    for(int i = 0; i < n; i++) { int k = i; uint32_t id = uni(H.eid[fe[i]]); while(k > 0 && (uint32_t)uni(H.eid[fe[ord[k - 1]]]) > id) { ord[k] = ord[k - 1]; k--; } ord[k] = i; }
+    double mdc = 0;
+    for(int q = 0; q < n; q++) { double w = fw[ord[q]]; if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } mdc = (q == 0) ? w : mdc + w; }
+    H.ew[c] = mdc;
+    for(int j = 0; j < n; j++) H.ew[fe[j]] = fw[j];
+    PROF_ADD(PF_T_SETUP);
+    const int far = A ? (int)uni(H.lk[c].es) : (int)uni(H.lk[c].et);
+    const double medc = uni(C.ed[c].med), cc = uni(C.ed[c].econf);
+    const int meic = uni(C.ed[c].mei), cntc = uni(C.ed[c].ecount), stc = uni(C.ed[c].estrand);
+    double vwt = uni(C.vx[x].vw); const int lt = uni(C.vx[x].lpos), rt = uni(C.vx[x].rpos), ov = uni(C.vx[x].v2v);
+    bool consumed = false;
+    for(int q = 0; q < n; q++) {
+        if(consumed) { C.vx[x].vw = vwt; fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }     // the general form would be handed a dead edge here
+        const int j = ord[q], f = fe[j]; const double ww = fw[j];
+        const double wcur = uni(H.ew[c]);                                   // what is left of c
+        const bool sc = !(fabs(wcur - ww) <= kSMIN);                        // split_edge(c, ww) cuts a piece off (scallop.cc:2433-2484)
+        int nid = uni(H.next_id);
+        if(nid >= 0xFFF0) { C.vx[x].vw = vwt; fail(ALD_ST_CAPACITY); return; }
+        double rem = wcur;
+        if(sc) { nid++; rem = wcur - ww; if(rem <= mw) rem = mw; H.ew[c] = rem; }    // the piece takes an id and disappears in the merge
+        H.next_id = nid + 1;                                                // id of the merged edge
+        const double wc0 = sc ? ww : wcur;
+        const double medc1 = sc ? medc * ww / wcur : medc;
+        const double medf = uni(C.ed[f].med), cf = uni(C.ed[f].econf);
+        const int meif = uni(C.ed[f].mei), cntf = uni(C.ed[f].ecount), stf = uni(C.ed[f].estrand);
+        PROF_ADD(PF_T_MERGE_LOAD);
+        if(!(cntc > 0 && cntf > 0)) { C.vx[x].vw = vwt; fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
+        if(!(A ? intersect_samples(c, f, f) : intersect_samples(f, c, f))) { C.vx[x].vw = vwt; return; }
+        PROF_ADD(PF_T_MERGE_ISECT);
+        C.ed[f].econf = A ? cc + cf : cf + cc;
+        { const int sty = A ? stf : stc, stx = A ? stc : stf; C.ed[f].estrand = (uint8_t)(sty != 0 ? sty : stx); }
+        for(int k = 0; k < NW; k++) C.ed[f].mask[k] = A ? (uni(C.ed[c].mask[k]) | uni(C.ed[f].mask[k])) : (uni(C.ed[f].mask[k]) | uni(C.ed[c].mask[k]));
+        if(ov >= 0) C.ed[f].mask[(ov >> 6)] |= (1ull << (ov & 63));
+        PROF_ADD(PF_T_MERGE_MASK);
+        // get_in_weights(x) / get_out_weights(x) with both pieces attached: c's side is (rest of c) + piece, the fan side is
+        // whatever has not been merged yet, in list order
+        double sfan = 0;
+        for(int k = 0; k < n; k++) if(fe[k] >= 0) sfan += fw[k];
+        double sc_side = 0; sc_side += sc ? rem : wcur; if(sc) sc_side += ww;
+        const double sum = A ? (sc_side + sfan) * 0.5 : (sfan + sc_side) * 0.5;
+        const double r1 = A ? vwt * (wc0 + ww) * 0.5 / sum : vwt * (ww + wc0) * 0.5 / sum;
+        vwt = vwt - r1;
+        const int mi = A ? rt - lt + meic + meif : rt - lt + meif + meic;
+        C.ed[f].med = A ? mi * r1 + medc1 + medf : mi * r1 + medf + medc1; C.ed[f].mei = mi;
+        PROF_ADD(PF_T_MERGE_SUMS);
+        // f becomes the merged edge: newest id, far endpoint of c, weight of the two equal pieces
+        const int other = A ? (int)uni(H.lk[f].et) : (int)uni(H.lk[f].es);
+        if(A) unlink_in(other, f); else unlink_out(other, f);
+        H.eid[f] = (uint16_t)nid; H.ew[f] = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
+        if(A) { H.lk[f].es = (IDX)far; link_in(other, f); link_out(far, f); }
+        else { H.lk[f].et = (IDX)far; link_out(other, f); link_in(far, f); }
+        fe[j] = -1;
+        PROF_ADD(PF_T_MERGE_ADD);
+        if(A) hs_replace2(c, f, f); else hs_replace2(f, c, f);
+        if(n == 1) hs_replace1(c, f);
+        if(!sc) consumed = true;
+        PROF_ADD(PF_T_HS);
+    }
+    C.vx[x].vw = vwt;
+    if(n >= 2) hs_remove(c);
+    if(!consumed) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }      // c kept a remainder: the reference asserts on the degree of x
+    // remove_edge(c); x is left without edges
+    if(A) unlink_out(far, c); else unlink_in(far, c);
+    H.lk[c].es = NIL; H.hflag[c] = 0;
+    { int fh = uni(H.free_head); H.lk[c].onx = fh < 0 ? NIL : (IDX)fh; H.free_head = c; H.free_cnt = uni(H.free_cnt) + 1; }
+    H.in_head[x] = NIL; H.out_head[x] = NIL; H.in_deg[x] = 0; H.out_deg[x] = 0; H.nz[x] = 0;
+    PROF_ADD(PF_T_TAIL);
+}
+ALD_FN void decompose_trivial_vertex(int x)
+{
+    x = uni(x);
+    PROF_DECL;
+    balance_vertex_i(x);
+    PROF_ADD(PF_T_BALANCE);
+    if(H.status) return;
+    const int nin = uni(H.in_deg[x]), nout = uni(H.out_deg[x]);
+    if(nin == 1 && nout >= 1 && nout <= STAR_MAX) decompose_trivial_star<true>(x);
+    else if(nout == 1 && nin >= 1 && nin <= STAR_MAX) decompose_trivial_star<false>(x);
+    else decompose_trivial_generic(x);
 }
 
 ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio);
