@@ -67,6 +67,7 @@ struct Hot {
     // decompose_vertex_extend appends vertices (exchange_sink, scallop.cc:2198-2215); here order comparisons map it to +inf
     // instead.  Physical order of all other vertices == the reference's index order.
     int32_t  sinkp, special_linked;
+    int32_t  maybe_broken;                      // 0 => no vertex can be broken (a degree only reaches 0 in unlink_*; new vertices appear in extend)
     // state of the trivial-vertex sweep in flight (scan_trivial <-> sweep_trivial)
     double   sw_best_r, sw_hit_r; int32_t sw_best_v, sw_hit, sw_vend, sw_dom_base; uint32_t sw_need_lo, sw_need_hi;
     int32_t  scr_i[SCR_I]; double scr_d[SCR_D];
@@ -204,7 +205,7 @@ ALD_INL void unlink_in(int v, int e)
     if(cur != e) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }       // cannot happen on a consistent state; never walk off a list
     IDX nx = uni(H.lk[e].inx);
     if(prev < 0) H.in_head[v] = nx; else H.lk[prev].inx = nx;
-    H.in_deg[v]--;
+    { int dg = (int)uni(H.in_deg[v]) - 1; H.in_deg[v] = (IDX)dg; if(dg == 0) H.maybe_broken = 1; }
 }
 ALD_INL void unlink_out(int v, int e)
 {
@@ -215,7 +216,45 @@ ALD_INL void unlink_out(int v, int e)
     if(cur != e) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
     IDX nx = uni(H.lk[e].onx);
     if(prev < 0) H.out_head[v] = nx; else H.lk[prev].onx = nx;
-    H.out_deg[v]--;
+    { int dg = (int)uni(H.out_deg[v]) - 1; H.out_deg[v] = (IDX)dg; if(dg == 0) H.maybe_broken = 1; }
+}
+// e stays in v's in-list but its key becomes (ks, newest id): one walk finds its predecessor and its new place
+ALD_INL void relink_in(int v, int e, uint32_t ks)
+{
+    v = uni(v); e = uni(e);
+    if(v == uni(H.sinkp) && !uni(H.special_linked)) return;
+    int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
+    for(int cur = u_first_in(v); cur >= 0; ) {
+        uint64_t w = lkw(cur); int nx = lk_next((uint32_t)((w >> 32) & 0xFFFF));
+        if(cur == e) { pe = last; seen = true; if(placed) break; }
+        else { if(!placed && (uint32_t)(w & 0xFFFF) > ks) { ip = last; placed = true; if(seen) break; } last = cur; }
+        cur = nx;
+    }
+    if(!seen) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
+    if(!placed) ip = last;
+    if(ip == pe) return;                                   // same place
+    IDX nxe = uni(H.lk[e].inx);
+    if(pe < 0) H.in_head[v] = nxe; else H.lk[pe].inx = nxe;
+    if(ip < 0) { H.lk[e].inx = uni(H.in_head[v]); H.in_head[v] = (IDX)e; } else { H.lk[e].inx = uni(H.lk[ip].inx); H.lk[ip].inx = (IDX)e; }
+}
+ALD_INL void relink_out(int v, int e, uint32_t kt)         // kt already mapped by tkey()
+{
+    v = uni(v); e = uni(e);
+    if(v == 0 && !uni(H.special_linked)) return;
+    const uint32_t sk = (uint32_t)uni(H.sinkp);
+    int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
+    for(int cur = u_first_out(v); cur >= 0; ) {
+        uint64_t w = lkw(cur); int nx = lk_next((uint32_t)(w >> 48));
+        if(cur == e) { pe = last; seen = true; if(placed) break; }
+        else { uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu; if(!placed && ct > kt) { ip = last; placed = true; if(seen) break; } last = cur; }
+        cur = nx;
+    }
+    if(!seen) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
+    if(!placed) ip = last;
+    if(ip == pe) return;
+    IDX nxe = uni(H.lk[e].onx);
+    if(pe < 0) H.out_head[v] = nxe; else H.lk[pe].onx = nxe;
+    if(ip < 0) { H.lk[e].onx = uni(H.out_head[v]); H.out_head[v] = (IDX)e; } else { H.lk[e].onx = uni(H.lk[ip].onx); H.lk[ip].onx = (IDX)e; }
 }
 ALD_INL int free_slots() { return uni(H.free_cnt) + (MAXE - uni(H.slot_hw)); }
 // directed_graph::add_edge (directed_graph.cc:38-48) + i2e.push_back: the new id is the largest
@@ -669,6 +708,7 @@ template<bool A> ALD_INL void decompose_trivial_star(int x)
     const int far = A ? (int)uni(H.lk[c].es) : (int)uni(H.lk[c].et);
     const double medc = uni(C.ed[c].med), cc = uni(C.ed[c].econf);
     const int meic = uni(C.ed[c].mei), cntc = uni(C.ed[c].ecount), stc = uni(C.ed[c].estrand);
+    const uint32_t nsc = uni(C.ed[c].sp_len); const int idc = uni(C.ed[c].s0id); const double abc = uni(C.ed[c].s0abd);     // c's support never changes
     double vwt = uni(C.vx[x].vw); const int lt = uni(C.vx[x].lpos), rt = uni(C.vx[x].rpos), ov = uni(C.vx[x].v2v);
     bool consumed = false;
     for(int q = 0; q < n; q++) {
@@ -687,7 +727,12 @@ template<bool A> ALD_INL void decompose_trivial_star(int x)
         const int meif = uni(C.ed[f].mei), cntf = uni(C.ed[f].ecount), stf = uni(C.ed[f].estrand);
         PROF_ADD(PF_T_MERGE_LOAD);
         if(!(cntc > 0 && cntf > 0)) { C.vx[x].vw = vwt; fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
-        if(!(A ? intersect_samples(c, f, f) : intersect_samples(f, c, f))) { C.vx[x].vw = vwt; return; }
+        if(nsc == 1 && uni(C.ed[f].sp_len) == 1) {      // one supporting sample on both sides: intersect_samples' inline case, c's half already in registers
+            const int idf = uni(C.ed[f].s0id); const double abf = uni(C.ed[f].s0abd);
+            if(idf == idc) { const double xa = A ? abc : abf, ya = A ? abf : abc; const double mn = (ya < xa) ? ya : xa; C.ed[f].sp_off = 0; C.ed[f].ecount = 1; C.ed[f].eabd = 0.0 + mn; C.ed[f].s0abd = mn; }
+            else { C.ed[f].sp_off = 0; C.ed[f].sp_len = 0; C.ed[f].ecount = 0; C.ed[f].eabd = 0; C.ed[f].s0id = 0; C.ed[f].s0abd = 0; }
+        }
+        else if(!(A ? intersect_samples(c, f, f) : intersect_samples(f, c, f))) { C.vx[x].vw = vwt; return; }
         PROF_ADD(PF_T_MERGE_ISECT);
         C.ed[f].econf = A ? cc + cf : cf + cc;
         { const int sty = A ? stf : stc, stx = A ? stc : stf; C.ed[f].estrand = (uint8_t)(sty != 0 ? sty : stx); }
@@ -707,10 +752,9 @@ template<bool A> ALD_INL void decompose_trivial_star(int x)
         PROF_ADD(PF_T_MERGE_SUMS);
         // f becomes the merged edge: newest id, far endpoint of c, weight of the two equal pieces
         const int other = A ? (int)uni(H.lk[f].et) : (int)uni(H.lk[f].es);
-        if(A) unlink_in(other, f); else unlink_out(other, f);
         H.eid[f] = (uint16_t)nid; H.ew[f] = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
-        if(A) { H.lk[f].es = (IDX)far; link_in(other, f); link_out(far, f); }
-        else { H.lk[f].et = (IDX)far; link_out(other, f); link_in(far, f); }
+        if(A) { H.lk[f].es = (IDX)far; relink_in(other, f, (uint32_t)far); link_out(far, f); }
+        else { H.lk[f].et = (IDX)far; relink_out(other, f, tkey((uint32_t)far)); link_in(far, f); }
         fe[j] = -1;
         PROF_ADD(PF_T_MERGE_ADD);
         if(A) hs_replace2(c, f, f); else hs_replace2(f, c, f);
@@ -738,7 +782,12 @@ ALD_FN void decompose_trivial_vertex(int x)
     const int nin = uni(H.in_deg[x]), nout = uni(H.out_deg[x]);
     if(nin == 1 && nout >= 1 && nout <= STAR_MAX) decompose_trivial_star<true>(x);
     else if(nout == 1 && nin >= 1 && nin <= STAR_MAX) decompose_trivial_star<false>(x);
-    else decompose_trivial_generic(x);
+    else {
+#ifdef ALD_EMU
+        if(getenv("ALD_EMU_VERBOSE")) fprintf(stderr, "[emu] generic trivial: in %d out %d\n", nin, nout);
+#endif
+        decompose_trivial_generic(x);
+    }
 }
 
 ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio);
@@ -782,6 +831,7 @@ ALD_FN void decompose_vertex_extend(int root, int n)
     int newedges = 0;
     for(int i = 0; i < n; i++) { int u1 = PLOC(a[i]), u2 = PLOC(b[i]); if(mdeg[u1] == 1 && mdeg[u2] == 1) evx[u1] = nn++; else if(mdeg[u1] >= 2 && mdeg[u2] >= 2) newedges++; }
     if(nn > MAXV || free_slots() < newedges) { fail(ALD_ST_CAPACITY); return; }
+    H.maybe_broken = 1;
     for(int i = m; i < nn; i++) { H.in_head[i] = NIL; H.out_head[i] = NIL; H.in_deg[i] = 0; H.out_deg[i] = 0; H.nz[i] = 1; C.vx[i].vw = 0; C.vx[i].lpos = 0; C.vx[i].rpos = 0; C.vx[i].vtype = -1; C.vx[i].v2v = -1; }
     H.nv = nn;
     for(int i = 0; i < nin; i++) {               // ev1: detach in-edges onto their new vertex
@@ -917,6 +967,7 @@ ALD_INL int eval_smallest(int i, double &r)
 // scallop::resolve_broken_vertex (scallop.cc:190-236)
 ALD_FN bool resolve_broken_vertex()
 {
+    if(!uni(H.maybe_broken)) return false;
     const int lane = lane_id();
     int vend = H.nv; int x = -1;
     for(int base = 0; base < vend && x < 0; base += ALD_WAVE) {
@@ -925,7 +976,7 @@ ALD_FN bool resolve_broken_vertex()
         uint64_t m = wballot(p);
         if(m) x = base + ffs64(m);
     }
-    if(x < 0) return false;
+    if(x < 0) { wsync(); if(lane == 0) H.maybe_broken = 0; wsync(); return false; }
     if(lane == 0) {
         if(H.in_deg[x] + H.out_deg[x] == 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);      // assert(ve.size() >= 1)
         else {
@@ -1392,13 +1443,26 @@ ALD_FN void materialize_special()
         if((int)uni(H.lk[e].et) == sinkp) link_in(sinkp, e);
     }
 }
-// scallop::collect_existing_st_paths (scallop.cc:2742-2752): ascending edge index == ascending creation id
+// scallop::collect_existing_st_paths (scallop.cc:2742-2752): ascending edge index == ascending creation id.
+// out(0) / in(sink) are not linked at this point (see link_out): the source->sink edges are picked out of the slot array by the
+// whole wave and ordered by id on lane 0; collect_path's remove_edge then only counts.  Called by ALL lanes.
 ALD_FN void collect_existing_st_paths()
 {
-    int sink = H.sinkp;
-    // the source's out-list is ordered by (target, id) with the sink last: the edges to the sink are its tail, ascending in id
-    int e = u_first_out(0); int guard = MAXE;
-    while(e >= 0 && guard-- > 0) { int nx = u_next_out(e); if((int)uni(H.lk[e].et) == sink) { collect_path(e); if(H.status) return; } e = nx; }
+    COLD;
+    const int lane = lane_id();
+    const int sink = uni(H.sinkp), hw = uni(H.slot_hw);
+    ALD_GLOBAL int32_t *lst = C.wi; int n = 0;           // lane 0's list (work array of the slab: up to MAXE entries)
+    for(int base = 0; base < hw; base += ALD_WAVE) {
+        int e = base + lane;
+        bool p = e < hw && H.lk[e].es == 0 && (int)H.lk[e].et == sink;
+        uint64_t m = wballot(p);
+        if(lane == 0) while(m) { int b = ffs64(m); m &= m - 1; lst[n++] = base + b; }
+    }
+    if(lane == 0) {
+        for(int i = 1; i < n; i++) { int x = lst[i]; uint32_t id = uni(H.eid[x]); int j = i - 1; while(j >= 0 && (uint32_t)uni(H.eid[lst[j]]) > id) { lst[j + 1] = lst[j]; j--; } lst[j + 1] = x; }
+        for(int i = 0; i < n && !H.status; i++) collect_path(lst[i]);
+    }
+    wsync();
 }
 // splice_graph::compute_maximum_path_w (splice_graph.cc:819-885) + directed_graph::topological_sort (directed_graph.cc:420-451)
 // path edges -> upper half of wi, length -> H.tmp0
@@ -1449,6 +1513,7 @@ ALD_FN void greedy_decompose()
     bool any = false;
     for(int i = 0; i < H.nv && !any; i++) if(H.out_deg[i]) any = true;
     if(!any) return;
+    materialize_special();                         // the DP and the path surgery walk out(0) / in(sink)
     PROF_DECL;
     for(int rep = 0; rep < 2; rep++) for(int i = 1; i < H.nv; i++) { if(i == H.sinkp) continue; balance_vertex(i); if(H.status) return; }
     PROF_ADD(PF_G_BALANCE);
@@ -1491,7 +1556,7 @@ ALD_FN bool load_graph()
     int64_t ov = A->in.off_v[g], ovo = ov + g, oe = A->in.off_e[g], oeo = oe + g, os = A->in.off_s[g], op = A->in.off_p[g], opo = op + g, opv = A->in.off_pv[g];
     if(lane == 0) {
         H.V0 = V; H.gstrand = (int)(unsigned char)A->in.graph_strand[g];
-        H.sinkp = V - 1; H.special_linked = 0;
+        H.sinkp = V - 1; H.special_linked = 0; H.maybe_broken = 1;
         H.nv = V; H.next_id = E; H.slot_hw = E; H.free_head = -1; H.free_cnt = 0; H.pend_head = -1; H.status = 0; H.any_strand = 0; H.hs_dirty = 1;
         H.n_paths = 0; H.n_iters = 0; H.n_trace = 0; H.sp_used = 0; H.hl_used = 0; H.hl_n = 0;
     }
@@ -1607,13 +1672,13 @@ ALD_FN void run_graph()
         if(uni(sweep_trivial(1, 2, r_triv))) continue;
         break;
     }
-    if(lane_id() == 0 && H.status == 0) {
-        if(guard <= 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);
-        else {
-            PROF_RESET();
-            materialize_special();
-            collect_existing_st_paths();
-            PROF_ADD(PF_COLLECT0);
+    if(lane_id() == 0 && H.status == 0 && guard <= 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);
+    wsync();
+    if(uni(H.status) == 0) {
+        PROF_RESET();
+        collect_existing_st_paths();
+        PROF_ADD(PF_COLLECT0);
+        if(lane_id() == 0) {
             if(H.status == 0) greedy_decompose();
             if(H.status == 0 && skipped) H.status = ALD_ST_SKIPPED_LARGE;
         }
