@@ -334,12 +334,15 @@ int ald_batch_download(ald_batch *b)
     HIPCHK(hipMemcpy(&used, b->d_poolused.p, 8, hipMemcpyDeviceToHost));
     if(used > b->pool_cap_words) used = b->pool_cap_words;
     b->res.clear();
-    b->res.pool.resize(used);
+    // the records land in a pinned buffer (kept across runs) through an async copy on the batch stream: the copy engine moves them
+    // while another batch's kernel may be running, and the host thread only waits
+    if(b->pin_out.ensure(4 * (size_t)used + 64)) return set_err(ALD_ERR_NOMEM, "pinned result buffer");
     if(n > 0) {
         HIPCHK(hipMemcpy(b->n_paths.data(), b->d_npaths.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(b->n_iters.data(), b->d_niters.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
     }
-    if(used) HIPCHK(hipMemcpy(b->res.pool.data(), b->d_pool.p, 4 * used, hipMemcpyDeviceToHost));
+    if(used) { HIPCHK(hipMemcpyAsync(b->pin_out.p, b->d_pool.p, 4 * used, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream)); }
+    b->res.ext_pool = (const uint32_t*)b->pin_out.p; b->res.ext_words = used;
     b->res.status = b->status; b->res.n_iters = b->n_iters; b->res.attempt = b->attempt;
     b->indexed = false;
     if(b->trace_cap > 0 && n > 0) {
@@ -526,7 +529,7 @@ int ald_tset_export(const ald_tset *t, uint64_t *hash, int32_t *count, char *str
 int ald_batch_raw_records(const ald_batch *b, const uint32_t **words, int64_t *n_words)
 {
     if(!b || !b->downloaded || !words || !n_words) return ALD_ERR_INVALID;
-    *words = b->res.pool.data(); *n_words = (int64_t)b->res.pool.size();
+    *words = b->res.pool_data(); *n_words = (int64_t)b->res.pool_size();
     return ALD_OK;
 }
 

@@ -31,6 +31,10 @@
 
 namespace ALD_CLASS_NS {
 using namespace ald;
+#ifdef ALD_EMU_COUNT
+static long g_cnt_router = 0, g_cnt_unsweep = 0;
+struct CntPrinter { ~CntPrinter() { if(g_cnt_unsweep) fprintf(stderr, "[emu-count] class %d: unsplittable sweeps %ld router runs %ld\n", ALD_CLASS_ID, g_cnt_unsweep, g_cnt_router); } }; static CntPrinter g_cnt_printer;
+#endif
 
 enum { MAXV = ClassDims<ALD_CLASS_ID>::MAXV, MAXE = ClassDims<ALD_CLASS_ID>::MAXE, NW = ClassDims<ALD_CLASS_ID>::NW };
 typedef uint16_t IDX;
@@ -1151,6 +1155,9 @@ ALD_FN bool sweep_smallest(double max_ratio)
 // Results in H.ro_type / H.ro_degree / H.ro_ratio / H.ro_npairs; pe2w pairs (sorted, clamped) in the pair area.
 ALD_FN bool router_run(int root, int want_type, int max_degree)
 {
+#ifdef ALD_EMU_COUNT
+    g_cnt_router++;
+#endif
     root = uni(root); want_type = uni(want_type); max_degree = uni(max_degree);
     COLD;
     // ---- build_indices (router.cc:225-248)
@@ -1346,6 +1353,9 @@ ALD_FN void restore_pairs(int n)
 // scallop::resolve_unsplittable_vertex (scallop.cc:1004-1060)
 ALD_FN bool sweep_unsplittable(int type, int degree, double max_ratio)
 {
+#ifdef ALD_EMU_COUNT
+    g_cnt_unsweep++;
+#endif
     type = uni(type); degree = uni(degree); max_ratio = uni(max_ratio);
     const int lane = lane_id();
     int vend = H.nv;

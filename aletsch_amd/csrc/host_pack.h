@@ -184,20 +184,23 @@ struct HostResults {
     std::vector<int32_t> status, n_iters, attempt;       // per graph (attempt = pass that produced the final answer)
     std::vector<int64_t> path_begin;                     // [n+1] into paths (sorted by graph, index)
     std::vector<PathRec> paths;
-    std::vector<uint32_t> pool;                          // raw record words (vertex lists are read in place)
+    std::vector<uint32_t> pool;                          // raw record words (vertex lists are read in place) ...
+    const uint32_t *ext_pool = nullptr; uint64_t ext_words = 0;   // ... or a borrowed buffer (the batch's pinned D2H landing area)
     int64_t out_bytes = 0;                               // algorithmic output bytes: sum(4*len + 40)
-    void clear() { status.clear(); n_iters.clear(); attempt.clear(); path_begin.clear(); paths.clear(); pool.clear(); out_bytes = 0; }
-    const uint32_t *vertices(const PathRec &p) const { return pool.data() + p.vert_off; }
+    void clear() { status.clear(); n_iters.clear(); attempt.clear(); path_begin.clear(); paths.clear(); pool.clear(); ext_pool = nullptr; ext_words = 0; out_bytes = 0; }
+    const uint32_t *pool_data() const { return ext_pool ? ext_pool : pool.data(); }
+    uint64_t pool_size() const { return ext_pool ? ext_words : (uint64_t)pool.size(); }
+    const uint32_t *vertices(const PathRec &p) const { return pool_data() + p.vert_off; }
 
     // parse `words` record words; keep only records whose attempt tag matches the graph's final attempt
     int build(int n, const std::vector<int32_t> &n_paths_dev)
     {
         paths.clear(); out_bytes = 0;
         std::vector<int64_t> cnt(n + 1, 0);
-        uint64_t o = 0, W = pool.size();
+        uint64_t o = 0, W = pool_size();
         std::vector<PathRec> tmp;
         while(o + REC_HDR_WORDS <= W) {
-            const uint32_t *r = pool.data() + o;
+            const uint32_t *r = pool_data() + o;
             PathRec p; p.graph = (int32_t)r[0]; p.index = (int32_t)r[1]; p.nv = (int32_t)r[2]; p.length = (int32_t)r[3]; p.count = (int32_t)r[4];
             p.strand = (char)(r[5] & 0xFF); p.attempt = (int)((r[5] >> 8) & 0xFF);
             if(p.nv < 2 || p.graph < 0 || p.graph >= n) return -1;

@@ -66,32 +66,48 @@ def main():
     dev = local if dist_on else 0
     seed = 1002 if world == 1 else 1004 + rank          # SURVEY.md 8d seeds: cfg2 = 1002, cfg4 = 1004 + rank
     pg = A.synth(seed=seed, n_graphs=args.graphs, v_min=args.vertices, v_max=args.vertices, fixed_edges=args.edges)
-    batch = A.DecompBatch(dev)
-    batch.add(pg)
-    batch.upload()                                      # inputs resident in HBM before the timed region
+    # Two batch objects over the same resident input, used alternately: the D2H of batch k's path records (SDMA, own stream)
+    # overlaps batch k+1's kernel.  Kernels never overlap each other (the previous one is synchronised before the next launch),
+    # so the per-launch HIP-event time stays the time of ONE kernel on an otherwise idle GPU.
+    batches = [A.DecompBatch(dev), A.DecompBatch(dev)]
+    for b in batches:
+        b.add(pg)
+        b.upload()                                      # inputs resident in HBM before the timed region
+    batch = batches[0]
 
     from aletsch_amd.distributed import gather_records as rccl_gather
 
-    def gather_records():
+    def gather_records(b):
         """RCCL gather of the packed path records to rank 0 (graph ids made global: rank * graphs_per_gpu)."""
-        return rccl_gather(batch.raw_records(), torch.device("cuda", dev), graph_offset=rank * args.graphs)
+        return rccl_gather(b.raw_records(), torch.device("cuda", dev), graph_offset=rank * args.graphs)
 
-    def step():
-        batch.run()
-        batch.download()                                # stream sync + D2H of status / packed records (+ class retries)
+    def finish(b):
+        b.download()                                    # stream sync + D2H of status / packed records (+ class retries)
         if dist_on:
-            gather_records()
-        return batch.kernel_ms()
+            gather_records(b)
+        return b.kernel_ms()
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(k):
+        """k complete passes (kernel + results on the host); returns the per-launch kernel times"""
+        ms = []; prev = None
+        for i in range(k):
+            cur = batches[i % 2]
+            if prev is not None:
+                prev.sync()                             # the previous kernel is done ...
+            cur.run()                                   # ... the next one starts ...
+            if prev is not None:
+                ms.append(finish(prev))                 # ... while the previous records travel to the host
+            prev = cur
+        if prev is not None:
+            ms.append(finish(prev))
+        return ms
+
+    run_steps(args.warmup)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kms = []
-    for _ in range(args.steps):
-        kms.append(step())
+    kms = run_steps(args.steps)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
