@@ -699,10 +699,32 @@ template<bool A> ALD_INL void decompose_trivial_star(int x)
     int32_t *fe = (int32_t*)H.scr_i + 4 * LP;      // [n] fan edges in adjacency-list order, -1 once merged  (the arena part of the
     int32_t *ord = fe + STAR_MAX;                   // [n] positions in fe, ascending creation id            LDS scratch: the parked
     double *fw = (double*)H.scr_d + 2 * LP;         // [n] pe2w weight of (c, fan edge)                       pair area stays intact)
-    int n = 0; const double wc = uni(H.ew[c]);
+    // balance_vertex(x) (scallop.cc:2486-2576) on the gathered weights: the same sums, ratios, clamps and remainder fix-up in the
+    // same order as the list-walking form (balance_vertex_i), but the fan is walked once and nothing is written back until the
+    // pe2w sums below are known
+    int n = 0; double wcen = uni(H.ew[c]);
+    if(!(wcen >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
+    double sfan0 = 0;
     for(int e = A ? u_first_out(x) : u_first_in(x); e >= 0; e = A ? u_next_out(e) : u_next_in(e)) {
-        double w2 = uni(H.ew[e]); fe[n] = e; fw[n] = A ? (wc <= w2 ? wc : w2) : (w2 <= wc ? w2 : wc); n++;
+        double w2 = uni(H.ew[e]); if(!(w2 >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
+        fe[n] = e; fw[n] = w2; sfan0 += w2; n++;
     }
+    {
+        double scen0 = 0; scen0 += wcen;
+        const double w_in = A ? scen0 : sfan0, w_out = A ? sfan0 : scen0;
+        const double bw = sqrt(w_in * w_out);
+        const double r_in = bw / w_in, r_out = bw / w_out;
+        double m_cen = 0, m_fan = 0;
+        { double wy = wcen * (A ? r_in : r_out); if(wy < mw) { m_cen += mw - wy; wy = mw; } wcen = wy; }
+        if(A) { /* in side first (c), then the fan: the order only matters for which sum a clamp goes to */ }
+        for(int j = 0; j < n; j++) { double wy = fw[j] * (A ? r_out : r_in); if(wy < mw) { m_fan += mw - wy; wy = mw; } fw[j] = wy; }
+        const double m1 = A ? m_cen : m_fan, m2 = A ? m_fan : m_cen;            // m1: in side, m2: out side
+        if(m1 > m2) { if(A) fw[0] = fw[0] + m1 - m2; else wcen = wcen + m1 - m2; }          // first out-edge
+        else if(m1 < m2) { if(A) wcen = wcen + m2 - m1; else fw[0] = fw[0] + m2 - m1; }     // first in-edge
+    }
+    PROF_ADD(PF_T_BALANCE);
+    const double wc = wcen;
+    for(int j = 0; j < n; j++) { double w2 = fw[j]; fw[j] = A ? (wc <= w2 ? wc : w2) : (w2 <= wc ? w2 : wc); }
     for(int i = 0; i < n; i++) { int k = i; uint32_t id = uni(H.eid[fe[i]]); while(k > 0 && (uint32_t)uni(H.eid[fe[ord[k - 1]]]) > id) { ord[k] = ord[k - 1]; k--; } ord[k] = i; }
     double mdc = 0;
     for(int q = 0; q < n; q++) { double w = fw[ord[q]]; if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } mdc = (q == 0) ? w : mdc + w; }
@@ -727,12 +749,14 @@ template<bool A> ALD_INL void decompose_trivial_star(int x)
         H.next_id = nid + 1;                                                // id of the merged edge
         const double wc0 = sc ? ww : wcur;
         const double medc1 = sc ? medc * ww / wcur : medc;
+        // everything the step needs from f's record, in one round of independent loads (one 64-byte line for NW == 1)
         const double medf = uni(C.ed[f].med), cf = uni(C.ed[f].econf);
         const int meif = uni(C.ed[f].mei), cntf = uni(C.ed[f].ecount), stf = uni(C.ed[f].estrand);
+        const uint32_t nsf = uni(C.ed[f].sp_len); const int idf = uni(C.ed[f].s0id); const double abf = uni(C.ed[f].s0abd);
+        const uint64_t mk0 = uni(C.ed[f].mask[0]) | uni(C.ed[c].mask[0]);
         PROF_ADD(PF_T_MERGE_LOAD);
         if(!(cntc > 0 && cntf > 0)) { C.vx[x].vw = vwt; fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
-        if(nsc == 1 && uni(C.ed[f].sp_len) == 1) {      // one supporting sample on both sides: intersect_samples' inline case, c's half already in registers
-            const int idf = uni(C.ed[f].s0id); const double abf = uni(C.ed[f].s0abd);
+        if(nsc == 1 && nsf == 1) {      // one supporting sample on both sides: intersect_samples' inline case, c's half already in registers
             if(idf == idc) { const double xa = A ? abc : abf, ya = A ? abf : abc; const double mn = (ya < xa) ? ya : xa; C.ed[f].sp_off = 0; C.ed[f].ecount = 1; C.ed[f].eabd = 0.0 + mn; C.ed[f].s0abd = mn; }
             else { C.ed[f].sp_off = 0; C.ed[f].sp_len = 0; C.ed[f].ecount = 0; C.ed[f].eabd = 0; C.ed[f].s0id = 0; C.ed[f].s0abd = 0; }
         }
@@ -740,8 +764,8 @@ template<bool A> ALD_INL void decompose_trivial_star(int x)
         PROF_ADD(PF_T_MERGE_ISECT);
         C.ed[f].econf = A ? cc + cf : cf + cc;
         { const int sty = A ? stf : stc, stx = A ? stc : stf; C.ed[f].estrand = (uint8_t)(sty != 0 ? sty : stx); }
-        for(int k = 0; k < NW; k++) C.ed[f].mask[k] = A ? (uni(C.ed[c].mask[k]) | uni(C.ed[f].mask[k])) : (uni(C.ed[f].mask[k]) | uni(C.ed[c].mask[k]));
-        if(ov >= 0) C.ed[f].mask[(ov >> 6)] |= (1ull << (ov & 63));
+        C.ed[f].mask[0] = (ov >= 0 && ov < 64) ? (mk0 | (1ull << ov)) : mk0;
+        for(int k = 1; k < NW; k++) { uint64_t mk = uni(C.ed[c].mask[k]) | uni(C.ed[f].mask[k]); if(ov >= 0 && (ov >> 6) == k) mk |= (1ull << (ov & 63)); C.ed[f].mask[k] = mk; }
         PROF_ADD(PF_T_MERGE_MASK);
         // get_in_weights(x) / get_out_weights(x) with both pieces attached: c's side is (rest of c) + piece, the fan side is
         // whatever has not been merged yet, in list order
@@ -779,14 +803,12 @@ template<bool A> ALD_INL void decompose_trivial_star(int x)
 ALD_FN void decompose_trivial_vertex(int x)
 {
     x = uni(x);
-    PROF_DECL;
-    balance_vertex_i(x);
-    PROF_ADD(PF_T_BALANCE);
-    if(H.status) return;
     const int nin = uni(H.in_deg[x]), nout = uni(H.out_deg[x]);
     if(nin == 1 && nout >= 1 && nout <= STAR_MAX) decompose_trivial_star<true>(x);
     else if(nout == 1 && nin >= 1 && nin <= STAR_MAX) decompose_trivial_star<false>(x);
     else {
+        balance_vertex_i(x);
+        if(H.status) return;
 #ifdef ALD_EMU
         if(getenv("ALD_EMU_VERBOSE")) fprintf(stderr, "[emu] generic trivial: in %d out %d\n", nin, nout);
 #endif
@@ -1054,7 +1076,7 @@ ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
     mode = uni(mode); type = uni(type); jump_ratio = uni(jump_ratio);
     const int lane = lane_id();
     PROF_DECL;
-    if(lane == 0) { hs_refresh_flags(); H.sw_vend = H.nv; H.sw_best_r = DBL_MAX; H.sw_best_v = -1; H.sw_dom_base = -1; }
+    if(lane == 0) { if(uni(H.hs_dirty)) hs_refresh_flags(); H.sw_vend = H.nv; H.sw_best_r = DBL_MAX; H.sw_best_v = -1; H.sw_dom_base = -1; }
     wsync();
     bool flag = false;
     int start = 1;
@@ -1076,7 +1098,7 @@ ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
             const int hit = H.sw_hit;
             trace(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, vlog(hit), mode == 1 ? type : 0, H.sw_hit_r);
             decompose_trivial_vertex(hit);
-            hs_refresh_flags();
+            if(uni(H.hs_dirty)) hs_refresh_flags();
             H.sw_dom_base = -1;
         }
         wsync();
@@ -1107,7 +1129,7 @@ ALD_FN bool sweep_smallest(double max_ratio)
     double best_r = max_ratio; int best_e = -1, best_v = -1;
     int start = 1;
     PROF_DECL;
-    if(lane == 0) hs_refresh_flags();
+    if(lane == 0 && uni(H.hs_dirty)) hs_refresh_flags();
     wsync();
     while(start < vend) {
         int hit = -1, hit_e = -1; double hit_r = 0;
@@ -1133,7 +1155,7 @@ ALD_FN bool sweep_smallest(double max_ratio)
         if(hit < 0) break;
         if(lane == 0) {
             trace(OP_SMALL_NOW, (int)H.eid[hit_e], vlog(hit), hit_r);
-            kill_edge(hit_e); hs_remove(hit_e); hs_refresh_flags();
+            kill_edge_i(hit_e); hs_remove(hit_e); if(uni(H.hs_dirty)) hs_refresh_flags();
         }
         wsync();
         PROF_ADD(PF_SMALL_MUT);
@@ -1659,7 +1681,7 @@ ALD_FN void run_graph()
         if(uni(H.nv) > max_exons) { skipped = true; break; }
         if(uni(H.status)) break;
         PROF_RESET();
-        bool brk = uni(resolve_broken_vertex());
+        bool brk = uni(H.maybe_broken) != 0 && uni(resolve_broken_vertex());
         PROF_ADD(PF_BROKEN);
         if(brk) continue;
         if(r_triv > 1.0) { if(uni(sweep_trivial(0, 1, r_triv))) continue; }     // resolve_trivial_vertex_fast: a no-op for jump_ratio <= 1 (r >= 1 always)
