@@ -71,6 +71,7 @@ struct Hot {
     // decompose_vertex_extend appends vertices (exchange_sink, scallop.cc:2198-2215); here order comparisons map it to +inf
     // instead.  Physical order of all other vertices == the reference's index order.
     int32_t  sinkp, special_linked;
+    int32_t  maybe_triv;                        // 0 => no type-1 trivial vertex exists (set when a degree drops to <= 1, phasing flags change, vertices appear)
     int32_t  maybe_broken;                      // 0 => no vertex can be broken (a degree only reaches 0 in unlink_*; new vertices appear in extend)
     // state of the trivial-vertex sweep in flight (scan_trivial <-> sweep_trivial)
     double   sw_best_r, sw_hit_r; int32_t sw_best_v, sw_hit, sw_vend, sw_dom_base; uint32_t sw_need_lo, sw_need_hi;
@@ -209,7 +210,7 @@ ALD_INL void unlink_in(int v, int e)
     if(cur != e) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }       // cannot happen on a consistent state; never walk off a list
     IDX nx = uni(H.lk[e].inx);
     if(prev < 0) H.in_head[v] = nx; else H.lk[prev].inx = nx;
-    { int dg = (int)uni(H.in_deg[v]) - 1; H.in_deg[v] = (IDX)dg; if(dg == 0) H.maybe_broken = 1; }
+    { int dg = (int)uni(H.in_deg[v]) - 1; H.in_deg[v] = (IDX)dg; if(dg <= 1) { H.maybe_triv = 1; if(dg == 0) H.maybe_broken = 1; } }
 }
 ALD_INL void unlink_out(int v, int e)
 {
@@ -220,7 +221,7 @@ ALD_INL void unlink_out(int v, int e)
     if(cur != e) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
     IDX nx = uni(H.lk[e].onx);
     if(prev < 0) H.out_head[v] = nx; else H.lk[prev].onx = nx;
-    { int dg = (int)uni(H.out_deg[v]) - 1; H.out_deg[v] = (IDX)dg; if(dg == 0) H.maybe_broken = 1; }
+    { int dg = (int)uni(H.out_deg[v]) - 1; H.out_deg[v] = (IDX)dg; if(dg <= 1) { H.maybe_triv = 1; if(dg == 0) H.maybe_broken = 1; } }
 }
 // e stays in v's in-list but its key becomes (ks, newest id): one walk finds its predecessor and its new place
 ALD_INL void relink_in(int v, int e, uint32_t ks)
@@ -369,6 +370,7 @@ ALD_FN double common_abd(int e1, int e2)
 ALD_FN void hs_refresh_flags()                  // per-slot OCC / LEXT / REXT: hyper_set.cc:949-983 left/right_extend
 {
     if(!H.hs_dirty) return;
+    H.maybe_triv = 1;
     COLD;
     for(int e = 0; e < H.slot_hw; e++) H.hflag[e] &= (uint8_t)HF_PROT;
     int nl = H.hl_n;
@@ -807,6 +809,7 @@ ALD_FN void decompose_trivial_vertex(int x)
     if(nin == 1 && nout >= 1 && nout <= STAR_MAX) decompose_trivial_star<true>(x);
     else if(nout == 1 && nin >= 1 && nin <= STAR_MAX) decompose_trivial_star<false>(x);
     else {
+        H.maybe_triv = 1;
         balance_vertex_i(x);
         if(H.status) return;
 #ifdef ALD_EMU
@@ -857,7 +860,7 @@ ALD_FN void decompose_vertex_extend(int root, int n)
     int newedges = 0;
     for(int i = 0; i < n; i++) { int u1 = PLOC(a[i]), u2 = PLOC(b[i]); if(mdeg[u1] == 1 && mdeg[u2] == 1) evx[u1] = nn++; else if(mdeg[u1] >= 2 && mdeg[u2] >= 2) newedges++; }
     if(nn > MAXV || free_slots() < newedges) { fail(ALD_ST_CAPACITY); return; }
-    H.maybe_broken = 1;
+    H.maybe_broken = 1; H.maybe_triv = 1;
     for(int i = m; i < nn; i++) { H.in_head[i] = NIL; H.out_head[i] = NIL; H.in_deg[i] = 0; H.out_deg[i] = 0; H.nz[i] = 1; C.vx[i].vw = 0; C.vx[i].lpos = 0; C.vx[i].rpos = 0; C.vx[i].vtype = -1; C.vx[i].v2v = -1; }
     H.nv = nn;
     for(int i = 0; i < nin; i++) {               // ev1: detach in-edges onto their new vertex
@@ -1006,6 +1009,7 @@ ALD_FN bool resolve_broken_vertex()
     if(lane == 0) {
         if(H.in_deg[x] + H.out_deg[x] == 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);      // assert(ve.size() >= 1)
         else {
+            H.maybe_triv = 1;
             trace(OP_BROKEN, vlog(x), H.in_deg[x] + H.out_deg[x], 0);
             int guard = MAXE;
             while(first_in(x) >= 0 && guard-- > 0) { int e = first_in(x); kill_edge(e); hs_remove(e); }
@@ -1078,6 +1082,11 @@ ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
     PROF_DECL;
     if(lane == 0) { if(uni(H.hs_dirty)) hs_refresh_flags(); H.sw_vend = H.nv; H.sw_best_r = DBL_MAX; H.sw_best_v = -1; H.sw_dom_base = -1; }
     wsync();
+    // R3 (mode 1, type 1) acts whenever a type-1 vertex exists.  After a sweep that found none, one can only appear when a degree
+    // drops to <= 1, the phasing flags change or vertices are created -- all of which raise maybe_triv; until then the scan is
+    // skipped.  (Stranded graphs also gain candidates when a removal un-mixes a vertex: they always scan.)
+    const bool skippable = (mode == 1 && type == 1 && !uni(H.any_strand));
+    if(skippable && !uni(H.maybe_triv)) return false;
     bool flag = false;
     int start = 1;
     while(start < uni(H.sw_vend)) {
@@ -1109,7 +1118,7 @@ ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
     }
     if(flag) return true;
     if(mode == 0) return false;
-    if(H.sw_best_v < 0) return false;
+    if(uni(H.sw_best_v) < 0) { if(skippable) { if(lane == 0) H.maybe_triv = 0; wsync(); } return false; }
     if(lane == 0) {
         trace(OP_TRIVIAL_BEST, vlog(H.sw_best_v), type, H.sw_best_r);
         decompose_trivial_vertex(H.sw_best_v);
@@ -1588,7 +1597,7 @@ ALD_FN bool load_graph()
     int64_t ov = A->in.off_v[g], ovo = ov + g, oe = A->in.off_e[g], oeo = oe + g, os = A->in.off_s[g], op = A->in.off_p[g], opo = op + g, opv = A->in.off_pv[g];
     if(lane == 0) {
         H.V0 = V; H.gstrand = (int)(unsigned char)A->in.graph_strand[g];
-        H.sinkp = V - 1; H.special_linked = 0; H.maybe_broken = 1;
+        H.sinkp = V - 1; H.special_linked = 0; H.maybe_broken = 1; H.maybe_triv = 1;
         H.nv = V; H.next_id = E; H.slot_hw = E; H.free_head = -1; H.free_cnt = 0; H.pend_head = -1; H.status = 0; H.any_strand = 0; H.hs_dirty = 1;
         H.n_paths = 0; H.n_iters = 0; H.n_trace = 0; H.sp_used = 0; H.hl_used = 0; H.hl_n = 0;
     }
