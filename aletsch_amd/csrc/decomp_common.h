@@ -118,7 +118,7 @@ struct ColdLayoutT {
     static constexpr int32_t  W_CAP = 8 * MAXE;          // scalar work arrays (ints / doubles)
     // per-vertex and per-edge-slot cold state are arrays of records (ColdVertex / ColdEdge in decomp_device.h): one merge
     // touches the two or three records involved, i.e. two or three cache lines, instead of one line per field
-    static constexpr uint64_t VX_BYTES = 24;                                        // vw f64, lpos, rpos, vtype, v2v i32
+    static constexpr uint64_t VX_BYTES = 32;                                        // vw f64, lpos, rpos, vtype, v2v, memo i32 (+ pad)
     static constexpr uint64_t ED_BYTES = (56 + 8ull * NW + 63) / 64 * 64;          // 4 f64 + mask[NW] + 5 i32 + strand, padded to whole lines
     static constexpr uint64_t o_vx = 0;
     static constexpr uint64_t o_ed = (o_vx + VX_BYTES * MAXV + 63) / 64 * 64;

@@ -58,6 +58,7 @@ struct Hot {
     ALD_GLOBAL const KernelArgs *args;
     double   ro_ratio;                          // router result
     int32_t  ro_type, ro_degree, ro_npairs, tmp0;
+    int32_t  ro_epoch;                          // bumps whenever the graph changes between router classifications (see sweep_unsplittable)
     int32_t  g, V0, gstrand;
     int32_t  nv, next_id, slot_hw, free_head, free_cnt, pend_head, status, any_strand, hs_dirty, n_paths, n_iters, n_trace;
     uint32_t sp_used, hl_used; int32_t hl_n;
@@ -95,7 +96,7 @@ __shared__ Hot g_H;
 #endif
 
 // cold state: typed views at compile-time offsets of the slab
-struct ColdVertex { double vw; int32_t lpos, rpos, vtype, v2v; };                 // splice_graph::vwrt / vertex_info + scallop::v2v
+struct ColdVertex { double vw; int32_t lpos, rpos, vtype, v2v, memo, pad_; };     // splice_graph::vwrt / vertex_info + scallop::v2v; memo: router class of this vertex (epoch << 16 | type << 13 | degree)
 struct alignas(64) ColdEdge {
     double   med, eabd, econf, s0abd;            // scallop::med, edge_info.abd / confidence, abundance of the first supporting sample
     uint64_t mask[NW];                           // scallop::mev as a bitmask over ORIGINAL vertices
@@ -861,7 +862,7 @@ ALD_FN void decompose_vertex_extend(int root, int n)
     for(int i = 0; i < n; i++) { int u1 = PLOC(a[i]), u2 = PLOC(b[i]); if(mdeg[u1] == 1 && mdeg[u2] == 1) evx[u1] = nn++; else if(mdeg[u1] >= 2 && mdeg[u2] >= 2) newedges++; }
     if(nn > MAXV || free_slots() < newedges) { fail(ALD_ST_CAPACITY); return; }
     H.maybe_broken = 1; H.maybe_triv = 1;
-    for(int i = m; i < nn; i++) { H.in_head[i] = NIL; H.out_head[i] = NIL; H.in_deg[i] = 0; H.out_deg[i] = 0; H.nz[i] = 1; C.vx[i].vw = 0; C.vx[i].lpos = 0; C.vx[i].rpos = 0; C.vx[i].vtype = -1; C.vx[i].v2v = -1; }
+    for(int i = m; i < nn; i++) { H.in_head[i] = NIL; H.out_head[i] = NIL; H.in_deg[i] = 0; H.out_deg[i] = 0; H.nz[i] = 1; C.vx[i].vw = 0; C.vx[i].lpos = 0; C.vx[i].rpos = 0; C.vx[i].vtype = -1; C.vx[i].v2v = -1; C.vx[i].memo = 0; }
     H.nv = nn;
     for(int i = 0; i < nin; i++) {               // ev1: detach in-edges onto their new vertex
         int k = evx[i]; if(k < 0) continue; int e = loc_e[i];
@@ -1263,7 +1264,7 @@ ALD_FN bool router_run(int root, int want_type, int max_degree)
         for(int r = nin; r < n; r++) { if(iso[r] == 2) continue; double c = ALD_COMMON(v, r); sum_abd += c; if(c > max_abd) { max_abd = c; partner = r; } }
         if(partner < 0) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
         us[nue] = v; ut[nue] = partner; uw[nue] = max_abd; ualive[nue] = 1; udeg[v]++; udeg[partner]++; nue++;
-        iso[v] = 1; econf[v] = log(max_abd / sum_abd);
+        iso[v] = 1; econf[v] = max_abd / sum_abd;        // the log is taken where it is used (end of build())
     }
     for(int v = nin; v < n; v++) {
         if(iso[v] == 2) continue;
@@ -1272,7 +1273,7 @@ ALD_FN bool router_run(int root, int want_type, int max_degree)
         for(int l = 0; l < nin; l++) { if(iso[l] == 2) continue; double c = ALD_COMMON(l, v); sum_abd += c; if(c > max_abd) { max_abd = c; partner = l; } }
         if(partner < 0) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
         us[nue] = partner; ut[nue] = v; uw[nue] = max_abd; ualive[nue] = 1; udeg[v]++; udeg[partner]++; nue++;
-        iso[v] = 1; econf[v] = log(max_abd / sum_abd);
+        iso[v] = 1; econf[v] = max_abd / sum_abd;        // the log is taken where it is used (end of build())
     }
     // ---- classify_plain_vertex (router.cc:116-171)
     H.ro_npairs = 0; H.ro_ratio = 0;
@@ -1356,7 +1357,7 @@ ALD_FN bool router_run(int root, int want_type, int max_degree)
     double weight_remain = 0;
     for(int i = 0; i < n; i++) { if(vw[i] <= 0) continue; weight_remain += vw[i]; }
     H.ro_ratio = weight_remain / weight_sum;
-    for(int i = 0; i < n; i++) if(iso[i] == 1) C.ed[u2e[i]].econf += econf[i];     // router.cc:849-855: side effect of every build()
+    for(int i = 0; i < n; i++) if(iso[i] == 1) C.ed[u2e[i]].econf += log(econf[i]);     // router.cc:849-855: side effect of every build()
     sort_pairs(np);
     const double mw = H.p_min_w;
     for(int i = 0; i < np; i++) if(pwt[i] < mw) pwt[i] = mw;                // router.cc:217-220
@@ -1388,6 +1389,7 @@ ALD_FN bool sweep_unsplittable(int type, int degree, double max_ratio)
     g_cnt_unsweep++;
 #endif
     type = uni(type); degree = uni(degree); max_ratio = uni(max_ratio);
+    COLD;
     const int lane = lane_id();
     int vend = H.nv;
     bool flag = false;
@@ -1405,11 +1407,27 @@ ALD_FN bool sweep_unsplittable(int type, int degree, double max_ratio)
         if(i < 0) break;
         int act = 0;
         if(lane == 0) {
-            if(router_run(i, type, degree) && H.ro_type == type && H.ro_degree <= degree) {
+            PROF_DECL;
+            // classify() comes first in the reference and build() -- with its side effect on the edge confidences -- only runs when
+            // type and degree fit (router.cc:61-81, scallop.cc:1004-1030).  The six passes of one iteration classify the same vertices
+            // on the same graph: the class is kept per vertex (stamped with an epoch that moves on every change of the graph), and a
+            // pass that cannot use the vertex does not run the router again.
+            const int ep = uni(H.ro_epoch); const bool memo_on = ep < 0xFFFF;
+            const int mm = uni(C.vx[i].memo);
+            const bool known = memo_on && ((mm >> 16) & 0xFFFF) == ep;
+            bool rok;
+            if(known && (((mm >> 13) & 7) != type || (mm & 0x1FFF) > (degree < 0x1FFF ? degree : 0x1FFF))) rok = false;
+            else {
+                rok = router_run(i, type, degree);
+                if(rok && memo_on) { int dg = uni(H.ro_degree); if(dg > 0x1FFF) dg = 0x1FFF; if(dg < 0) dg = 0; C.vx[i].memo = (ep << 16) | ((uni(H.ro_type) & 7) << 13) | dg; }
+            }
+            PROF_ADD(PF_G_BALANCE);
+            if(rok && H.ro_type == type && H.ro_degree <= degree) {
                 double rr = H.ro_ratio;
                 if(rr < 0.01) {
                     trace(OP_UNSPLIT_NOW, vlog(i), type, rr);
                     decompose_vertex_extend(i, H.ro_npairs);
+                    PROF_ADD(PF_G_DP);
                     act = 1;
                 } else if(!(rr > ratio)) {
                     root = i; ratio = rr; best_np = H.ro_npairs;
@@ -1420,16 +1438,18 @@ ALD_FN bool sweep_unsplittable(int type, int degree, double max_ratio)
         wsync();
         act = wshfl(act, 0);
         if(H.status) return true;
-        if(act) flag = true;
+        if(act) { flag = true; if(lane == 0) H.ro_epoch = uni(H.ro_epoch) + 1; wsync(); }
         cur = i + 1;
     }
     if(flag) return true;
     root = wshfl(root, 0);
     if(root < 0) return false;
     if(lane == 0) {
+        PROF_DECL;
         restore_pairs(best_np);
         trace(OP_UNSPLIT_BEST, vlog(root), type, ratio);
         decompose_vertex_extend(root, best_np);
+        PROF_ADD(PF_G_DP);
     }
     wsync();
     return true;
@@ -1597,7 +1617,7 @@ ALD_FN bool load_graph()
     int64_t ov = A->in.off_v[g], ovo = ov + g, oe = A->in.off_e[g], oeo = oe + g, os = A->in.off_s[g], op = A->in.off_p[g], opo = op + g, opv = A->in.off_pv[g];
     if(lane == 0) {
         H.V0 = V; H.gstrand = (int)(unsigned char)A->in.graph_strand[g];
-        H.sinkp = V - 1; H.special_linked = 0; H.maybe_broken = 1; H.maybe_triv = 1;
+        H.sinkp = V - 1; H.special_linked = 0; H.maybe_broken = 1; H.maybe_triv = 1; H.ro_epoch = 1;
         H.nv = V; H.next_id = E; H.slot_hw = E; H.free_head = -1; H.free_cnt = 0; H.pend_head = -1; H.status = 0; H.any_strand = 0; H.hs_dirty = 1;
         H.n_paths = 0; H.n_iters = 0; H.n_trace = 0; H.sp_used = 0; H.hl_used = 0; H.hl_n = 0;
     }
@@ -1615,7 +1635,7 @@ ALD_FN bool load_graph()
         for(int k = o0; k < o1; k++) { H.lk[k].es = (IDX)i; H.lk[k].onx = (k + 1 < o1) ? (IDX)(k + 1) : NIL; }
         for(int k = i0; k < i1; k++) { H.lk[ie[k]].inx = (k + 1 < i1) ? (IDX)ie[k + 1] : NIL; }
         C.vx[i].vw = A->in.vertex_weight[ov + i]; C.vx[i].lpos = A->in.vertex_lpos[ov + i]; C.vx[i].rpos = A->in.vertex_rpos[ov + i];
-        C.vx[i].vtype = A->in.vertex_type[ov + i]; C.vx[i].v2v = i;
+        C.vx[i].vtype = A->in.vertex_type[ov + i]; C.vx[i].v2v = i; C.vx[i].memo = 0;
     }
     bool strand = false;
     ALD_GLOBAL const int32_t *so = A->in.edge_sample_offset + oeo;
@@ -1697,6 +1717,8 @@ ALD_FN void run_graph()
         if(uni(sweep_trivial(1, 1, r_triv))) continue;
         if(uni(sweep_smallest(r_small))) continue;
         PROF_RESET();
+        if(lane_id() == 0) H.ro_epoch = uni(H.ro_epoch) + 1;      // anything may have changed since the last cascade
+        wsync();
         bool un = uni(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, 1, 0.01)) || uni(sweep_unsplittable(T_SPLITTABLE_PURE, 1, 0.01))
                || uni(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, r_single)) || uni(sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, r_pure))
                || uni(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, DBL_MAX)) || uni(sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, DBL_MAX));
