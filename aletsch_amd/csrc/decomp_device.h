@@ -1130,7 +1130,7 @@ ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
 }
 
 // scallop::resolve_smallest_edges (scallop.cc:844-945)
-ALD_FN bool sweep_smallest(double max_ratio)
+ALD_FN bool sweep_smallest_rescan(double max_ratio)      // every sweep evaluates every vertex (classes with more than 128 vertices)
 {
     max_ratio = uni(max_ratio);
     const int lane = lane_id();
@@ -1180,6 +1180,89 @@ ALD_FN bool sweep_smallest(double max_ratio)
     }
     wsync();
     PROF_ADD(PF_SMALL_MUT);
+    return true;
+}
+
+// The same rule for graphs of at most two 64-vertex chunks, with the per-vertex result (ratio, edge) kept in registers: removing
+// edge s->t changes the lists of s and t only (degree guards elsewhere cannot flip while no degree drops to <= 1, phasing flags
+// only change with hs_dirty), so after a removal just those two lanes evaluate again.  And while nothing else can fire -- no
+// broken vertex, no type-1 trivial vertex, phasing flags untouched: exactly what R1..R3 would find out -- the next sweep of the
+// reference's outer loop (scallop.cc:38-188) starts right here instead of going back through the cascade.
+ALD_FN bool sweep_smallest(double max_ratio)
+{
+    max_ratio = uni(max_ratio);
+    const int lane = lane_id();
+    const int vend = uni(H.nv);
+    constexpr int NC = 128 / ALD_WAVE;            // two chunks of a 64-lane wave (the single-lane emulation walks 128 chunks of one)
+    if(vend > NC * ALD_WAVE) return sweep_smallest_rescan(max_ratio);
+    PROF_DECL;
+    if(lane == 0 && uni(H.hs_dirty)) hs_refresh_flags();
+    wsync();
+    double cr[NC]; int ce[NC];
+    for(int c = 0; c < NC; c++) { cr[c] = 0; ce[c] = -1; int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend) ce[c] = eval_smallest(i, cr[c]); }
+    const bool may_chain = !(uni(H.p_ratio[7]) > 1.0) && !uni(H.any_strand);
+    bool any = false;
+    int guard = MAXE + 8;
+    while(guard-- > 0) {                          // one sweep of the reference per iteration
+        bool flag = false;
+        double best_r = max_ratio; int best_e = -1, best_v = -1;
+        int start = 1;
+        while(start < vend) {
+            int hit = -1, hit_e = -1; double hit_r = 0;
+            for(int c = start / ALD_WAVE; c < NC && c * ALD_WAVE < vend && hit < 0; c++) {
+                const int base = c * ALD_WAVE, i = base + lane;
+                const bool in = (i >= start && i < vend);
+                const double r = cr[c]; const int e = in ? ce[c] : -1;
+                if(wballot(e == -3)) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); wsync(); return true; }
+                bool cand = e >= 0;
+                uint64_t now = wballot(cand && r < 0.01);
+                int lim = now ? ffs64(now) : ALD_WAVE;
+                bool mine = cand && lane < lim;
+                double rr = mine ? r : DBL_MAX; int vv = mine ? i : -1; int ee = mine ? e : -1;
+                for(int off = ALD_WAVE / 2; off >= 1; off >>= 1) {
+                    double r2 = wshfl(rr, lane ^ off); int v2 = wshfl(vv, lane ^ off); int e2 = wshfl(ee, lane ^ off);
+                    bool take = (v2 >= 0) && (vv < 0 || r2 < rr || (r2 == rr && v2 > vv));
+                    if(take) { rr = r2; vv = v2; ee = e2; }
+                }
+                rr = wshfl(rr, 0); vv = wshfl(vv, 0); ee = wshfl(ee, 0);
+                if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = ee; }   // if(ratio < r) continue;
+                if(now) { int l = ffs64(now); hit = base + l; hit_e = wshfl(e, l); hit_r = wshfl(r, l); }
+            }
+            PROF_ADD(PF_SMALL_EVAL);
+            if(hit < 0) break;
+            const int ds = H.lk[hit_e].es, dt = H.lk[hit_e].et;         // the two vertices whose lists change
+            if(lane == 0) {
+                trace(OP_SMALL_NOW, (int)H.eid[hit_e], vlog(hit), hit_r);
+                kill_edge_i(hit_e); hs_remove(hit_e);
+            }
+            wsync();
+            // other vertices only look at ds / dt through the guards out_deg[ds] > 1 and in_deg[dt] > 1 (both held for the edge just
+            // removed); if one of them stops holding, or the phasing flags moved, every lane evaluates again
+            const bool all = uni(H.hs_dirty) != 0 || (int)uni(H.out_deg[ds]) <= 1 || (int)uni(H.in_deg[dt]) <= 1;
+            if(uni(H.hs_dirty)) { if(lane == 0) hs_refresh_flags(); wsync(); }
+            for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (all || i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } }
+            PROF_ADD(PF_SMALL_MUT);
+            flag = true;
+            start = hit + 1;
+        }
+        if(!flag) {
+            if(best_e < 0) return any;
+            const int ds = H.lk[best_e].es, dt = H.lk[best_e].et;
+            if(lane == 0) {
+                trace(OP_SMALLEST, (int)H.eid[best_e], vlog(best_v), best_r);
+                kill_edge_i(best_e); hs_remove(best_e);
+            }
+            wsync();
+            any = true;
+            // back to the cascade unless R1..R3 provably have nothing to do
+            if(!may_chain || uni(H.status) || uni(H.maybe_broken) || uni(H.maybe_triv) || uni(H.hs_dirty)) { PROF_ADD(PF_SMALL_MUT); return true; }
+            for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } }
+            PROF_ADD(PF_SMALL_MUT);
+        } else {
+            any = true;
+            if(!may_chain || uni(H.status) || uni(H.maybe_broken) || uni(H.maybe_triv) || uni(H.hs_dirty)) return true;
+        }
+    }
     return true;
 }
 

@@ -18,6 +18,16 @@ def test_engine_matches_oracle(name):
     assert np.array_equal(it, st[:, 3])
 
 
+def test_engine_matches_oracle_at_scale():
+    """10 000 graphs of the bench shape (64v / 256e): rare interleavings of the cascade (a removal that flips a degree guard of a
+    vertex evaluated earlier, a fan above the fast-path limit, ...) need thousands of graphs to occur at all"""
+    pg = A.synth(seed=1002, n_graphs=10000, v_min=64, v_max=64, fixed_edges=256)
+    want, st, _, _ = common.oracle_run(pg, threads=4)
+    got, it, cl = common.emu_run(pg)
+    assert not common.compare_results(want, got, pg.n)
+    assert np.array_equal(it, st[:, 3])
+
+
 def test_engine_op_trace_matches_oracle():
     """rule id / vertex or edge id / ratio of every firing, in order -- the sharpest parity check available"""
     pg = A.synth(**dict(common.PARITY_CONFIGS["everything"], n_graphs=25))

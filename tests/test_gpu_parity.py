@@ -120,10 +120,11 @@ def test_full_size_properties():
     lim = int(r1.path_offset[1000])
     assert np.array_equal(sub.path_offset, r1.path_offset[:1001]) and np.array_equal(sub.weight, r1.weight[:lim])
     assert np.array_equal(sub.path_vertices, r1.path_vertices[: int(r1.pv_offset[lim])])
-    # oracle parity on a sample of the full-size batch
-    want = common.oracle_run(pg.select(np.arange(0, 300)))[0]
-    got = A.decompose(pg.select(np.arange(0, 300)), 0)
-    assert not common.compare_results(want, got, 300, conf_tol=1e-9)
+    # oracle parity on the WHOLE full-size batch (the oracle runs on all host cores: ~10 s); rare interleavings of the rule cascade
+    # only show up at this scale (a stale evaluation that changed 7 graphs in 100 000 was caught exactly here)
+    import os
+    want = common.oracle_run(pg, threads=max(1, min(16, len(os.sched_getaffinity(0)))))[0]
+    assert not common.compare_results(want, r1, n, conf_tol=1e-9)
 
 
 def test_transcripts_match_oracle():
