@@ -1,6 +1,6 @@
 #!/bin/bash
 # diagnostic: several --pmc passes over a short bench run (never combined with --stats); results under gpurun_out/pmc_<tag>_<i>/
-# usage (on the GPU box, via gpurun):  bash tests/_gpu_pmc.sh <tag> "<counters pass 1>" "<counters pass 2>" ...
+# usage (on the GPU box, via gpurun):  bash tools/_gpu_pmc.sh <tag> "<counters pass 1>" "<counters pass 2>" ...
 R=$GRAFT_REPO_ROOT; tag=$1; shift; cd /tmp; export TMPDIR=/tmp; i=0
 for set in "$@"; do
   i=$((i+1))
