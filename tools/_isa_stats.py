@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static instruction mix per device function of one size class (diagnostic):  python tests/_isa_stats.py [class_id] [waves_per_eu]"""
+"""Static instruction mix per device function of one size class (diagnostic):  python tools/_isa_stats.py [class_id] [waves_per_eu]"""
 import collections, re, subprocess, sys, os
 cid = sys.argv[1] if len(sys.argv) > 1 else "1"; waves = sys.argv[2] if len(sys.argv) > 2 else "5"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
