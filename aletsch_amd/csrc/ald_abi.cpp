@@ -525,6 +525,27 @@ int ald_tset_export(const ald_tset *t, uint64_t *hash, int32_t *count, char *str
     return ALD_OK;
 }
 
+int ald_batch_device_records(const ald_batch *b, const void **device_words, int64_t *n_words)
+{
+    if(!b || !device_words || !n_words) return ALD_ERR_INVALID;
+    if(!b->downloaded) return set_err(ALD_ERR_STATE, "ald_batch_device_records before ald_batch_download");
+    *device_words = b->d_pool.p; *n_words = (int64_t)b->res.pool_size();
+    return ALD_OK;
+}
+
+int ald_records_add_graph_offset(uint32_t *words, int64_t n_words, int32_t graph_offset)
+{
+    if((!words && n_words > 0) || n_words < 0) return ALD_ERR_INVALID;
+    int64_t o = 0;
+    while(o + REC_HDR_WORDS <= n_words) {
+        words[o] += (uint32_t)graph_offset;
+        int64_t w = REC_HDR_WORDS + (int64_t)words[o + 2]; w += w & 1;
+        if(words[o + 2] < 2 || o + w > n_words) return set_err(ALD_ERR_INVALID, "malformed record stream");
+        o += w;
+    }
+    return ALD_OK;
+}
+
 /* raw packed record stream of the last download (what ranks exchange over RCCL in the multi-GPU gather) */
 int ald_batch_raw_records(const ald_batch *b, const uint32_t **words, int64_t *n_words)
 {

@@ -63,6 +63,8 @@ def load_library():
                  "ald_batch_download", "ald_batch_num_graphs"):
         getattr(lib, name).argtypes = [C.c_void_p]
     lib.ald_batch_enable_trace.argtypes = [C.c_void_p, C.c_int32]
+    lib.ald_batch_device_records.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    lib.ald_records_add_graph_offset.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     lib.ald_tset_destroy.argtypes = [C.c_void_p]
     lib.ald_tset_create.argtypes = [C.c_double, C.POINTER(C.c_void_p)]
     lib.ald_tset_add.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 10 + [C.c_int32]
@@ -171,6 +173,12 @@ class DecompBatch:
             return np.zeros(0, np.uint32)
         return np.ctypeslib.as_array(w, shape=(n.value,)).copy()
 
+    def device_records(self):
+        """(device pointer, word count) of the record stream in HBM -- for a zero-copy hand-over to RCCL (distributed.py)."""
+        p = C.c_void_p(); n = C.c_int64()
+        _check(self._lib.ald_batch_device_records(self._h, C.byref(p), C.byref(n)))
+        return int(p.value or 0), int(n.value)
+
     def result(self) -> DecompResult:
         return export_via(self._lib.ald_batch_export, self._h, self.n)
 
@@ -260,6 +268,13 @@ class TranscriptSink:
                             count1=int(c1[i]), count2=int(c2[i]), tid=int(tid[i]), exons=[(int(lr[2 * k]), int(lr[2 * k + 1])) for k in range(eo[i], eo[i + 1])],
                             samples=[dict(sid=int(ssid[k]), cov2=float(scov2[k]), conf=float(sconf[k]), abd=float(sabd[k]), count1=int(sc1[k])) for k in range(so[i], so[i + 1])]))
         return out
+
+
+def records_add_graph_offset(words: np.ndarray, graph_offset: int):
+    """In place: make the graph ids of a record stream global (C loop over the variable-length records)."""
+    assert words.dtype == np.uint32 and words.flags.c_contiguous and words.flags.writeable
+    _check(load_library().ald_records_add_graph_offset(C.c_void_p(words.ctypes.data), C.c_int64(words.size), C.c_int32(int(graph_offset))))
+    return words
 
 
 def decompose(pg: PackedGraphs, device: int = 0, params: Optional[AldParams] = None) -> DecompResult:

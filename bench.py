@@ -55,9 +55,10 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
-    dist_on = world > 1
+    dist_on = world > 1 or bool(os.environ.get("ALD_BENCH_FORCE_DIST"))      # the override runs the exchange path with one rank (rehearsal on a 1-GPU box)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", str(rank)); os.environ.setdefault("WORLD_SIZE", str(world))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
@@ -75,11 +76,14 @@ def main():
         b.upload()                                      # inputs resident in HBM before the timed region
     batch = batches[0]
 
-    from aletsch_amd.distributed import gather_records as rccl_gather
+    from aletsch_amd.distributed import RecordGatherer, _device_words
+    gatherer = RecordGatherer(torch.device("cuda", dev)) if dist_on else None
 
     def gather_records(b):
-        """RCCL gather of the packed path records to rank 0 (graph ids made global: rank * graphs_per_gpu)."""
-        return rccl_gather(b.raw_records(), torch.device("cuda", dev), graph_offset=rank * args.graphs)
+        """RCCL gather of the packed path records to rank 0, straight from the batch's record pool in HBM (no host round trip);
+        each rank's graph-id offset (rank * graphs_per_gpu) travels with the sizes"""
+        ptr, n = b.device_records()
+        gatherer.gather(_device_words(ptr, n, torch.device("cuda", dev)), graph_offset=rank * args.graphs)
 
     def finish(b):
         b.download()                                    # stream sync + D2H of status / packed records (+ class retries)
@@ -151,7 +155,7 @@ def main():
                          "kernel": "ald_decomp_kernel_c1", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": in_b + out_b,
                          "bytes_per_graph": (in_b + out_b) / args.graphs, "kernel_graphs_per_s": args.graphs / (k_ms / 1e3)},
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:           # reported at N = 1 only
             # the GPU box gives each GPU a share of the host (16 cores per GPU): use the cores this process may actually run on
             try:
                 cores = len(os.sched_getaffinity(0))
@@ -164,7 +168,8 @@ def main():
                                     "sample": f"first {sample.n} graphs of the same workload, oracle/ (CPU restatement of the reference scallop core), "
                                               f"{cores} threads over independent graphs, {cpu_sec:.2f} s"}
         print(json.dumps(line), flush=True)
-    batch.close()
+    for b in batches:
+        b.close()
     if dist_on:
         dist.destroy_process_group()
 

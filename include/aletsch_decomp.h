@@ -184,6 +184,12 @@ int  ald_tset_export(const ald_tset *t, uint64_t *hash, int32_t *count, char *st
                      int32_t *count1, int32_t *count2, int64_t *tid, int64_t *exon_offset, int32_t *exon_lr,
                      int64_t *sample_offset, int32_t *sample_sid, double *sample_cov2, double *sample_conf, double *sample_abd, int32_t *sample_count1);
 
+/* the same record stream where the kernels wrote it, in DEVICE memory (valid from ald_batch_download until the next ald_batch_run):
+ * lets a multi-GPU caller hand the records to RCCL without a host round trip */
+int  ald_batch_device_records(const ald_batch *b, const void **device_words, int64_t *n_words);
+/* host helper for the rank that receives several record streams: adds `graph_offset` to the graph word of every record */
+int  ald_records_add_graph_offset(uint32_t *words, int64_t n_words, int32_t graph_offset);
+
 /* raw packed path-record stream of the last download: 4-byte words, record = [graph, path index, #vertices, length, count,
  * strand | attempt<<8, weight f64, abd f64, conf f64, reads f64, vertices..., pad to even].  This is what ranks exchange
  * over RCCL for the final transcript gather (bench.py --gpus N). */

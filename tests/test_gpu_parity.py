@@ -174,3 +174,31 @@ def test_catch_all_class_on_gpu():
         got = b.result()
         assert b.class_info(5)["n_graphs"] == 3
     assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
+
+
+def test_record_exchange_from_device_memory():
+    """the multi-GPU exchange step with one rank over RCCL: the record pool is handed over in HBM (zero-copy view of
+    ald_batch_device_records) and comes back on rank 0 identical to the host copy, graph ids made global by the C helper"""
+    import os
+    import torch
+    import torch.distributed as dist
+    from aletsch_amd.distributed import RecordGatherer, _device_words, parse_records
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        pg = A.synth(seed=46, n_graphs=500, v_min=8, v_max=60, edges_per_vertex=3)
+        with A.DecompBatch(0) as b:
+            b.add(pg); b.upload(); b.run(); b.download()
+            raw = b.raw_records(); ptr, n = b.device_records()
+            assert n == raw.size and ptr != 0
+            g = RecordGatherer(torch.device("cuda", 0))
+            for rep in range(2):                                   # buffers are reused on the second step
+                g.gather(_device_words(ptr, n, torch.device("cuda", 0)), graph_offset=1000)
+                (words, off), = g.streams()
+                assert off == 1000 and np.array_equal(words, raw)
+            glob = A.records_add_graph_offset(words.copy(), off)
+            recs = parse_records(glob); local = parse_records(raw)
+            assert [r["graph"] for r in recs] == [r["graph"] + 1000 for r in local] and [r["v"] for r in recs] == [r["v"] for r in local]
+    finally:
+        dist.destroy_process_group()
