@@ -1183,7 +1183,7 @@ ALD_FN bool sweep_smallest_rescan(double max_ratio)      // every sweep evaluate
     return true;
 }
 
-// The same rule for graphs of at most two 64-vertex chunks, with the per-vertex result (ratio, edge) kept in registers: removing
+// The same rule with the per-vertex result (ratio, edge) kept per lane: removing
 // edge s->t changes the lists of s and t only (degree guards elsewhere cannot flip while no degree drops to <= 1, phasing flags
 // only change with hs_dirty), so after a removal just those two lanes evaluate again.  And while nothing else can fire -- no
 // broken vertex, no type-1 trivial vertex, phasing flags untouched: exactly what R1..R3 would find out -- the next sweep of the
@@ -1193,7 +1193,7 @@ ALD_FN bool sweep_smallest(double max_ratio)
     max_ratio = uni(max_ratio);
     const int lane = lane_id();
     const int vend = uni(H.nv);
-    constexpr int NC = 128 / ALD_WAVE;            // two chunks of a 64-lane wave (the single-lane emulation walks 128 chunks of one)
+    constexpr int NC = MAXV / ALD_WAVE;           // per-lane results for every chunk of the class (registers for the small classes, private memory beyond)
     if(vend > NC * ALD_WAVE) return sweep_smallest_rescan(max_ratio);
     PROF_DECL;
     if(lane == 0 && uni(H.hs_dirty)) hs_refresh_flags();
