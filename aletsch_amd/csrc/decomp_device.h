@@ -1209,6 +1209,8 @@ ALD_FN bool sweep_smallest(double max_ratio)
         int start = 1;
         while(start < vend) {
             int hit = -1, hit_e = -1; double hit_r = 0;
+            if(NC <= 2) {
+            // at most two chunks: one pass, the reduction right in the chunk loop
             for(int c = start / ALD_WAVE; c < NC && c * ALD_WAVE < vend && hit < 0; c++) {
                 const int base = c * ALD_WAVE, i = base + lane;
                 const bool in = (i >= start && i < vend);
@@ -1227,6 +1229,32 @@ ALD_FN bool sweep_smallest(double max_ratio)
                 rr = wshfl(rr, 0); vv = wshfl(vv, 0); ee = wshfl(ee, 0);
                 if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = ee; }   // if(ratio < r) continue;
                 if(now) { int l = ffs64(now); hit = base + l; hit_e = wshfl(e, l); hit_r = wshfl(r, l); }
+            }
+            } else {
+            // (1) chunk by chunk, cheap: an invalid evaluation anywhere in the chunk, else the first "now" vertex (ratio < 0.01)
+            for(int c = start / ALD_WAVE; c < NC && c * ALD_WAVE < vend && hit < 0; c++) {
+                const int i = c * ALD_WAVE + lane;
+                const int e = (i >= start && i < vend) ? ce[c] : -1;
+                if(wballot(e == -3)) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); wsync(); return true; }
+                const uint64_t now = wballot(e >= 0 && cr[c] < 0.01);
+                if(now) { const int l = ffs64(now); hit = c * ALD_WAVE + l; hit_e = wshfl(e, l); hit_r = wshfl(cr[c], l); }
+            }
+            // (2) the candidates before it: each lane folds its own chunks (later vertex wins ties), then ONE reduction across lanes
+            {
+                const int lim = hit >= 0 ? hit : vend;
+                double rr = DBL_MAX; int vv = -1, ee = -1;
+                for(int c = start / ALD_WAVE; c < NC && c * ALD_WAVE < lim; c++) {
+                    const int i = c * ALD_WAVE + lane;
+                    if(i >= start && i < lim && ce[c] >= 0 && (vv < 0 || !(rr < cr[c]))) { rr = cr[c]; vv = i; ee = ce[c]; }
+                }
+                for(int off = ALD_WAVE / 2; off >= 1; off >>= 1) {
+                    double r2 = wshfl(rr, lane ^ off); int v2 = wshfl(vv, lane ^ off); int e2 = wshfl(ee, lane ^ off);
+                    bool take = (v2 >= 0) && (vv < 0 || r2 < rr || (r2 == rr && v2 > vv));
+                    if(take) { rr = r2; vv = v2; ee = e2; }
+                }
+                rr = wshfl(rr, 0); vv = wshfl(vv, 0); ee = wshfl(ee, 0);
+                if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = ee; }   // if(ratio < r) continue;
+            }
             }
             PROF_ADD(PF_SMALL_EVAL);
             if(hit < 0) break;
