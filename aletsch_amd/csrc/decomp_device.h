@@ -1038,6 +1038,7 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
     double best_r = H.sw_best_r; int best_v = H.sw_best_v;
     const int dom_base = H.sw_dom_base;        // chunk whose dominate queries the driver has answered (scr_i[lane]), or -1
     int code = SC_NONE, hit = -1; double hit_r = 0;
+    double frr = DBL_MAX; int fvv = -1;          // this lane's best candidate over the chunks scanned (later vertex wins ties)
     for(int base = (start / ALD_WAVE) * ALD_WAVE; base < vend; base += ALD_WAVE) {
         int i = base + lane;
         int cls = -9; double r = 0; bool bad = false;
@@ -1059,18 +1060,18 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
         }
         // sequential semantics: candidates before the first "now" vertex update (ratio, root); ties go to the LATER vertex
         int lim = now ? ffs64(now) : ALD_WAVE;
-        if(mode == 1) {
-            bool mine = cand && lane < lim;
-            double rr = mine ? r : DBL_MAX; int vv = mine ? i : -1;
-            for(int off = ALD_WAVE / 2; off >= 1; off >>= 1) {
-                double r2 = wshfl(rr, lane ^ off); int v2 = wshfl(vv, lane ^ off);
-                bool take = (v2 >= 0) && (vv < 0 || r2 < rr || (r2 == rr && v2 > vv));
-                if(take) { rr = r2; vv = v2; }
-            }
-            rr = wshfl(rr, 0); vv = wshfl(vv, 0);
-            if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; }      // if(ratio < r) continue;
-        }
+        if(mode == 1 && cand && lane < lim && (fvv < 0 || !(frr < r))) { frr = r; fvv = i; }     // folded per lane; ONE reduction after the loop
         if(now) { hit = base + ffs64(now); hit_r = wshfl(r, ffs64(now)); code = SC_HIT; break; }
+    }
+    if(mode == 1 && code != SC_STOP && code != SC_BAD) {
+        double rr = frr; int vv = fvv;
+        for(int off = ALD_WAVE / 2; off >= 1; off >>= 1) {
+            double r2 = wshfl(rr, lane ^ off); int v2 = wshfl(vv, lane ^ off);
+            bool take = (v2 >= 0) && (vv < 0 || r2 < rr || (r2 == rr && v2 > vv));
+            if(take) { rr = r2; vv = v2; }
+        }
+        rr = wshfl(rr, 0); vv = wshfl(vv, 0);
+        if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; }      // if(ratio < r) continue;
     }
     if(lane == 0) { H.sw_best_r = best_r; H.sw_best_v = best_v; H.sw_hit = hit; H.sw_hit_r = hit_r; }
     wsync();
