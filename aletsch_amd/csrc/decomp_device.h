@@ -620,88 +620,27 @@ ALD_INL void sort_pairs(int n)                   // insertion sort by (id(e1), i
     }
 }
 
-// scallop::decompose_vertex_replace (scallop.cc:2009-2142), pe2w = n sorted pairs in the work area
-ALD_INL void decompose_vertex_replace(int root, int n)
-{
-    PROF_DECL;
-    const Pairs P = pairs_cur();
-    int32_t *a = P.a, *b = P.b; double *w = P.w;
-    const int deg = (int)uni(H.in_deg[root]) + (int)uni(H.out_deg[root]);
-    const Arena AR = arena_at(2 * deg <= ARENA_I && deg <= ARENA_D);
-    if(2 * deg > AR.cap_i || deg > AR.cap_d) { fail(ALD_ST_CAPACITY); return; }
-    double *md = AR.d;                            // per-edge sum of its pe2w entries, in pe2w order
-    int nloc = 0; int32_t *loc_e = AR.i;
-    for(int e = u_first_in(root); e >= 0; e = u_next_in(e)) { loc_e[nloc] = e; md[nloc] = 0; nloc++; }
-    for(int e = u_first_out(root); e >= 0; e = u_next_out(e)) { loc_e[nloc] = e; md[nloc] = 0; nloc++; }
-    int32_t *mdeg = AR.i + deg;                   // [nloc] pe2w degree m[e]
-    for(int i = 0; i < nloc; i++) mdeg[i] = 0;
-    const double mw = H.p_min_w;
-    for(int i = 0; i < n; i++) {
-        if(!(w[i] >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
-        int u1 = PLOC(a[i]), u2 = PLOC(b[i]);
-        if(mdeg[u1] == 0) md[u1] = w[i]; else md[u1] += w[i];
-        if(mdeg[u2] == 0) md[u2] = w[i]; else md[u2] += w[i];
-        mdeg[u1]++; mdeg[u2]++;
-    }
-    for(int i = 0; i < nloc; i++) { if(mdeg[i] == 0) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; } H.ew[loc_e[i]] = md[i]; H.hflag[loc_e[i]] |= HF_PROT; }
-    PROF_ADD(PF_T_SETUP);
-    for(int i = 0; i < n; i++) {
-        int e1 = PSLOT(a[i]), e2 = PSLOT(b[i]);
-        int m1 = mdeg[PLOC(a[i])], m2 = mdeg[PLOC(b[i])];
-        if(free_slots() < 1) { fail(ALD_ST_CAPACITY); return; }
-        // an edge that takes part in this pair only has every phasing occurrence replaced right below (hs_replace1), so the
-        // final hs.remove on it is a no-op in the reference: its slot need not stay parked until the end of the decomposition
-        if(m1 == 1) H.hflag[e1] &= (uint8_t)~HF_PROT;
-        if(m2 == 1) H.hflag[e2] &= (uint8_t)~HF_PROT;
-        PROF_RESET();
-        int e = merge_adjacent_edges_i(e1, e2, w[i]);
-        PROF_RESET();
-        if(e < 0 || H.status) { if(!H.status) fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
-        hs_replace2(e1, e2, e);
-        if(m1 == 1) hs_replace1(e1, e);
-        if(m2 == 1) hs_replace1(e2, e);
-        PROF_ADD(PF_T_HS);
-    }
-    for(int i = 0; i < nloc; i++) if(mdeg[i] >= 2) hs_remove(loc_e[i]);      // single-pair edges were fully replaced above (their slots may already be reused)
-    flush_pending();
-    PROF_ADD(PF_T_TAIL);
-    if(H.in_deg[root] != 0 || uni(H.out_deg[root]) != 0) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }
-    H.nz[root] = 0;
-}
-// scallop::decompose_trivial_vertex (scallop.cc:2144-2167), general form: pe2w = in x out, then decompose_vertex_replace
-ALD_FN void decompose_trivial_generic(int x)
-{
-    x = uni(x);
-    PROF_DECL;
-    const int np = (int)uni(H.in_deg[x]) * (int)uni(H.out_deg[x]);
-    H.pw_lds = (np <= LP) ? 1 : 0;
-    const Pairs P = pairs_cur();
-    int32_t *a = P.a, *b = P.b; double *w = P.w; int n = 0;
-    if(np > P.cap) { fail(ALD_ST_CAPACITY); return; }
-    const int nin = uni(H.in_deg[x]); int ui = 0;
-    for(int e1 = u_first_in(x); e1 >= 0; e1 = u_next_in(e1), ui++) { double w1 = uni(H.ew[e1]); int uj = nin;
-        for(int e2 = u_first_out(x); e2 >= 0; e2 = u_next_out(e2), uj++) { double w2 = uni(H.ew[e2]); a[n] = PMAKE(e1, ui); b[n] = PMAKE(e2, uj); w[n] = w1 <= w2 ? w1 : w2; n++; } }
-    sort_pairs(n);
-    PROF_ADD(PF_T_PAIRS);
-    decompose_vertex_replace(x, n);
-}
-// The same decomposition for the shape every trivial vertex has -- ONE edge c on one side (A: the in-edge, else the out-edge)
-// and a fan of d edges on the other -- without the pair array: pe2w is {(c, f_j)} with weight min(w(c), w(f_j)), visited in
+// scallop::decompose_trivial_vertex (scallop.cc:2144-2167) = balance_vertex + pe2w (in x out) + decompose_vertex_replace
+// (scallop.cc:2009-2142), written for the shape every trivial vertex has -- ONE edge c on one side (A: the in-edge, else the
+// out-edge) and a fan of d edges on the other -- without the pair array: pe2w is {(c, f_j)} with weight min(w(c), w(f_j)), visited in
 // creation-id order of f_j (the sorted order of map<PI,double>, router.h:23).  What merge_adjacent_edges (scallop.cc:2394-2431)
 // does to such a pair is known in advance: the fan edge is never cut (its weight IS the pair weight), c is cut until the last
 // pair consumes it, and the merged edge differs from f_j only in one endpoint.  So the merged edge takes over f_j's slot (new id,
 // new endpoint, re-sorted into the two lists it belongs to), c's record and the vertex are read once, and the weight sums
 // around x are taken from the gathered fan in list order -- the same additions, in the same order, as the general form.
 enum { STAR_MAX = 32 };
-template<bool A> ALD_INL void decompose_trivial_star(int x)
+template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
 {
     COLD;
     PROF_DECL;
     const double mw = H.p_min_w;
     const int c = A ? u_first_in(x) : u_first_out(x);
-    int32_t *fe = (int32_t*)H.scr_i + 4 * LP;      // [n] fan edges in adjacency-list order, -1 once merged  (the arena part of the
-    int32_t *ord = fe + STAR_MAX;                   // [n] positions in fe, ascending creation id            LDS scratch: the parked
-    double *fw = (double*)H.scr_d + 2 * LP;         // [n] pe2w weight of (c, fan edge)                       pair area stays intact)
+    // [n] fan edges in adjacency-list order, -1 once merged / [n] positions in fe, ascending creation id / [n] pe2w weight of (c, fan
+    // edge): a fan of at most STAR_MAX edges uses the arena part of the LDS scratch (the parked pair area stays intact), a larger
+    // one the first quarter of the slab's work arrays (the region [3/8, 1/2) of wi belongs to decompose_vertex_extend)
+    int32_t *fe = SMALL ? (int32_t*)H.scr_i + 4 * LP : (int32_t*)C.wi;
+    int32_t *ord = SMALL ? fe + STAR_MAX : (int32_t*)(C.wi + Cold::w_cap / 8);
+    double *fw = SMALL ? (double*)H.scr_d + 2 * LP : (double*)C.wd;
     // balance_vertex(x) (scallop.cc:2486-2576) on the gathered weights: the same sums, ratios, clamps and remainder fix-up in the
     // same order as the list-walking form (balance_vertex_i), but the fan is walked once and nothing is written back until the
     // pe2w sums below are known
@@ -803,21 +742,17 @@ template<bool A> ALD_INL void decompose_trivial_star(int x)
     H.in_head[x] = NIL; H.out_head[x] = NIL; H.in_deg[x] = 0; H.out_deg[x] = 0; H.nz[x] = 0;
     PROF_ADD(PF_T_TAIL);
 }
+// fans above STAR_MAX are rare (hubs next to the source / sink late in the run): out of line, so the common path stays compact
+ALD_FN void decompose_trivial_star_large(int x, int in_side) { x = uni(x); if(uni(in_side)) decompose_trivial_star<true, false>(x); else decompose_trivial_star<false, false>(x); }
 ALD_FN void decompose_trivial_vertex(int x)
 {
     x = uni(x);
     const int nin = uni(H.in_deg[x]), nout = uni(H.out_deg[x]);
-    if(nin == 1 && nout >= 1 && nout <= STAR_MAX) decompose_trivial_star<true>(x);
-    else if(nout == 1 && nin >= 1 && nin <= STAR_MAX) decompose_trivial_star<false>(x);
-    else {
-        H.maybe_triv = 1;
-        balance_vertex_i(x);
-        if(H.status) return;
-#ifdef ALD_EMU
-        if(getenv("ALD_EMU_VERBOSE")) fprintf(stderr, "[emu] generic trivial: in %d out %d\n", nin, nout);
-#endif
-        decompose_trivial_generic(x);
-    }
+    if(nin == 1 && nout >= 1 && nout <= STAR_MAX) decompose_trivial_star<true, true>(x);
+    else if(nout == 1 && nin >= 1 && nin <= STAR_MAX) decompose_trivial_star<false, true>(x);
+    else if(nin == 1 && nout >= 1 && nout <= Cold::w_cap / 8) decompose_trivial_star_large(x, 1);
+    else if(nout == 1 && nin >= 1 && nin <= Cold::w_cap / 8) decompose_trivial_star_large(x, 0);
+    else fail(ALD_ST_INVARIANT + ALD_INV_OTHER);        // not a trivial vertex (a fan cannot exceed MAXE edges)
 }
 
 ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio);
