@@ -60,7 +60,7 @@ struct Hot {
     int32_t  ro_type, ro_degree, ro_npairs, tmp0;
     int32_t  ro_epoch;                          // bumps whenever the graph changes between router classifications (see sweep_unsplittable)
     int32_t  g, V0, gstrand;
-    int32_t  nv, next_id, slot_hw, free_head, free_cnt, pend_head, status, any_strand, hs_dirty, n_paths, n_iters, n_trace;
+    int32_t  nv, next_id, slot_hw, free_head, free_cnt, status, any_strand, hs_dirty, n_paths, n_iters, n_trace;
     uint32_t sp_used, hl_used; int32_t hl_n;
     int32_t  s_next;
     // parameters cached once per wave (saves a dependent HBM/L2 round per use)
@@ -277,23 +277,17 @@ ALD_INL int add_edge_i(int s, int t)
     link_out(s, e); link_in(t, e);
     return e;
 }
-// scallop::remove_edge (scallop.cc:2380-2392).  A slot that phasing lists may still name (HF_PROT) is parked
-// until the compound operation has called hs_remove on it; all others are recycled at once.
+// scallop::remove_edge (scallop.cc:2380-2392); the slot is recycled at once (every caller drops the edge from the phasing lists
+// -- hs_remove / hs_replace -- before it creates another edge)
 ALD_INL void kill_edge_i(int e)
 {
     e = uni(e);
     unlink_out(uni(H.lk[e].es), e); unlink_in(uni(H.lk[e].et), e);
     H.lk[e].es = NIL;
-    if(uni(H.hflag[e]) & HF_PROT) { int ph = uni(H.pend_head); H.lk[e].onx = ph < 0 ? NIL : (IDX)ph; H.pend_head = e; }
-    else { int fh = uni(H.free_head); H.lk[e].onx = fh < 0 ? NIL : (IDX)fh; H.free_head = e; H.free_cnt++; }
+    { int fh = uni(H.free_head); H.lk[e].onx = fh < 0 ? NIL : (IDX)fh; H.free_head = e; H.free_cnt = uni(H.free_cnt) + 1; }
 }
 ALD_FN int add_edge(int s, int t) { return add_edge_i(uni(s), uni(t)); }
 ALD_FN void kill_edge(int e) { kill_edge_i(uni(e)); }
-ALD_FN void flush_pending()
-{
-    int guard = MAXE;
-    while(uni(H.pend_head) >= 0 && guard-- > 0) { int e = uni(H.pend_head); IDX nx = uni(H.lk[e].onx); H.pend_head = nx == NIL ? -1 : (int)nx; H.hflag[e] = 0; int fh = uni(H.free_head); H.lk[e].onx = fh < 0 ? NIL : (IDX)fh; H.free_head = e; H.free_cnt++; }
-}
 ALD_FN void move_edge(int e, int x, int y)      // directed_graph.cc:180-194
 {
     e = uni(e); x = uni(x); y = uni(y);
@@ -373,7 +367,7 @@ ALD_FN void hs_refresh_flags()                  // per-slot OCC / LEXT / REXT: h
     if(!H.hs_dirty) return;
     H.maybe_triv = 1;
     COLD;
-    for(int e = 0; e < H.slot_hw; e++) H.hflag[e] &= (uint8_t)HF_PROT;
+    for(int e = 0; e < H.slot_hw; e++) H.hflag[e] = 0;
     int nl = H.hl_n;
     for(int k = 0; k < nl; k++) {
         ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]);
@@ -1665,7 +1659,7 @@ ALD_FN bool load_graph()
     if(lane == 0) {
         H.V0 = V; H.gstrand = (int)(unsigned char)A->in.graph_strand[g];
         H.sinkp = V - 1; H.special_linked = 0; H.maybe_broken = 1; H.maybe_triv = 1; H.ro_epoch = 1;
-        H.nv = V; H.next_id = E; H.slot_hw = E; H.free_head = -1; H.free_cnt = 0; H.pend_head = -1; H.status = 0; H.any_strand = 0; H.hs_dirty = 1;
+        H.nv = V; H.next_id = E; H.slot_hw = E; H.free_head = -1; H.free_cnt = 0; H.status = 0; H.any_strand = 0; H.hs_dirty = 1;
         H.n_paths = 0; H.n_iters = 0; H.n_trace = 0; H.sp_used = 0; H.hl_used = 0; H.hl_n = 0;
     }
     wsync();
