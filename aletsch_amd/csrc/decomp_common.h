@@ -104,7 +104,7 @@ template<> struct ClassDims<0> { enum { MAXV = 64,   MAXE = 160,  NW = 1 }; };
 template<> struct ClassDims<1> { enum { MAXV = 128,  MAXE = 288,  NW = 1 }; };
 template<> struct ClassDims<2> { enum { MAXV = 256,  MAXE = 640,  NW = 2 }; };
 template<> struct ClassDims<3> { enum { MAXV = 512,  MAXE = 1280, NW = 4 }; };
-template<> struct ClassDims<4> { enum { MAXV = 1024, MAXE = 2560, NW = 8 }; };
+template<> struct ClassDims<4> { enum { MAXV = 1024, MAXE = 2280, NW = 8 }; };    // 2280 edges: three workgroups per CU (3 x 54.2 KB of LDS); holds E <= 2052
 template<> struct ClassDims<5> { enum { MAXV = 4096, MAXE = 16384, NW = 64 }; };   // catch-all: hot state in the wave's HBM slab, not LDS
 #define ALD_FIRST_GLOBAL_CLASS 5
 
