@@ -1150,14 +1150,14 @@ ALD_FN bool sweep_smallest(double max_ratio)
                 uint64_t now = wballot(cand && r < 0.01);
                 int lim = now ? ffs64(now) : ALD_WAVE;
                 bool mine = cand && lane < lim;
-                double rr = mine ? r : DBL_MAX; int vv = mine ? i : -1; int ee = mine ? e : -1;
+                double rr = mine ? r : DBL_MAX; int vv = mine ? i : -1;
                 for(int off = ALD_WAVE / 2; off >= 1; off >>= 1) {
-                    double r2 = wshfl(rr, lane ^ off); int v2 = wshfl(vv, lane ^ off); int e2 = wshfl(ee, lane ^ off);
+                    double r2 = wshfl(rr, lane ^ off); int v2 = wshfl(vv, lane ^ off);
                     bool take = (v2 >= 0) && (vv < 0 || r2 < rr || (r2 == rr && v2 > vv));
-                    if(take) { rr = r2; vv = v2; ee = e2; }
+                    if(take) { rr = r2; vv = v2; }
                 }
-                rr = wshfl(rr, 0); vv = wshfl(vv, 0); ee = wshfl(ee, 0);
-                if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = ee; }   // if(ratio < r) continue;
+                rr = wshfl(rr, 0); vv = wshfl(vv, 0);
+                if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = wshfl(e, vv - base); }   // if(ratio < r) continue;  (the edge comes from the winning lane)
                 if(now) { int l = ffs64(now); hit = base + l; hit_e = wshfl(e, l); hit_r = wshfl(r, l); }
             }
             } else {
@@ -1172,18 +1172,18 @@ ALD_FN bool sweep_smallest(double max_ratio)
             // (2) the candidates before it: each lane folds its own chunks (later vertex wins ties), then ONE reduction across lanes
             {
                 const int lim = hit >= 0 ? hit : vend;
-                double rr = DBL_MAX; int vv = -1, ee = -1;
+                double rr = DBL_MAX; int vv = -1;
                 for(int c = start / ALD_WAVE; c < NC && c * ALD_WAVE < lim; c++) {
                     const int i = c * ALD_WAVE + lane;
-                    if(i >= start && i < lim && ce[c] >= 0 && (vv < 0 || !(rr < cr[c]))) { rr = cr[c]; vv = i; ee = ce[c]; }
+                    if(i >= start && i < lim && ce[c] >= 0 && (vv < 0 || !(rr < cr[c]))) { rr = cr[c]; vv = i; }
                 }
                 for(int off = ALD_WAVE / 2; off >= 1; off >>= 1) {
-                    double r2 = wshfl(rr, lane ^ off); int v2 = wshfl(vv, lane ^ off); int e2 = wshfl(ee, lane ^ off);
+                    double r2 = wshfl(rr, lane ^ off); int v2 = wshfl(vv, lane ^ off);
                     bool take = (v2 >= 0) && (vv < 0 || r2 < rr || (r2 == rr && v2 > vv));
-                    if(take) { rr = r2; vv = v2; ee = e2; }
+                    if(take) { rr = r2; vv = v2; }
                 }
-                rr = wshfl(rr, 0); vv = wshfl(vv, 0); ee = wshfl(ee, 0);
-                if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = ee; }   // if(ratio < r) continue;
+                rr = wshfl(rr, 0); vv = wshfl(vv, 0);
+                if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = wshfl(ce[vv / ALD_WAVE], vv % ALD_WAVE); }   // if(ratio < r) continue;
             }
             }
             PROF_ADD(PF_SMALL_EVAL);
