@@ -202,6 +202,20 @@ ALD_INL void link_out(int v, int e)
     if(prev < 0) H.out_head[v] = (IDX)e; else H.lk[prev].onx = (IDX)e;
     H.out_deg[v]++;
 }
+// link_out with a starting point: `hint` is an edge of v's out-list known to sort before e (its target key is smaller)
+ALD_INL void link_out_after(int v, int e, int hint)
+{
+    v = uni(v); e = uni(e); hint = uni(hint);
+    if(v == 0 && !uni(H.special_linked)) { H.out_deg[v]++; return; }
+    const uint32_t sk = (uint32_t)uni(H.sinkp);
+    uint32_t kt = uni(H.lk[e].et), kid = uni(H.eid[e]);
+    if(kt == sk) kt = 0xFFFFu;
+    int prev = hint, cur = u_next_out(hint);
+    while(cur >= 0) { uint64_t w = lkw(cur); uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu; if(ct > kt || (ct == kt && uni(H.eid[cur]) > kid)) break; prev = cur; cur = lk_next((uint32_t)(w >> 48)); }
+    H.lk[e].onx = cur < 0 ? NIL : (IDX)cur;
+    H.lk[prev].onx = (IDX)e;
+    H.out_deg[v]++;
+}
 ALD_INL void unlink_in(int v, int e)
 {
     v = uni(v); e = uni(e);
@@ -717,7 +731,9 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         // f becomes the merged edge: newest id, far endpoint of c, weight of the two equal pieces
         const int other = A ? (int)uni(H.lk[f].et) : (int)uni(H.lk[f].es);
         H.eid[f] = (uint16_t)nid; H.ew[f] = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
-        if(A) { H.lk[f].es = (IDX)far; relink_in(other, f, (uint32_t)far); link_out(far, f); }
+        // the new edge far -> other sorts behind c = far -> x whenever other's key is above x's (always, except for vertices added by
+        // decompose_vertex_extend): the walk starts at c
+        if(A) { H.lk[f].es = (IDX)far; relink_in(other, f, (uint32_t)far); if(tkey((uint32_t)other) > tkey((uint32_t)x)) link_out_after(far, f, c); else link_out(far, f); }
         else { H.lk[f].et = (IDX)far; relink_out(other, f, tkey((uint32_t)far)); link_in(far, f); }
         fe[j] = -1;
         PROF_ADD(PF_T_MERGE_ADD);
