@@ -618,9 +618,8 @@ ALD_INL bool pair_less(int a1, int a2, int b1, int b2)
     if(x1 != y1) return x1 < y1;
     return H.eid[a2] < H.eid[b2];
 }
-ALD_INL void sort_pairs(int n)                   // insertion sort by (id(e1), id(e2)); keys are unique
+ALD_INL void sort_pairs(const Pairs &P, int n)   // insertion sort by (id(e1), id(e2)); keys are unique
 {
-    Pairs P = pairs_cur();
     for(int i = 1; i < n; i++) {
         int x = P.a[i], y = P.b[i]; double z = P.w[i]; int j = i - 1;
         while(j >= 0 && pair_less(PSLOT(x), PSLOT(y), PSLOT(P.a[j]), PSLOT(P.b[j]))) { P.a[j + 1] = P.a[j]; P.b[j + 1] = P.b[j]; P.w[j + 1] = P.w[j]; j--; }
@@ -1242,21 +1241,17 @@ ALD_FN bool sweep_smallest(double max_ratio)
 
 // ---------------------------------------------------------------- router (scallop/router.cc), scalar on lane 0
 // Results in H.ro_type / H.ro_degree / H.ro_ratio / H.ro_npairs; pe2w pairs (sorted, clamped) in the pair area.
-ALD_FN bool router_run(int root, int want_type, int max_degree)
+// SMALL: every router array lives in the LDS scratch (the common case; the compiler then knows the address space and emits ds_*
+// instead of flat_* accesses); otherwise in the slab's work arrays
+template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_degree)
 {
-#ifdef ALD_EMU_COUNT
-    g_cnt_router++;
-#endif
-    root = uni(root); want_type = uni(want_type); max_degree = uni(max_degree);
     COLD;
     // ---- build_indices (router.cc:225-248)
     int nin = uni(H.in_deg[root]), nout = uni(H.out_deg[root]), n = nin + nout;
-    // small vertices (the common case) keep every router array in the LDS scratch; larger ones use the slab
     const int route_bound = (H.hl_n == 0) ? 0 : nin * nout;          // routes only come from phasing lists
-    const bool small = (route_bound + n <= LP) && (5 * n + 3 * (route_bound + n) <= ARENA_I) && (3 * n + route_bound + n <= ARENA_D);
-    H.pw_lds = small ? 1 : 0;
-    const Arena AR = arena_at(small);
-    const Pairs PW = pairs_cur();
+    H.pw_lds = SMALL ? 1 : 0;
+    const Arena AR = arena_at(SMALL);
+    const Pairs PW = pairs_at(SMALL, false);
     const int cap = AR.cap_i;
     if(5 * n > cap) { fail(ALD_ST_CAPACITY); return false; }
     int32_t *u2e = AR.i;
@@ -1281,7 +1276,7 @@ ALD_FN bool router_run(int root, int want_type, int max_degree)
                 else { if(nr >= half) { fail(ALD_ST_CAPACITY); return false; } ra[nr] = x; rb[nr] = y; rc[nr] = c; nr++; }
             }
         }
-        sort_pairs(nr);                        // MPII order == (id(e1), id(e2)) == creation order of the ug edges
+        sort_pairs(PW, nr);                    // MPII order == (id(e1), id(e2)) == creation order of the ug edges
     }
     // ---- arena (sized now that the number of routes is known)
     int maxue = nr + n;                        // + one edge per isolated node
@@ -1415,11 +1410,24 @@ ALD_FN bool router_run(int root, int want_type, int max_degree)
     for(int i = 0; i < n; i++) { if(vw[i] <= 0) continue; weight_remain += vw[i]; }
     H.ro_ratio = weight_remain / weight_sum;
     for(int i = 0; i < n; i++) if(iso[i] == 1) C.ed[u2e[i]].econf += log(econf[i]);     // router.cc:849-855: side effect of every build()
-    sort_pairs(np);
+    sort_pairs(PW, np);
     const double mw = H.p_min_w;
     for(int i = 0; i < np; i++) if(pwt[i] < mw) pwt[i] = mw;                // router.cc:217-220
     H.ro_npairs = np;
     return true;
+}
+ALD_FN bool router_small(int root, int want_type, int max_degree) { return router_body<true>(uni(root), uni(want_type), uni(max_degree)); }
+ALD_FN bool router_large(int root, int want_type, int max_degree) { return router_body<false>(uni(root), uni(want_type), uni(max_degree)); }
+ALD_INL bool router_run(int root, int want_type, int max_degree)
+{
+#ifdef ALD_EMU_COUNT
+    g_cnt_router++;
+#endif
+    root = uni(root);
+    const int nin = uni(H.in_deg[root]), nout = uni(H.out_deg[root]), n = nin + nout;
+    const int route_bound = (uni(H.hl_n) == 0) ? 0 : nin * nout;
+    const bool small = (route_bound + n <= LP) && (5 * n + 3 * (route_bound + n) <= ARENA_I) && (3 * n + route_bound + n <= ARENA_D);
+    return small ? uni(router_small(root, want_type, max_degree)) : uni(router_large(root, want_type, max_degree));
 }
 // park / un-park the best candidate's pe2w while an unsplittable sweep goes on
 ALD_FN void save_pairs(int n)
