@@ -225,12 +225,12 @@ int ald_batch_add_packed(ald_batch *b, int32_t n, const int32_t *g_nv, const int
                          const int32_t *vertex_offset, const int32_t *edge_target, const double *edge_weight, const uint8_t *edge_strand, const double *edge_abd,
                          const int32_t *edge_sample_offset, const int32_t *sample_id, const double *sample_abd,
                          const double *vertex_weight, const int32_t *vertex_lpos, const int32_t *vertex_rpos, const int32_t *vertex_type,
-                         const int32_t *phasing_offset, const int32_t *phasing_vertex, const int32_t *phasing_count, const char *graph_strand)
+                         const int32_t *phasing_offset, const int32_t *phasing_vertex, const int32_t *phasing_count, const char *graph_strand, const int32_t *edge_count)
 {
     if(!b || n < 0 || !g_nv || !g_ne) return ALD_ERR_INVALID;
     b->uploaded = b->ran = b->downloaded = false;
     int rc = b->hb.add_packed(n, g_nv, g_ne, g_np, vertex_offset, edge_target, edge_weight, edge_strand, edge_abd, edge_sample_offset, sample_id, sample_abd,
-                              vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand);
+                              vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand, edge_count);
     if(rc != ALD_OK) return set_err(rc, b->hb.err);
     return ALD_OK;
 }

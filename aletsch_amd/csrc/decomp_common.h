@@ -82,6 +82,7 @@ struct BatchIn {
     ALD_GLOBAL const int32_t *in_offset, *in_edge;                      // host-built in-CSR: ids sorted by (target, source, id)
     ALD_GLOBAL const int32_t *phasing_offset, *phasing_vertex, *phasing_count;
     ALD_GLOBAL const char    *graph_strand;
+    ALD_GLOBAL const int32_t *edge_count;                               // edge_info.count at hand-over (not always |samples|)
 };
 struct BatchOut {
     ALD_GLOBAL int32_t *status, *n_paths, *n_iters;        // [n]

@@ -1708,7 +1708,7 @@ ALD_FN bool load_graph()
         H.lk[k].et = (IDX)A->in.edge_target[oe + k]; H.ew[k] = A->in.edge_weight[oe + k]; H.eid[k] = (uint16_t)k; H.hflag[k] = 0;
         uint8_t st = A->in.edge_strand[oe + k]; C.ed[k].estrand = st; if(st) strand = true;
         C.ed[k].med = 0; C.ed[k].mei = 0; C.ed[k].econf = 0; C.ed[k].eabd = A->in.edge_abd[oe + k];
-        C.ed[k].sp_off = (uint32_t)so[k]; C.ed[k].sp_len = (uint32_t)(so[k + 1] - so[k]); C.ed[k].ecount = so[k + 1] - so[k];
+        C.ed[k].sp_off = (uint32_t)so[k]; C.ed[k].sp_len = (uint32_t)(so[k + 1] - so[k]); C.ed[k].ecount = A->in.edge_count[oe + k];
         if(so[k + 1] > so[k]) { C.ed[k].s0id = A->in.sample_id[os + so[k]]; C.ed[k].s0abd = A->in.sample_abd[os + so[k]]; } else { C.ed[k].s0id = 0; C.ed[k].s0abd = 0; }
         for(int q = 0; q < NW; q++) C.ed[k].mask[q] = 0;
     }

@@ -27,6 +27,7 @@ struct HostBatch {
     std::vector<double> vertex_weight; std::vector<int32_t> vertex_lpos, vertex_rpos, vertex_type;
     std::vector<int32_t> in_offset, in_edge;
     std::vector<int32_t> phasing_offset, phasing_vertex, phasing_count; std::vector<char> graph_strand;
+    std::vector<int32_t> edge_count;
     std::string err;
 
     int n() const { return (int)g_nv.size(); }
@@ -66,6 +67,8 @@ struct HostBatch {
                 for(size_t j = 0; j < t.size(); j++) { sample_id[base + j] = t[j].first; sample_abd[base + j] = t[j].second; }
             }
             edge_abd.push_back(g.edge_abd ? g.edge_abd[q] : sum);
+            if(g.edge_count && g.edge_count[q] < 0) { err = "negative edge count"; return ALD_ERR_INVALID; }
+            edge_count.push_back(g.edge_count ? g.edge_count[q] : (int32_t)(b - a));
             edge_sample_offset.push_back((int32_t)(sample_id.size() - s0));
         }
         for(int i = 0; i <= V; i++) vertex_offset.push_back(g.vertex_offset[i]);
@@ -111,7 +114,7 @@ struct HostBatch {
                    const int32_t *voff, const int32_t *etgt, const double *ew, const uint8_t *estrand, const double *eabd,
                    const int32_t *esoff, const int32_t *sid, const double *sabd,
                    const double *vw, const int32_t *lpos, const int32_t *rpos, const int32_t *vtype,
-                   const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand)
+                   const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand, const int32_t *ecount = nullptr)
     {
         int64_t ov = 0, ovo = 0, oe = 0, oeo = 0, os = 0, op = 0, opo = 0, opv = 0;
         for(int i = 0; i < n; i++) {
@@ -122,7 +125,7 @@ struct HostBatch {
             g.edge_sample_offset = esoff + oeo; g.sample_id = sid + os; g.sample_abd = sabd + os;
             g.vertex_weight = vw + ov; g.vertex_lpos = lpos + ov; g.vertex_rpos = rpos + ov; g.vertex_type = vtype ? vtype + ov : nullptr;
             g.phasing_offset = poff ? poff + opo : nullptr; g.phasing_vertex = pv ? pv + opv : nullptr; g.phasing_count = pc ? pc + op : nullptr;
-            g.strand = gstrand ? gstrand[i] : '.';
+            g.strand = gstrand ? gstrand[i] : '.'; g.edge_count = ecount ? ecount + oe : nullptr;
             if(V < 2 || E < 0) { err = "bad graph size"; return ALD_ERR_INVALID; }
             int64_t ns = E > 0 ? g.edge_sample_offset[E] : 0, npv = (P > 0 && poff) ? g.phasing_offset[P] : 0;
             int rc = add_graph(g);
@@ -135,7 +138,7 @@ struct HostBatch {
     // ---- one contiguous buffer; section offsets are 256-byte aligned ----
     struct Section { const void *src; uint64_t bytes; uint64_t off; };
     enum { S_NV, S_NE, S_NP, S_OFFV, S_OFFE, S_OFFS, S_OFFP, S_OFFPV, S_VOFF, S_ETGT, S_EW, S_ESTRAND, S_EABD, S_ESOFF, S_SID, S_SABD,
-           S_VW, S_LPOS, S_RPOS, S_VTYPE, S_INOFF, S_INEDGE, S_POFF, S_PV, S_PC, S_GSTRAND, S_COUNT };
+           S_VW, S_LPOS, S_RPOS, S_VTYPE, S_INOFF, S_INEDGE, S_POFF, S_PV, S_PC, S_GSTRAND, S_ECOUNT, S_COUNT };
     uint64_t layout(Section sec[S_COUNT]) const
     {
         auto set = [&](int i, const void *p, uint64_t b) { sec[i].src = p; sec[i].bytes = b; };
@@ -148,7 +151,7 @@ struct HostBatch {
         set(S_VW, vertex_weight.data(), 8ull * vertex_weight.size()); set(S_LPOS, vertex_lpos.data(), 4ull * vertex_lpos.size()); set(S_RPOS, vertex_rpos.data(), 4ull * vertex_rpos.size());
         set(S_VTYPE, vertex_type.data(), 4ull * vertex_type.size()); set(S_INOFF, in_offset.data(), 4ull * in_offset.size()); set(S_INEDGE, in_edge.data(), 4ull * in_edge.size());
         set(S_POFF, phasing_offset.data(), 4ull * phasing_offset.size()); set(S_PV, phasing_vertex.data(), 4ull * phasing_vertex.size()); set(S_PC, phasing_count.data(), 4ull * phasing_count.size());
-        set(S_GSTRAND, graph_strand.data(), graph_strand.size());
+        set(S_GSTRAND, graph_strand.data(), graph_strand.size()); set(S_ECOUNT, edge_count.data(), 4ull * edge_count.size());
         uint64_t o = 0;
         for(int i = 0; i < S_COUNT; i++) { sec[i].off = o; o = (o + sec[i].bytes + 255) / 256 * 256; }
         return o < 256 ? 256 : o;
@@ -166,7 +169,7 @@ struct HostBatch {
         b.edge_sample_offset = ALD_P(int32_t, S_ESOFF); b.sample_id = ALD_P(int32_t, S_SID); b.sample_abd = ALD_P(double, S_SABD);
         b.vertex_weight = ALD_P(double, S_VW); b.vertex_lpos = ALD_P(int32_t, S_LPOS); b.vertex_rpos = ALD_P(int32_t, S_RPOS); b.vertex_type = ALD_P(int32_t, S_VTYPE);
         b.in_offset = ALD_P(int32_t, S_INOFF); b.in_edge = ALD_P(int32_t, S_INEDGE);
-        b.phasing_offset = ALD_P(int32_t, S_POFF); b.phasing_vertex = ALD_P(int32_t, S_PV); b.phasing_count = ALD_P(int32_t, S_PC); b.graph_strand = ALD_P(char, S_GSTRAND);
+        b.phasing_offset = ALD_P(int32_t, S_POFF); b.phasing_vertex = ALD_P(int32_t, S_PV); b.phasing_count = ALD_P(int32_t, S_PC); b.graph_strand = ALD_P(char, S_GSTRAND); b.edge_count = ALD_P(int32_t, S_ECOUNT);
 #undef ALD_P
         return b;
     }

@@ -37,7 +37,7 @@
 namespace aletsch {
 
 struct staged_graph {                       // owning arrays behind one ald_graph_view
-    std::vector<int32_t> vertex_offset, edge_target, edge_sample_offset, sample_id, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count;
+    std::vector<int32_t> vertex_offset, edge_target, edge_sample_offset, sample_id, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, edge_count;
     std::vector<double> edge_weight, edge_abd, sample_abd, vertex_weight; std::vector<uint8_t> edge_strand; char strand = '.';
     ald_graph_view view() const {
         ald_graph_view g{};
@@ -46,7 +46,7 @@ struct staged_graph {                       // owning arrays behind one ald_grap
         g.edge_sample_offset = edge_sample_offset.data(); g.sample_id = sample_id.data(); g.sample_abd = sample_abd.data();
         g.vertex_weight = vertex_weight.data(); g.vertex_lpos = vertex_lpos.data(); g.vertex_rpos = vertex_rpos.data(); g.vertex_type = vertex_type.data();
         g.num_phasing = (int32_t)phasing_count.size(); g.phasing_offset = phasing_offset.data(); g.phasing_vertex = phasing_vertex.data(); g.phasing_count = phasing_count.data();
-        g.strand = strand;
+        g.strand = strand; g.edge_count = edge_count.data();
         return g;
     }
 };
@@ -68,9 +68,9 @@ staged_graph stage_graph(SpliceGraph &gr, const HyperSet &hs)
     for(const E &x : es) {
         const auto &ei = gr.get_edge_info(x.e);
         s.edge_target.push_back(x.dst); s.edge_weight.push_back(gr.get_edge_weight(x.e)); s.edge_strand.push_back((uint8_t)ei.strand); s.edge_abd.push_back(ei.abd);
-        // edge_info.count is the number of supporting samples (meta/assembler.cc:202-231); an edge whose count disagrees with
-        // its sample set cannot be expressed on the wire and is rejected rather than silently changed
-        if((int)ei.samples.size() != ei.count) throw std::invalid_argument("edge_info.count != |edge_info.samples|");
+        // edge_info.count travels as its own field: it starts as the number of supporting samples (meta/assembler.cc:202-231) but
+        // group_start_boundaries ADDS counts along a grouped boundary (graph_reviser.cc:965-975) without touching the sample sets
+        s.edge_count.push_back((int32_t)ei.count);
         for(int sp : ei.samples) { s.sample_id.push_back(sp); auto f = ei.spAbd.find(sp); s.sample_abd.push_back(f == ei.spAbd.end() ? 0.0 : f->second); }
         s.edge_sample_offset.push_back((int32_t)s.sample_id.size());
     }

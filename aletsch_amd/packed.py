@@ -40,10 +40,18 @@ class PackedGraphs:
     phasing_vertex: np.ndarray  # [sum len] int32
     phasing_count: np.ndarray   # [sum P] int32
     graph_strand: np.ndarray    # [n] int8 ('+', '-', '.')
+    edge_count: Optional[np.ndarray] = None   # [sum E] int32 edge_info.count at hand-over; None => the number of supporting samples
 
     @property
     def n(self) -> int:
         return int(self.g_nv.shape[0])
+
+    def sample_counts(self) -> np.ndarray:
+        """[sum E] number of supporting samples per edge (what edge_count defaults to)."""
+        E = self.g_ne.astype(np.int64); eo = np.concatenate([[0], np.cumsum(E + 1)])
+        d = np.diff(self.edge_sample_offset.astype(np.int64))
+        keep = np.ones(d.shape[0], bool); keep[eo[1:-1] - 1] = False            # drop the differences across graph borders
+        return d[keep].astype(np.int32)
 
     def c_args(self):
         """Pointers in the argument order shared by ald_batch_add_packed / ora_run_packed."""
@@ -59,6 +67,7 @@ class PackedGraphs:
             p(self.vertex_type, C.c_int32),
             p(self.phasing_offset, C.c_int32), p(self.phasing_vertex, C.c_int32), p(self.phasing_count, C.c_int32),
             p(self.graph_strand, C.c_char),
+            p(np.ascontiguousarray(self.edge_count, np.int32), C.c_int32) if self.edge_count is not None else None,
         )
 
     def graph_slices(self):
@@ -95,18 +104,21 @@ class PackedGraphs:
             vertex_rpos=cat(self.vertex_rpos, o["v"], V), vertex_type=cat(self.vertex_type, o["v"], V),
             phasing_offset=cat(self.phasing_offset, o["po"], P + 1), phasing_vertex=cat(self.phasing_vertex, o["pv"], npv),
             phasing_count=cat(self.phasing_count, o["p"], P), graph_strand=self.graph_strand[idx].copy(),
+            edge_count=None if self.edge_count is None else cat(self.edge_count, o["e"], E),
         )
 
     @staticmethod
     def concat(parts) -> "PackedGraphs":
-        kw = {f.name: np.concatenate([getattr(p, f.name) for p in parts]) for f in fields(PackedGraphs)}
+        kw = {f.name: np.concatenate([getattr(p, f.name) for p in parts]) for f in fields(PackedGraphs) if f.name != "edge_count"}
+        if any(p.edge_count is not None for p in parts):
+            kw["edge_count"] = np.concatenate([p.edge_count if p.edge_count is not None else p.sample_counts() for p in parts]).astype(np.int32)
         return PackedGraphs(**kw)
 
     @staticmethod
     def from_graphs(graphs) -> "PackedGraphs":
         """Build from a list of dicts: V, edges=[(s,t,w[,strand[,{sid:abd}]])], vw, lpos, rpos,
         optional vtype, phasing=[([v...], count)], strand.  Edges are sorted into CSR order."""
-        acc = {f.name: [] for f in fields(PackedGraphs)}
+        acc = {f.name: [] for f in fields(PackedGraphs) if f.name != "edge_count"}
         for g in graphs:
             V = int(g["V"]); edges = sorted(g["edges"], key=lambda e: (e[0], e[1]))
             voff = np.zeros(V + 1, _I32)

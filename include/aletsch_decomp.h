@@ -69,7 +69,7 @@ typedef struct ald_graph_view {
     const double  *edge_weight;         /* [E]   splice_graph::ewrt                      */
     const uint8_t *edge_strand;         /* [E]   edge_info.strand 0/1/2; NULL => all 0   */
     const double  *edge_abd;            /* [E]   edge_info.abd;      NULL => sum(sample_abd) */
-    const int32_t *edge_sample_offset;  /* [E+1] per-edge slice into sample_id/sample_abd; edge_info.count = slice length */
+    const int32_t *edge_sample_offset;  /* [E+1] per-edge slice into sample_id/sample_abd (edge_info.samples / spAbd)   */
     const int32_t *sample_id;           /* [S]   edge_info.samples, ascending per edge   */
     const double  *sample_abd;          /* [S]   edge_info.spAbd                         */
     const double  *vertex_weight;       /* [V]   splice_graph::vwrt                      */
@@ -81,6 +81,8 @@ typedef struct ald_graph_view {
     const int32_t *phasing_vertex;      /* vertex lists, ascending                       */
     const int32_t *phasing_count;       /* [P]                                           */
     char           strand;              /* splice_graph::strand '+','-','.'              */
+    const int32_t *edge_count;          /* [E]   edge_info.count; NULL => number of supporting samples.  The callers of assemble() hand over graphs
+                                          *       whose counts were ADDED along grouped boundaries (graph_reviser.cc:965-975): count != |samples| there */
 } ald_graph_view;
 
 /* One decomposed s-t path (reference rnacore/path.h:14-35, scallop.cc:2766-2834). */
@@ -124,7 +126,7 @@ int  ald_batch_add_packed(ald_batch *b, int32_t n,
                           const double *vertex_weight, const int32_t *vertex_lpos, const int32_t *vertex_rpos,
                           const int32_t *vertex_type,
                           const int32_t *phasing_offset, const int32_t *phasing_vertex, const int32_t *phasing_count,
-                          const char *graph_strand);
+                          const char *graph_strand, const int32_t *edge_count /* NULL => per-edge sample count */);
 int  ald_batch_num_graphs(const ald_batch *b);
 
 /* ---- execution (replaces `sx.assemble()`, scallop.cc:38-188) ---- */

@@ -29,7 +29,7 @@ struct Packed {
     const int32_t *vertex_offset, *edge_target; const double *edge_weight; const uint8_t *edge_strand; const double *edge_abd;
     const int32_t *edge_sample_offset, *sample_id; const double *sample_abd;
     const double *vertex_weight; const int32_t *vertex_lpos, *vertex_rpos, *vertex_type;
-    const int32_t *phasing_offset, *phasing_vertex, *phasing_count; const char *graph_strand;
+    const int32_t *phasing_offset, *phasing_vertex, *phasing_count; const char *graph_strand; const int32_t *edge_count;
 };
 
 struct Offsets { int64_t v, vo, e, eo, s, p, po, pv; };
@@ -53,7 +53,7 @@ void run_one(const Packed &P, const Offsets &o, int g, const ora::Params &cfg, b
         ei.strand = P.edge_strand ? P.edge_strand[o.e + k] : 0;
         double sum = 0;
         for(int j = so[k]; j < so[k + 1]; j++) { int sid = P.sample_id[o.s + j]; double a = P.sample_abd[o.s + j]; ei.samples.insert(sid); ei.spAbd[sid] = a; sum += a; }
-        ei.count = so[k + 1] - so[k];
+        ei.count = P.edge_count ? P.edge_count[o.e + k] : so[k + 1] - so[k];       // the hand-over count is not always |samples| (graph_reviser.cc:965-975)
         ei.abd = P.edge_abd ? P.edge_abd[o.e + k] : sum;
     }
     ora::HyperSet hs;
@@ -95,11 +95,11 @@ int ora_run_packed(int32_t n,
                    const double *vertex_weight, const int32_t *vertex_lpos, const int32_t *vertex_rpos,
                    const int32_t *vertex_type,
                    const int32_t *phasing_offset, const int32_t *phasing_vertex, const int32_t *phasing_count,
-                   const char *graph_strand,
+                   const char *graph_strand, const int32_t *edge_count,
                    const ald_params *prm, int32_t n_threads, int32_t want_trace, ora_result **out)
 {
     Packed P{n, g_nv, g_ne, g_np, vertex_offset, edge_target, edge_weight, edge_strand, edge_abd, edge_sample_offset, sample_id, sample_abd,
-             vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand};
+             vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand, edge_count};
     ora::Params cfg;
     if(prm) {
         for(int i = 0; i < 8; i++) cfg.max_decompose_error_ratio[i] = prm->max_decompose_error_ratio[i];

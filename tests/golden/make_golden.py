@@ -136,7 +136,8 @@ def main():
         pg = A.synth(**kw)
         r = common.oracle_run(pg)[0]
         for f in fields(PackedGraphs):
-            blob[f"{name}/in/{f.name}"] = getattr(pg, f.name)
+            if getattr(pg, f.name) is not None:
+                blob[f"{name}/in/{f.name}"] = getattr(pg, f.name)
         for k in ("status", "path_offset", "weight", "abd", "conf", "reads", "length", "count", "strand", "pv_offset", "path_vertices"):
             blob[f"{name}/out/{k}"] = getattr(r, k)
     np.savez_compressed(os.path.join(HERE, "oracle_paths.npz"), **blob)

@@ -21,11 +21,11 @@ int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_
                    const int32_t *voff, const int32_t *etgt, const double *ew, const uint8_t *estrand, const double *eabd,
                    const int32_t *esoff, const int32_t *sid, const double *sabd,
                    const double *vw, const int32_t *lpos, const int32_t *rpos, const int32_t *vtype,
-                   const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand,
+                   const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand, const int32_t *ecount,
                    const ald_params *prm, int32_t trace_cap, int32_t force_class, emu_result **out)
 {
     HostBatch B;
-    int rc = B.add_packed(n, nv, ne, np, voff, etgt, ew, estrand, eabd, esoff, sid, sabd, vw, lpos, rpos, vtype, poff, pv, pc, gstrand);
+    int rc = B.add_packed(n, nv, ne, np, voff, etgt, ew, estrand, eabd, esoff, sid, sabd, vw, lpos, rpos, vtype, poff, pv, pc, gstrand, ecount);
     if(rc != ALD_OK) { fprintf(stderr, "emu: add_packed failed: %s\n", B.err.c_str()); return rc; }
     HostBatch::Section sec[HostBatch::S_COUNT];
     uint64_t bytes = B.layout(sec);

@@ -128,3 +128,19 @@ def test_catch_all_class_large_graphs():
     assert (cl == 5).all()
     assert not common.compare_results(want, got, pg.n)
     assert np.array_equal(it, st[:, 3])
+
+
+def test_explicit_edge_counts():
+    """edge_info.count handed over separately from the sample sets (group_start_boundaries adds counts along grouped boundaries,
+    graph_reviser.cc:965-975): larger than |samples| on some edges, zero on a few (router.cc:269 treats those as absent; a merge of
+    such an edge is the reference's assert(ei1.count > 0 && ei2.count > 0))"""
+    pg = A.synth(seed=91, n_graphs=120, v_min=8, v_max=50, edges_per_vertex=3, n_samples=3, phasing_per_graph=3, weight_mode=1)
+    rng = np.random.default_rng(7)
+    cnt = pg.sample_counts() + rng.integers(0, 4, pg.edge_target.size).astype(np.int32)
+    cnt[rng.random(cnt.size) < 0.002] = 0
+    pg.edge_count = cnt.astype(np.int32)
+    want, st, _, _ = common.oracle_run(pg)
+    got, it, cl = common.emu_run(pg)
+    assert not common.compare_results(want, got, pg.n)
+    plain = common.oracle_run(A.synth(seed=91, n_graphs=120, v_min=8, v_max=50, edges_per_vertex=3, n_samples=3, phasing_per_graph=3, weight_mode=1))[0]
+    assert (want.status != 0).any() or not np.array_equal(want.count, plain.count)      # the counts do reach the output

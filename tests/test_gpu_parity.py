@@ -176,6 +176,18 @@ def test_catch_all_class_on_gpu():
     assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
 
 
+def test_explicit_edge_counts_on_gpu():
+    """edge_info.count handed over separately from the sample sets (see tests/test_emu_vs_oracle.py)"""
+    pg = A.synth(seed=91, n_graphs=300, v_min=8, v_max=90, edges_per_vertex=3, n_samples=3, phasing_per_graph=3, weight_mode=1)
+    rng = np.random.default_rng(7)
+    cnt = pg.sample_counts() + rng.integers(0, 4, pg.edge_target.size).astype(np.int32)
+    cnt[rng.random(cnt.size) < 0.002] = 0
+    pg.edge_count = cnt.astype(np.int32)
+    want = common.oracle_run(pg)[0]
+    got = A.decompose(pg, device=0)
+    assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
+
+
 def test_record_exchange_from_device_memory():
     """the multi-GPU exchange step with one rank over RCCL: the record pool is handed over in HBM (zero-copy view of
     ald_batch_device_records) and comes back on rank 0 identical to the host copy, graph ids made global by the C helper"""
