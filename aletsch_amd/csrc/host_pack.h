@@ -16,22 +16,43 @@
 #include <cstring>
 #include <string>
 #include <map>
+#include <thread>
+#include <cstdlib>
 
 namespace ald {
 
+// std::vector that does not zero-fill on resize(): the staging arrays are sized once and then written by block copies from
+// several threads (zero-filling 1.3 GB on one thread first costs more than the copies themselves)
+template<class T> struct raw_init_alloc : std::allocator<T> {
+    template<class U> struct rebind { typedef raw_init_alloc<U> other; };
+    raw_init_alloc() = default;
+    template<class U> raw_init_alloc(const raw_init_alloc<U> &) {}
+    template<class U, class... A> void construct(U *p, A &&... a) { if(sizeof...(A) == 0) ::new((void*)p) U; else ::new((void*)p) U(std::forward<A>(a)...); }
+};
+template<class T> using rvec = std::vector<T, raw_init_alloc<T>>;
+
 struct HostBatch {
-    std::vector<int32_t> g_nv, g_ne, g_np;
-    std::vector<int64_t> off_v{0}, off_e{0}, off_s{0}, off_p{0}, off_pv{0};
-    std::vector<int32_t> vertex_offset, edge_target; std::vector<double> edge_weight; std::vector<uint8_t> edge_strand; std::vector<double> edge_abd;
-    std::vector<int32_t> edge_sample_offset, sample_id; std::vector<double> sample_abd;
-    std::vector<double> vertex_weight; std::vector<int32_t> vertex_lpos, vertex_rpos, vertex_type;
-    std::vector<int32_t> in_offset, in_edge;
-    std::vector<int32_t> phasing_offset, phasing_vertex, phasing_count; std::vector<char> graph_strand;
-    std::vector<int32_t> edge_count;
+    rvec<int32_t> g_nv, g_ne, g_np;
+    rvec<int64_t> off_v{0}, off_e{0}, off_s{0}, off_p{0}, off_pv{0};
+    rvec<int32_t> vertex_offset, edge_target; rvec<double> edge_weight; rvec<uint8_t> edge_strand; rvec<double> edge_abd;
+    rvec<int32_t> edge_sample_offset, sample_id; rvec<double> sample_abd;
+    rvec<double> vertex_weight; rvec<int32_t> vertex_lpos, vertex_rpos, vertex_type;
+    rvec<int32_t> in_offset, in_edge;
+    rvec<int32_t> phasing_offset, phasing_vertex, phasing_count; rvec<char> graph_strand;
+    rvec<int32_t> edge_count;
     std::string err;
 
     int n() const { return (int)g_nv.size(); }
-    void clear() { *this = HostBatch(); }
+    void clear()        // keeps every array's capacity: the next batch of the same shape is staged without touching the allocator
+    {
+        g_nv.clear(); g_ne.clear(); g_np.clear();
+        off_v.assign(1, 0); off_e.assign(1, 0); off_s.assign(1, 0); off_p.assign(1, 0); off_pv.assign(1, 0);
+        vertex_offset.clear(); edge_target.clear(); edge_weight.clear(); edge_strand.clear(); edge_abd.clear();
+        edge_sample_offset.clear(); sample_id.clear(); sample_abd.clear();
+        vertex_weight.clear(); vertex_lpos.clear(); vertex_rpos.clear(); vertex_type.clear();
+        in_offset.clear(); in_edge.clear(); phasing_offset.clear(); phasing_vertex.clear(); phasing_count.clear(); graph_strand.clear(); edge_count.clear();
+        err.clear();
+    }
 
     int add_graph(const ald_graph_view &g)
     {
@@ -110,7 +131,7 @@ struct HostBatch {
         return ALD_OK;
     }
 
-    int add_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_t *np,
+    int add_packed_serial(int32_t n, const int32_t *nv, const int32_t *ne, const int32_t *np,
                    const int32_t *voff, const int32_t *etgt, const double *ew, const uint8_t *estrand, const double *eabd,
                    const int32_t *esoff, const int32_t *sid, const double *sabd,
                    const double *vw, const int32_t *lpos, const int32_t *rpos, const int32_t *vtype,
@@ -135,6 +156,128 @@ struct HostBatch {
         return ALD_OK;
     }
 
+    // Bulk form.  A batch whose graphs are already canonical -- CSR rows sorted by target, sample lists ascending, phasing lists
+    // strictly ascending and in lexicographic order: what the reference's containers give and what every generator here emits --
+    // is staged by block copies, the only per-edge work being the in-CSR counting sort, with the graphs split over host threads
+    // (all sizes are known up front, so every thread writes its own disjoint ranges).  Anything else takes the per-graph path
+    // above, which normalises.
+    int add_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_t *np,
+                   const int32_t *voff, const int32_t *etgt, const double *ew, const uint8_t *estrand, const double *eabd,
+                   const int32_t *esoff, const int32_t *sid, const double *sabd,
+                   const double *vw, const int32_t *lpos, const int32_t *rpos, const int32_t *vtype,
+                   const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand, const int32_t *ecount = nullptr)
+    {
+        if(n <= 0) return ALD_OK;
+        // offsets of every graph inside the caller's concatenated arrays
+        std::vector<int64_t> iv(n + 1, 0), ie(n + 1, 0), is(n + 1, 0), ip(n + 1, 0), ipv(n + 1, 0);
+        for(int i = 0; i < n; i++) {
+            const int V = nv[i], E = ne[i], P = np ? np[i] : 0;
+            if(V < 2 || E < 0 || P < 0) { err = "bad graph size"; return ALD_ERR_INVALID; }
+            if(P > 0 && (!poff || !pc)) { err = "null phasing arrays"; return ALD_ERR_INVALID; }
+            iv[i + 1] = iv[i] + V; ie[i + 1] = ie[i] + E; ip[i + 1] = ip[i] + P;
+            const int64_t ns = E > 0 ? esoff[ie[i] + i + E] : 0, npv = P > 0 ? poff[ip[i] + i + P] : 0;
+            if(ns < 0 || npv < 0) { err = "negative offsets"; return ALD_ERR_INVALID; }
+            is[i + 1] = is[i] + ns; ipv[i + 1] = ipv[i] + npv;
+        }
+        const int64_t TV = iv[n], TE = ie[n], TS = is[n], TP = ip[n], TPV = ipv[n];
+        if(TPV > 0 && !pv) { err = "null phasing arrays"; return ALD_ERR_INVALID; }
+        unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16;
+        if(const char *ev = getenv("ALD_STAGE_THREADS")) { int k = atoi(ev); if(k >= 1 && k <= 64) nthr = (unsigned)k; }
+        if((int64_t)nthr > (TE >> 16) + 1) nthr = (unsigned)((TE >> 16) + 1);                      // not worth a thread below ~64k edges
+        // ---- pass 1 (parallel): is every graph canonical and valid?
+        std::vector<int> verdict(nthr, 0);           // 0 ok, 1 not canonical, 2 invalid
+        auto check = [&](unsigned t) {
+            const int g0 = (int)((int64_t)n * t / nthr), g1 = (int)((int64_t)n * (t + 1) / nthr);
+            int worst = 0;
+            for(int g = g0; g < g1 && worst < 2; g++) {
+                const int V = nv[g], E = ne[g], P = np ? np[g] : 0;
+                const int32_t *vo = voff + iv[g] + g, *tg = etgt + ie[g], *so = esoff + ie[g] + g;
+                if(vo[0] != 0 || vo[V] != E || (E > 0 && so[0] != 0)) { worst = 2; break; }
+                for(int s = 0; s < V && worst < 2; s++) {
+                    if(vo[s + 1] < vo[s]) { worst = 2; break; }
+                    for(int k = vo[s]; k < vo[s + 1]; k++) { int t2 = tg[k]; if(t2 < 0 || t2 >= V || t2 == s) { worst = 2; break; } if(k > vo[s] && tg[k - 1] > t2) worst = 1; }
+                }
+                for(int k = 0; k < E && worst < 2; k++) {
+                    if(so[k + 1] < so[k]) { worst = 2; break; }
+                    if(estrand && estrand[ie[g] + k] > 2) { worst = 2; break; }
+                    if(ecount && ecount[ie[g] + k] < 0) { worst = 2; break; }
+                    for(int j = so[k] + 1; j < so[k + 1]; j++) if(sid[is[g] + j - 1] >= sid[is[g] + j]) worst = 1;
+                }
+                if(P > 0 && worst < 2) {
+                    const int32_t *po = poff + ip[g] + g, *v = pv + ipv[g];
+                    if(po[0] != 0) { worst = 2; break; }
+                    for(int p = 0; p < P && worst < 2; p++) {
+                        if(po[p + 1] < po[p]) { worst = 2; break; }
+                        for(int k = po[p] + 1; k < po[p + 1]; k++) if(v[k - 1] >= v[k]) worst = 1;
+                        if(p > 0 && !std::lexicographical_compare(v + po[p - 1], v + po[p], v + po[p], v + po[p + 1])) worst = 1;
+                    }
+                }
+            }
+            verdict[t] = worst;
+        };
+        run_threads(nthr, check);
+        int worst = 0; for(unsigned t = 0; t < nthr; t++) worst = std::max(worst, verdict[t]);
+        if(worst != 0)      // the per-graph path normalises, or names the defect
+            return add_packed_serial(n, nv, ne, np, voff, etgt, ew, estrand, eabd, esoff, sid, sabd, vw, lpos, rpos, vtype, poff, pv, pc, gstrand, ecount);
+        // ---- pass 2: size everything once, then fill disjoint ranges in parallel
+        const size_t n0 = g_nv.size(), v0 = vertex_weight.size(), vo0 = vertex_offset.size(), e0 = edge_target.size(), eo0 = edge_sample_offset.size(), s0 = sample_id.size(),
+                     p0 = phasing_count.size(), po0 = phasing_offset.size(), pv0 = phasing_vertex.size();
+        g_nv.insert(g_nv.end(), nv, nv + n); g_ne.insert(g_ne.end(), ne, ne + n);
+        if(np) g_np.insert(g_np.end(), np, np + n); else g_np.resize(n0 + n, 0);
+        graph_strand.resize(n0 + n); for(int i = 0; i < n; i++) graph_strand[n0 + i] = (gstrand && gstrand[i]) ? gstrand[i] : '.';
+        off_v.resize(n0 + n + 1); off_e.resize(n0 + n + 1); off_s.resize(n0 + n + 1); off_p.resize(n0 + n + 1); off_pv.resize(n0 + n + 1);
+        for(int i = 0; i < n; i++) { off_v[n0 + i + 1] = off_v[n0] + iv[i + 1]; off_e[n0 + i + 1] = off_e[n0] + ie[i + 1]; off_s[n0 + i + 1] = off_s[n0] + is[i + 1]; off_p[n0 + i + 1] = off_p[n0] + ip[i + 1]; off_pv[n0 + i + 1] = off_pv[n0] + ipv[i + 1]; }
+        vertex_offset.resize(vo0 + TV + n); in_offset.resize(vo0 + TV + n);
+        edge_target.resize(e0 + TE); edge_weight.resize(e0 + TE); edge_strand.resize(e0 + TE); edge_abd.resize(e0 + TE); edge_count.resize(e0 + TE); in_edge.resize(e0 + TE);
+        edge_sample_offset.resize(eo0 + TE + n); sample_id.resize(s0 + TS); sample_abd.resize(s0 + TS);
+        vertex_weight.resize(v0 + TV); vertex_lpos.resize(v0 + TV); vertex_rpos.resize(v0 + TV); vertex_type.resize(v0 + TV);
+        phasing_offset.resize(po0 + TP + n); phasing_vertex.resize(pv0 + TPV); phasing_count.resize(p0 + TP);
+        auto fill = [&](unsigned t) {
+            const int g0 = (int)((int64_t)n * t / nthr), g1 = (int)((int64_t)n * (t + 1) / nthr);
+            if(g0 >= g1) return;
+            // whole-range block copies for the arrays that need no per-graph work
+            const int64_t a_v = iv[g0], b_v = iv[g1], a_e = ie[g0], b_e = ie[g1], a_s = is[g0], b_s = is[g1], a_p = ip[g0], b_p = ip[g1], a_pv = ipv[g0], b_pv = ipv[g1];
+            memcpy(&vertex_offset[vo0 + a_v + g0], voff + a_v + g0, 4 * (size_t)(b_v - a_v + (g1 - g0)));
+            memcpy(&edge_sample_offset[eo0 + a_e + g0], esoff + a_e + g0, 4 * (size_t)(b_e - a_e + (g1 - g0)));
+            if(b_e > a_e) {
+                memcpy(&edge_target[e0 + a_e], etgt + a_e, 4 * (size_t)(b_e - a_e)); memcpy(&edge_weight[e0 + a_e], ew + a_e, 8 * (size_t)(b_e - a_e));
+                if(estrand) memcpy(&edge_strand[e0 + a_e], estrand + a_e, (size_t)(b_e - a_e)); else memset(&edge_strand[e0 + a_e], 0, (size_t)(b_e - a_e));
+                if(eabd) memcpy(&edge_abd[e0 + a_e], eabd + a_e, 8 * (size_t)(b_e - a_e));
+                if(ecount) memcpy(&edge_count[e0 + a_e], ecount + a_e, 4 * (size_t)(b_e - a_e));
+            }
+            if(b_s > a_s) { memcpy(&sample_id[s0 + a_s], sid + a_s, 4 * (size_t)(b_s - a_s)); memcpy(&sample_abd[s0 + a_s], sabd + a_s, 8 * (size_t)(b_s - a_s)); }
+            memcpy(&vertex_weight[v0 + a_v], vw + a_v, 8 * (size_t)(b_v - a_v)); memcpy(&vertex_lpos[v0 + a_v], lpos + a_v, 4 * (size_t)(b_v - a_v)); memcpy(&vertex_rpos[v0 + a_v], rpos + a_v, 4 * (size_t)(b_v - a_v));
+            if(vtype) memcpy(&vertex_type[v0 + a_v], vtype + a_v, 4 * (size_t)(b_v - a_v)); else for(int64_t k = a_v; k < b_v; k++) vertex_type[v0 + k] = -1;
+            if(poff) memcpy(&phasing_offset[po0 + a_p + g0], poff + a_p + g0, 4 * (size_t)(b_p - a_p + (g1 - g0))); else memset(&phasing_offset[po0 + a_p + g0], 0, 4 * (size_t)(b_p - a_p + (g1 - g0)));
+            if(b_pv > a_pv) memcpy(&phasing_vertex[pv0 + a_pv], pv + a_pv, 4 * (size_t)(b_pv - a_pv));
+            if(b_p > a_p) memcpy(&phasing_count[p0 + a_p], pc + a_p, 4 * (size_t)(b_p - a_p));
+            // per graph: defaults that depend on the sample lists, and the in-CSR (counting sort of edge ids by target)
+            std::vector<int32_t> cur;
+            for(int g = g0; g < g1; g++) {
+                const int V = nv[g], E = ne[g];
+                const int32_t *so = esoff + ie[g] + g, *tg = etgt + ie[g];
+                if(!eabd) for(int k = 0; k < E; k++) { double sum = 0; for(int j = so[k]; j < so[k + 1]; j++) sum += sabd[is[g] + j]; edge_abd[e0 + ie[g] + k] = sum; }
+                if(!ecount) for(int k = 0; k < E; k++) edge_count[e0 + ie[g] + k] = so[k + 1] - so[k];
+                int32_t *io = &in_offset[vo0 + iv[g] + g]; int32_t *ied = E > 0 ? &in_edge[e0 + ie[g]] : nullptr;
+                for(int i = 0; i <= V; i++) io[i] = 0;
+                for(int k = 0; k < E; k++) io[tg[k] + 1]++;
+                for(int i = 0; i < V; i++) io[i + 1] += io[i];
+                cur.assign(io, io + V);
+                for(int k = 0; k < E; k++) ied[cur[tg[k]]++] = k;
+            }
+        };
+        run_threads(nthr, fill);
+        return ALD_OK;
+    }
+    template<class F> static void run_threads(unsigned nthr, F &&f)
+    {
+        if(nthr <= 1) { f(0u); return; }
+        std::vector<std::thread> th; th.reserve(nthr - 1);
+        for(unsigned t = 1; t < nthr; t++) th.emplace_back([&f, t]() { f(t); });
+        f(0u);
+        for(auto &x : th) x.join();
+    }
+
     // ---- one contiguous buffer; section offsets are 256-byte aligned ----
     struct Section { const void *src; uint64_t bytes; uint64_t off; };
     enum { S_NV, S_NE, S_NP, S_OFFV, S_OFFE, S_OFFS, S_OFFP, S_OFFPV, S_VOFF, S_ETGT, S_EW, S_ESTRAND, S_EABD, S_ESOFF, S_SID, S_SABD,
@@ -156,7 +299,21 @@ struct HostBatch {
         for(int i = 0; i < S_COUNT; i++) { sec[i].off = o; o = (o + sec[i].bytes + 255) / 256 * 256; }
         return o < 256 ? 256 : o;
     }
-    void pack_into(uint8_t *dst, const Section sec[S_COUNT]) const { for(int i = 0; i < S_COUNT; i++) if(sec[i].bytes) memcpy(dst + sec[i].off, sec[i].src, sec[i].bytes); }
+    void pack_into(uint8_t *dst, const Section sec[S_COUNT]) const
+    {
+        uint64_t tot = 0; for(int i = 0; i < S_COUNT; i++) tot += sec[i].bytes;
+        unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16;
+        if(const char *ev = getenv("ALD_STAGE_THREADS")) { int k = atoi(ev); if(k >= 1 && k <= 64) nthr = (unsigned)k; }
+        if(tot < (8u << 20)) nthr = 1;
+        // every thread copies its slice of every section (sections differ in size by orders of magnitude)
+        run_threads(nthr, [&](unsigned t) {
+            for(int i = 0; i < S_COUNT; i++) {
+                const uint64_t b = sec[i].bytes; if(!b) continue;
+                const uint64_t lo = b * t / nthr, hi = b * (t + 1) / nthr;
+                if(hi > lo) memcpy(dst + sec[i].off + lo, (const uint8_t*)sec[i].src + lo, hi - lo);
+            }
+        });
+    }
     // BatchIn whose pointers are `base + section offset` (base = device address, or the host buffer for the emulation)
     BatchIn make_batch_in(uint8_t *base, const Section sec[S_COUNT]) const
     {
