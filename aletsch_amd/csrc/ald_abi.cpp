@@ -6,6 +6,8 @@
 // entry point fails with ALD_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include "host_pack.h"
+#include <thread>
+#include <iterator>
 #include "../host/transcript_sink.hpp"
 #include <mutex>
 #include <string>
@@ -451,7 +453,14 @@ int ald_batch_export_transcripts(const ald_batch *b, int64_t *total_exons, doubl
 }
 
 /* ---- result sink: transcript_set restated (aletsch_amd/host/transcript_sink.hpp) ---- */
-struct ald_tset { aletsch::transcript_sink sink; explicit ald_tset(double ov) : sink(ov) {} };
+// Buckets (intron-chain hashes) never interact: the set is kept as NSHARD independent tables, bucket h in table h % NSHARD, so that a
+// whole batch can be merged by NSHARD host threads without a lock; the export walks all keys in ascending order.
+enum { ALD_TSET_SHARDS = 16 };
+struct ald_tset {
+    std::vector<aletsch::transcript_sink> shard; double overlap;
+    explicit ald_tset(double ov) : shard(ALD_TSET_SHARDS, aletsch::transcript_sink(ov)), overlap(ov) {}
+    void add(aletsch::transcript_sink &ts) { for(auto &x : ts.mt) shard[x.first % ALD_TSET_SHARDS].add_bucket(x.first, x.second); }
+};
 
 int ald_tset_create(double single_exon_overlap, ald_tset **out) { if(!out) return ALD_ERR_INVALID; *out = new ald_tset(single_exon_overlap); return ALD_OK; }
 int ald_tset_destroy(ald_tset *t) { delete t; return ALD_OK; }
@@ -462,7 +471,7 @@ int ald_tset_add(ald_tset *t, int32_t n_groups, const int64_t *group_offset, con
 {
     if(!t || n_groups < 0 || (n_groups > 0 && (!group_offset || !group_sid || !strand || !coverage || !conf || !abd || !count1 || !tid || !exon_offset || !exon_lr))) return ALD_ERR_INVALID;
     for(int g = 0; g < n_groups; g++) {
-        aletsch::transcript_sink ts(t->sink.single_exon_overlap());
+        aletsch::transcript_sink ts(t->overlap);
         for(int64_t i = group_offset[g]; i < group_offset[g + 1]; i++) {
             aletsch::sink_transcript x;
             x.strand = strand[i]; x.coverage = coverage[i]; x.cov2 = coverage[i]; x.conf = conf[i]; x.abd = abd[i]; x.count1 = count1[i]; x.count2 = 1; x.tid = tid[i];
@@ -470,31 +479,67 @@ int ald_tset_add(ald_tset *t, int32_t n_groups, const int64_t *group_offset, con
             if(x.exons.size() <= 1 && skip_single_exon) continue;           // assembler.cc:1117
             ts.add(x, 1, group_sid[g]);                                      // assembler.cc:1120
         }
-        t->sink.add(ts);                                                     // assembler.cc:1130
+        t->add(ts);                                                          // assembler.cc:1130
     }
     return ALD_OK;
 }
 
+// transcript::get_intron_chain_hashing (gtf/transcript.cc:183-201) over the flat exon list of join_exons
+static size_t chain_hash(const std::vector<int32_t> &ex)
+{
+    const size_t ne = ex.size() / 2;
+    if(ne == 0) return 0;
+    if(ne == 1) return (size_t)((ex[0] + ex[1]) / 10000) + 1;
+    size_t seed = 2 * (ne - 1);
+    for(size_t k = 1; k < 2 * ne - 1; k++) seed ^= (size_t)(ex[k]) + 0x9e3779b9 + (seed << 6) + (seed >> 2);      // r0, l1, r1, l2, ..., l_last
+    return (seed & 0x7FFFFFFF) + 1;
+}
+
+// The merge of a whole batch.  Buckets (intron-chain hashes) never interact, so they are dealt to the host threads by hash: every
+// thread walks the graphs in ascending order, builds the per-graph set of ITS buckets and merges it -- the same sequence of
+// trans_item::merge calls per bucket as the serial loop of assembler.cc:1105-1133, hence the same result, without `mylock`.
 int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int64_t tid_base, int32_t skip_single_exon)
 {
     if(!t || !b || !b->downloaded) return ALD_ERR_INVALID;
     { int rc = ensure_index(b); if(rc != ALD_OK) return rc; }
-    std::vector<int32_t> ex;
     const int n = b->hb.n();
-    for(int g = 0; g < n; g++) {
-        aletsch::transcript_sink ts(t->sink.single_exon_overlap());
-        for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++) {
-            const PathRec &p = b->res.paths[i];
-            join_exons(b, g, p, ex);
-            aletsch::sink_transcript x;
-            x.strand = p.strand; x.coverage = log(1.0 + p.weight); x.cov2 = x.coverage; x.conf = p.conf; x.abd = p.abd; x.count1 = p.count; x.count2 = 1;
-            x.tid = tid_base + (((int64_t)g << 20) | (int64_t)(i - b->res.path_begin[g]));
-            for(size_t k = 0; k + 1 < ex.size(); k += 2) x.exons.push_back(std::make_pair(ex[k], ex[k + 1]));
-            if(x.exons.size() <= 1 && skip_single_exon) continue;
-            ts.add(x, 1, sid ? sid[g] : -1);
+    const int64_t np = (int64_t)b->res.paths.size();
+    unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16;
+    if(const char *ev = getenv("ALD_SINK_THREADS")) { int k = atoi(ev); if(k >= 1 && k <= 64) nthr = (unsigned)k; }
+    else if(np < 20000) nthr = 1;
+    if(nthr > ALD_TSET_SHARDS) nthr = ALD_TSET_SHARDS;
+    // pass 1: bucket of every transcript (hashes are below 2^31 + 1; ALD_NO_BUCKET = dropped)
+    const uint32_t ALD_NO_BUCKET = 0xFFFFFFFFu;
+    std::vector<uint32_t> bucket((size_t)np, ALD_NO_BUCKET);
+    HostBatch::run_threads(nthr, [&](unsigned th) {
+        std::vector<int32_t> ex;
+        const int g0 = (int)((int64_t)n * th / nthr), g1 = (int)((int64_t)n * (th + 1) / nthr);
+        for(int g = g0; g < g1; g++) for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++) {
+            join_exons(b, g, b->res.paths[i], ex);
+            if(ex.size() <= 2 && skip_single_exon) continue;                 // assembler.cc:1117
+            bucket[(size_t)i] = (uint32_t)chain_hash(ex);                     // <= 2^31
         }
-        t->sink.add(ts);
-    }
+    });
+    // pass 2: thread th owns the tables th, th + nthr, ...; it walks the graphs in order and merges the per-graph set of its buckets
+    HostBatch::run_threads(nthr, [&](unsigned th) {
+        std::vector<int32_t> ex;
+        for(int g = 0; g < n; g++) {
+            aletsch::transcript_sink ts(t->overlap); bool any = false;
+            for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++) {
+                const uint32_t h = bucket[(size_t)i];
+                if(h == ALD_NO_BUCKET || (h % ALD_TSET_SHARDS) % nthr != th) continue;
+                const PathRec &p = b->res.paths[i];
+                join_exons(b, g, p, ex);
+                aletsch::sink_transcript x;
+                x.strand = p.strand; x.coverage = log(1.0 + p.weight); x.cov2 = x.coverage; x.conf = p.conf; x.abd = p.abd; x.count1 = p.count; x.count2 = 1;
+                x.tid = tid_base + (((int64_t)g << 20) | (int64_t)(i - b->res.path_begin[g]));
+                x.exons.reserve(ex.size() / 2);
+                for(size_t k = 0; k + 1 < ex.size(); k += 2) x.exons.push_back(std::make_pair(ex[k], ex[k + 1]));
+                ts.add(x, 1, sid ? sid[g] : -1); any = true;                   // assembler.cc:1120
+            }
+            if(any) t->add(ts);                                                // assembler.cc:1130 (only tables this thread owns are touched)
+        }
+    });
     return ALD_OK;
 }
 
@@ -502,7 +547,7 @@ int ald_tset_size(const ald_tset *t, int64_t *n_items, int64_t *n_exons, int64_t
 {
     if(!t) return ALD_ERR_INVALID;
     int64_t a = 0, e = 0, s = 0;
-    for(auto &x : t->sink.mt) for(auto &z : x.second) { a++; e += (int64_t)z.trst.exons.size(); s += (int64_t)z.samples.size(); }
+    for(auto &sh : t->shard) for(auto &x : sh.mt) for(auto &z : x.second) { a++; e += (int64_t)z.trst.exons.size(); s += (int64_t)z.samples.size(); }
     if(n_items) *n_items = a; if(n_exons) *n_exons = e; if(n_samples) *n_samples = s;
     return ALD_OK;
 }
@@ -513,9 +558,11 @@ int ald_tset_export(const ald_tset *t, uint64_t *hash, int32_t *count, char *str
 {
     if(!t || !hash || !count || !strand || !coverage || !cov2 || !conf || !abd || !count1 || !count2 || !tid || !exon_offset || !exon_lr || !sample_offset || !sample_sid || !sample_cov2 || !sample_conf || !sample_abd || !sample_count1) return ALD_ERR_INVALID;
     int64_t i = 0, e = 0, s = 0;
-    for(auto &x : t->sink.mt) for(auto &z : x.second) {
+    std::vector<size_t> keys; for(auto &sh : t->shard) for(auto &x : sh.mt) keys.push_back(x.first);
+    std::sort(keys.begin(), keys.end());
+    for(size_t key : keys) for(auto &z : t->shard[key % ALD_TSET_SHARDS].mt.find(key)->second) {        // the reference's iteration order: ascending hash
         const aletsch::sink_transcript &r = z.trst;
-        hash[i] = (uint64_t)x.first; count[i] = z.count; strand[i] = r.strand; coverage[i] = r.coverage; cov2[i] = r.cov2; conf[i] = r.conf; abd[i] = r.abd;
+        hash[i] = (uint64_t)key; count[i] = z.count; strand[i] = r.strand; coverage[i] = r.coverage; cov2[i] = r.cov2; conf[i] = r.conf; abd[i] = r.abd;
         count1[i] = r.count1; count2[i] = r.count2; tid[i] = r.tid; exon_offset[i] = e; sample_offset[i] = s;
         for(auto &q : r.exons) { exon_lr[2 * e] = q.first; exon_lr[2 * e + 1] = q.second; e++; }
         for(auto &q : z.samples) { sample_sid[s] = q.first; sample_cov2[s] = q.second.cov2; sample_conf[s] = q.second.conf; sample_abd[s] = q.second.abd; sample_count1[s] = q.second.count1; s++; }

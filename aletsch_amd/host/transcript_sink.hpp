@@ -11,6 +11,8 @@
 #pragma once
 #include <vector>
 #include <map>
+#include <unordered_map>
+#include <algorithm>
 #include <cstdint>
 #include <cstddef>
 #include <utility>
@@ -77,11 +79,17 @@ struct sink_transcript {
     }
 };
 
+struct sink_sample {                             // what the reference keeps of the per-sample transcript copy in trans_item::samples:
+    double coverage = 0, cov2 = 0, conf = 0, abd = 0; int count1 = 0, count2 = 0;     // the fields merge() reads and writes (exons are those of trst)
+};
 struct sink_item {                               // trans_item (transcript_set.h:20-33)
     sink_transcript trst; int count = 0;
-    std::map<int, sink_transcript> samples;
+    std::map<int, sink_sample> samples;
     sink_item() {}
-    sink_item(const sink_transcript &t, int c, int s) : trst(t), count(c) { samples.insert(std::make_pair(s, t)); for(auto &x : samples) x.second.count2 = (int)samples.size(); }
+    sink_item(const sink_transcript &t, int c, int s) : trst(t), count(c) {
+        sink_sample x; x.coverage = t.coverage; x.cov2 = t.cov2; x.conf = t.conf; x.abd = t.abd; x.count1 = t.count1; x.count2 = 1;
+        samples.insert(std::make_pair(s, x));
+    }
     void merge(sink_item &ti) {                  // TRANSCRIPT_COUNT_ADD_COVERAGE_ADD (transcript_set.cc:38-75)
         if(trst.exons.size() >= 2) trst.coverage += ti.trst.coverage;
         else if(trst.coverage < ti.trst.coverage) trst.coverage = ti.trst.coverage;
@@ -109,20 +117,30 @@ struct sink_item {                               // trans_item (transcript_set.h
 class transcript_sink {                          // transcript_set (transcript_set.h:37-59), one chromosome / region per sink
 public:
     explicit transcript_sink(double single_exon_overlap = 0.8) : overlap_(single_exon_overlap) {}
-    std::map<size_t, std::vector<sink_item>> mt;
+    // the reference's map<size_t, vector<trans_item>> (transcript_set.h:43) is only ever probed by key and walked in key order at the
+    // end: a hash table for the probes (a million buckets make every tree descent a chain of cache misses), keys sorted on demand
+    std::unordered_map<size_t, std::vector<sink_item>> mt;
+    std::vector<size_t> sorted_keys() const { std::vector<size_t> k; k.reserve(mt.size()); for(auto &x : mt) k.push_back(x.first); std::sort(k.begin(), k.end()); return k; }
 
-    void add(const sink_transcript &t, int count, int sid) {        // transcript_set.cc:149-154
-        transcript_sink ts(overlap_);
-        std::vector<sink_item> v; v.emplace_back(t, count, sid);
-        ts.mt.emplace(t.intron_chain_hashing(), std::move(v));
-        add(ts);
+    // transcript_set::add(t, count, sid) (transcript_set.cc:149-154) = a one-item set merged in.  merge_sorted_trans_items with a
+    // single y walks the bucket while compare1 says "x first", then merges into the first equal item or inserts y right there.
+    void add(const sink_transcript &t, int count, int sid) {
+        sink_item y(t, count, sid);
+        auto z = mt.find(t.intron_chain_hashing());
+        if(z == mt.end()) { std::vector<sink_item> v; v.emplace_back(std::move(y)); mt.emplace(t.intron_chain_hashing(), std::move(v)); return; }
+        std::vector<sink_item> &vx = z->second;
+        size_t kx = 0; int b = +1;
+        while(kx < vx.size() && (b = vx[kx].trst.compare1(y.trst, overlap_)) == +1) kx++;
+        if(kx < vx.size() && b == 0) vx[kx].merge(y);
+        else vx.insert(vx.begin() + kx, std::move(y));
     }
     void add(transcript_sink &ts) {              // transcript_set.cc:156-175
-        for(auto &x : ts.mt) {
-            auto z = mt.find(x.first);
-            if(z == mt.end()) mt.emplace(std::move(x));
-            else merge_sorted(z->second, x.second);
-        }
+        for(auto &x : ts.mt) add_bucket(x.first, x.second);
+    }
+    void add_bucket(size_t key, std::vector<sink_item> &vy) {       // one iteration of that loop
+        auto z = mt.find(key);
+        if(z == mt.end()) mt.emplace(key, std::move(vy));
+        else merge_sorted(z->second, vy);
     }
     size_t size() const { size_t n = 0; for(auto &x : mt) n += x.second.size(); return n; }
     void clear() { mt.clear(); }

@@ -160,6 +160,22 @@ def test_batch_into_result_sink():
     a, c = s.items(), t.items()
     assert len(a) > 0 and a == c
     assert sum(x["count"] for x in a) == len(cov)           # every transcript landed in exactly one item
+    # the batch merge deals the hash buckets to host threads: any number of threads, and a sink that already holds items, give the same set
+    import os
+    for thr in ("1", "3", "8"):
+        os.environ["ALD_SINK_THREADS"] = thr
+        try:
+            with A.DecompBatch(0) as b:
+                b.add(pg); b.upload(); b.run(); b.download()
+                u = A.TranscriptSink(0.8); u.add_batch(b, sid, tid_base=0)
+                w = A.TranscriptSink(0.8); w.add_batch(b, sid, tid_base=0); w.add_batch(b, (sid + 1) % 5, tid_base=1 << 40)
+        finally:
+            del os.environ["ALD_SINK_THREADS"]
+        assert u.items() == a
+        if thr == "1":
+            twice = w.items()
+        else:
+            assert w.items() == twice
 
 
 def test_catch_all_class_on_gpu():
