@@ -352,35 +352,58 @@ struct HostResults {
     uint64_t pool_size() const { return ext_pool ? ext_words : (uint64_t)pool.size(); }
     const uint32_t *vertices(const PathRec &p) const { return pool_data() + p.vert_off; }
 
-    // parse `words` record words; keep only records whose attempt tag matches the graph's final attempt
+    // parse the record words; keep only records whose attempt tag matches the graph's final attempt.  Record boundaries need one
+    // serial walk (lengths are in the records); decoding and placing them is split over the host threads.
     int build(int n, const std::vector<int32_t> &n_paths_dev)
     {
         paths.clear(); out_bytes = 0;
+        const uint64_t W = pool_size(); const uint32_t *pw = pool_data();
+        std::vector<uint64_t> offs; offs.reserve((size_t)(W / 24) + 16);
+        for(uint64_t o = 0; o + REC_HDR_WORDS <= W; ) {
+            const uint32_t nv = pw[o + 2];
+            uint64_t words = REC_HDR_WORDS + (uint64_t)nv; words += words & 1;
+            if(nv < 2 || o + words > W) return -1;
+            offs.push_back(o); o += words;
+        }
+        const size_t R = offs.size();
+        unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16;
+        if(R < 50000) nthr = 1;
+        std::vector<PathRec> tmp(R); std::vector<uint8_t> keep(R, 0); std::vector<int> bad(nthr, 0);
+        auto run = [&](unsigned nt, auto &&f) {
+            if(nt <= 1) { f(0u); return; }
+            std::vector<std::thread> th; for(unsigned t = 1; t < nt; t++) th.emplace_back([&f, t]() { f(t); });
+            f(0u); for(auto &x : th) x.join();
+        };
+        run(nthr, [&](unsigned t) {
+            for(size_t i = R * t / nthr; i < R * (t + 1) / nthr; i++) {
+                const uint32_t *r = pw + offs[i];
+                PathRec &p = tmp[i]; p.graph = (int32_t)r[0]; p.index = (int32_t)r[1]; p.nv = (int32_t)r[2]; p.length = (int32_t)r[3]; p.count = (int32_t)r[4];
+                p.strand = (char)(r[5] & 0xFF); p.attempt = (int)((r[5] >> 8) & 0xFF);
+                if(p.graph < 0 || p.graph >= n) { bad[t] = 1; return; }
+                memcpy(&p.weight, r + 6, 8); memcpy(&p.abd, r + 8, 8); memcpy(&p.conf, r + 10, 8); memcpy(&p.reads, r + 12, 8);
+                p.vert_off = offs[i] + REC_HDR_WORDS;
+                keep[i] = ((status[p.graph] == ALD_ST_OK || status[p.graph] == ALD_ST_SKIPPED_LARGE) && p.attempt == attempt[p.graph]) ? 1 : 0;
+            }
+        });
+        for(unsigned t = 0; t < nthr; t++) if(bad[t]) return -1;
         std::vector<int64_t> cnt(n + 1, 0);
-        uint64_t o = 0, W = pool_size();
-        std::vector<PathRec> tmp;
-        while(o + REC_HDR_WORDS <= W) {
-            const uint32_t *r = pool_data() + o;
-            PathRec p; p.graph = (int32_t)r[0]; p.index = (int32_t)r[1]; p.nv = (int32_t)r[2]; p.length = (int32_t)r[3]; p.count = (int32_t)r[4];
-            p.strand = (char)(r[5] & 0xFF); p.attempt = (int)((r[5] >> 8) & 0xFF);
-            if(p.nv < 2 || p.graph < 0 || p.graph >= n) return -1;
-            memcpy(&p.weight, r + 6, 8); memcpy(&p.abd, r + 8, 8); memcpy(&p.conf, r + 10, 8); memcpy(&p.reads, r + 12, 8);
-            p.vert_off = o + REC_HDR_WORDS;
-            uint64_t words = REC_HDR_WORDS + (uint64_t)p.nv; words += words & 1;
-            if(o + words > W) return -1;
-            o += words;
-            bool ok = (status[p.graph] == ALD_ST_OK || status[p.graph] == ALD_ST_SKIPPED_LARGE) && p.attempt == attempt[p.graph];
-            if(ok) tmp.push_back(p);
-        }
-        for(auto &p : tmp) cnt[p.graph + 1]++;
+        for(size_t i = 0; i < R; i++) if(keep[i]) cnt[tmp[i].graph + 1]++;
         path_begin.assign(n + 1, 0);
-        for(int g = 0; g < n; g++) path_begin[g + 1] = path_begin[g] + cnt[g + 1];
-        paths.resize(tmp.size());
-        for(auto &p : tmp) {
-            if(p.index < 0 || p.index >= cnt[p.graph + 1]) return -2;
-            paths[path_begin[p.graph] + p.index] = p;
-            out_bytes += 4ll * p.nv + 40;
-        }
+        int64_t kept = 0;
+        for(int g = 0; g < n; g++) { path_begin[g + 1] = path_begin[g] + cnt[g + 1]; kept += cnt[g + 1]; }
+        paths.resize((size_t)kept);
+        std::vector<int64_t> ob(nthr, 0);
+        for(unsigned t = 0; t < nthr; t++) bad[t] = 0;
+        run(nthr, [&](unsigned t) {
+            for(size_t i = R * t / nthr; i < R * (t + 1) / nthr; i++) {
+                if(!keep[i]) continue;
+                const PathRec &p = tmp[i];
+                if(p.index < 0 || p.index >= cnt[p.graph + 1]) { bad[t] = 2; return; }
+                paths[(size_t)(path_begin[p.graph] + p.index)] = p;            // (graph, index) is unique per kept record: disjoint writes
+                ob[t] += 4ll * p.nv + 40;
+            }
+        });
+        for(unsigned t = 0; t < nthr; t++) { if(bad[t]) return -2; out_bytes += ob[t]; }
         for(int g = 0; g < n; g++) if((status[g] == ALD_ST_OK || status[g] == ALD_ST_SKIPPED_LARGE) && cnt[g + 1] != n_paths_dev[g]) return -3;
         return 0;
     }
