@@ -46,10 +46,11 @@ enum { LP = 16, ARENA_I = 96, ARENA_D = 48, SCR_I = 4 * LP + ARENA_I, SCR_D = 2 
 // hot state: ONE instance per workgroup (= per wavefront)
 // ---------------------------------------------------------------------------------------------
 struct Hot {
-    double   ew[MAXE];                          // splice_graph::ewrt
-    uint16_t eid[MAXE];                         // creation id == scallop edge index (ids >= 65535 -> the graph moves up a class)
     struct alignas(8) Link { IDX es, et, inx, onx; };      // endpoints (es == NIL <=> slot dead) + next edge in the target's in-list / the source's
-    Link     lk[MAXE];                          // out-list (both sorted); one 8-byte word so that a list step is ONE LDS round trip
+                                                // out-list (both sorted); one 8-byte word so that a list step is ONE LDS round trip
+    struct alignas(16) EdgeHot { double w; Link lk; };     // splice_graph::ewrt + the links: 16 bytes, so a walk that needs the weight too
+    EdgeHot  ed[MAXE];                          // (sums, balance, smallest-edge evaluation) still makes one LDS access per step
+    uint16_t eid[MAXE];                         // creation id == scallop edge index (ids >= 65535 -> the graph moves up a class)
     IDX      in_head[MAXV], out_head[MAXV], in_deg[MAXV], out_deg[MAXV];
     uint8_t  nz[MAXV];                          // scallop::nonzeroset membership
     uint8_t  hflag[MAXE];                       // HF_* (phasing occupancy / extend flags / protect)
@@ -161,14 +162,14 @@ ALD_INL void trace(int code, int a, int b, double v) { H.n_iters++; if(H.p_trace
 // u_*: the same accessors for the scalar (lane-0) routines, with the result marked wave-uniform (see uni() in decomp_common.h)
 ALD_INL int u_first_in(int v) { IDX h = uni(H.in_head[v]); return h == NIL ? -1 : (int)h; }
 ALD_INL int u_first_out(int v) { IDX h = uni(H.out_head[v]); return h == NIL ? -1 : (int)h; }
-ALD_INL int u_next_in(int e) { IDX h = uni(H.lk[e].inx); return h == NIL ? -1 : (int)h; }
-ALD_INL int u_next_out(int e) { IDX h = uni(H.lk[e].onx); return h == NIL ? -1 : (int)h; }
+ALD_INL int u_next_in(int e) { IDX h = uni(H.ed[e].lk.inx); return h == NIL ? -1 : (int)h; }
+ALD_INL int u_next_out(int e) { IDX h = uni(H.ed[e].lk.onx); return h == NIL ? -1 : (int)h; }
 ALD_INL int first_in(int v) { return H.in_head[v] == NIL ? -1 : (int)H.in_head[v]; }
 ALD_INL int first_out(int v) { return H.out_head[v] == NIL ? -1 : (int)H.out_head[v]; }
-ALD_INL int next_in(int e) { return H.lk[e].inx == NIL ? -1 : (int)H.lk[e].inx; }
-ALD_INL int next_out(int e) { return H.lk[e].onx == NIL ? -1 : (int)H.lk[e].onx; }
-ALD_INL double in_weights(int v) { double w = 0; for(int e = first_in(v); e >= 0; e = next_in(e)) w += H.ew[e]; return w; }    // splice_graph.cc:187-198
-ALD_INL double out_weights(int v) { double w = 0; for(int e = first_out(v); e >= 0; e = next_out(e)) w += H.ew[e]; return w; } // splice_graph.cc:174-185
+ALD_INL int next_in(int e) { return H.ed[e].lk.inx == NIL ? -1 : (int)H.ed[e].lk.inx; }
+ALD_INL int next_out(int e) { return H.ed[e].lk.onx == NIL ? -1 : (int)H.ed[e].lk.onx; }
+ALD_INL double in_weights(int v) { double w = 0; for(int e = first_in(v); e >= 0; e = next_in(e)) w += H.ed[e].w; return w; }    // splice_graph.cc:187-198
+ALD_INL double out_weights(int v) { double w = 0; for(int e = first_out(v); e >= 0; e = next_out(e)) w += H.ed[e].w; return w; } // splice_graph.cc:174-185
 
 // ---------------------------------------------------------------- sorted adjacency lists (scalar code)
 // in-list of v ordered by (source, id); out-list ordered by (target, id): graph/edge_base.h:35-45
@@ -176,17 +177,17 @@ ALD_INL double out_weights(int v) { double w = 0; for(int e = first_out(v); e >=
 // greedy phase (materialize_special) edges are only counted there, not linked.
 ALD_INL uint32_t tkey(uint32_t p) { return (int)p == H.sinkp ? 0xFFFFu : p; }      // the sink sorts after every other vertex
 ALD_INL int vlog(int p) { return p < H.V0 - 1 ? p : (p == H.sinkp ? H.nv - 1 : p - 1); }   // physical -> reference index (traces)
-ALD_INL uint64_t lkw(int e) { return uni(*(const uint64_t*)&H.lk[e]); }            // es | et << 16 | inx << 32 | onx << 48
+ALD_INL uint64_t lkw(int e) { return uni(*(const uint64_t*)&H.ed[e].lk); }            // es | et << 16 | inx << 32 | onx << 48
 ALD_INL int lk_next(uint32_t f) { return f == 0xFFFFu ? -1 : (int)f; }
 ALD_INL void link_in(int v, int e)
 {
     v = uni(v); e = uni(e);
     if(v == uni(H.sinkp) && !uni(H.special_linked)) { H.in_deg[v]++; return; }
-    uint32_t ks = uni(H.lk[e].es), kid = uni(H.eid[e]);
+    uint32_t ks = uni(H.ed[e].lk.es), kid = uni(H.eid[e]);
     int prev = -1, cur = u_first_in(v);
     while(cur >= 0) { uint64_t w = lkw(cur); uint32_t cs = (uint32_t)(w & 0xFFFF); if(cs > ks || (cs == ks && uni(H.eid[cur]) > kid)) break; prev = cur; cur = lk_next((uint32_t)((w >> 32) & 0xFFFF)); }
-    H.lk[e].inx = cur < 0 ? NIL : (IDX)cur;
-    if(prev < 0) H.in_head[v] = (IDX)e; else H.lk[prev].inx = (IDX)e;
+    H.ed[e].lk.inx = cur < 0 ? NIL : (IDX)cur;
+    if(prev < 0) H.in_head[v] = (IDX)e; else H.ed[prev].lk.inx = (IDX)e;
     H.in_deg[v]++;
 }
 ALD_INL void link_out(int v, int e)
@@ -194,12 +195,12 @@ ALD_INL void link_out(int v, int e)
     v = uni(v); e = uni(e);
     if(v == 0 && !uni(H.special_linked)) { H.out_deg[v]++; return; }
     const uint32_t sk = (uint32_t)uni(H.sinkp);
-    uint32_t kt = uni(H.lk[e].et), kid = uni(H.eid[e]);
+    uint32_t kt = uni(H.ed[e].lk.et), kid = uni(H.eid[e]);
     if(kt == sk) kt = 0xFFFFu;
     int prev = -1, cur = u_first_out(v);
     while(cur >= 0) { uint64_t w = lkw(cur); uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu; if(ct > kt || (ct == kt && uni(H.eid[cur]) > kid)) break; prev = cur; cur = lk_next((uint32_t)(w >> 48)); }
-    H.lk[e].onx = cur < 0 ? NIL : (IDX)cur;
-    if(prev < 0) H.out_head[v] = (IDX)e; else H.lk[prev].onx = (IDX)e;
+    H.ed[e].lk.onx = cur < 0 ? NIL : (IDX)cur;
+    if(prev < 0) H.out_head[v] = (IDX)e; else H.ed[prev].lk.onx = (IDX)e;
     H.out_deg[v]++;
 }
 // link_out with a starting point: `hint` is an edge of v's out-list known to sort before e (its target key is smaller)
@@ -208,12 +209,12 @@ ALD_INL void link_out_after(int v, int e, int hint)
     v = uni(v); e = uni(e); hint = uni(hint);
     if(v == 0 && !uni(H.special_linked)) { H.out_deg[v]++; return; }
     const uint32_t sk = (uint32_t)uni(H.sinkp);
-    uint32_t kt = uni(H.lk[e].et), kid = uni(H.eid[e]);
+    uint32_t kt = uni(H.ed[e].lk.et), kid = uni(H.eid[e]);
     if(kt == sk) kt = 0xFFFFu;
     int prev = hint, cur = u_next_out(hint);
     while(cur >= 0) { uint64_t w = lkw(cur); uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu; if(ct > kt || (ct == kt && uni(H.eid[cur]) > kid)) break; prev = cur; cur = lk_next((uint32_t)(w >> 48)); }
-    H.lk[e].onx = cur < 0 ? NIL : (IDX)cur;
-    H.lk[prev].onx = (IDX)e;
+    H.ed[e].lk.onx = cur < 0 ? NIL : (IDX)cur;
+    H.ed[prev].lk.onx = (IDX)e;
     H.out_deg[v]++;
 }
 ALD_INL void unlink_in(int v, int e)
@@ -223,8 +224,8 @@ ALD_INL void unlink_in(int v, int e)
     int prev = -1, cur = u_first_in(v), guard = MAXE;
     while(cur >= 0 && cur != e && guard-- > 0) { prev = cur; cur = u_next_in(cur); }
     if(cur != e) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }       // cannot happen on a consistent state; never walk off a list
-    IDX nx = uni(H.lk[e].inx);
-    if(prev < 0) H.in_head[v] = nx; else H.lk[prev].inx = nx;
+    IDX nx = uni(H.ed[e].lk.inx);
+    if(prev < 0) H.in_head[v] = nx; else H.ed[prev].lk.inx = nx;
     { int dg = (int)uni(H.in_deg[v]) - 1; H.in_deg[v] = (IDX)dg; if(dg <= 1) { H.maybe_triv = 1; if(dg == 0) H.maybe_broken = 1; } }
 }
 ALD_INL void unlink_out(int v, int e)
@@ -234,8 +235,8 @@ ALD_INL void unlink_out(int v, int e)
     int prev = -1, cur = u_first_out(v), guard = MAXE;
     while(cur >= 0 && cur != e && guard-- > 0) { prev = cur; cur = u_next_out(cur); }
     if(cur != e) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
-    IDX nx = uni(H.lk[e].onx);
-    if(prev < 0) H.out_head[v] = nx; else H.lk[prev].onx = nx;
+    IDX nx = uni(H.ed[e].lk.onx);
+    if(prev < 0) H.out_head[v] = nx; else H.ed[prev].lk.onx = nx;
     { int dg = (int)uni(H.out_deg[v]) - 1; H.out_deg[v] = (IDX)dg; if(dg <= 1) { H.maybe_triv = 1; if(dg == 0) H.maybe_broken = 1; } }
 }
 // e stays in v's in-list but its key becomes (ks, newest id): one walk finds its predecessor and its new place
@@ -253,9 +254,9 @@ ALD_INL void relink_in(int v, int e, uint32_t ks)
     if(!seen) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
     if(!placed) ip = last;
     if(ip == pe) return;                                   // same place
-    IDX nxe = uni(H.lk[e].inx);
-    if(pe < 0) H.in_head[v] = nxe; else H.lk[pe].inx = nxe;
-    if(ip < 0) { H.lk[e].inx = uni(H.in_head[v]); H.in_head[v] = (IDX)e; } else { H.lk[e].inx = uni(H.lk[ip].inx); H.lk[ip].inx = (IDX)e; }
+    IDX nxe = uni(H.ed[e].lk.inx);
+    if(pe < 0) H.in_head[v] = nxe; else H.ed[pe].lk.inx = nxe;
+    if(ip < 0) { H.ed[e].lk.inx = uni(H.in_head[v]); H.in_head[v] = (IDX)e; } else { H.ed[e].lk.inx = uni(H.ed[ip].lk.inx); H.ed[ip].lk.inx = (IDX)e; }
 }
 ALD_INL void relink_out(int v, int e, uint32_t kt)         // kt already mapped by tkey()
 {
@@ -272,9 +273,9 @@ ALD_INL void relink_out(int v, int e, uint32_t kt)         // kt already mapped 
     if(!seen) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
     if(!placed) ip = last;
     if(ip == pe) return;
-    IDX nxe = uni(H.lk[e].onx);
-    if(pe < 0) H.out_head[v] = nxe; else H.lk[pe].onx = nxe;
-    if(ip < 0) { H.lk[e].onx = uni(H.out_head[v]); H.out_head[v] = (IDX)e; } else { H.lk[e].onx = uni(H.lk[ip].onx); H.lk[ip].onx = (IDX)e; }
+    IDX nxe = uni(H.ed[e].lk.onx);
+    if(pe < 0) H.out_head[v] = nxe; else H.ed[pe].lk.onx = nxe;
+    if(ip < 0) { H.ed[e].lk.onx = uni(H.out_head[v]); H.out_head[v] = (IDX)e; } else { H.ed[e].lk.onx = uni(H.ed[ip].lk.onx); H.ed[ip].lk.onx = (IDX)e; }
 }
 ALD_INL int free_slots() { return uni(H.free_cnt) + (MAXE - uni(H.slot_hw)); }
 // directed_graph::add_edge (directed_graph.cc:38-48) + i2e.push_back: the new id is the largest
@@ -282,12 +283,12 @@ ALD_INL int add_edge_i(int s, int t)
 {
     s = uni(s); t = uni(t);
     int e; int fh = uni(H.free_head), hw = uni(H.slot_hw);
-    if(fh >= 0) { e = fh; IDX nx = uni(H.lk[e].onx); H.free_head = nx == NIL ? -1 : (int)nx; H.free_cnt--; }
+    if(fh >= 0) { e = fh; IDX nx = uni(H.ed[e].lk.onx); H.free_head = nx == NIL ? -1 : (int)nx; H.free_cnt--; }
     else if(hw < MAXE) { e = hw; H.slot_hw = hw + 1; }
     else { fail(ALD_ST_CAPACITY); return -1; }
     int id = uni(H.next_id); H.next_id = id + 1;
     if(id >= 0xFFFF) { fail(ALD_ST_CAPACITY); return -1; }
-    H.lk[e].es = (IDX)s; H.lk[e].et = (IDX)t; H.eid[e] = (uint16_t)id; H.hflag[e] = 0; H.ew[e] = 0;
+    H.ed[e].lk.es = (IDX)s; H.ed[e].lk.et = (IDX)t; H.eid[e] = (uint16_t)id; H.hflag[e] = 0; H.ed[e].w = 0;
     link_out(s, e); link_in(t, e);
     return e;
 }
@@ -296,17 +297,17 @@ ALD_INL int add_edge_i(int s, int t)
 ALD_INL void kill_edge_i(int e)
 {
     e = uni(e);
-    unlink_out(uni(H.lk[e].es), e); unlink_in(uni(H.lk[e].et), e);
-    H.lk[e].es = NIL;
-    { int fh = uni(H.free_head); H.lk[e].onx = fh < 0 ? NIL : (IDX)fh; H.free_head = e; H.free_cnt = uni(H.free_cnt) + 1; }
+    unlink_out(uni(H.ed[e].lk.es), e); unlink_in(uni(H.ed[e].lk.et), e);
+    H.ed[e].lk.es = NIL;
+    { int fh = uni(H.free_head); H.ed[e].lk.onx = fh < 0 ? NIL : (IDX)fh; H.free_head = e; H.free_cnt = uni(H.free_cnt) + 1; }
 }
 ALD_FN int add_edge(int s, int t) { return add_edge_i(uni(s), uni(t)); }
 ALD_FN void kill_edge(int e) { kill_edge_i(uni(e)); }
 ALD_FN void move_edge(int e, int x, int y)      // directed_graph.cc:180-194
 {
     e = uni(e); x = uni(x); y = uni(y);
-    unlink_out(uni(H.lk[e].es), e); unlink_in(uni(H.lk[e].et), e);
-    H.lk[e].es = (IDX)x; H.lk[e].et = (IDX)y;
+    unlink_out(uni(H.ed[e].lk.es), e); unlink_in(uni(H.ed[e].lk.et), e);
+    H.ed[e].lk.es = (IDX)x; H.ed[e].lk.et = (IDX)y;
     link_out(x, e); link_in(y, e);
 }
 
@@ -491,16 +492,16 @@ ALD_FN int split_edge(int ei, double w)
 {
     ei = uni(ei); w = uni(w);
     if(!(w >= H.p_min_w - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
-    double ww = uni(H.ew[ei]);
+    double ww = uni(H.ed[ei].w);
     if(fabs(ww - w) <= kSMIN) return ei;
-    int s = uni(H.lk[ei].es), t = uni(H.lk[ei].et);
+    int s = uni(H.ed[ei].lk.es), t = uni(H.ed[ei].lk.et);
     int p2 = add_edge(s, t);
     if(p2 < 0) return -1;
     COLD;
     double www = ww - w;
     double mw = H.p_min_w;
     if(www <= mw) www = mw;
-    H.ew[ei] = www; H.ew[p2] = w;
+    H.ed[ei].w = www; H.ed[p2].w = w;
     C.ed[p2].estrand = uni(C.ed[ei].estrand); C.ed[p2].ecount = uni(C.ed[ei].ecount); C.ed[p2].eabd = uni(C.ed[ei].eabd); C.ed[p2].econf = uni(C.ed[ei].econf);
     C.ed[p2].sp_off = uni(C.ed[ei].sp_off); C.ed[p2].sp_len = uni(C.ed[ei].sp_len); C.ed[p2].s0id = uni(C.ed[ei].s0id); C.ed[p2].s0abd = uni(C.ed[ei].s0abd);   // immutable support lists are shared
     for(int k = 0; k < NW; k++) C.ed[p2].mask[k] = uni(C.ed[ei].mask[k]);
@@ -516,12 +517,12 @@ ALD_INL int merge_adjacent_edges_i(int x, int y, double ww)
     const double mw = H.p_min_w;
     if(!(ww >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
     if(x < 0 || y < 0) return -1;
-    if(H.lk[x].et != uni(H.lk[y].es)) { int t = x; x = y; y = t; }
-    const int xs = uni(H.lk[x].es), xt = uni(H.lk[x].et), yt = uni(H.lk[y].et);
-    if((int)uni(H.lk[y].es) != xt) return -1;
+    if(H.ed[x].lk.et != uni(H.ed[y].lk.es)) { int t = x; x = y; y = t; }
+    const int xs = uni(H.ed[x].lk.es), xt = uni(H.ed[x].lk.et), yt = uni(H.ed[y].lk.et);
+    if((int)uni(H.ed[y].lk.es) != xt) return -1;
     PROF_DECL;
     COLD;
-    const double wx = uni(H.ew[x]), wy = uni(H.ew[y]);
+    const double wx = uni(H.ed[x].w), wy = uni(H.ed[y].w);
     const bool sx = !(fabs(wx - ww) <= kSMIN), sy = !(fabs(wy - ww) <= kSMIN);     // does split_edge cut a piece off?
     // cold state of the originals (one round of independent loads)
     const double medx = uni(C.ed[x].med), medy = uni(C.ed[y].med), cx = uni(C.ed[x].econf), cy = uni(C.ed[y].econf), vwt = uni(C.vx[xt].vw);
@@ -529,8 +530,8 @@ ALD_INL int merge_adjacent_edges_i(int x, int y, double ww)
     const int stx = uni(C.ed[x].estrand), sty = uni(C.ed[y].estrand);
     // split_edge(x, ww), split_edge(y, ww): a piece of weight ww gets the next id, the original keeps max(w - ww, min_w)
     if(uni(H.next_id) >= 0xFFF0) { fail(ALD_ST_CAPACITY); return -1; }
-    if(sx) { H.next_id++; double r = wx - ww; if(r <= mw) r = mw; H.ew[x] = r; }
-    if(sy) { H.next_id++; double r = wy - ww; if(r <= mw) r = mw; H.ew[y] = r; }
+    if(sx) { H.next_id++; double r = wx - ww; if(r <= mw) r = mw; H.ed[x].w = r; }
+    if(sy) { H.next_id++; double r = wy - ww; if(r <= mw) r = mw; H.ed[y].w = r; }
     const double wx0 = sx ? ww : wx, wy0 = sy ? ww : wy;                 // weights of the two pieces being merged
     const double medx1 = sx ? medx * ww / wx : medx, medy1 = sy ? medy * ww / wy : medy;
     // merge_adjacent_equal_edges(piece x, piece y)
@@ -539,7 +540,7 @@ ALD_INL int merge_adjacent_edges_i(int x, int y, double ww)
     PROF_ADD(PF_T_MERGE_ADD);
     if(n < 0) return -1;
     if(!(fabs(wx0 - wy0) <= kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_MERGE_EQUAL); return -1; }
-    H.ew[n] = wx0 * 0.5 + wy0 * 0.5;
+    H.ed[n].w = wx0 * 0.5 + wy0 * 0.5;
     if(!(cntx > 0 && cnty > 0)) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return -1; }
     if(!intersect_samples(x, y, n)) return -1;
     PROF_ADD(PF_T_MERGE_ISECT);
@@ -551,8 +552,8 @@ ALD_INL int merge_adjacent_edges_i(int x, int y, double ww)
     // same far endpoint (its id is the newest), before the first edge with a larger one
     PROF_ADD(PF_T_MERGE_MASK);
     double sum1 = 0, sum2 = 0;
-    { bool ins = !sx; for(int e = u_first_in(xt); e >= 0; e = u_next_in(e)) { if(!ins && (int)uni(H.lk[e].es) > xs) { sum1 += ww; ins = true; } sum1 += uni(H.ew[e]); } if(!ins) sum1 += ww; }
-    { bool ins = !sy; for(int e = u_first_out(xt); e >= 0; e = u_next_out(e)) { if(!ins && tkey(H.lk[e].et) > tkey(yt)) { sum2 += ww; ins = true; } sum2 += uni(H.ew[e]); } if(!ins) sum2 += ww; }
+    { bool ins = !sx; for(int e = u_first_in(xt); e >= 0; e = u_next_in(e)) { if(!ins && (int)uni(H.ed[e].lk.es) > xs) { sum1 += ww; ins = true; } sum1 += uni(H.ed[e].w); } if(!ins) sum1 += ww; }
+    { bool ins = !sy; for(int e = u_first_out(xt); e >= 0; e = u_next_out(e)) { if(!ins && tkey(H.ed[e].lk.et) > tkey(yt)) { sum2 += ww; ins = true; } sum2 += uni(H.ed[e].w); } if(!ins) sum2 += ww; }
     const double sum = (sum1 + sum2) * 0.5;
     const double r1 = vwt * (wx0 + wy0) * 0.5 / sum;
     C.vx[xt].vw = vwt - r1;
@@ -573,15 +574,15 @@ ALD_INL void balance_vertex_i(int v)
     if(H.in_deg[v] == 0 || uni(H.out_deg[v]) == 0) return;
     const double mw = H.p_min_w;
     double w1 = 0, w2 = 0;
-    for(int e = u_first_in(v); e >= 0; e = u_next_in(e)) { double w = uni(H.ew[e]); if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w1 += w; }
-    for(int e = u_first_out(v); e >= 0; e = u_next_out(e)) { double w = uni(H.ew[e]); if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w2 += w; }
+    for(int e = u_first_in(v); e >= 0; e = u_next_in(e)) { double w = uni(H.ed[e].w); if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w1 += w; }
+    for(int e = u_first_out(v); e >= 0; e = u_next_out(e)) { double w = uni(H.ed[e].w); if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w2 += w; }
     double ww = sqrt(w1 * w2);
     double r1 = ww / w1, r2 = ww / w2;
     double m1 = 0, m2 = 0;
-    for(int e = u_first_in(v); e >= 0; e = u_next_in(e)) { double wy = uni(H.ew[e]) * r1; if(wy < mw) { m1 += mw - wy; wy = mw; } H.ew[e] = wy; }
-    for(int e = u_first_out(v); e >= 0; e = u_next_out(e)) { double wy = uni(H.ew[e]) * r2; if(wy < mw) { m2 += mw - wy; wy = mw; } H.ew[e] = wy; }
-    if(m1 > m2) { int e = u_first_out(v); H.ew[e] = uni(H.ew[e]) + m1 - m2; }
-    else if(m1 < m2) { int e = u_first_in(v); H.ew[e] = uni(H.ew[e]) + m2 - m1; }
+    for(int e = u_first_in(v); e >= 0; e = u_next_in(e)) { double wy = uni(H.ed[e].w) * r1; if(wy < mw) { m1 += mw - wy; wy = mw; } H.ed[e].w = wy; }
+    for(int e = u_first_out(v); e >= 0; e = u_next_out(e)) { double wy = uni(H.ed[e].w) * r2; if(wy < mw) { m2 += mw - wy; wy = mw; } H.ed[e].w = wy; }
+    if(m1 > m2) { int e = u_first_out(v); H.ed[e].w = uni(H.ed[e].w) + m1 - m2; }
+    else if(m1 < m2) { int e = u_first_in(v); H.ed[e].w = uni(H.ed[e].w) + m2 - m1; }
 }
 
 ALD_FN void balance_vertex(int v) { balance_vertex_i(uni(v)); }
@@ -651,11 +652,11 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     // balance_vertex(x) (scallop.cc:2486-2576) on the gathered weights: the same sums, ratios, clamps and remainder fix-up in the
     // same order as the list-walking form (balance_vertex_i), but the fan is walked once and nothing is written back until the
     // pe2w sums below are known
-    int n = 0; double wcen = uni(H.ew[c]);
+    int n = 0; double wcen = uni(H.ed[c].w);
     if(!(wcen >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
     double sfan0 = 0;
     for(int e = A ? u_first_out(x) : u_first_in(x); e >= 0; e = A ? u_next_out(e) : u_next_in(e)) {
-        double w2 = uni(H.ew[e]); if(!(w2 >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
+        double w2 = uni(H.ed[e].w); if(!(w2 >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
         fe[n] = e; fw[n] = w2; sfan0 += w2; n++;
     }
     {
@@ -677,10 +678,10 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     for(int i = 0; i < n; i++) { int k = i; uint32_t id = uni(H.eid[fe[i]]); while(k > 0 && (uint32_t)uni(H.eid[fe[ord[k - 1]]]) > id) { ord[k] = ord[k - 1]; k--; } ord[k] = i; }
     double mdc = 0;
     for(int q = 0; q < n; q++) { double w = fw[ord[q]]; if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } mdc = (q == 0) ? w : mdc + w; }
-    H.ew[c] = mdc;
-    for(int j = 0; j < n; j++) H.ew[fe[j]] = fw[j];
+    H.ed[c].w = mdc;
+    for(int j = 0; j < n; j++) H.ed[fe[j]].w = fw[j];
     PROF_ADD(PF_T_SETUP);
-    const int far = A ? (int)uni(H.lk[c].es) : (int)uni(H.lk[c].et);
+    const int far = A ? (int)uni(H.ed[c].lk.es) : (int)uni(H.ed[c].lk.et);
     const double medc = uni(C.ed[c].med), cc = uni(C.ed[c].econf);
     const int meic = uni(C.ed[c].mei), cntc = uni(C.ed[c].ecount), stc = uni(C.ed[c].estrand);
     const uint32_t nsc = uni(C.ed[c].sp_len); const int idc = uni(C.ed[c].s0id); const double abc = uni(C.ed[c].s0abd);     // c's support never changes
@@ -689,12 +690,12 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     for(int q = 0; q < n; q++) {
         if(consumed) { C.vx[x].vw = vwt; fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }     // the general form would be handed a dead edge here
         const int j = ord[q], f = fe[j]; const double ww = fw[j];
-        const double wcur = uni(H.ew[c]);                                   // what is left of c
+        const double wcur = uni(H.ed[c].w);                                   // what is left of c
         const bool sc = !(fabs(wcur - ww) <= kSMIN);                        // split_edge(c, ww) cuts a piece off (scallop.cc:2433-2484)
         int nid = uni(H.next_id);
         if(nid >= 0xFFF0) { C.vx[x].vw = vwt; fail(ALD_ST_CAPACITY); return; }
         double rem = wcur;
-        if(sc) { nid++; rem = wcur - ww; if(rem <= mw) rem = mw; H.ew[c] = rem; }    // the piece takes an id and disappears in the merge
+        if(sc) { nid++; rem = wcur - ww; if(rem <= mw) rem = mw; H.ed[c].w = rem; }    // the piece takes an id and disappears in the merge
         H.next_id = nid + 1;                                                // id of the merged edge
         const double wc0 = sc ? ww : wcur;
         const double medc1 = sc ? medc * ww / wcur : medc;
@@ -728,12 +729,12 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         C.ed[f].med = A ? mi * r1 + medc1 + medf : mi * r1 + medf + medc1; C.ed[f].mei = mi;
         PROF_ADD(PF_T_MERGE_SUMS);
         // f becomes the merged edge: newest id, far endpoint of c, weight of the two equal pieces
-        const int other = A ? (int)uni(H.lk[f].et) : (int)uni(H.lk[f].es);
-        H.eid[f] = (uint16_t)nid; H.ew[f] = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
+        const int other = A ? (int)uni(H.ed[f].lk.et) : (int)uni(H.ed[f].lk.es);
+        H.eid[f] = (uint16_t)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
         // the new edge far -> other sorts behind c = far -> x whenever other's key is above x's (always, except for vertices added by
         // decompose_vertex_extend): the walk starts at c
-        if(A) { H.lk[f].es = (IDX)far; relink_in(other, f, (uint32_t)far); if(tkey((uint32_t)other) > tkey((uint32_t)x)) link_out_after(far, f, c); else link_out(far, f); }
-        else { H.lk[f].et = (IDX)far; relink_out(other, f, tkey((uint32_t)far)); link_in(far, f); }
+        if(A) { H.ed[f].lk.es = (IDX)far; relink_in(other, f, (uint32_t)far); if(tkey((uint32_t)other) > tkey((uint32_t)x)) link_out_after(far, f, c); else link_out(far, f); }
+        else { H.ed[f].lk.et = (IDX)far; relink_out(other, f, tkey((uint32_t)far)); link_in(far, f); }
         fe[j] = -1;
         PROF_ADD(PF_T_MERGE_ADD);
         if(A) hs_replace2(c, f, f); else hs_replace2(f, c, f);
@@ -746,8 +747,8 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     if(!consumed) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }      // c kept a remainder: the reference asserts on the degree of x
     // remove_edge(c); x is left without edges
     if(A) unlink_out(far, c); else unlink_in(far, c);
-    H.lk[c].es = NIL; H.hflag[c] = 0;
-    { int fh = uni(H.free_head); H.lk[c].onx = fh < 0 ? NIL : (IDX)fh; H.free_head = c; H.free_cnt = uni(H.free_cnt) + 1; }
+    H.ed[c].lk.es = NIL; H.hflag[c] = 0;
+    { int fh = uni(H.free_head); H.ed[c].lk.onx = fh < 0 ? NIL : (IDX)fh; H.free_head = c; H.free_cnt = uni(H.free_cnt) + 1; }
     H.in_head[x] = NIL; H.out_head[x] = NIL; H.in_deg[x] = 0; H.out_deg[x] = 0; H.nz[x] = 0;
     PROF_ADD(PF_T_TAIL);
 }
@@ -810,32 +811,32 @@ ALD_FN void decompose_vertex_extend(int root, int n)
     H.nv = nn;
     for(int i = 0; i < nin; i++) {               // ev1: detach in-edges onto their new vertex
         int k = evx[i]; if(k < 0) continue; int e = loc_e[i];
-        int p = uni(C.vx[uni(H.lk[e].es)].rpos);
-        move_edge(e, uni(H.lk[e].es), k); C.vx[k].lpos = p; C.vx[k].rpos = p; C.vx[k].vtype = -1; C.vx[k].vw = 0; C.vx[k].v2v = -2;
+        int p = uni(C.vx[uni(H.ed[e].lk.es)].rpos);
+        move_edge(e, uni(H.ed[e].lk.es), k); C.vx[k].lpos = p; C.vx[k].rpos = p; C.vx[k].vtype = -1; C.vx[k].vw = 0; C.vx[k].v2v = -2;
     }
     for(int i = nin; i < nloc; i++) {            // ev2
         int k = evx[i]; if(k < 0) continue; int e = loc_e[i];
-        int p = uni(C.vx[uni(H.lk[e].et)].lpos);
-        move_edge(e, k, uni(H.lk[e].et)); C.vx[k].lpos = p; C.vx[k].rpos = p; C.vx[k].vtype = -1; C.vx[k].vw = 0; C.vx[k].v2v = -2;
+        int p = uni(C.vx[uni(H.ed[e].lk.et)].lpos);
+        move_edge(e, k, uni(H.ed[e].lk.et)); C.vx[k].lpos = p; C.vx[k].rpos = p; C.vx[k].vtype = -1; C.vx[k].vw = 0; C.vx[k].v2v = -2;
     }
     int rv = uni(C.vx[root].v2v);
     for(int i = 0; i < n; i++) {
         int e1 = PSLOT(a[i]), e2 = PSLOT(b[i]); int u1 = PLOC(a[i]), u2 = PLOC(b[i]); double ww = w[i];
         if(mdeg[u1] == 1 && mdeg[u2] >= 2) {
             borrow_edge_strand(C, e1, e2);
-            move_edge(e1, uni(H.lk[e1].es), evx[u2]);
+            move_edge(e1, uni(H.ed[e1].lk.es), evx[u2]);
             if(rv >= 0) C.ed[e1].mask[(rv >> 6)] |= (1ull << (rv & 63));
             C.ed[e1].med += mweight[u1]; C.ed[e1].mei += rlen;
         } else if(mdeg[u2] == 1) {
             if(evx[u1] < 0) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
             borrow_edge_strand(C, e2, e1);
-            move_edge(e2, evx[u1], uni(H.lk[e2].et));
+            move_edge(e2, evx[u1], uni(H.ed[e2].lk.et));
             if(rv >= 0) C.ed[e2].mask[(rv >> 6)] |= (1ull << (rv & 63));
             C.ed[e2].med += mweight[u2]; C.ed[e2].mei += rlen;
         } else {
             int z = add_edge(evx[u1], evx[u2]);
             if(z < 0) return;
-            H.ew[z] = ww;
+            H.ed[z].w = ww;
             if(!(C.ed[e1].ecount > 0 && uni(C.ed[e2].ecount) > 0)) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
             if(!intersect_samples(e1, e2, z)) return;
             if(C.ed[z].ecount <= 0) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
@@ -875,8 +876,8 @@ ALD_INL int classify_trivial_fastpath(int x, bool fast)
     int d1 = H.in_deg[x], d2 = H.out_deg[x];
     if(d1 != 1 && d2 != 1) return -1;
     int e1 = first_in(x), e2 = first_out(x);
-    if(d1 == 1) { int s = H.lk[e1].es; if(H.out_deg[s] == 1) return 1; if(fast) { if(!(H.hflag[e1] & HF_OCC)) return 1; return -2; } }
-    if(d2 == 1) { int t = H.lk[e2].et; if(H.in_deg[t] == 1) return 1; if(fast) { if(!(H.hflag[e2] & HF_OCC)) return 1; return -2; } }
+    if(d1 == 1) { int s = H.ed[e1].lk.es; if(H.out_deg[s] == 1) return 1; if(fast) { if(!(H.hflag[e1] & HF_OCC)) return 1; return -2; } }
+    if(d2 == 1) { int t = H.ed[e2].lk.et; if(H.in_deg[t] == 1) return 1; if(fast) { if(!(H.hflag[e2] & HF_OCC)) return 1; return -2; } }
     return 2;
 }
 ALD_FN int classify_trivial_vertex(int x, bool fast)     // scalar version with the dominate queries
@@ -885,8 +886,8 @@ ALD_FN int classify_trivial_vertex(int x, bool fast)     // scalar version with 
     int d1 = uni(H.in_deg[x]), d2 = uni(H.out_deg[x]);
     if(d1 != 1 && d2 != 1) return -1;
     int e1 = u_first_in(x), e2 = u_first_out(x);
-    if(d1 == 1) { int s = uni(H.lk[e1].es); if(H.out_deg[s] == 1) return 1; if(fast && hs_dominate(e1, 1)) return 1; }
-    if(d2 == 1) { int t = uni(H.lk[e2].et); if(H.in_deg[t] == 1) return 1; if(fast && hs_dominate(e2, 2)) return 1; }
+    if(d1 == 1) { int s = uni(H.ed[e1].lk.es); if(H.out_deg[s] == 1) return 1; if(fast && hs_dominate(e1, 1)) return 1; }
+    if(d2 == 1) { int t = uni(H.ed[e2].lk.et); if(H.in_deg[t] == 1) return 1; if(fast && hs_dominate(e2, 2)) return 1; }
     return 2;
 }
 ALD_INL double compute_balance_ratio(int v, bool &ok)    // scallop.cc:2578-2602
@@ -916,13 +917,13 @@ ALD_INL int eval_smallest(int i, double &r)
     if(!H.nz[i]) return -1;
     if(H.in_deg[i] <= 1 || H.out_deg[i] <= 1) return -1;
     int e1 = -1, e2 = -1; double sum1 = 0, sum2 = 0, min1 = DBL_MAX, min2 = DBL_MAX;
-    for(int e = first_in(i); e >= 0; e = next_in(e)) { double w = H.ew[e]; sum1 += w; if(w > min1) continue; min1 = w; e1 = e; }
-    for(int e = first_out(i); e >= 0; e = next_out(e)) { double w = H.ew[e]; sum2 += w; if(w > min2) continue; min2 = w; e2 = e; }
+    for(int e = first_in(i); e >= 0; e = next_in(e)) { double w = H.ed[e].w; sum1 += w; if(w > min1) continue; min1 = w; e1 = e; }
+    for(int e = first_out(i); e >= 0; e = next_out(e)) { double w = H.ed[e].w; sum2 += w; if(w > min2) continue; min2 = w; e2 = e; }
     if(e1 < 0 || e2 < 0) return -1;
     if(!(sum1 >= kSMIN) || !(sum2 >= kSMIN)) return -3;          // reference assert(sum1 >= SMIN)
     double r1 = min1 / sum1, r2 = min2 / sum2;
     int e; if(r1 < r2) { r = r1; e = e1; } else { r = r2; e = e2; }
-    int s = H.lk[e].es, t = H.lk[e].et;
+    int s = H.ed[e].lk.es, t = H.ed[e].lk.et;
     if(H.out_deg[s] <= 1) return -1;
     if(H.in_deg[t] <= 1) return -1;
     uint8_t f = H.hflag[e];
@@ -1074,61 +1075,7 @@ ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
     return true;
 }
 
-// scallop::resolve_smallest_edges (scallop.cc:844-945)
-ALD_FN bool sweep_smallest_rescan(double max_ratio)      // every sweep evaluates every vertex (classes with more than 128 vertices)
-{
-    max_ratio = uni(max_ratio);
-    const int lane = lane_id();
-    int vend = H.nv;
-    bool flag = false;
-    double best_r = max_ratio; int best_e = -1, best_v = -1;
-    int start = 1;
-    PROF_DECL;
-    if(lane == 0 && uni(H.hs_dirty)) hs_refresh_flags();
-    wsync();
-    while(start < vend) {
-        int hit = -1, hit_e = -1; double hit_r = 0;
-        for(int base = (start / ALD_WAVE) * ALD_WAVE; base < vend && hit < 0; base += ALD_WAVE) {
-            int i = base + lane; double r = 0; int e = -1;
-            if(i >= start && i < vend) e = eval_smallest(i, r);
-            if(wballot(e == -3)) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); wsync(); return true; }
-            bool cand = e >= 0;
-            uint64_t now = wballot(cand && r < 0.01);
-            int lim = now ? ffs64(now) : ALD_WAVE;
-            bool mine = cand && lane < lim;
-            double rr = mine ? r : DBL_MAX; int vv = mine ? i : -1; int ee = mine ? e : -1;
-            for(int off = ALD_WAVE / 2; off >= 1; off >>= 1) {
-                double r2 = wshfl(rr, lane ^ off); int v2 = wshfl(vv, lane ^ off); int e2 = wshfl(ee, lane ^ off);
-                bool take = (v2 >= 0) && (vv < 0 || r2 < rr || (r2 == rr && v2 > vv));
-                if(take) { rr = r2; vv = v2; ee = e2; }
-            }
-            rr = wshfl(rr, 0); vv = wshfl(vv, 0); ee = wshfl(ee, 0);
-            if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = ee; }   // if(ratio < r) continue;
-            if(now) { int l = ffs64(now); hit = base + l; hit_e = wshfl(e, l); hit_r = wshfl(r, l); }
-        }
-        PROF_ADD(PF_SMALL_EVAL);
-        if(hit < 0) break;
-        if(lane == 0) {
-            trace(OP_SMALL_NOW, (int)H.eid[hit_e], vlog(hit), hit_r);
-            kill_edge_i(hit_e); hs_remove(hit_e); if(uni(H.hs_dirty)) hs_refresh_flags();
-        }
-        wsync();
-        PROF_ADD(PF_SMALL_MUT);
-        flag = true;
-        start = hit + 1;
-    }
-    if(flag) return true;
-    if(best_e < 0) return false;
-    if(lane == 0) {
-        trace(OP_SMALLEST, (int)H.eid[best_e], vlog(best_v), best_r);
-        kill_edge(best_e); hs_remove(best_e);
-    }
-    wsync();
-    PROF_ADD(PF_SMALL_MUT);
-    return true;
-}
-
-// The same rule with the per-vertex result (ratio, edge) kept per lane: removing
+// scallop::resolve_smallest_edges (scallop.cc:844-945), with the per-vertex result (ratio, edge) kept per lane: removing
 // edge s->t changes the lists of s and t only (degree guards elsewhere cannot flip while no degree drops to <= 1, phasing flags
 // only change with hs_dirty), so after a removal just those two lanes evaluate again.  And while nothing else can fire -- no
 // broken vertex, no type-1 trivial vertex, phasing flags untouched: exactly what R1..R3 would find out -- the next sweep of the
@@ -1139,7 +1086,7 @@ ALD_FN bool sweep_smallest(double max_ratio)
     const int lane = lane_id();
     const int vend = uni(H.nv);
     constexpr int NC = MAXV / ALD_WAVE;           // per-lane results for every chunk of the class (registers for the small classes, private memory beyond)
-    if(vend > NC * ALD_WAVE) return sweep_smallest_rescan(max_ratio);
+    if(vend > NC * ALD_WAVE) { if(lane == 0) fail(ALD_ST_CAPACITY); wsync(); return true; }     // cannot happen: nv <= MAXV
     PROF_DECL;
     if(lane == 0 && uni(H.hs_dirty)) hs_refresh_flags();
     wsync();
@@ -1203,7 +1150,7 @@ ALD_FN bool sweep_smallest(double max_ratio)
             }
             PROF_ADD(PF_SMALL_EVAL);
             if(hit < 0) break;
-            const int ds = H.lk[hit_e].es, dt = H.lk[hit_e].et;         // the two vertices whose lists change
+            const int ds = H.ed[hit_e].lk.es, dt = H.ed[hit_e].lk.et;         // the two vertices whose lists change
             if(lane == 0) {
                 trace(OP_SMALL_NOW, (int)H.eid[hit_e], vlog(hit), hit_r);
                 kill_edge_i(hit_e); hs_remove(hit_e);
@@ -1220,7 +1167,7 @@ ALD_FN bool sweep_smallest(double max_ratio)
         }
         if(!flag) {
             if(best_e < 0) return any;
-            const int ds = H.lk[best_e].es, dt = H.lk[best_e].et;
+            const int ds = H.ed[best_e].lk.es, dt = H.ed[best_e].lk.et;
             if(lane == 0) {
                 trace(OP_SMALLEST, (int)H.eid[best_e], vlog(best_v), best_r);
                 kill_edge_i(best_e); hs_remove(best_e);
@@ -1269,7 +1216,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
             for(int i = 0; i + 1 < len; i++) {
                 int x = v[i], y = v[i + 1];
                 if(x < 0 || y < 0) continue;
-                if(H.lk[x].es == NIL || (int)uni(H.lk[x].et) != root) continue;
+                if(H.ed[x].lk.es == NIL || (int)uni(H.ed[x].lk.et) != root) continue;
                 int f = -1;
                 for(int j = 0; j < nr; j++) if(ra[j] == x && rb[j] == y) { f = j; break; }
                 if(f >= 0) rc[f] += c;
@@ -1295,7 +1242,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     for(int i = 0; i < n; i++) { udeg[i] = 0; iso[i] = 0; }
     for(int j = 0; j < nr; j++) {
         int y = rb[j];
-        if(H.lk[y].es == NIL || (int)uni(H.lk[y].es) != root) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }   // assert(e2u.find(e2) != end)
+        if(H.ed[y].lk.es == NIL || (int)uni(H.ed[y].lk.es) != root) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }   // assert(e2u.find(e2) != end)
         int s = -1, t = -1;                       // local indices by search (routes exist only with phasing paths)
         for(int q = 0; q < nin; q++) if(u2e[q] == ra[j]) { s = q; break; }
         for(int q = nin; q < n; q++) if(u2e[q] == y) { t = q; break; }
@@ -1359,7 +1306,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     for(int i = 0; i < n; i++) vw[i] = 0;
     for(int c = 0; c < ncomp; c++) {
         double sum1 = 0, sum2 = 0;
-        for(int i = 0; i < n; i++) { if(comp[i] != c) continue; double wgt = uni(H.ew[u2e[i]]); if(i < nin) sum1 += wgt; else sum2 += wgt; vw[i] = wgt; }
+        for(int i = 0; i < n; i++) { if(comp[i] != c) continue; double wgt = uni(H.ed[u2e[i]].w); if(i < nin) sum1 += wgt; else sum2 += wgt; vw[i] = wgt; }
         double r1 = sqrt(sum2 / sum1), r2 = sqrt(sum1 / sum2);
         for(int i = 0; i < n; i++) { if(comp[i] != c) continue; if(i < nin) vw[i] *= r1; else vw[i] *= r2; }
     }
@@ -1544,13 +1491,13 @@ ALD_FN void collect_path(int e)
         if(st == '.') st = H.gstrand;
         r[0] = (uint32_t)H.g; r[1] = (uint32_t)H.n_paths; r[2] = (uint32_t)nvp; r[3] = (uint32_t)mi; r[4] = (uint32_t)uni(C.ed[e].ecount); r[5] = (uint32_t)st | ((uint32_t)(A->attempt & 0xFF) << 8);
         ALD_GLOBAL double *d = (ALD_GLOBAL double*)(r + 6);
-        d[0] = uni(H.ew[e]); d[1] = uni(C.ed[e].eabd); d[2] = exp(C.ed[e].econf); d[3] = uni(C.ed[e].med);
+        d[0] = uni(H.ed[e].w); d[1] = uni(C.ed[e].eabd); d[2] = exp(C.ed[e].econf); d[3] = uni(C.ed[e].med);
         ALD_GLOBAL uint32_t *pv = r + REC_HDR_WORDS; int w = 0;
         pv[w++] = 0;
         for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.ed[e].mask[k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; pv[w++] = (uint32_t)(k * 64 + b); } }
         pv[w++] = (uint32_t)n;
         if((REC_HDR_WORDS + nvp) & 1) pv[w] = 0;
-        if(tracing()) { int save = H.n_iters; trace(OP_COLLECT, (int)uni(H.eid[e]), nvp, uni(H.ew[e])); H.n_iters = save; }
+        if(tracing()) { int save = H.n_iters; trace(OP_COLLECT, (int)uni(H.eid[e]), nvp, uni(H.ed[e].w)); H.n_iters = save; }
         H.n_paths++;
     }
     H.hflag[e] = 0;
@@ -1564,9 +1511,9 @@ ALD_FN void materialize_special()
     const int sinkp = H.sinkp;
     H.out_head[0] = NIL; H.in_head[sinkp] = NIL; H.out_deg[0] = 0; H.in_deg[sinkp] = 0;
     for(int e = 0; e < H.slot_hw; e++) {
-        if(H.lk[e].es == NIL) continue;
-        if((int)uni(H.lk[e].es) == 0) link_out(0, e);
-        if((int)uni(H.lk[e].et) == sinkp) link_in(sinkp, e);
+        if(H.ed[e].lk.es == NIL) continue;
+        if((int)uni(H.ed[e].lk.es) == 0) link_out(0, e);
+        if((int)uni(H.ed[e].lk.et) == sinkp) link_in(sinkp, e);
     }
 }
 // scallop::collect_existing_st_paths (scallop.cc:2742-2752): ascending edge index == ascending creation id.
@@ -1580,7 +1527,7 @@ ALD_FN void collect_existing_st_paths()
     ALD_GLOBAL int32_t *lst = C.wi; int n = 0;           // lane 0's list (work array of the slab: up to MAXE entries)
     for(int base = 0; base < hw; base += ALD_WAVE) {
         int e = base + lane;
-        bool p = e < hw && H.lk[e].es == 0 && (int)H.lk[e].et == sink;
+        bool p = e < hw && H.ed[e].lk.es == 0 && (int)H.ed[e].lk.et == sink;
         uint64_t m = wballot(p);
         if(lane == 0) while(m) { int b = ffs64(m); m &= m - 1; lst[n++] = base + b; }
     }
@@ -1604,7 +1551,7 @@ ALD_FN double compute_maximum_path()
     for(int i = 0; i < n; i++) { int d = uni(H.in_deg[i]); vd[i] = d; if(d == 0 && i != sinkp) q[qt++] = i; table[i] = -1; back[i] = -1; }
     if(vd[sinkp] == 0) q[qt++] = sinkp;
     int k = 0;
-    while(k < qt) { int x = q[k++]; for(int e = u_first_out(x); e >= 0; e = u_next_out(e)) { int t = uni(H.lk[e].et); if(--vd[t] == 0) q[qt++] = t; } }
+    while(k < qt) { int x = q[k++]; for(int e = u_first_out(x); e >= 0; e = u_next_out(e)) { int t = uni(H.ed[e].lk.et); if(--vd[t] == 0) q[qt++] = t; } }
     H.tmp0 = 0;
     if(qt != n) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return -1; }
     int ssi = -1, tti = -1;
@@ -1615,10 +1562,10 @@ ALD_FN double compute_maximum_path()
         if(H.in_deg[i] + uni(H.out_deg[i]) == 0) continue;
         double max_abd = 0; int max_edge = -1;
         for(int e = u_first_in(i); e >= 0; e = u_next_in(e)) {
-            int s = uni(H.lk[e].es);
+            int s = uni(H.ed[e].lk.es);
             double ts = table[s];
             if(ts <= -1) continue;
-            double xw = uni(H.ew[e]);
+            double xw = uni(H.ed[e].w);
             double ww = xw < ts ? xw : ts;
             if(ww >= max_abd) { max_abd = ww; max_edge = e; }
         }
@@ -1627,7 +1574,7 @@ ALD_FN double compute_maximum_path()
     }
     int plen = 0;
     int x = sinkp;
-    while(plen < n) { int e = back[x]; if(e < 0) break; path[plen++] = e; x = uni(H.lk[e].es); }
+    while(plen < n) { int e = back[x]; if(e < 0) break; path[plen++] = e; x = uni(H.ed[e].lk.es); }
     for(int i = 0; i < plen / 2; i++) { int t = path[i]; path[i] = path[plen - 1 - i]; path[plen - 1 - i] = t; }
     H.tmp0 = plen;
     return table[sinkp];
@@ -1697,15 +1644,15 @@ ALD_FN bool load_graph()
         H.out_head[i] = (o1 > o0 && i != 0) ? (IDX)o0 : NIL; H.out_deg[i] = (IDX)(o1 - o0);
         H.in_head[i] = (i1 > i0 && i != V - 1) ? (IDX)ie[i0] : NIL; H.in_deg[i] = (IDX)(i1 - i0);
         H.nz[i] = (i >= 1 && i < V - 1 && (o1 - o0) + (i1 - i0) > 0) ? 1 : 0;
-        for(int k = o0; k < o1; k++) { H.lk[k].es = (IDX)i; H.lk[k].onx = (k + 1 < o1) ? (IDX)(k + 1) : NIL; }
-        for(int k = i0; k < i1; k++) { H.lk[ie[k]].inx = (k + 1 < i1) ? (IDX)ie[k + 1] : NIL; }
+        for(int k = o0; k < o1; k++) { H.ed[k].lk.es = (IDX)i; H.ed[k].lk.onx = (k + 1 < o1) ? (IDX)(k + 1) : NIL; }
+        for(int k = i0; k < i1; k++) { H.ed[ie[k]].lk.inx = (k + 1 < i1) ? (IDX)ie[k + 1] : NIL; }
         C.vx[i].vw = A->in.vertex_weight[ov + i]; C.vx[i].lpos = A->in.vertex_lpos[ov + i]; C.vx[i].rpos = A->in.vertex_rpos[ov + i];
         C.vx[i].vtype = A->in.vertex_type[ov + i]; C.vx[i].v2v = i; C.vx[i].memo = 0;
     }
     bool strand = false;
     ALD_GLOBAL const int32_t *so = A->in.edge_sample_offset + oeo;
     for(int k = lane; k < E; k += ALD_WAVE) {
-        H.lk[k].et = (IDX)A->in.edge_target[oe + k]; H.ew[k] = A->in.edge_weight[oe + k]; H.eid[k] = (uint16_t)k; H.hflag[k] = 0;
+        H.ed[k].lk.et = (IDX)A->in.edge_target[oe + k]; H.ed[k].w = A->in.edge_weight[oe + k]; H.eid[k] = (uint16_t)k; H.hflag[k] = 0;
         uint8_t st = A->in.edge_strand[oe + k]; C.ed[k].estrand = st; if(st) strand = true;
         C.ed[k].med = 0; C.ed[k].mei = 0; C.ed[k].econf = 0; C.ed[k].eabd = A->in.edge_abd[oe + k];
         C.ed[k].sp_off = (uint32_t)so[k]; C.ed[k].sp_len = (uint32_t)(so[k + 1] - so[k]); C.ed[k].ecount = A->in.edge_count[oe + k];
@@ -1731,8 +1678,8 @@ ALD_FN bool load_graph()
                 int s = A->in.phasing_vertex[opv + a + k], t = A->in.phasing_vertex[opv + a + k + 1];
                 if(!(s < t) || s < 0 || t >= V) { H.status = ALD_ST_INVARIANT + ALD_INV_OTHER; ok = false; break; }
                 int best = -1;
-                if(s == 0) { for(int e = vo[0]; e < vo[1]; e++) { int tt = H.lk[e].et; if(tt == t) best = e; else if(tt > t) break; } }      // row 0 is not linked: scan the CSR row
-                else for(int e = first_out(s); e >= 0; e = next_out(e)) { int tt = H.lk[e].et; if(tt == t) best = e; else if(tt > t) break; }
+                if(s == 0) { for(int e = vo[0]; e < vo[1]; e++) { int tt = H.ed[e].lk.et; if(tt == t) best = e; else if(tt > t) break; } }      // row 0 is not linked: scan the CSR row
+                else for(int e = first_out(s); e >= 0; e = next_out(e)) { int tt = H.ed[e].lk.et; if(tt == t) best = e; else if(tt > t) break; }
                 if(best < 0) ok = false; else C.hl[used + k] = best;
             }
             if(!ok || len - 1 < 2) continue;
