@@ -30,52 +30,63 @@ def _device_words(ptr: int, n_words: int, device: torch.device) -> torch.Tensor:
 class RecordGatherer:
     """The one exchange step of the multi-GPU path: every rank's packed path records -> rank 0.
 
-    Sizes travel by all_gather, payloads by a padded `gather` (RCCL when the tensors are on the GPU, gloo on CPU).  Buffers are
-    kept across steps.  Nothing on the data path is touched by Python per record: graph ids stay local in the stream and each
-    rank's `graph_offset` travels with the sizes, so rank 0 can make them global when it consumes a stream
-    (`aletsch_amd.records_add_graph_offset`, a C loop).  On a GPU rank 0 the gathered streams are copied to pinned host memory
-    with an async copy on the current stream (the copy engine works while the next batch's kernel runs); `streams()` waits for it.
+    Every rank sends a fixed-capacity buffer [n_words, graph_offset, 0, 0, records...] through a `gather` (RCCL when the tensors
+    are on the GPU, gloo on CPU).  The capacity is agreed once (all_gather of the first step's sizes, plus head-room), so a step
+    needs no size exchange and NOTHING in it blocks the host: the gather is only enqueued, the next batch's kernel is launched
+    right behind it and the two share the GPU, and on rank 0 the gathered streams go to pinned host memory by async copies that
+    the copy engine performs meanwhile.  Graph ids stay local in the stream; each rank's `graph_offset` rides in the header, so
+    rank 0 makes them global when it consumes a stream (`aletsch_amd.records_add_graph_offset`, a C loop).  A stream that
+    outgrows the capacity triggers a new agreement (every rank sees the overflow flag of every other rank one step late, so a
+    varying workload should call `renegotiate()` itself whenever its batch shape changes).
     """
+    HDR = 4
 
-    def __init__(self, device: torch.device):
+    def __init__(self, device: torch.device, headroom: float = 1.0 / 32):
         self.device = device
         self.world = dist.get_world_size(); self.rank = dist.get_rank()
-        self._pad = None; self._out = None; self._host = None; self._meta = None; self._done = None
+        self.headroom = headroom
+        self.cap = 0
+        self._pad = None; self._out = None; self._host = None; self._done = None
+
+    def renegotiate(self, n_words: int):
+        """Blocking: agree on a capacity that holds every rank's stream of this shape."""
+        dev = self.device
+        mine = torch.tensor([int(n_words)], dtype=torch.int64, device=dev)
+        allv = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        dist.all_gather(allv, mine)
+        mx = max(int(v.item()) for v in allv)
+        cap = self.HDR + mx + int(mx * self.headroom) + 1024
+        cap += (-cap) % 64
+        if self._done is not None:
+            self._done.synchronize()
+        self.cap = cap
+        self._pad = torch.zeros(cap, dtype=torch.int32, device=dev)
+        if self.rank == 0:
+            self._out = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(self.world)]
+            self._host = torch.empty((self.world, cap), dtype=torch.int32, pin_memory=(dev.type == "cuda"))
 
     def gather(self, words: torch.Tensor, graph_offset: int = 0):
-        """words: 1-D int32 tensor on self.device (this rank's record stream).  Starts the exchange; rank 0 reads `streams()`."""
+        """words: 1-D int32 tensor on self.device (this rank's record stream).  Enqueues the exchange and returns an event (None on
+        CPU) that is reached once `words` has been read -- the caller waits for it before it lets anything overwrite `words`."""
         dev = self.device
-        mine = torch.tensor([int(words.numel()), int(graph_offset)], dtype=torch.int64, device=dev)
-        meta = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(self.world)]
-        dist.all_gather(meta, mine)
-        self._meta = [(int(m[0].item()), int(m[1].item())) for m in meta]
-        mx = max(max(n for n, _ in self._meta), 1)
-        if self._pad is None or self._pad.numel() < mx:
-            cap = mx + mx // 8 + 64                                       # head-room: the stream length varies a little from batch to batch
-            self._pad = torch.zeros(cap, dtype=torch.int32, device=dev)
-            self._out = None
+        n = int(words.numel())
+        if self.cap == 0 or self.HDR + n > self.cap:
+            self.renegotiate(n)                                           # collective: every rank of a fixed-shape workload gets here together
         if self._done is not None:
-            self._done.synchronize()                                      # the previous step's host copy must be out of the buffers
-        pad = self._pad[:mx]
-        pad[: words.numel()] = words
-        if self.rank == 0:
-            if self._out is None or self._out[0].numel() < mx:
-                cap = self._pad.numel()
-                self._out = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(self.world)]
-                self._host = torch.empty((self.world, cap), dtype=torch.int32, pin_memory=(dev.type == "cuda"))
-            outs = [o[:mx] for o in self._out]
-            dist.gather(pad, outs, dst=0)
-        else:
-            outs = None
-            dist.gather(pad, None, dst=0)
+            self._done.synchronize()                                      # the previous step's host copies must be out of the buffers
+        pad = self._pad
+        pad[: self.HDR] = torch.tensor([n, int(graph_offset), 0, 0], dtype=torch.int32).to(dev, non_blocking=True)
+        pad[self.HDR: self.HDR + n] = words
+        read = None
         if dev.type == "cuda":
-            # the exchange has read `words` (the batch's record pool, which its next run overwrites) once this event is reached
-            ev = torch.cuda.Event(); ev.record(); ev.synchronize()
+            read = torch.cuda.Event(); read.record()
+        dist.gather(pad, self._out if self.rank == 0 else None, dst=0)
         if self.rank == 0:
-            for i, o in enumerate(outs):
-                self._host[i, :mx].copy_(o, non_blocking=True)            # pinned target: the copy engine works behind the next kernel
+            for i, o in enumerate(self._out):
+                self._host[i].copy_(o, non_blocking=True)                 # pinned target: the copy engine works behind the next kernel
             if dev.type == "cuda":
                 self._done = torch.cuda.Event(); self._done.record()
+        return read
 
     def streams(self):
         """Rank 0: [(uint32 record words of rank i, graph_offset of rank i)] in rank order == ascending global graph id."""
@@ -83,7 +94,11 @@ class RecordGatherer:
             return None
         if self._done is not None:
             self._done.synchronize()
-        return [(self._host[i, :n].numpy().view(np.uint32), off) for i, (n, off) in enumerate(self._meta)]
+        out = []
+        for i in range(self.world):
+            row = self._host[i]; n = int(row[0]); off = int(row[1])
+            out.append((row[self.HDR: self.HDR + n].numpy().view(np.uint32), off))
+        return out
 
 
 def gather_records(rec, device: torch.device, graph_offset: int = 0):

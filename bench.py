@@ -79,11 +79,13 @@ def main():
     from aletsch_amd.distributed import RecordGatherer, _device_words
     gatherer = RecordGatherer(torch.device("cuda", dev)) if dist_on else None
 
+    pool_read = {}                                       # batch -> event reached once the exchange has read its record pool
+
     def gather_records(b):
         """RCCL gather of the packed path records to rank 0, straight from the batch's record pool in HBM (no host round trip);
-        each rank's graph-id offset (rank * graphs_per_gpu) travels with the sizes"""
+        only enqueued: the next kernel is launched behind it and the host never waits for a collective"""
         ptr, n = b.device_records()
-        gatherer.gather(_device_words(ptr, n, torch.device("cuda", dev)), graph_offset=rank * args.graphs)
+        pool_read[id(b)] = gatherer.gather(_device_words(ptr, n, torch.device("cuda", dev)), graph_offset=rank * args.graphs)
 
     def finish(b):
         b.download()                                    # stream sync + D2H of status / packed records (+ class retries)
@@ -98,6 +100,9 @@ def main():
             cur = batches[i % 2]
             if prev is not None:
                 prev.sync()                             # the previous kernel is done ...
+            ev = pool_read.pop(id(cur), None)
+            if ev is not None:
+                ev.synchronize()                        # (the exchange of this batch's previous records has read its pool)
             cur.run()                                   # ... the next one starts ...
             if prev is not None:
                 ms.append(finish(prev))                 # ... while the previous records travel to the host
