@@ -148,6 +148,7 @@ public:
         return out;
     }
     void clear() { ald_batch_clear(b_); lpos_.clear(); rpos_.clear(); }
+    ald_batch *handle() const { return b_; }        // for the calls that take the batch itself (ald_tset_add_batch, ald_batch_export_transcripts, ...)
 private:
     ald_batch *b_ = nullptr;
     std::vector<std::vector<int32_t>> lpos_, rpos_;
