@@ -768,15 +768,16 @@ ALD_FN void decompose_trivial_vertex(int x)
 ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio);
 
 // scallop::decompose_vertex_extend (scallop.cc:1675-1986); pe2w = n sorted pairs in the work area
-ALD_FN void decompose_vertex_extend(int root, int n)
+// SMALL: pe2w and the work arrays are in the LDS scratch (known address space -> ds_* accesses); otherwise wherever the router and
+// the capacity rules put them
+template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
 {
-    root = uni(root); n = uni(n);
     COLD;
-    const Pairs P = pairs_cur();
+    const Pairs P = SMALL ? pairs_at(true, false) : pairs_cur();
     int32_t *a = P.a, *b = P.b; double *w = P.w;
     const int deg = (int)uni(H.in_deg[root]) + (int)uni(H.out_deg[root]);
     // the visiting order of the nested decompositions (jump_ratio > 1 only) must survive them: it always lives in the slab
-    const Arena AR = arena_at(4 * deg <= ARENA_I && deg <= ARENA_D && !(H.p_ratio[7] > 1.0));
+    const Arena AR = SMALL ? arena_at(true) : arena_at(4 * deg <= ARENA_I && deg <= ARENA_D && !(H.p_ratio[7] > 1.0));
     if(4 * deg > AR.cap_i || deg > AR.cap_d || deg > C.w_cap / 16) { fail(ALD_ST_CAPACITY); return; }
     int nloc = 0; int32_t *loc_e = AR.i;
     for(int e = u_first_in(root); e >= 0; e = u_next_in(e)) { loc_e[nloc++] = e; }
@@ -867,6 +868,16 @@ ALD_FN void decompose_vertex_extend(int root, int n)
         }
         for(int q = 0; q < no; q++) { resolve_single_trivial_vertex(order[q], jump); if(H.status) return; }
     }
+}
+
+ALD_FN void decompose_vertex_extend_small(int root, int n) { decompose_vertex_extend_body<true>(uni(root), uni(n)); }
+ALD_FN void decompose_vertex_extend_any(int root, int n) { decompose_vertex_extend_body<false>(uni(root), uni(n)); }
+ALD_INL void decompose_vertex_extend(int root, int n)
+{
+    root = uni(root); n = uni(n);
+    const int deg = (int)uni(H.in_deg[root]) + (int)uni(H.out_deg[root]);
+    if(uni(H.pw_lds) != 0 && 4 * deg <= ARENA_I && deg <= ARENA_D && !(uni(H.p_ratio[7]) > 1.0)) decompose_vertex_extend_small(root, n);
+    else decompose_vertex_extend_any(root, n);
 }
 
 // ---------------------------------------------------------------- per-vertex rule evaluation (one vertex per lane)
