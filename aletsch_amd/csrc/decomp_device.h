@@ -183,11 +183,15 @@ ALD_INL void link_in(int v, int e)
 {
     v = uni(v); e = uni(e);
     if(v == uni(H.sinkp) && !uni(H.special_linked)) { H.in_deg[v]++; return; }
-    uint32_t ks = uni(H.ed[e].lk.es), kid = uni(H.eid[e]);
-    int prev = -1, cur = u_first_in(v);
-    while(cur >= 0) { uint64_t w = lkw(cur); uint32_t cs = (uint32_t)(w & 0xFFFF); if(cs > ks || (cs == ks && uni(H.eid[cur]) > kid)) break; prev = cur; cur = lk_next((uint32_t)((w >> 32) & 0xFFFF)); }
-    H.ed[e].lk.inx = cur < 0 ? NIL : (IDX)cur;
-    if(prev < 0) H.in_head[v] = (IDX)e; else H.ed[prev].lk.inx = (IDX)e;
+    const uint32_t ks = uni(H.ed[e].lk.es), kid = uni(H.eid[e]);
+    IDX *pp = &H.in_head[v]; IDX cur = *pp;
+    while(uni(cur != NIL)) {
+        const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; const uint32_t cs = (uint32_t)(w & 0xFFFF);
+        bool stop = cs > ks; if(uni(cs == ks)) stop = H.eid[cur] > kid;
+        if(uni(stop)) break;
+        pp = &H.ed[cur].lk.inx; cur = (IDX)((w >> 32) & 0xFFFF);
+    }
+    H.ed[e].lk.inx = cur; *pp = (IDX)e;
     H.in_deg[v]++;
 }
 ALD_INL void link_out(int v, int e)
@@ -195,12 +199,16 @@ ALD_INL void link_out(int v, int e)
     v = uni(v); e = uni(e);
     if(v == 0 && !uni(H.special_linked)) { H.out_deg[v]++; return; }
     const uint32_t sk = (uint32_t)uni(H.sinkp);
-    uint32_t kt = uni(H.ed[e].lk.et), kid = uni(H.eid[e]);
+    uint32_t kt = uni(H.ed[e].lk.et); const uint32_t kid = uni(H.eid[e]);
     if(kt == sk) kt = 0xFFFFu;
-    int prev = -1, cur = u_first_out(v);
-    while(cur >= 0) { uint64_t w = lkw(cur); uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu; if(ct > kt || (ct == kt && uni(H.eid[cur]) > kid)) break; prev = cur; cur = lk_next((uint32_t)(w >> 48)); }
-    H.ed[e].lk.onx = cur < 0 ? NIL : (IDX)cur;
-    if(prev < 0) H.out_head[v] = (IDX)e; else H.ed[prev].lk.onx = (IDX)e;
+    IDX *pp = &H.out_head[v]; IDX cur = *pp;
+    while(uni(cur != NIL)) {
+        const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu;
+        bool stop = ct > kt; if(uni(ct == kt)) stop = H.eid[cur] > kid;
+        if(uni(stop)) break;
+        pp = &H.ed[cur].lk.onx; cur = (IDX)(w >> 48);
+    }
+    H.ed[e].lk.onx = cur; *pp = (IDX)e;
     H.out_deg[v]++;
 }
 // link_out with a starting point: `hint` is an edge of v's out-list known to sort before e (its target key is smaller)
@@ -209,34 +217,38 @@ ALD_INL void link_out_after(int v, int e, int hint)
     v = uni(v); e = uni(e); hint = uni(hint);
     if(v == 0 && !uni(H.special_linked)) { H.out_deg[v]++; return; }
     const uint32_t sk = (uint32_t)uni(H.sinkp);
-    uint32_t kt = uni(H.ed[e].lk.et), kid = uni(H.eid[e]);
+    uint32_t kt = uni(H.ed[e].lk.et); const uint32_t kid = uni(H.eid[e]);
     if(kt == sk) kt = 0xFFFFu;
-    int prev = hint, cur = u_next_out(hint);
-    while(cur >= 0) { uint64_t w = lkw(cur); uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu; if(ct > kt || (ct == kt && uni(H.eid[cur]) > kid)) break; prev = cur; cur = lk_next((uint32_t)(w >> 48)); }
-    H.ed[e].lk.onx = cur < 0 ? NIL : (IDX)cur;
-    H.ed[prev].lk.onx = (IDX)e;
+    IDX *pp = &H.ed[hint].lk.onx; IDX cur = *pp;
+    while(uni(cur != NIL)) {
+        const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu;
+        bool stop = ct > kt; if(uni(ct == kt)) stop = H.eid[cur] > kid;
+        if(uni(stop)) break;
+        pp = &H.ed[cur].lk.onx; cur = (IDX)(w >> 48);
+    }
+    H.ed[e].lk.onx = cur; *pp = (IDX)e;
     H.out_deg[v]++;
 }
+// The walks below keep the cursor in a vector register (an LDS address has to be in one anyway) and follow the ADDRESS of the link
+// that points at the current edge; only the loop condition is made wave-uniform.
 ALD_INL void unlink_in(int v, int e)
 {
     v = uni(v); e = uni(e);
     if(v == uni(H.sinkp) && !uni(H.special_linked)) { H.in_deg[v]--; return; }
-    int prev = -1, cur = u_first_in(v), guard = MAXE;
-    while(cur >= 0 && cur != e && guard-- > 0) { prev = cur; cur = u_next_in(cur); }
-    if(cur != e) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }       // cannot happen on a consistent state; never walk off a list
-    IDX nx = uni(H.ed[e].lk.inx);
-    if(prev < 0) H.in_head[v] = nx; else H.ed[prev].lk.inx = nx;
+    IDX *pp = &H.in_head[v]; IDX cur = *pp; int guard = MAXE;
+    while(uni((int)cur != e && cur != NIL) && guard-- > 0) { pp = &H.ed[cur].lk.inx; cur = *pp; }
+    if(uni((int)cur != e)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }       // cannot happen on a consistent state; never walk off a list
+    *pp = H.ed[e].lk.inx;
     { int dg = (int)uni(H.in_deg[v]) - 1; H.in_deg[v] = (IDX)dg; if(dg <= 1) { H.maybe_triv = 1; if(dg == 0) H.maybe_broken = 1; } }
 }
 ALD_INL void unlink_out(int v, int e)
 {
     v = uni(v); e = uni(e);
     if(v == 0 && !uni(H.special_linked)) { H.out_deg[v]--; return; }
-    int prev = -1, cur = u_first_out(v), guard = MAXE;
-    while(cur >= 0 && cur != e && guard-- > 0) { prev = cur; cur = u_next_out(cur); }
-    if(cur != e) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
-    IDX nx = uni(H.ed[e].lk.onx);
-    if(prev < 0) H.out_head[v] = nx; else H.ed[prev].lk.onx = nx;
+    IDX *pp = &H.out_head[v]; IDX cur = *pp; int guard = MAXE;
+    while(uni((int)cur != e && cur != NIL) && guard-- > 0) { pp = &H.ed[cur].lk.onx; cur = *pp; }
+    if(uni((int)cur != e)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
+    *pp = H.ed[e].lk.onx;
     { int dg = (int)uni(H.out_deg[v]) - 1; H.out_deg[v] = (IDX)dg; if(dg <= 1) { H.maybe_triv = 1; if(dg == 0) H.maybe_broken = 1; } }
 }
 // e stays in v's in-list but its key becomes (ks, newest id): one walk finds its predecessor and its new place
