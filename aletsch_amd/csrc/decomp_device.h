@@ -664,11 +664,11 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     // balance_vertex(x) (scallop.cc:2486-2576) on the gathered weights: the same sums, ratios, clamps and remainder fix-up in the
     // same order as the list-walking form (balance_vertex_i), but the fan is walked once and nothing is written back until the
     // pe2w sums below are known
-    int n = 0; double wcen = uni(H.ed[c].w);
-    if(!(wcen >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
+    int n = 0; double wcen = H.ed[c].w;          // weights stay in vector registers: they only feed FP arithmetic and LDS stores
+    if(uni(!(wcen >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
     double sfan0 = 0;
     for(int e = A ? u_first_out(x) : u_first_in(x); e >= 0; e = A ? u_next_out(e) : u_next_in(e)) {
-        double w2 = uni(H.ed[e].w); if(!(w2 >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
+        double w2 = H.ed[e].w; if(uni(!(w2 >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
         fe[n] = e; fw[n] = w2; sfan0 += w2; n++;
     }
     {
@@ -694,16 +694,16 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     for(int j = 0; j < n; j++) H.ed[fe[j]].w = fw[j];
     PROF_ADD(PF_T_SETUP);
     const int far = A ? (int)uni(H.ed[c].lk.es) : (int)uni(H.ed[c].lk.et);
-    const double medc = uni(C.ed[c].med), cc = uni(C.ed[c].econf);
+    const double medc = C.ed[c].med, cc = C.ed[c].econf;
     const int meic = uni(C.ed[c].mei), cntc = uni(C.ed[c].ecount), stc = uni(C.ed[c].estrand);
-    const uint32_t nsc = uni(C.ed[c].sp_len); const int idc = uni(C.ed[c].s0id); const double abc = uni(C.ed[c].s0abd);     // c's support never changes
-    double vwt = uni(C.vx[x].vw); const int lt = uni(C.vx[x].lpos), rt = uni(C.vx[x].rpos), ov = uni(C.vx[x].v2v);
+    const uint32_t nsc = uni(C.ed[c].sp_len); const int idc = uni(C.ed[c].s0id); const double abc = C.ed[c].s0abd;     // c's support never changes
+    double vwt = C.vx[x].vw; const int lt = uni(C.vx[x].lpos), rt = uni(C.vx[x].rpos), ov = uni(C.vx[x].v2v);
     bool consumed = false;
     for(int q = 0; q < n; q++) {
         if(consumed) { C.vx[x].vw = vwt; fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }     // the general form would be handed a dead edge here
         const int j = ord[q], f = fe[j]; const double ww = fw[j];
-        const double wcur = uni(H.ed[c].w);                                   // what is left of c
-        const bool sc = !(fabs(wcur - ww) <= kSMIN);                        // split_edge(c, ww) cuts a piece off (scallop.cc:2433-2484)
+        const double wcur = H.ed[c].w;                                   // what is left of c
+        const bool sc = uni(!(fabs(wcur - ww) <= kSMIN));                        // split_edge(c, ww) cuts a piece off (scallop.cc:2433-2484)
         int nid = uni(H.next_id);
         if(nid >= 0xFFF0) { C.vx[x].vw = vwt; fail(ALD_ST_CAPACITY); return; }
         double rem = wcur;
@@ -712,10 +712,10 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         const double wc0 = sc ? ww : wcur;
         const double medc1 = sc ? medc * ww / wcur : medc;
         // everything the step needs from f's record, in one round of independent loads (one 64-byte line for NW == 1)
-        const double medf = uni(C.ed[f].med), cf = uni(C.ed[f].econf);
+        const double medf = C.ed[f].med, cf = C.ed[f].econf;
         const int meif = uni(C.ed[f].mei), cntf = uni(C.ed[f].ecount), stf = uni(C.ed[f].estrand);
-        const uint32_t nsf = uni(C.ed[f].sp_len); const int idf = uni(C.ed[f].s0id); const double abf = uni(C.ed[f].s0abd);
-        const uint64_t mk0 = uni(C.ed[f].mask[0]) | uni(C.ed[c].mask[0]);
+        const uint32_t nsf = uni(C.ed[f].sp_len); const int idf = uni(C.ed[f].s0id); const double abf = C.ed[f].s0abd;
+        const uint64_t mk0 = C.ed[f].mask[0] | C.ed[c].mask[0];
         PROF_ADD(PF_T_MERGE_LOAD);
         if(!(cntc > 0 && cntf > 0)) { C.vx[x].vw = vwt; fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
         if(nsc == 1 && nsf == 1) {      // one supporting sample on both sides: intersect_samples' inline case, c's half already in registers
@@ -727,7 +727,7 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         C.ed[f].econf = A ? cc + cf : cf + cc;
         { const int sty = A ? stf : stc, stx = A ? stc : stf; C.ed[f].estrand = (uint8_t)(sty != 0 ? sty : stx); }
         C.ed[f].mask[0] = (ov >= 0 && ov < 64) ? (mk0 | (1ull << ov)) : mk0;
-        for(int k = 1; k < NW; k++) { uint64_t mk = uni(C.ed[c].mask[k]) | uni(C.ed[f].mask[k]); if(ov >= 0 && (ov >> 6) == k) mk |= (1ull << (ov & 63)); C.ed[f].mask[k] = mk; }
+        for(int k = 1; k < NW; k++) { uint64_t mk = C.ed[c].mask[k] | C.ed[f].mask[k]; if(ov >= 0 && (ov >> 6) == k) mk |= (1ull << (ov & 63)); C.ed[f].mask[k] = mk; }
         PROF_ADD(PF_T_MERGE_MASK);
         // get_in_weights(x) / get_out_weights(x) with both pieces attached: c's side is (rest of c) + piece, the fan side is
         // whatever has not been merged yet, in list order
