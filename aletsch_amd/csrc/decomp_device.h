@@ -185,7 +185,7 @@ ALD_INL void link_in(int v, int e)
     if(v == uni(H.sinkp) && !uni(H.special_linked)) { H.in_deg[v]++; return; }
     const uint32_t ks = uni(H.ed[e].lk.es), kid = uni(H.eid[e]);
     IDX *pp = &H.in_head[v]; IDX cur = *pp;
-    while(uni(cur != NIL)) {
+    for(int guard = MAXE; uni(cur != NIL) && guard > 0; guard--) {      // (the guard only matters on a corrupted list: never spin)
         const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; const uint32_t cs = (uint32_t)(w & 0xFFFF);
         bool stop = cs > ks; if(uni(cs == ks)) stop = H.eid[cur] > kid;
         if(uni(stop)) break;
@@ -202,7 +202,7 @@ ALD_INL void link_out(int v, int e)
     uint32_t kt = uni(H.ed[e].lk.et); const uint32_t kid = uni(H.eid[e]);
     if(kt == sk) kt = 0xFFFFu;
     IDX *pp = &H.out_head[v]; IDX cur = *pp;
-    while(uni(cur != NIL)) {
+    for(int guard = MAXE; uni(cur != NIL) && guard > 0; guard--) {      // (the guard only matters on a corrupted list: never spin)
         const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu;
         bool stop = ct > kt; if(uni(ct == kt)) stop = H.eid[cur] > kid;
         if(uni(stop)) break;
@@ -220,7 +220,7 @@ ALD_INL void link_out_after(int v, int e, int hint)
     uint32_t kt = uni(H.ed[e].lk.et); const uint32_t kid = uni(H.eid[e]);
     if(kt == sk) kt = 0xFFFFu;
     IDX *pp = &H.ed[hint].lk.onx; IDX cur = *pp;
-    while(uni(cur != NIL)) {
+    for(int guard = MAXE; uni(cur != NIL) && guard > 0; guard--) {      // (the guard only matters on a corrupted list: never spin)
         const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu;
         bool stop = ct > kt; if(uni(ct == kt)) stop = H.eid[cur] > kid;
         if(uni(stop)) break;
@@ -257,7 +257,8 @@ ALD_INL void relink_in(int v, int e, uint32_t ks)
     v = uni(v); e = uni(e);
     if(v == uni(H.sinkp) && !uni(H.special_linked)) return;
     int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
-    for(int cur = u_first_in(v); cur >= 0; ) {
+    int guard = MAXE;
+    for(int cur = u_first_in(v); cur >= 0 && guard-- > 0; ) {
         uint64_t w = lkw(cur); int nx = lk_next((uint32_t)((w >> 32) & 0xFFFF));
         if(cur == e) { pe = last; seen = true; if(placed) break; }
         else { if(!placed && (uint32_t)(w & 0xFFFF) > ks) { ip = last; placed = true; if(seen) break; } last = cur; }
@@ -276,7 +277,8 @@ ALD_INL void relink_out(int v, int e, uint32_t kt)         // kt already mapped 
     if(v == 0 && !uni(H.special_linked)) return;
     const uint32_t sk = (uint32_t)uni(H.sinkp);
     int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
-    for(int cur = u_first_out(v); cur >= 0; ) {
+    int guard = MAXE;
+    for(int cur = u_first_out(v); cur >= 0 && guard-- > 0; ) {
         uint64_t w = lkw(cur); int nx = lk_next((uint32_t)(w >> 48));
         if(cur == e) { pe = last; seen = true; if(placed) break; }
         else { uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu; if(!placed && ct > kt) { ip = last; placed = true; if(seen) break; } last = cur; }
