@@ -14,7 +14,11 @@
  * **parity unpinned**.  What IS pinned against the real reference, compiled from its
  * own sources into oracle/_ref/ (oracle/Makefile):
  *   - subsetsum (scallop/subsetsum.cc)           -> oracle/subsetsum_oracle.hpp vs _ref/ref_subsetsum
- *   - graph-layer ordering / toposort / components (graph/*.cc) -> tests/test_ref_graph.py
+ *   - graph-layer ordering / toposort / components (graph/*.cc) -> _ref/ref_graph, tests/golden/ref_graph.json
+ *   - the result sink (rnacore/transcript_set.cc, gtf/transcript.cc) -> _ref/ref_tset, tests/golden/ref_tset.json
+ *     (all three in tests/test_oracle_pins.py / tests/test_tset_cpu.py)
+ * and, as a band only, the aggregates the survey measured on the real reference: paths per graph,
+ * rule mix, router evaluations, graph growth (tests/test_oracle_pins.py).
  *
  * Canonical order: the reference orders edges by raw pointer; here
  * "pointer order" := creation order, and an edge's creation number IS its scallop

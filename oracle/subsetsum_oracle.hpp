@@ -2,7 +2,7 @@
  * subsetsum_oracle.hpp -- TEST INFRASTRUCTURE ONLY.
  * CPU restatement of the reference's two-sided subset-sum DP (scallop/subsetsum.cc:20-206).
  * PINNED: checked against the reference's own known-answer test (subsetsum.cc:263-282:
- * source {10,20,39} target {29,54} -> S=(3 1), T=(2), error 0.05) in tests/test_subsetsum.py and,
+ * source {10,20,39} target {29,54} -> S=(3 1), T=(2), error 0.05) in tests/test_oracle_pins.py and,
  * on random instances, against oracle/_ref/ref_subsetsum (the reference's subsetsum.cc + equation.cc
  * compiled unmodified from /root/reference by oracle/Makefile).
  */
