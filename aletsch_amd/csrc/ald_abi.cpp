@@ -19,10 +19,10 @@ using namespace ald;
 
 extern "C" {
 int ald_launch_c0(const KernelArgs *, int, hipStream_t); int ald_launch_c1(const KernelArgs *, int, hipStream_t); int ald_launch_c2(const KernelArgs *, int, hipStream_t);
-int ald_launch_c3(const KernelArgs *, int, hipStream_t); int ald_launch_c4(const KernelArgs *, int, hipStream_t); int ald_launch_c5(const KernelArgs *, int, hipStream_t);
-int ald_occupancy_c0(); int ald_occupancy_c1(); int ald_occupancy_c2(); int ald_occupancy_c3(); int ald_occupancy_c4(); int ald_occupancy_c5();
+int ald_launch_c3(const KernelArgs *, int, hipStream_t); int ald_launch_c4(const KernelArgs *, int, hipStream_t); int ald_launch_c5(const KernelArgs *, int, hipStream_t); int ald_launch_c6(const KernelArgs *, int, hipStream_t);
+int ald_occupancy_c0(); int ald_occupancy_c1(); int ald_occupancy_c2(); int ald_occupancy_c3(); int ald_occupancy_c4(); int ald_occupancy_c5(); int ald_occupancy_c6();
 unsigned long long ald_hot_slab_bytes_c0(); unsigned long long ald_hot_slab_bytes_c1(); unsigned long long ald_hot_slab_bytes_c2();
-unsigned long long ald_hot_slab_bytes_c3(); unsigned long long ald_hot_slab_bytes_c4(); unsigned long long ald_hot_slab_bytes_c5();
+unsigned long long ald_hot_slab_bytes_c3(); unsigned long long ald_hot_slab_bytes_c4(); unsigned long long ald_hot_slab_bytes_c5(); unsigned long long ald_hot_slab_bytes_c6();
 }
 
 namespace {
@@ -34,9 +34,9 @@ int set_err(int code, const std::string &s) { g_err = s; return code; }
 typedef int (*launch_fn)(const KernelArgs *, int, hipStream_t);
 typedef int (*occ_fn)();
 typedef unsigned long long (*hot_fn)();
-const launch_fn k_launch[ALD_NUM_CLASSES] = {ald_launch_c0, ald_launch_c1, ald_launch_c2, ald_launch_c3, ald_launch_c4, ald_launch_c5};
-const occ_fn k_occ[ALD_NUM_CLASSES] = {ald_occupancy_c0, ald_occupancy_c1, ald_occupancy_c2, ald_occupancy_c3, ald_occupancy_c4, ald_occupancy_c5};
-const hot_fn k_hot[ALD_NUM_CLASSES] = {ald_hot_slab_bytes_c0, ald_hot_slab_bytes_c1, ald_hot_slab_bytes_c2, ald_hot_slab_bytes_c3, ald_hot_slab_bytes_c4, ald_hot_slab_bytes_c5};
+const launch_fn k_launch[ALD_NUM_CLASSES] = {ald_launch_c0, ald_launch_c1, ald_launch_c2, ald_launch_c3, ald_launch_c4, ald_launch_c5, ald_launch_c6};
+const occ_fn k_occ[ALD_NUM_CLASSES] = {ald_occupancy_c0, ald_occupancy_c1, ald_occupancy_c2, ald_occupancy_c3, ald_occupancy_c4, ald_occupancy_c5, ald_occupancy_c6};
+const hot_fn k_hot[ALD_NUM_CLASSES] = {ald_hot_slab_bytes_c0, ald_hot_slab_bytes_c1, ald_hot_slab_bytes_c2, ald_hot_slab_bytes_c3, ald_hot_slab_bytes_c4, ald_hot_slab_bytes_c5, ald_hot_slab_bytes_c6};
 
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
@@ -51,6 +51,7 @@ struct PinBuf {
 
 } // namespace
 
+enum { ALD_SIDE_STREAMS = 3 };
 struct ald_batch {
     int device = 0; int n_cus = 0;
     Params prm;
@@ -58,13 +59,15 @@ struct ald_batch {
     HostBatch::Section sec[HostBatch::S_COUNT];
     uint64_t in_bytes = 0;
     hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipStream_t cstream[ALD_NUM_CLASSES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};    // one stream per size class: the classes run concurrently
-    hipEvent_t cdone[ALD_NUM_CLASSES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // the size classes run concurrently on a few side streams.  Not one per class: a process only gets a handful of hardware queues
+    // (4 by default) and streams beyond that share them in creation order, which can put the two heaviest classes behind each other
+    hipStream_t cstream[ALD_SIDE_STREAMS] = {};
+    hipEvent_t cdone[ALD_NUM_CLASSES] = {};
     PinBuf pin_in, pin_out;
     DevBuf d_in, d_status, d_npaths, d_niters, d_pool, d_poolused, d_trace_n, d_trace_codes, d_trace_vals, d_work, d_counter, d_args;
     DevBuf d_slabs[ALD_NUM_CLASSES];
-    int blocks[ALD_NUM_CLASSES] = {0, 0, 0, 0, 0, 0};
-    int occ[ALD_NUM_CLASSES] = {-1, -1, -1, -1, -1, -1};
+    int blocks[ALD_NUM_CLASSES] = {};
+    int occ[ALD_NUM_CLASSES] = {-1, -1, -1, -1, -1, -1, -1};
     uint64_t pool_cap_words = 0;
     int trace_cap = 0;
     bool uploaded = false, ran = false, downloaded = false;
@@ -139,15 +142,27 @@ int launch_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], 
     HIPCHK(hipMemcpyAsync(b->d_work.p, flat.data(), 4 * tot, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->d_args.p, args.data(), sizeof(KernelArgs) * ALD_NUM_CLASSES, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));          // flat / args are stack-lifetime host buffers
-    // fork: every class with work launches on its own stream behind ev0, the batch stream joins them all before ev1
-    // (big graphs first: the long poles start early and the small classes fill the LDS they leave free)
-    HIPCHK(hipEventRecord(b->ev0, b->stream));
-    for(int c = ALD_NUM_CLASSES - 1; c >= 0; c--) {
+    // fork: classes with work are dealt to the side streams, heaviest first onto the least loaded stream (cost ~ sum of V * E: the
+    // rule cascade is superlinear in the graph size); the batch stream joins them all before ev1
+    double cost[ALD_NUM_CLASSES]; int order[ALD_NUM_CLASSES]; int nord = 0;
+    for(int c = 0; c < ALD_NUM_CLASSES; c++) {
+        cost[c] = 0;
         if(nblk[c] == 0) continue;
+        for(int32_t g : work[c]) cost[c] += (double)b->hb.g_nv[g] * (double)b->hb.g_ne[g];
+        cost[c] /= (double)nblk[c];                       // per resident wave
+        order[nord++] = c;
+    }
+    std::sort(order, order + nord, [&](int x, int y) { return cost[x] > cost[y]; });
+    double load[ALD_SIDE_STREAMS] = {0, 0, 0};
+    HIPCHK(hipEventRecord(b->ev0, b->stream));
+    for(int k = 0; k < nord; k++) {
+        const int c = order[k];
+        int st = 0; for(int q = 1; q < ALD_SIDE_STREAMS; q++) if(load[q] < load[st]) st = q;
+        load[st] += cost[c];
         b->blocks[c] = nblk[c];
-        HIPCHK(hipStreamWaitEvent(b->cstream[c], b->ev0, 0));
-        if(k_launch[c]((const KernelArgs*)b->d_args.p + c, nblk[c], b->cstream[c]) != 0) return set_err(ALD_ERR_HIP, "kernel launch failed");
-        HIPCHK(hipEventRecord(b->cdone[c], b->cstream[c]));
+        HIPCHK(hipStreamWaitEvent(b->cstream[st], b->ev0, 0));
+        if(k_launch[c]((const KernelArgs*)b->d_args.p + c, nblk[c], b->cstream[st]) != 0) return set_err(ALD_ERR_HIP, "kernel launch failed");
+        HIPCHK(hipEventRecord(b->cdone[c], b->cstream[st]));
         HIPCHK(hipStreamWaitEvent(b->stream, b->cdone[c], 0));
     }
     HIPCHK(hipEventRecord(b->ev1, b->stream));
@@ -184,7 +199,8 @@ int ald_batch_create(const ald_params *p, int device, ald_batch **out)
     b->device = device; b->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     params_from_abi(p, b->prm);
     bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev1) == hipSuccess;
-    for(int c = 0; c < ALD_NUM_CLASSES && ok; c++) ok = hipStreamCreateWithFlags(&b->cstream[c], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&b->cdone[c], hipEventDisableTiming) == hipSuccess;
+    for(int q = 0; q < ALD_SIDE_STREAMS && ok; q++) ok = hipStreamCreateWithFlags(&b->cstream[q], hipStreamNonBlocking) == hipSuccess;
+    for(int c = 0; c < ALD_NUM_CLASSES && ok; c++) ok = hipEventCreateWithFlags(&b->cdone[c], hipEventDisableTiming) == hipSuccess;
     if(!ok) { ald_batch_destroy(b); return set_err(ALD_ERR_HIP, "stream/event creation failed"); }
     *out = b;
     return ALD_OK;
@@ -199,7 +215,8 @@ int ald_batch_destroy(ald_batch *b)
     DevBuf *bufs[] = {&b->d_in, &b->d_status, &b->d_npaths, &b->d_niters, &b->d_pool, &b->d_poolused, &b->d_trace_n, &b->d_trace_codes, &b->d_trace_vals, &b->d_work, &b->d_counter, &b->d_args};
     for(DevBuf *d : bufs) d->release();
     for(int c = 0; c < ALD_NUM_CLASSES; c++) b->d_slabs[c].release();
-    for(int c = 0; c < ALD_NUM_CLASSES; c++) { if(b->cstream[c]) { hipStreamSynchronize(b->cstream[c]); hipStreamDestroy(b->cstream[c]); } if(b->cdone[c]) hipEventDestroy(b->cdone[c]); }
+    for(int q = 0; q < ALD_SIDE_STREAMS; q++) if(b->cstream[q]) { hipStreamSynchronize(b->cstream[q]); hipStreamDestroy(b->cstream[q]); }
+    for(int c = 0; c < ALD_NUM_CLASSES; c++) if(b->cdone[c]) hipEventDestroy(b->cdone[c]);
     if(b->ev0) hipEventDestroy(b->ev0);
     if(b->ev1) hipEventDestroy(b->ev1);
     if(b->stream) hipStreamDestroy(b->stream);

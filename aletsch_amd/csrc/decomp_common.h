@@ -99,15 +99,16 @@ struct KernelArgs {                               // lives in device memory; eve
 };
 
 // ---- size classes ----
-#define ALD_NUM_CLASSES 6
+#define ALD_NUM_CLASSES 7
 template<int ID> struct ClassDims;
 template<> struct ClassDims<0> { enum { MAXV = 64,   MAXE = 160,  NW = 1 }; };
 template<> struct ClassDims<1> { enum { MAXV = 128,  MAXE = 288,  NW = 1 }; };
 template<> struct ClassDims<2> { enum { MAXV = 256,  MAXE = 640,  NW = 2 }; };
 template<> struct ClassDims<3> { enum { MAXV = 512,  MAXE = 1280, NW = 4 }; };
 template<> struct ClassDims<4> { enum { MAXV = 1024, MAXE = 2280, NW = 8 }; };    // 2280 edges: three workgroups per CU (3 x 54.2 KB of LDS); holds E <= 2052
-template<> struct ClassDims<5> { enum { MAXV = 4096, MAXE = 16384, NW = 64 }; };   // catch-all: hot state in the wave's HBM slab, not LDS
-#define ALD_FIRST_GLOBAL_CLASS 5
+template<> struct ClassDims<5> { enum { MAXV = 2048, MAXE = 6600, NW = 32 }; };    // one workgroup per CU: 145 KB of its 160 KB LDS; V <= 1024, E <= 5940
+template<> struct ClassDims<6> { enum { MAXV = 4096, MAXE = 16384, NW = 64 }; };   // catch-all: hot state in the wave's HBM slab, not LDS
+#define ALD_FIRST_GLOBAL_CLASS 6
 
 // per-wave HBM slab, laid out at compile time (so that cold pointers cost no registers)
 template<int MAXV, int MAXE, int NW>
@@ -142,7 +143,7 @@ static inline ClassInfo class_info(int c)
     switch(c) {
 #define ALD_CI(ID) case ID: { typedef ColdLayoutT<ClassDims<ID>::MAXV, ClassDims<ID>::MAXE, ClassDims<ID>::NW> L; \
         return ClassInfo{ClassDims<ID>::MAXV, ClassDims<ID>::MAXE, ClassDims<ID>::NW, L::SP_CAP, L::HL_CAP, L::total}; }
-    ALD_CI(0) ALD_CI(1) ALD_CI(2) ALD_CI(3) ALD_CI(4) ALD_CI(5)
+    ALD_CI(0) ALD_CI(1) ALD_CI(2) ALD_CI(3) ALD_CI(4) ALD_CI(5) ALD_CI(6)
 #undef ALD_CI
     }
     return ClassInfo{0, 0, 0, 0, 0, 0};
