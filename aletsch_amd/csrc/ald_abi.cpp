@@ -18,11 +18,9 @@
 using namespace ald;
 
 extern "C" {
-int ald_launch_c0(const KernelArgs *, int, hipStream_t); int ald_launch_c1(const KernelArgs *, int, hipStream_t); int ald_launch_c2(const KernelArgs *, int, hipStream_t);
-int ald_launch_c3(const KernelArgs *, int, hipStream_t); int ald_launch_c4(const KernelArgs *, int, hipStream_t); int ald_launch_c5(const KernelArgs *, int, hipStream_t); int ald_launch_c6(const KernelArgs *, int, hipStream_t);
-int ald_occupancy_c0(); int ald_occupancy_c1(); int ald_occupancy_c2(); int ald_occupancy_c3(); int ald_occupancy_c4(); int ald_occupancy_c5(); int ald_occupancy_c6();
-unsigned long long ald_hot_slab_bytes_c0(); unsigned long long ald_hot_slab_bytes_c1(); unsigned long long ald_hot_slab_bytes_c2();
-unsigned long long ald_hot_slab_bytes_c3(); unsigned long long ald_hot_slab_bytes_c4(); unsigned long long ald_hot_slab_bytes_c5(); unsigned long long ald_hot_slab_bytes_c6();
+#define ALD_DECL(ID) int ald_launch_c##ID(const KernelArgs *, int, hipStream_t); int ald_occupancy_c##ID(); unsigned long long ald_hot_slab_bytes_c##ID();
+ALD_FOR_EACH_CLASS(ALD_DECL)
+#undef ALD_DECL
 }
 
 namespace {
@@ -34,9 +32,15 @@ int set_err(int code, const std::string &s) { g_err = s; return code; }
 typedef int (*launch_fn)(const KernelArgs *, int, hipStream_t);
 typedef int (*occ_fn)();
 typedef unsigned long long (*hot_fn)();
-const launch_fn k_launch[ALD_NUM_CLASSES] = {ald_launch_c0, ald_launch_c1, ald_launch_c2, ald_launch_c3, ald_launch_c4, ald_launch_c5, ald_launch_c6};
-const occ_fn k_occ[ALD_NUM_CLASSES] = {ald_occupancy_c0, ald_occupancy_c1, ald_occupancy_c2, ald_occupancy_c3, ald_occupancy_c4, ald_occupancy_c5, ald_occupancy_c6};
-const hot_fn k_hot[ALD_NUM_CLASSES] = {ald_hot_slab_bytes_c0, ald_hot_slab_bytes_c1, ald_hot_slab_bytes_c2, ald_hot_slab_bytes_c3, ald_hot_slab_bytes_c4, ald_hot_slab_bytes_c5, ald_hot_slab_bytes_c6};
+#define ALD_L(ID) ald_launch_c##ID,
+#define ALD_O(ID) ald_occupancy_c##ID,
+#define ALD_H(ID) ald_hot_slab_bytes_c##ID,
+const launch_fn k_launch[ALD_NUM_CLASSES] = { ALD_FOR_EACH_CLASS(ALD_L) };
+const occ_fn k_occ[ALD_NUM_CLASSES] = { ALD_FOR_EACH_CLASS(ALD_O) };
+const hot_fn k_hot[ALD_NUM_CLASSES] = { ALD_FOR_EACH_CLASS(ALD_H) };
+#undef ALD_L
+#undef ALD_O
+#undef ALD_H
 
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
@@ -67,7 +71,7 @@ struct ald_batch {
     DevBuf d_in, d_status, d_npaths, d_niters, d_pool, d_poolused, d_trace_n, d_trace_codes, d_trace_vals, d_work, d_counter, d_args;
     DevBuf d_slabs[ALD_NUM_CLASSES];
     int blocks[ALD_NUM_CLASSES] = {};
-    int occ[ALD_NUM_CLASSES] = {-1, -1, -1, -1, -1, -1, -1};
+    int occ[ALD_NUM_CLASSES]; ald_batch() { for(int c = 0; c < ALD_NUM_CLASSES; c++) occ[c] = -1; }
     uint64_t pool_cap_words = 0;
     int trace_cap = 0;
     bool uploaded = false, ran = false, downloaded = false;

@@ -99,16 +99,23 @@ struct KernelArgs {                               // lives in device memory; eve
 };
 
 // ---- size classes ----
-#define ALD_NUM_CLASSES 7
+// Geometric-ish ladder: a graph pays for the LDS of its class for as long as it runs, and a mixed batch is bound by exactly that
+// product (LDS bytes x time), so the steps are fine where the time is spent (257..512 vertices in cfg3).
+#define ALD_NUM_CLASSES 11
+#define ALD_FOR_EACH_CLASS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 template<int ID> struct ClassDims;
-template<> struct ClassDims<0> { enum { MAXV = 64,   MAXE = 160,  NW = 1 }; };
-template<> struct ClassDims<1> { enum { MAXV = 128,  MAXE = 288,  NW = 1 }; };
-template<> struct ClassDims<2> { enum { MAXV = 256,  MAXE = 640,  NW = 2 }; };
-template<> struct ClassDims<3> { enum { MAXV = 512,  MAXE = 1280, NW = 4 }; };
-template<> struct ClassDims<4> { enum { MAXV = 1024, MAXE = 2280, NW = 8 }; };    // 2280 edges: three workgroups per CU (3 x 54.2 KB of LDS); holds E <= 2052
-template<> struct ClassDims<5> { enum { MAXV = 2048, MAXE = 6600, NW = 32 }; };    // one workgroup per CU: 145 KB of its 160 KB LDS; V <= 1024, E <= 5940
-template<> struct ClassDims<6> { enum { MAXV = 4096, MAXE = 16384, NW = 64 }; };   // catch-all: hot state in the wave's HBM slab, not LDS
-#define ALD_FIRST_GLOBAL_CLASS 6
+template<> struct ClassDims<0>  { enum { MAXV = 64,   MAXE = 160,  NW = 1 }; };     // V <= 32
+template<> struct ClassDims<1>  { enum { MAXV = 128,  MAXE = 288,  NW = 1 }; };     // V <= 64   (the bench workload: 20 workgroups per CU)
+template<> struct ClassDims<2>  { enum { MAXV = 256,  MAXE = 640,  NW = 2 }; };     // V <= 128
+template<> struct ClassDims<3>  { enum { MAXV = 384,  MAXE = 960,  NW = 3 }; };     // V <= 192
+template<> struct ClassDims<4>  { enum { MAXV = 512,  MAXE = 1280, NW = 4 }; };     // V <= 256
+template<> struct ClassDims<5>  { enum { MAXV = 640,  MAXE = 1440, NW = 5 }; };     // V <= 320
+template<> struct ClassDims<6>  { enum { MAXV = 768,  MAXE = 1696, NW = 6 }; };     // V <= 384  (1696 edges: four workgroups per CU)
+template<> struct ClassDims<7>  { enum { MAXV = 896,  MAXE = 2000, NW = 7 }; };     // V <= 448
+template<> struct ClassDims<8>  { enum { MAXV = 1024, MAXE = 2280, NW = 8 }; };     // V <= 512  (2280 edges: three workgroups per CU; holds E <= 2052)
+template<> struct ClassDims<9>  { enum { MAXV = 2048, MAXE = 6600, NW = 32 }; };    // one workgroup per CU: 145 KB of its 160 KB LDS; V <= 1024, E <= 5940
+template<> struct ClassDims<10> { enum { MAXV = 4096, MAXE = 16384, NW = 64 }; };   // catch-all: hot state in the wave's HBM slab, not LDS
+#define ALD_FIRST_GLOBAL_CLASS 10
 
 // per-wave HBM slab, laid out at compile time (so that cold pointers cost no registers)
 template<int MAXV, int MAXE, int NW>
@@ -143,7 +150,7 @@ static inline ClassInfo class_info(int c)
     switch(c) {
 #define ALD_CI(ID) case ID: { typedef ColdLayoutT<ClassDims<ID>::MAXV, ClassDims<ID>::MAXE, ClassDims<ID>::NW> L; \
         return ClassInfo{ClassDims<ID>::MAXV, ClassDims<ID>::MAXE, ClassDims<ID>::NW, L::SP_CAP, L::HL_CAP, L::total}; }
-    ALD_CI(0) ALD_CI(1) ALD_CI(2) ALD_CI(3) ALD_CI(4) ALD_CI(5) ALD_CI(6)
+    ALD_FOR_EACH_CLASS(ALD_CI)
 #undef ALD_CI
     }
     return ClassInfo{0, 0, 0, 0, 0, 0};

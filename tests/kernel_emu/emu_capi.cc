@@ -8,8 +8,9 @@
 #include <cstdlib>
 
 extern "C" {
-void emu_run_class_0(const ald::KernelArgs *); void emu_run_class_1(const ald::KernelArgs *); void emu_run_class_2(const ald::KernelArgs *);
-void emu_run_class_3(const ald::KernelArgs *); void emu_run_class_4(const ald::KernelArgs *); void emu_run_class_5(const ald::KernelArgs *); void emu_run_class_6(const ald::KernelArgs *);
+#define ALD_DECL(ID) void emu_run_class_##ID(const ald::KernelArgs *);
+ALD_FOR_EACH_CLASS(ALD_DECL)
+#undef ALD_DECL
 }
 using namespace ald;
 
@@ -50,7 +51,9 @@ int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_
         if(cls[g] < 0) status[g] = ALD_ST_CAPACITY; else work[cls[g]].push_back(g);
     }
     typedef void (*run_fn)(const KernelArgs *);
-    run_fn runs[ALD_NUM_CLASSES] = {emu_run_class_0, emu_run_class_1, emu_run_class_2, emu_run_class_3, emu_run_class_4, emu_run_class_5, emu_run_class_6};
+#define ALD_R(ID) emu_run_class_##ID,
+    run_fn runs[ALD_NUM_CLASSES] = { ALD_FOR_EACH_CLASS(ALD_R) };
+#undef ALD_R
     for(int pass = 0; pass < ALD_NUM_CLASSES + 1; pass++) {
         bool any = false;
         for(int c = 0; c < ALD_NUM_CLASSES; c++) {

@@ -120,14 +120,16 @@ def test_staging_normalises_unsorted_input():
     assert not common.compare_results(ra, rb, a.n)
 
 
-def test_catch_all_class_large_graphs():
-    """graphs beyond the LDS classes (V > 512) run in the catch-all class whose hot state lives in the wave's slab"""
-    pg = A.synth(seed=99, n_graphs=2, v_min=700, v_max=900, edges_per_vertex=4)
-    want, st, _, _ = common.oracle_run(pg)
-    got, it, cl = common.emu_run(pg)
-    assert (cl == 5).all()
-    assert not common.compare_results(want, got, pg.n)
-    assert np.array_equal(it, st[:, 3])
+def test_large_classes():
+    """graphs beyond 512 vertices: the one-workgroup-per-CU class up to 1024 vertices, then the catch-all class whose hot state lives
+    in the wave's slab"""
+    for kw, want_cls in ((dict(seed=99, n_graphs=2, v_min=700, v_max=900, edges_per_vertex=4), 9), (dict(seed=96, n_graphs=2, v_min=1100, v_max=1300, edges_per_vertex=3), 10)):
+        pg = A.synth(**kw)
+        want, st, _, _ = common.oracle_run(pg)
+        got, it, cl = common.emu_run(pg)
+        assert (cl == want_cls).all(), cl
+        assert not common.compare_results(want, got, pg.n)
+        assert np.array_equal(it, st[:, 3])
 
 
 def test_explicit_edge_counts():

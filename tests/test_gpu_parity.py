@@ -179,7 +179,7 @@ def test_batch_into_result_sink():
 
 
 def test_large_classes_on_gpu():
-    """V > 512: class 5 (one workgroup per CU, 145 KB of LDS) up to 1024 vertices, beyond that the catch-all class 6 with its hot
+    """V > 512: class 9 (one workgroup per CU, 145 KB of LDS) up to 1024 vertices, beyond that the catch-all class 10 with its hot
     state in HBM; mixed with small graphs in the same batch (concurrent class streams)"""
     big = A.synth(seed=99, n_graphs=3, v_min=900, v_max=1000, edges_per_vertex=4)
     huge = A.synth(seed=97, n_graphs=2, v_min=1200, v_max=1500, edges_per_vertex=3)
@@ -190,7 +190,7 @@ def test_large_classes_on_gpu():
     with A.DecompBatch(0) as b:
         b.add(pg); b.upload(); b.run(); b.download()
         got = b.result()
-        assert b.class_info(5)["n_graphs"] == 3 and b.class_info(6)["n_graphs"] == 2
+        assert b.class_info(9)["n_graphs"] == 3 and b.class_info(10)["n_graphs"] == 2
     assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
 
 
