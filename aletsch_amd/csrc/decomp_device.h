@@ -689,7 +689,22 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     PROF_ADD(PF_T_BALANCE);
     const double wc = wcen;
     for(int j = 0; j < n; j++) { double w2 = fw[j]; fw[j] = A ? (wc <= w2 ? wc : w2) : (w2 <= wc ? w2 : wc); }
-    for(int i = 0; i < n; i++) { int k = i; uint32_t id = uni(H.eid[fe[i]]); while(k > 0 && (uint32_t)uni(H.eid[fe[ord[k - 1]]]) > id) { ord[k] = ord[k - 1]; k--; } ord[k] = i; }
+    int32_t *aux = SMALL ? nullptr : (int32_t*)(C.wi + 2 * (Cold::w_cap / 8));        // [n] second buffer of the large form (merge sort, deferred inserts)
+    if(SMALL) { for(int i = 0; i < n; i++) { int k = i; uint32_t id = uni(H.eid[fe[i]]); while(k > 0 && (uint32_t)uni(H.eid[fe[ord[k - 1]]]) > id) { ord[k] = ord[k - 1]; k--; } ord[k] = i; } }
+    else {      // a hub's fan can hold hundreds of edges: bottom-up merge sort of the positions by creation id
+        for(int i = 0; i < n; i++) ord[i] = i;
+        int32_t *src = ord, *dst = aux;
+        for(int wdt = 1; wdt < n; wdt *= 2) {
+            for(int lo = 0; lo < n; lo += 2 * wdt) {
+                int mid = lo + wdt < n ? lo + wdt : n, hi = lo + 2 * wdt < n ? lo + 2 * wdt : n, i = lo, j = mid, k = lo;
+                while(i < mid && j < hi) { if((uint32_t)H.eid[fe[src[j]]] < (uint32_t)H.eid[fe[src[i]]]) dst[k++] = src[j++]; else dst[k++] = src[i++]; }
+                while(i < mid) dst[k++] = src[i++];
+                while(j < hi) dst[k++] = src[j++];
+            }
+            int32_t *t2 = src; src = dst; dst = t2;
+        }
+        if(src != ord) for(int i = 0; i < n; i++) ord[i] = src[i];
+    }
     double mdc = 0;
     for(int q = 0; q < n; q++) { double w = fw[ord[q]]; if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } mdc = (q == 0) ? w : mdc + w; }
     H.ed[c].w = mdc;
@@ -747,8 +762,9 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         H.eid[f] = (uint16_t)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
         // the new edge far -> other sorts behind c = far -> x whenever other's key is above x's (always, except for vertices added by
         // decompose_vertex_extend): the walk starts at c
-        if(A) { H.ed[f].lk.es = (IDX)far; relink_in(other, f, (uint32_t)far); if(tkey((uint32_t)other) > tkey((uint32_t)x)) link_out_after(far, f, c); else link_out(far, f); }
-        else { H.ed[f].lk.et = (IDX)far; relink_out(other, f, tkey((uint32_t)far)); link_in(far, f); }
+        if(A) { H.ed[f].lk.es = (IDX)far; relink_in(other, f, (uint32_t)far); if(SMALL) { if(tkey((uint32_t)other) > tkey((uint32_t)x)) link_out_after(far, f, c); else link_out(far, f); } }
+        else { H.ed[f].lk.et = (IDX)far; relink_out(other, f, tkey((uint32_t)far)); if(SMALL) link_in(far, f); }
+        if(!SMALL) aux[q] = f;            // large form: the far vertex's list takes all new edges in ONE merge after the loop (nothing reads it meanwhile)
         fe[j] = -1;
         PROF_ADD(PF_T_MERGE_ADD);
         if(A) hs_replace2(c, f, f); else hs_replace2(f, c, f);
@@ -757,6 +773,38 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         PROF_ADD(PF_T_HS);
     }
     C.vx[x].vw = vwt;
+    if(!SMALL) {
+        // aux[0..n) = the merged edges in creation order; stable merge sort by the list's primary key (target for an out-list, source
+        // for an in-list) gives (key, id) order, then one walk of far's list places them all
+        int32_t *src = aux, *dst = ord;
+        for(int wdt = 1; wdt < n; wdt *= 2) {
+            for(int lo = 0; lo < n; lo += 2 * wdt) {
+                int mid = lo + wdt < n ? lo + wdt : n, hi = lo + 2 * wdt < n ? lo + 2 * wdt : n, i = lo, j = mid, k = lo;
+                while(i < mid && j < hi) {
+                    const uint32_t kj = A ? tkey(H.ed[src[j]].lk.et) : (uint32_t)H.ed[src[j]].lk.es, ki = A ? tkey(H.ed[src[i]].lk.et) : (uint32_t)H.ed[src[i]].lk.es;
+                    if(kj < ki) dst[k++] = src[j++]; else dst[k++] = src[i++];
+                }
+                while(i < mid) dst[k++] = src[i++];
+                while(j < hi) dst[k++] = src[j++];
+            }
+            int32_t *t2 = src; src = dst; dst = t2;
+        }
+        const bool counted = A ? (far == 0 && !uni(H.special_linked)) : (far == (int)uni(H.sinkp) && !uni(H.special_linked));
+        if(!counted) {
+            IDX *pp = A ? &H.out_head[far] : &H.in_head[far]; IDX cur = *pp; int guard = MAXE + n;
+            for(int q = 0; q < n; q++) {
+                const int e = src[q]; const uint32_t ke = A ? tkey(H.ed[e].lk.et) : (uint32_t)H.ed[e].lk.es;
+                while(uni(cur != NIL) && guard-- > 0) {       // existing edges with key <= ke stay in front (their ids are older)
+                    const uint32_t kc = A ? tkey(H.ed[cur].lk.et) : (uint32_t)H.ed[cur].lk.es;
+                    if(uni(kc > ke)) break;
+                    pp = A ? &H.ed[cur].lk.onx : &H.ed[cur].lk.inx; cur = *pp;
+                }
+                if(A) H.ed[e].lk.onx = cur; else H.ed[e].lk.inx = cur;
+                *pp = (IDX)e; pp = A ? &H.ed[e].lk.onx : &H.ed[e].lk.inx;
+            }
+        }
+        if(A) H.out_deg[far] = (IDX)((int)uni(H.out_deg[far]) + n); else H.in_deg[far] = (IDX)((int)uni(H.in_deg[far]) + n);
+    }
     if(n >= 2) hs_remove(c);
     if(!consumed) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }      // c kept a remainder: the reference asserts on the degree of x
     // remove_edge(c); x is left without edges
