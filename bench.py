@@ -157,6 +157,7 @@ def main():
                        "failed_graphs": n_bad, "paths_per_graph": float(len(res.weight)) / max(1, args.graphs),
                        "workgroups_per_cu": info["blocks_per_cu"], "grid": info["blocks_last_run"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_gbs": (traffic / (k_ms / 1e3) / 1e9) if traffic else None,      # measured HBM traffic over this run's kernel time
                          "kernel": "ald_decomp_kernel_c1", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": in_b + out_b,
                          "bytes_per_graph": (in_b + out_b) / args.graphs, "kernel_graphs_per_s": args.graphs / (k_ms / 1e3)},
         }
