@@ -1233,7 +1233,12 @@ ALD_FN bool sweep_smallest(double max_ratio)
             // removed); if one of them stops holding, or the phasing flags moved, every lane evaluates again
             const bool all = uni(H.hs_dirty) != 0 || (int)uni(H.out_deg[ds]) <= 1 || (int)uni(H.in_deg[dt]) <= 1;
             if(uni(H.hs_dirty)) { if(lane == 0) hs_refresh_flags(); wsync(); }
-            for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (all || i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } }
+            if(NC <= 2 || all) { for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (all || i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } } }
+            else {                                                          // many chunks: go straight to the (one or two) chunks of ds and dt
+                const int c1 = uni(ds) / ALD_WAVE, c2 = uni(dt) / ALD_WAVE;
+                { int i = c1 * ALD_WAVE + lane; if(i >= 1 && i < vend && (i == ds || i == dt)) { cr[c1] = 0; ce[c1] = eval_smallest(i, cr[c1]); } }
+                if(c2 != c1) { int i = c2 * ALD_WAVE + lane; if(i >= 1 && i < vend && i == dt) { cr[c2] = 0; ce[c2] = eval_smallest(i, cr[c2]); } }
+            }
             PROF_ADD(PF_SMALL_MUT);
             flag = true;
             start = hit + 1;
@@ -1249,7 +1254,12 @@ ALD_FN bool sweep_smallest(double max_ratio)
             any = true;
             // back to the cascade unless R1..R3 provably have nothing to do
             if(!may_chain || uni(H.status) || uni(H.maybe_broken) || uni(H.maybe_triv) || uni(H.hs_dirty)) { PROF_ADD(PF_SMALL_MUT); return true; }
-            for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } }
+            if(NC <= 2) { for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } } }
+            else {
+                const int c1 = uni(ds) / ALD_WAVE, c2 = uni(dt) / ALD_WAVE;
+                { int i = c1 * ALD_WAVE + lane; if(i >= 1 && i < vend && (i == ds || i == dt)) { cr[c1] = 0; ce[c1] = eval_smallest(i, cr[c1]); } }
+                if(c2 != c1) { int i = c2 * ALD_WAVE + lane; if(i >= 1 && i < vend && i == dt) { cr[c2] = 0; ce[c2] = eval_smallest(i, cr[c2]); } }
+            }
             PROF_ADD(PF_SMALL_MUT);
         } else {
             any = true;
