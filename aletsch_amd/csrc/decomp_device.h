@@ -25,6 +25,11 @@
 #ifndef ALD_CLASS_ID
 #error "compile with -DALD_CLASS_ID=<0..4> (one translation unit per size class)"
 #endif
+#if defined(__HIP__) || defined(__clang__)
+  #define ALD_UNROLL _Pragma("unroll")
+#else
+  #define ALD_UNROLL _Pragma("GCC unroll 16")
+#endif
 #define ALD_CAT2(a, b) a##b
 #define ALD_CAT(a, b) ALD_CAT2(a, b)
 #define ALD_CLASS_NS ALD_CAT(ald_c, ALD_CLASS_ID)
@@ -1164,7 +1169,20 @@ ALD_FN bool sweep_smallest(double max_ratio)
     if(lane == 0 && uni(H.hs_dirty)) hs_refresh_flags();
     wsync();
     double cr[NC]; int ce[NC];
-    for(int c = 0; c < NC; c++) { cr[c] = 0; ce[c] = -1; int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend) ce[c] = eval_smallest(i, cr[c]); }
+    // Classes of 3..16 chunks keep the arrays in registers: every loop over the chunks is fully unrolled (constant indices) and the few
+    // accesses with a run-time chunk number go through a select chain; with a run-time index they would live in scratch memory and
+    // every sweep would wait for it chunk by chunk.  Smaller classes are unrolled anyway, larger ones use private memory.
+    constexpr bool REG = (NC > 2 && NC <= 16);
+    auto cput = [&](int c, double r, int e) { if(!REG) { cr[c] = r; ce[c] = e; } else { ALD_UNROLL for(int k = 0; k < NC; k++) if(k == c) { cr[k] = r; ce[k] = e; } } };
+    auto cget_e = [&](int c) -> int { if(!REG) return ce[c]; int v = -1; ALD_UNROLL for(int k = 0; k < NC; k++) if(k == c) v = ce[k]; return v; };
+    auto eval_chunk = [&](int c, bool every, int ds, int dt) {        // (re-)evaluate this lane's vertex of chunk c
+        int i = c * ALD_WAVE + lane; double r = 0; int e = -1; bool mine = i >= 1 && i < vend && (every || i == ds || i == dt);
+        if(mine) e = eval_smallest(i, r);
+        if(!REG) { if(mine) { cr[c] = r; ce[c] = e; } }
+        else { ALD_UNROLL for(int k = 0; k < NC; k++) if(k == c && mine) { cr[k] = r; ce[k] = e; } }
+    };
+    ALD_UNROLL for(int c = 0; c < NC; c++) { cr[c] = 0; ce[c] = -1; }
+    { const int nch = (vend + ALD_WAVE - 1) / ALD_WAVE; for(int c = 0; c < nch; c++) eval_chunk(c, true, -1, -1); }
     const bool may_chain = !(uni(H.p_ratio[7]) > 1.0) && !uni(H.any_strand);
     bool any = false;
     int guard = MAXE + 8;
@@ -1197,18 +1215,22 @@ ALD_FN bool sweep_smallest(double max_ratio)
             }
             } else {
             // (1) chunk by chunk, cheap: an invalid evaluation anywhere in the chunk, else the first "now" vertex (ratio < 0.01)
-            for(int c = start / ALD_WAVE; c < NC && c * ALD_WAVE < vend && hit < 0; c++) {
+            const int c0 = start / ALD_WAVE; bool badw = false;
+            ALD_UNROLL for(int c = 0; c < NC; c++) {
+                if(c < c0 || c * ALD_WAVE >= vend || hit >= 0 || badw) continue;          // (wave-uniform)
                 const int i = c * ALD_WAVE + lane;
                 const int e = (i >= start && i < vend) ? ce[c] : -1;
-                if(wballot(e == -3)) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); wsync(); return true; }
+                if(wballot(e == -3)) { badw = true; continue; }
                 const uint64_t now = wballot(e >= 0 && cr[c] < 0.01);
                 if(now) { const int l = ffs64(now); hit = c * ALD_WAVE + l; hit_e = wshfl(e, l); hit_r = wshfl(cr[c], l); }
             }
+            if(badw) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); wsync(); return true; }
             // (2) the candidates before it: each lane folds its own chunks (later vertex wins ties), then ONE reduction across lanes
             {
                 const int lim = hit >= 0 ? hit : vend;
                 double rr = DBL_MAX; int vv = -1;
-                for(int c = start / ALD_WAVE; c < NC && c * ALD_WAVE < lim; c++) {
+                ALD_UNROLL for(int c = 0; c < NC; c++) {
+                    if(c < c0 || c * ALD_WAVE >= lim) continue;
                     const int i = c * ALD_WAVE + lane;
                     if(i >= start && i < lim && ce[c] >= 0 && (vv < 0 || !(rr < cr[c]))) { rr = cr[c]; vv = i; }
                 }
@@ -1218,7 +1240,7 @@ ALD_FN bool sweep_smallest(double max_ratio)
                     if(take) { rr = r2; vv = v2; }
                 }
                 rr = wshfl(rr, 0); vv = wshfl(vv, 0);
-                if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = wshfl(ce[vv / ALD_WAVE], vv % ALD_WAVE); }   // if(ratio < r) continue;
+                if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = wshfl(cget_e(vv / ALD_WAVE), vv % ALD_WAVE); }   // if(ratio < r) continue;
             }
             }
             PROF_ADD(PF_SMALL_EVAL);
@@ -1233,11 +1255,12 @@ ALD_FN bool sweep_smallest(double max_ratio)
             // removed); if one of them stops holding, or the phasing flags moved, every lane evaluates again
             const bool all = uni(H.hs_dirty) != 0 || (int)uni(H.out_deg[ds]) <= 1 || (int)uni(H.in_deg[dt]) <= 1;
             if(uni(H.hs_dirty)) { if(lane == 0) hs_refresh_flags(); wsync(); }
-            if(NC <= 2 || all) { for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (all || i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } } }
+            if(NC <= 2) { for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (all || i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } } }
+            else if(all) { const int nch = (vend + ALD_WAVE - 1) / ALD_WAVE; for(int c = 0; c < nch; c++) eval_chunk(c, true, -1, -1); }
             else {                                                          // many chunks: go straight to the (one or two) chunks of ds and dt
                 const int c1 = uni(ds) / ALD_WAVE, c2 = uni(dt) / ALD_WAVE;
-                { int i = c1 * ALD_WAVE + lane; if(i >= 1 && i < vend && (i == ds || i == dt)) { cr[c1] = 0; ce[c1] = eval_smallest(i, cr[c1]); } }
-                if(c2 != c1) { int i = c2 * ALD_WAVE + lane; if(i >= 1 && i < vend && i == dt) { cr[c2] = 0; ce[c2] = eval_smallest(i, cr[c2]); } }
+                eval_chunk(c1, false, ds, dt);
+                if(c2 != c1) eval_chunk(c2, false, ds, dt);
             }
             PROF_ADD(PF_SMALL_MUT);
             flag = true;
@@ -1257,8 +1280,8 @@ ALD_FN bool sweep_smallest(double max_ratio)
             if(NC <= 2) { for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } } }
             else {
                 const int c1 = uni(ds) / ALD_WAVE, c2 = uni(dt) / ALD_WAVE;
-                { int i = c1 * ALD_WAVE + lane; if(i >= 1 && i < vend && (i == ds || i == dt)) { cr[c1] = 0; ce[c1] = eval_smallest(i, cr[c1]); } }
-                if(c2 != c1) { int i = c2 * ALD_WAVE + lane; if(i >= 1 && i < vend && i == dt) { cr[c2] = 0; ce[c2] = eval_smallest(i, cr[c2]); } }
+                eval_chunk(c1, false, ds, dt);
+                if(c2 != c1) eval_chunk(c2, false, ds, dt);
             }
             PROF_ADD(PF_SMALL_MUT);
         } else {
