@@ -56,6 +56,12 @@ struct PinBuf {
 } // namespace
 
 enum { ALD_SIDE_STREAMS = 3 };
+// one pass of a batch, staged: work lists, kernel arguments, grid sizes, stream assignment (see stage_pass)
+struct StagedPass {
+    std::vector<int32_t> flat; std::vector<KernelArgs> args;
+    int nblk[ALD_NUM_CLASSES]; int order[ALD_NUM_CLASSES]; int stream_of[ALD_NUM_CLASSES]; int nord = 0; size_t tot = 0;
+};
+
 struct ald_batch {
     int device = 0; int n_cus = 0;
     Params prm;
@@ -72,6 +78,7 @@ struct ald_batch {
     DevBuf d_slabs[ALD_NUM_CLASSES];
     int blocks[ALD_NUM_CLASSES] = {};
     int occ[ALD_NUM_CLASSES]; ald_batch() { for(int c = 0; c < ALD_NUM_CLASSES; c++) occ[c] = -1; }
+    StagedPass *pass0 = nullptr; bool pass0_on_device = false; std::vector<int32_t> cls0;      // first pass of the uploaded batch, staged at upload time
     uint64_t pool_cap_words = 0;
     int trace_cap = 0;
     bool uploaded = false, ran = false, downloaded = false;
@@ -105,21 +112,31 @@ int occupancy_for(ald_batch *b, int c)
 }
 
 // launch one pass: every class that has work gets its own persistent grid on the batch stream
-int launch_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], int pass)
+// One pass = one persistent grid per size class that has work.  Staging (work lists and kernel arguments in HBM, slabs sized,
+// classes dealt to the side streams) is separate from firing, so that the first pass of a batch is staged once, at upload time:
+// a run is then three memsets and the launches.
+int push_pass(ald_batch *b, const StagedPass &P)         // work lists + arguments -> HBM
+{
+    if(P.tot == 0) return ALD_OK;
+    HIPCHK(hipMemcpyAsync(b->d_work.p, P.flat.data(), 4 * P.tot, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_args.p, P.args.data(), sizeof(KernelArgs) * ALD_NUM_CLASSES, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return ALD_OK;
+}
+
+int stage_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], int pass, StagedPass &P)
 {
     const int n = b->hb.n();
-    size_t tot = 0; for(int c = 0; c < ALD_NUM_CLASSES; c++) tot += work[c].size();
-    if(tot == 0) return ALD_OK;
+    P.tot = 0; for(int c = 0; c < ALD_NUM_CLASSES; c++) P.tot += work[c].size();
+    P.nord = 0;
+    if(P.tot == 0) return ALD_OK;
     if(b->d_work.ensure(4 * (size_t)n + 64)) return set_err(ALD_ERR_NOMEM, "work list");
     if(b->d_counter.ensure(4 * ALD_NUM_CLASSES * 64)) return set_err(ALD_ERR_NOMEM, "counters");
     if(b->d_args.ensure(sizeof(KernelArgs) * ALD_NUM_CLASSES)) return set_err(ALD_ERR_NOMEM, "kernel args");
-    HIPCHK(hipMemsetAsync(b->d_counter.p, 0, 4 * ALD_NUM_CLASSES * 64, b->stream));
     size_t woff = 0;
-    std::vector<KernelArgs> args(ALD_NUM_CLASSES);
-    std::vector<int32_t> flat(tot);
-    int nblk[ALD_NUM_CLASSES];
+    P.args.assign(ALD_NUM_CLASSES, KernelArgs()); P.flat.resize(P.tot);
     for(int c = 0; c < ALD_NUM_CLASSES; c++) {
-        nblk[c] = 0;
+        P.nblk[c] = 0;
         if(work[c].empty()) continue;
         ClassInfo ci = class_info(c);
         int per_cu = occupancy_for(b, c);
@@ -130,9 +147,9 @@ int launch_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], 
         if((size_t)want > work[c].size()) want = (int)work[c].size();
         if(want < 1) want = 1;
         if(b->d_slabs[c].ensure((size_t)want * stride)) return set_err(ALD_ERR_NOMEM, "class slab");
-        nblk[c] = want;
-        memcpy(flat.data() + woff, work[c].data(), 4 * work[c].size());
-        KernelArgs &A = args[c]; memset(&A, 0, sizeof(A));
+        P.nblk[c] = want;
+        memcpy(P.flat.data() + woff, work[c].data(), 4 * work[c].size());
+        KernelArgs &A = P.args[c]; memset(&A, 0, sizeof(A));
         A.in = b->hb.make_batch_in((uint8_t*)b->d_in.p, b->sec);
         A.out.status = (int32_t*)b->d_status.p; A.out.n_paths = (int32_t*)b->d_npaths.p; A.out.n_iters = (int32_t*)b->d_niters.p;
         A.out.pool_used = (unsigned long long*)b->d_poolused.p; A.out.pool = (uint32_t*)b->d_pool.p; A.out.pool_cap = b->pool_cap_words;
@@ -143,34 +160,50 @@ int launch_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], 
         A.slabs = (uint8_t*)b->d_slabs[c].p; A.slab_stride = stride;
         woff += work[c].size();
     }
-    HIPCHK(hipMemcpyAsync(b->d_work.p, flat.data(), 4 * tot, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(b->d_args.p, args.data(), sizeof(KernelArgs) * ALD_NUM_CLASSES, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));          // flat / args are stack-lifetime host buffers
-    // fork: classes with work are dealt to the side streams, heaviest first onto the least loaded stream (cost ~ sum of V * E: the
-    // rule cascade is superlinear in the graph size); the batch stream joins them all before ev1
-    double cost[ALD_NUM_CLASSES]; int order[ALD_NUM_CLASSES]; int nord = 0;
+    // classes with work are dealt to the side streams, heaviest first onto the least loaded stream (cost ~ sum of V * E: the rule
+    // cascade is superlinear in the graph size)
+    double cost[ALD_NUM_CLASSES];
     for(int c = 0; c < ALD_NUM_CLASSES; c++) {
         cost[c] = 0;
-        if(nblk[c] == 0) continue;
+        if(P.nblk[c] == 0) continue;
         for(int32_t g : work[c]) cost[c] += (double)b->hb.g_nv[g] * (double)b->hb.g_ne[g];
-        cost[c] /= (double)nblk[c];                       // per resident wave
-        order[nord++] = c;
+        cost[c] /= (double)P.nblk[c];                     // per resident wave
+        P.order[P.nord++] = c;
     }
-    std::sort(order, order + nord, [&](int x, int y) { return cost[x] > cost[y]; });
+    std::sort(P.order, P.order + P.nord, [&](int x, int y) { return cost[x] > cost[y]; });
     double load[ALD_SIDE_STREAMS] = {0, 0, 0};
-    HIPCHK(hipEventRecord(b->ev0, b->stream));
-    for(int k = 0; k < nord; k++) {
-        const int c = order[k];
+    for(int k = 0; k < P.nord; k++) {
+        const int c = P.order[k];
         int st = 0; for(int q = 1; q < ALD_SIDE_STREAMS; q++) if(load[q] < load[st]) st = q;
-        load[st] += cost[c];
-        b->blocks[c] = nblk[c];
+        load[st] += cost[c]; P.stream_of[c] = st;
+    }
+    return push_pass(b, P);
+}
+
+int fire_pass(ald_batch *b, const StagedPass &P)          // fork on the side streams behind ev0, join on the batch stream before ev1
+{
+    if(P.tot == 0) return ALD_OK;
+    HIPCHK(hipMemsetAsync(b->d_counter.p, 0, 4 * ALD_NUM_CLASSES * 64, b->stream));
+    HIPCHK(hipEventRecord(b->ev0, b->stream));
+    for(int k = 0; k < P.nord; k++) {
+        const int c = P.order[k], st = P.stream_of[c];
+        b->blocks[c] = P.nblk[c];
         HIPCHK(hipStreamWaitEvent(b->cstream[st], b->ev0, 0));
-        if(k_launch[c]((const KernelArgs*)b->d_args.p + c, nblk[c], b->cstream[st]) != 0) return set_err(ALD_ERR_HIP, "kernel launch failed");
+        if(k_launch[c]((const KernelArgs*)b->d_args.p + c, P.nblk[c], b->cstream[st]) != 0) return set_err(ALD_ERR_HIP, "kernel launch failed");
         HIPCHK(hipEventRecord(b->cdone[c], b->cstream[st]));
         HIPCHK(hipStreamWaitEvent(b->stream, b->cdone[c], 0));
     }
     HIPCHK(hipEventRecord(b->ev1, b->stream));
     return ALD_OK;
+}
+
+int launch_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], int pass)      // a retry pass: staged and fired at once
+{
+    StagedPass P;
+    int rc = stage_pass(b, work, pass, P);
+    if(rc != ALD_OK) return rc;
+    b->pass0_on_device = false;                          // the work-list / argument buffers now hold this pass
+    return fire_pass(b, P);
 }
 
 } // namespace
@@ -215,7 +248,7 @@ int ald_batch_destroy(ald_batch *b)
     if(!b) return ALD_OK;
     hipSetDevice(b->device);
     if(b->stream) hipStreamSynchronize(b->stream);
-    b->pin_in.release(); b->pin_out.release();
+    b->pin_in.release(); b->pin_out.release(); delete b->pass0; b->pass0 = nullptr;
     DevBuf *bufs[] = {&b->d_in, &b->d_status, &b->d_npaths, &b->d_niters, &b->d_pool, &b->d_poolused, &b->d_trace_n, &b->d_trace_codes, &b->d_trace_vals, &b->d_work, &b->d_counter, &b->d_args};
     for(DevBuf *d : bufs) d->release();
     for(int c = 0; c < ALD_NUM_CLASSES; c++) b->d_slabs[c].release();
@@ -287,6 +320,25 @@ int ald_batch_upload(ald_batch *b)
         HIPCHK(hipMemsetAsync(b->d_trace_n.p, 0, 4 * (size_t)n + 4, b->stream));
     }
     HIPCHK(hipStreamSynchronize(b->stream));
+    // the first pass is part of what "resident" means: size class of every graph, longest-processing-time-first order inside a class
+    // (the persistent waves pull graphs in list order, so the big graphs of a class start early and the tail is made of small ones),
+    // work lists and kernel arguments in HBM
+    {
+        b->cls0.assign(n, -1);
+        std::vector<int32_t> work[ALD_NUM_CLASSES];
+        for(int g = 0; g < n; g++) {
+            int64_t ns = b->hb.off_s[g + 1] - b->hb.off_s[g], npv = b->hb.off_pv[g + 1] - b->hb.off_pv[g];
+            int c = pick_class(b->hb.g_nv[g], b->hb.g_ne[g], ns, npv);
+            b->cls0[g] = c;
+            if(c >= 0) work[c].push_back(g);
+        }
+        for(int c = 0; c < ALD_NUM_CLASSES; c++)
+            std::stable_sort(work[c].begin(), work[c].end(), [&](int32_t x, int32_t y) { return b->hb.g_ne[x] > b->hb.g_ne[y]; });
+        if(!b->pass0) b->pass0 = new StagedPass();
+        int rc = stage_pass(b, work, 0, *b->pass0);
+        if(rc != ALD_OK) return rc;
+        b->pass0_on_device = true;
+    }
     b->uploaded = true; b->ran = false; b->downloaded = false;
     return ALD_OK;
 }
@@ -294,26 +346,16 @@ int ald_batch_upload(ald_batch *b)
 int ald_batch_run(ald_batch *b)
 {
     if(!b) return ALD_ERR_INVALID;
-    if(!b->uploaded) return set_err(ALD_ERR_STATE, "ald_batch_run before ald_batch_upload");
+    if(!b->uploaded || !b->pass0) return set_err(ALD_ERR_STATE, "ald_batch_run before ald_batch_upload");
     HIPCHK(hipSetDevice(b->device));
     const int n = b->hb.n();
     HIPCHK(hipMemsetAsync(b->d_poolused.p, 0, 64, b->stream));
     HIPCHK(hipMemsetAsync(b->d_status.p, 0, 4 * (size_t)n + 4, b->stream));
     HIPCHK(hipMemsetAsync(b->d_npaths.p, 0, 4 * (size_t)n + 4, b->stream));
-    b->cls.assign(n, -1); b->attempt.assign(n, 0); b->status.assign(n, 0);
-    std::vector<int32_t> work[ALD_NUM_CLASSES];
-    for(int g = 0; g < n; g++) {
-        int64_t ns = b->hb.off_s[g + 1] - b->hb.off_s[g], npv = b->hb.off_pv[g + 1] - b->hb.off_pv[g];
-        int c = pick_class(b->hb.g_nv[g], b->hb.g_ne[g], ns, npv);
-        b->cls[g] = c;
-        if(c >= 0) work[c].push_back(g);
-    }
-    // longest-processing-time-first inside a class: the persistent waves pull graphs in list order, so the big graphs of a
-    // class start early and the tail of the launch is made of small ones
-    for(int c = 0; c < ALD_NUM_CLASSES; c++)
-        std::stable_sort(work[c].begin(), work[c].end(), [&](int32_t x, int32_t y) { return b->hb.g_ne[x] > b->hb.g_ne[y]; });
+    b->cls = b->cls0; b->attempt.assign(n, 0); b->status.assign(n, 0);
     b->passes = 0; b->kernel_ms = 0;
-    int rc = launch_pass(b, work, 0);
+    if(!b->pass0_on_device) { int rc = push_pass(b, *b->pass0); if(rc != ALD_OK) return rc; b->pass0_on_device = true; }      // a retry pass of the last run used the buffers
+    int rc = fire_pass(b, *b->pass0);
     if(rc != ALD_OK) return rc;
     b->ran = true; b->downloaded = false;
     return ALD_OK;
