@@ -328,7 +328,7 @@ int ald_batch_upload(ald_batch *b)
         std::vector<int32_t> work[ALD_NUM_CLASSES];
         for(int g = 0; g < n; g++) {
             int64_t ns = b->hb.off_s[g + 1] - b->hb.off_s[g], npv = b->hb.off_pv[g + 1] - b->hb.off_pv[g];
-            int c = pick_class(b->hb.g_nv[g], b->hb.g_ne[g], ns, npv);
+            int c = debug_underclass(pick_class(b->hb.g_nv[g], b->hb.g_ne[g], ns, npv));
             b->cls0[g] = c;
             if(c >= 0) work[c].push_back(g);
         }

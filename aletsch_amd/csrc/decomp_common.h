@@ -1,5 +1,6 @@
 // decomp_common.h -- types shared by the device engine (decomp_device.h), the kernels and the host ABI.
 #pragma once
+#include <cstdlib>
 #include <stdint.h>
 #include <math.h>
 #include <float.h>
@@ -166,5 +167,17 @@ static inline int pick_class(int V, int E, int64_t n_samples, int64_t n_phasing_
     }
     return -1;
 }
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// test knob: ALD_DEBUG_UNDERCLASS=k starts every graph k classes below the one pick_class chose, so that the capacity-retry path
+// (status ALD_ST_CAPACITY -> re-queued one class up, stale records dropped) runs on ordinary inputs
+static inline int debug_underclass(int c)
+{
+    const char *e = getenv("ALD_DEBUG_UNDERCLASS");
+    const int k = e ? atoi(e) : 0;
+    if(c < 0 || k <= 0) return c;
+    return c - k < 0 ? 0 : c - k;
+}
+#endif
 
 } // namespace ald

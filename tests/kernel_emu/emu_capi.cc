@@ -47,7 +47,7 @@ int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_
     std::vector<int32_t> work[ALD_NUM_CLASSES];
     for(int g = 0; g < n; g++) {
         int64_t ns = B.off_s[g + 1] - B.off_s[g], npv = B.off_pv[g + 1] - B.off_pv[g];
-        cls[g] = pick_class(B.g_nv[g], B.g_ne[g], ns, npv, force_class);
+        cls[g] = debug_underclass(pick_class(B.g_nv[g], B.g_ne[g], ns, npv, force_class));
         if(cls[g] < 0) status[g] = ALD_ST_CAPACITY; else work[cls[g]].push_back(g);
     }
     typedef void (*run_fn)(const KernelArgs *);

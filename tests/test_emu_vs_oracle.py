@@ -45,12 +45,19 @@ def test_engine_op_trace_matches_oracle():
 
 
 def test_capacity_retry_moves_up_a_class():
-    """forcing every graph into a class that is too small must end with identical results after the automatic retry"""
-    pg = A.synth(seed=77, n_graphs=20, v_min=40, v_max=60, edges_per_vertex=4)
+    """ALD_DEBUG_UNDERCLASS starts every graph two classes too low: the engine must report ALD_ST_CAPACITY for it, the host re-queues
+    it one class up until it fits, and the final answer is the same (records of abandoned attempts are dropped)"""
+    import os
+    pg = A.synth(seed=77, n_graphs=40, v_min=40, v_max=200, edges_per_vertex=4, phasing_per_graph=3)
     want = common.oracle_run(pg)[0]
-    got, _, cl = common.emu_run(pg, force_class=0)
+    _, _, cl_plain = common.emu_run(pg)
+    os.environ["ALD_DEBUG_UNDERCLASS"] = "2"
+    try:
+        got, _, cl = common.emu_run(pg)
+    finally:
+        del os.environ["ALD_DEBUG_UNDERCLASS"]
     assert not common.compare_results(want, got, pg.n)
-    assert (cl >= 1).all()
+    assert (cl >= np.maximum(cl_plain - 2, 0)).all() and (cl > np.maximum(cl_plain - 2, 0)).any()      # at least one graph had to climb
 
 
 def test_nondefault_parameters():

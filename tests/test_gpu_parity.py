@@ -194,6 +194,23 @@ def test_large_classes_on_gpu():
     assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
 
 
+def test_capacity_retry_on_gpu():
+    """graphs started two classes too low (ALD_DEBUG_UNDERCLASS): CAPACITY -> re-queued one class up inside ald_batch_download until
+    they fit; same answer; and a second run of the same resident batch (first pass re-staged after the retries) as well"""
+    import os
+    pg = A.synth(seed=78, n_graphs=300, v_min=20, v_max=300, edges_per_vertex=4, phasing_per_graph=3)
+    want = common.oracle_run(pg, threads=4)[0]
+    os.environ["ALD_DEBUG_UNDERCLASS"] = "2"
+    try:
+        with A.DecompBatch(0) as b:
+            b.add(pg); b.upload()
+            for rep in range(2):
+                b.run(); b.download()
+                assert not common.compare_results(want, b.result(), pg.n, conf_tol=1e-9)
+    finally:
+        del os.environ["ALD_DEBUG_UNDERCLASS"]
+
+
 def test_explicit_edge_counts_on_gpu():
     """edge_info.count handed over separately from the sample sets (see tests/test_emu_vs_oracle.py)"""
     pg = A.synth(seed=91, n_graphs=300, v_min=8, v_max=90, edges_per_vertex=3, n_samples=3, phasing_per_graph=3, weight_mode=1)
