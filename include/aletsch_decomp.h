@@ -37,7 +37,7 @@ extern "C" {
 
 /* ---- per-graph status words (ald_result_view.status) ---- */
 #define ALD_ST_OK              0
-#define ALD_ST_SKIPPED_LARGE   1   /* |V| > max_num_exons: main loop skipped (scallop.cc:49), greedy still ran */
+#define ALD_ST_SKIPPED_LARGE   1   /* the rule loop left through |V| > max_num_exons (scallop.cc:49: at once, or after the graph grew past it); greedy still ran */
 #define ALD_ST_CAPACITY        2   /* device working-set capacity exceeded after all retries  */
 #define ALD_ST_INVARIANT     100   /* 100+n: the reference would have hit assert class n      */
 

@@ -68,9 +68,9 @@ void run_one(const Packed &P, const Offsets &o, int g, const ora::Params &cfg, b
     try {
         ora::Scallop sc(gr, hs, cfg);
         if(want_trace) sc.trace = &out.trace;
-        if(V > cfg.max_num_exons) out.status = ALD_ST_SKIPPED_LARGE;
         sc.assemble();
         out.paths = sc.paths; out.trsts = sc.trsts; out.st = sc.st; out.iterations = sc.st.iterations;
+        if(sc.st.cut_short) out.status = ALD_ST_SKIPPED_LARGE;        // the loop left through `num_vertices() > max_num_exons` (scallop.cc:49), at the start or after growing
     } catch(const ora::AssertFail &a) {
         out.status = ALD_ST_INVARIANT + a.cls;
         out.paths.clear(); out.trsts.clear();

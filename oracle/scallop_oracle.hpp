@@ -581,7 +581,7 @@ struct TraceEvent { int code, a, b; double val; };
 enum { OP_BROKEN = 1, OP_TRIVIAL_FAST = 2, OP_TRIVIAL_NOW = 3, OP_TRIVIAL_BEST = 4, OP_SMALL_NOW = 5, OP_SMALLEST = 6,
        OP_UNSPLIT_NOW = 7, OP_UNSPLIT_BEST = 8, OP_GREEDY = 9, OP_COLLECT = 10 };
 
-struct Stats { int max_live_edges = 0, max_vertices = 0, total_edge_ids = 0, iterations = 0, router_builds = 0, max_mev = 0; };
+struct Stats { int max_live_edges = 0, max_vertices = 0, total_edge_ids = 0, iterations = 0, router_builds = 0, max_mev = 0, cut_short = 0; };
 
 // ---------------------------------------------------------------------------------------------
 // scallop (scallop/scallop.cc)
@@ -608,7 +608,7 @@ struct Scallop {
     int assemble() {                            // scallop.cc:38-188
         gr_ori = gr;
         while(true) {
-            if(gr.num_vertices() > cfg.max_num_exons) break;
+            if(gr.num_vertices() > cfg.max_num_exons) { st.cut_short = 1; break; }     // also when the graph GROWS past the limit mid-run
             track();
             if(resolve_broken_vertex()) continue;
             if(resolve_trivial_vertex_fast(cfg.max_decompose_error_ratio[TRIVIAL_VERTEX])) continue;

@@ -153,3 +153,17 @@ def test_explicit_edge_counts():
     assert not common.compare_results(want, got, pg.n)
     plain = common.oracle_run(A.synth(seed=91, n_graphs=120, v_min=8, v_max=50, edges_per_vertex=3, n_samples=3, phasing_per_graph=3, weight_mode=1))[0]
     assert (want.status != 0).any() or not np.array_equal(want.count, plain.count)      # the counts do reach the output
+
+
+def test_max_num_exons_skips_the_cascade():
+    """|V| > max_num_exons: the rule cascade is skipped and the greedy phase decomposes the untouched graph (scallop.cc:49); status
+    ALD_ST_SKIPPED_LARGE = 1 for those graphs, paths still reported"""
+    p = A.default_params(); p.max_num_exons = 30
+    pg = A.synth(seed=55, n_graphs=80, v_min=10, v_max=60, edges_per_vertex=3, weight_mode=2, phasing_per_graph=2)
+    want, st, _, _ = common.oracle_run(pg, params=p)
+    got, it, cl = common.emu_run(pg, params=p)
+    assert not common.compare_results(want, got, pg.n)
+    big = pg.g_nv > 30
+    assert big.any() and (~big).any()
+    assert (want.status[big] == 1).all() and (want.status[~big] == 0).any() and (want.status[~big] == 1).any()     # some grow past the limit mid-run
+    assert (np.diff(want.path_offset)[big] > 0).any()

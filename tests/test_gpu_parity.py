@@ -194,6 +194,16 @@ def test_large_classes_on_gpu():
     assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
 
 
+def test_max_num_exons_on_gpu():
+    """|V| > max_num_exons: cascade skipped, greedy phase only (scallop.cc:49), status ALD_ST_SKIPPED_LARGE"""
+    p = A.default_params(); p.max_num_exons = 30
+    pg = A.synth(seed=55, n_graphs=400, v_min=10, v_max=120, edges_per_vertex=3, weight_mode=2, phasing_per_graph=2)
+    want = common.oracle_run(pg, params=p, threads=4)[0]
+    got = A.decompose(pg, device=0, params=p)
+    assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
+    assert (got.status[pg.g_nv > 30] == 1).all() and (got.status[pg.g_nv <= 30] == 0).any()
+
+
 def test_capacity_retry_on_gpu():
     """graphs started two classes too low (ALD_DEBUG_UNDERCLASS): CAPACITY -> re-queued one class up inside ald_batch_download until
     they fit; same answer; and a second run of the same resident batch (first pass re-staged after the retries) as well"""
