@@ -18,6 +18,7 @@ while time.time() < t_end:
     if rng.random() < 0.3: p.max_decompose_error_ratio[7] = float(rng.choice([1.2, 1.5, 3.0]))
     if rng.random() < 0.3: p.max_decompose_error_ratio[0] = float(rng.choice([0.1, 0.2, 0.5]))
     if rng.random() < 0.2: p.min_transcript_coverage = float(rng.choice([0.5, 5.0]))
+    if rng.random() < 0.2: p.max_num_exons = int(rng.choice([12, 40, 150]))       # cascade cut short -> the greedy phase does the work
     pg = A.synth(**kw)
     if rng.random() < 0.3:
         cnt = pg.sample_counts() + rng.integers(0, 3, pg.edge_target.size).astype(np.int32); pg.edge_count = cnt.astype(np.int32)
@@ -25,6 +26,6 @@ while time.time() < t_end:
     got = A.decompose(pg, device=0, params=p)
     bad = common.compare_results(want, got, pg.n, conf_tol=1e-9)
     ntot += pg.n; nbad += len(bad)
-    print(k, "graphs", pg.n, {a: b for a, b in kw.items() if a != "n_graphs"}, "params", [round(x, 2) for x in p.max_decompose_error_ratio], p.min_transcript_coverage,
+    print(k, "graphs", pg.n, {a: b for a, b in kw.items() if a != "n_graphs"}, "params", [round(x, 2) for x in p.max_decompose_error_ratio], p.min_transcript_coverage, p.max_num_exons,
           "status!=0", int((want.status != 0).sum()), "MISMATCH " + str(bad[:3]) if bad else "ok", flush=True)
 print("TOTAL graphs", ntot, "mismatches", nbad, flush=True)
