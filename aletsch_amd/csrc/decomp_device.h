@@ -694,6 +694,8 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     PROF_ADD(PF_T_BALANCE);
     const double wc = wcen;
     for(int j = 0; j < n; j++) { double w2 = fw[j]; fw[j] = A ? (wc <= w2 ? wc : w2) : (w2 <= wc ? w2 : wc); }
+    double *pfx = SMALL ? nullptr : (double*)(C.wd + Cold::w_cap / 8);     // [n] large form only: prefix sums of fw over the live fan edges (list order)
+    if(!SMALL) { double run = 0; for(int k = 0; k < n; k++) { run += fw[k]; pfx[k] = run; } }
     int32_t *aux = SMALL ? nullptr : (int32_t*)(C.wi + 2 * (Cold::w_cap / 8));        // [n] second buffer of the large form (merge sort, deferred inserts)
     if(SMALL) { for(int i = 0; i < n; i++) { int k = i; uint32_t id = uni(H.eid[fe[i]]); while(k > 0 && (uint32_t)uni(H.eid[fe[ord[k - 1]]]) > id) { ord[k] = ord[k - 1]; k--; } ord[k] = i; } }
     else {      // a hub's fan can hold hundreds of edges: bottom-up merge sort of the positions by creation id
@@ -754,7 +756,8 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         // get_in_weights(x) / get_out_weights(x) with both pieces attached: c's side is (rest of c) + piece, the fan side is
         // whatever has not been merged yet, in list order
         double sfan = 0;
-        for(int k = 0; k < n; k++) if(fe[k] >= 0) sfan += fw[k];
+        if(SMALL) { for(int k = 0; k < n; k++) if(fe[k] >= 0) sfan += fw[k]; }
+        else sfan = pfx[n - 1];                      // large form: running left-to-right sums over the live fan edges, kept up to date below
         double sc_side = 0; sc_side += sc ? rem : wcur; if(sc) sc_side += ww;
         const double sum = A ? (sc_side + sfan) * 0.5 : (sfan + sc_side) * 0.5;
         const double r1 = A ? vwt * (wc0 + ww) * 0.5 / sum : vwt * (ww + wc0) * 0.5 / sum;
@@ -771,6 +774,7 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         else { H.ed[f].lk.et = (IDX)far; relink_out(other, f, tkey((uint32_t)far)); if(SMALL) link_in(far, f); }
         if(!SMALL) aux[q] = f;            // large form: the far vertex's list takes all new edges in ONE merge after the loop (nothing reads it meanwhile)
         fe[j] = -1;
+        if(!SMALL) { double run = j > 0 ? pfx[j - 1] : 0.0; for(int k = j; k < n; k++) { if(fe[k] >= 0) run += fw[k]; pfx[k] = run; } }      // same additions, same order, from j on
         PROF_ADD(PF_T_MERGE_ADD);
         if(A) hs_replace2(c, f, f); else hs_replace2(f, c, f);
         if(n == 1) hs_replace1(c, f);
