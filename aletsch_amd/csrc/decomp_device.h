@@ -155,6 +155,7 @@ ALD_INL void fail_(int st, int line)
     if(H.status == 0) H.status = st;
 }
 #define fail(st) fail_((st), __LINE__)
+#define ALD_UNLIKELY(x) __builtin_expect(!!(x), 0)     // the checks that mirror the reference's asserts: the common path falls through
 ALD_FN void trace_emit(int code, int a, int b, double v)
 {
     int cap = H.p_trace_cap;
@@ -242,7 +243,7 @@ ALD_INL void unlink_in(int v, int e)
     if(v == uni(H.sinkp) && !uni(H.special_linked)) { H.in_deg[v]--; return; }
     IDX *pp = &H.in_head[v]; IDX cur = *pp; int guard = MAXE;
     while(uni((int)cur != e && cur != NIL) && guard-- > 0) { pp = &H.ed[cur].lk.inx; cur = *pp; }
-    if(uni((int)cur != e)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }       // cannot happen on a consistent state; never walk off a list
+    if(ALD_UNLIKELY(uni((int)cur != e))) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }       // cannot happen on a consistent state; never walk off a list
     *pp = H.ed[e].lk.inx;
     { int dg = (int)uni(H.in_deg[v]) - 1; H.in_deg[v] = (IDX)dg; if(dg <= 1) { H.maybe_triv = 1; if(dg == 0) H.maybe_broken = 1; } }
 }
@@ -252,7 +253,7 @@ ALD_INL void unlink_out(int v, int e)
     if(v == 0 && !uni(H.special_linked)) { H.out_deg[v]--; return; }
     IDX *pp = &H.out_head[v]; IDX cur = *pp; int guard = MAXE;
     while(uni((int)cur != e && cur != NIL) && guard-- > 0) { pp = &H.ed[cur].lk.onx; cur = *pp; }
-    if(uni((int)cur != e)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
+    if(ALD_UNLIKELY(uni((int)cur != e))) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
     *pp = H.ed[e].lk.onx;
     { int dg = (int)uni(H.out_deg[v]) - 1; H.out_deg[v] = (IDX)dg; if(dg <= 1) { H.maybe_triv = 1; if(dg == 0) H.maybe_broken = 1; } }
 }
@@ -269,7 +270,7 @@ ALD_INL void relink_in(int v, int e, uint32_t ks)
         else { if(!placed && (uint32_t)(w & 0xFFFF) > ks) { ip = last; placed = true; if(seen) break; } last = cur; }
         cur = nx;
     }
-    if(!seen) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
+    if(ALD_UNLIKELY(!seen)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
     if(!placed) ip = last;
     if(ip == pe) return;                                   // same place
     IDX nxe = uni(H.ed[e].lk.inx);
@@ -289,7 +290,7 @@ ALD_INL void relink_out(int v, int e, uint32_t kt)         // kt already mapped 
         else { uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu; if(!placed && ct > kt) { ip = last; placed = true; if(seen) break; } last = cur; }
         cur = nx;
     }
-    if(!seen) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
+    if(ALD_UNLIKELY(!seen)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
     if(!placed) ip = last;
     if(ip == pe) return;
     IDX nxe = uni(H.ed[e].lk.onx);
@@ -306,7 +307,7 @@ ALD_INL int add_edge_i(int s, int t)
     else if(hw < MAXE) { e = hw; H.slot_hw = hw + 1; }
     else { fail(ALD_ST_CAPACITY); return -1; }
     int id = uni(H.next_id); H.next_id = id + 1;
-    if(id >= 0xFFFF) { fail(ALD_ST_CAPACITY); return -1; }
+    if(ALD_UNLIKELY(id >= 0xFFFF)) { fail(ALD_ST_CAPACITY); return -1; }
     H.ed[e].lk.es = (IDX)s; H.ed[e].lk.et = (IDX)t; H.eid[e] = (uint16_t)id; H.hflag[e] = 0; H.ed[e].w = 0;
     link_out(s, e); link_in(t, e);
     return e;
@@ -365,7 +366,7 @@ ALD_FN bool intersect_samples(int e1, int e2, int z)
     const int i1 = uni(C.ed[e1].s0id), i2 = uni(C.ed[e2].s0id); const double a1 = uni(C.ed[e1].s0abd), a2 = uni(C.ed[e2].s0abd);
     const uint32_t need = n1 < n2 ? n1 : n2;
     const uint32_t o = H.sp_used;
-    if(o + need > C.sp_cap) { fail(ALD_ST_CAPACITY); return false; }
+    if(ALD_UNLIKELY(o + need > C.sp_cap)) { fail(ALD_ST_CAPACITY); return false; }
     uint32_t i = 0, j = 0, k = 0; double abd = 0; int first_id = 0; double first_abd = 0;
     while(i < n1 && j < n2) {
         int a = n1 == 1 ? i1 : uni(C.sp_id[o1 + i]), b = n2 == 1 ? i2 : uni(C.sp_id[o2 + j]);
@@ -456,7 +457,7 @@ ALD_FN void hs_insert_between_lists(int x, int y, int e)   // hyper_set.cc:865-9
         if(cnt == 0) continue;
         if(n + cnt > uni(C.hl_capk[k])) {             // relocate the list to the end of the pool with slack
             uint32_t ncap = (uint32_t)(n + cnt) * 2u + 4u, o = H.hl_used;
-            if(o + ncap > C.hl_cap) { fail(ALD_ST_CAPACITY); return; }
+            if(ALD_UNLIKELY(o + ncap > C.hl_cap)) { fail(ALD_ST_CAPACITY); return; }
             for(int i = 0; i < n; i++) C.hl[o + i] = v[i];
             H.hl_used = o + ncap; C.hl_off[k] = (int32_t)o; C.hl_capk[k] = (int32_t)ncap; v = C.hl + o;
         }
@@ -510,7 +511,7 @@ ALD_FN bool hs_dominate(int e, int side)
 ALD_FN int split_edge(int ei, double w)
 {
     ei = uni(ei); w = uni(w);
-    if(!(w >= H.p_min_w - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
+    if(ALD_UNLIKELY(!(w >= H.p_min_w - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
     double ww = uni(H.ed[ei].w);
     if(fabs(ww - w) <= kSMIN) return ei;
     int s = uni(H.ed[ei].lk.es), t = uni(H.ed[ei].lk.et);
@@ -534,7 +535,7 @@ ALD_FN int split_edge(int ei, double w)
 ALD_INL int merge_adjacent_edges_i(int x, int y, double ww)
 {
     const double mw = H.p_min_w;
-    if(!(ww >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
+    if(ALD_UNLIKELY(!(ww >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
     if(x < 0 || y < 0) return -1;
     if(H.ed[x].lk.et != uni(H.ed[y].lk.es)) { int t = x; x = y; y = t; }
     const int xs = uni(H.ed[x].lk.es), xt = uni(H.ed[x].lk.et), yt = uni(H.ed[y].lk.et);
@@ -548,7 +549,7 @@ ALD_INL int merge_adjacent_edges_i(int x, int y, double ww)
     const int meix = uni(C.ed[x].mei), meiy = uni(C.ed[y].mei), cntx = uni(C.ed[x].ecount), cnty = uni(C.ed[y].ecount), lt = uni(C.vx[xt].lpos), rt = uni(C.vx[xt].rpos), ov = uni(C.vx[xt].v2v);
     const int stx = uni(C.ed[x].estrand), sty = uni(C.ed[y].estrand);
     // split_edge(x, ww), split_edge(y, ww): a piece of weight ww gets the next id, the original keeps max(w - ww, min_w)
-    if(uni(H.next_id) >= 0xFFF0) { fail(ALD_ST_CAPACITY); return -1; }
+    if(ALD_UNLIKELY(uni(H.next_id) >= 0xFFF0)) { fail(ALD_ST_CAPACITY); return -1; }
     if(sx) { H.next_id++; double r = wx - ww; if(r <= mw) r = mw; H.ed[x].w = r; }
     if(sy) { H.next_id++; double r = wy - ww; if(r <= mw) r = mw; H.ed[y].w = r; }
     const double wx0 = sx ? ww : wx, wy0 = sy ? ww : wy;                 // weights of the two pieces being merged
@@ -558,9 +559,9 @@ ALD_INL int merge_adjacent_edges_i(int x, int y, double ww)
     int n = add_edge_i(xs, yt);
     PROF_ADD(PF_T_MERGE_ADD);
     if(n < 0) return -1;
-    if(!(fabs(wx0 - wy0) <= kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_MERGE_EQUAL); return -1; }
+    if(ALD_UNLIKELY(!(fabs(wx0 - wy0) <= kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_MERGE_EQUAL); return -1; }
     H.ed[n].w = wx0 * 0.5 + wy0 * 0.5;
-    if(!(cntx > 0 && cnty > 0)) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return -1; }
+    if(ALD_UNLIKELY(!(cntx > 0 && cnty > 0))) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return -1; }
     if(!intersect_samples(x, y, n)) return -1;
     PROF_ADD(PF_T_MERGE_ISECT);
     C.ed[n].econf = cx + cy;
@@ -593,8 +594,8 @@ ALD_INL void balance_vertex_i(int v)
     if(H.in_deg[v] == 0 || uni(H.out_deg[v]) == 0) return;
     const double mw = H.p_min_w;
     double w1 = 0, w2 = 0;
-    for(int e = u_first_in(v); e >= 0; e = u_next_in(e)) { double w = uni(H.ed[e].w); if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w1 += w; }
-    for(int e = u_first_out(v); e >= 0; e = u_next_out(e)) { double w = uni(H.ed[e].w); if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w2 += w; }
+    for(int e = u_first_in(v); e >= 0; e = u_next_in(e)) { double w = uni(H.ed[e].w); if(ALD_UNLIKELY(!(w >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w1 += w; }
+    for(int e = u_first_out(v); e >= 0; e = u_next_out(e)) { double w = uni(H.ed[e].w); if(ALD_UNLIKELY(!(w >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w2 += w; }
     double ww = sqrt(w1 * w2);
     double r1 = ww / w1, r2 = ww / w2;
     double m1 = 0, m2 = 0;
@@ -672,10 +673,10 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     // same order as the list-walking form (balance_vertex_i), but the fan is walked once and nothing is written back until the
     // pe2w sums below are known
     int n = 0; double wcen = H.ed[c].w;          // weights stay in vector registers: they only feed FP arithmetic and LDS stores
-    if(uni(!(wcen >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
+    if(ALD_UNLIKELY(uni(!(wcen >= mw - kSMIN)))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
     double sfan0 = 0;
     for(int e = A ? u_first_out(x) : u_first_in(x); e >= 0; e = A ? u_next_out(e) : u_next_in(e)) {
-        double w2 = H.ed[e].w; if(uni(!(w2 >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
+        double w2 = H.ed[e].w; if(ALD_UNLIKELY(uni(!(w2 >= mw - kSMIN)))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
         fe[n] = e; fw[n] = w2; sfan0 += w2; n++;
     }
     {
@@ -713,7 +714,7 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         if(src != ord) for(int i = 0; i < n; i++) ord[i] = src[i];
     }
     double mdc = 0;
-    for(int q = 0; q < n; q++) { double w = fw[ord[q]]; if(!(w >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } mdc = (q == 0) ? w : mdc + w; }
+    for(int q = 0; q < n; q++) { double w = fw[ord[q]]; if(ALD_UNLIKELY(!(w >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } mdc = (q == 0) ? w : mdc + w; }
     H.ed[c].w = mdc;
     for(int j = 0; j < n; j++) H.ed[fe[j]].w = fw[j];
     PROF_ADD(PF_T_SETUP);
@@ -815,7 +816,7 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         if(A) H.out_deg[far] = (IDX)((int)uni(H.out_deg[far]) + n); else H.in_deg[far] = (IDX)((int)uni(H.in_deg[far]) + n);
     }
     if(n >= 2) hs_remove(c);
-    if(!consumed) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }      // c kept a remainder: the reference asserts on the degree of x
+    if(ALD_UNLIKELY(!consumed)) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }      // c kept a remainder: the reference asserts on the degree of x
     // remove_edge(c); x is left without edges
     if(A) unlink_out(far, c); else unlink_in(far, c);
     H.ed[c].lk.es = NIL; H.hflag[c] = 0;
@@ -849,7 +850,7 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
     const int deg = (int)uni(H.in_deg[root]) + (int)uni(H.out_deg[root]);
     // the visiting order of the nested decompositions (jump_ratio > 1 only) must survive them: it always lives in the slab
     const Arena AR = SMALL ? arena_at(true) : arena_at(4 * deg <= ARENA_I && deg <= ARENA_D && !(H.p_ratio[7] > 1.0));
-    if(4 * deg > AR.cap_i || deg > AR.cap_d || deg > C.w_cap / 16) { fail(ALD_ST_CAPACITY); return; }
+    if(ALD_UNLIKELY(4 * deg > AR.cap_i || deg > AR.cap_d || deg > C.w_cap / 16)) { fail(ALD_ST_CAPACITY); return; }
     int nloc = 0; int32_t *loc_e = AR.i;
     for(int e = u_first_in(root); e >= 0; e = u_next_in(e)) { loc_e[nloc++] = e; }
     int nin = nloc;
@@ -861,7 +862,7 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
     const double mw = H.p_min_w;
     double total_weight = 0;
     for(int i = 0; i < n; i++) {
-        if(!(w[i] >= mw - kSMIN)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
+        if(ALD_UNLIKELY(!(w[i] >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
         int u1 = PLOC(a[i]), u2 = PLOC(b[i]);
         total_weight += w[i];
         if(mdeg[u1] == 0) mweight[u1] = w[i]; else mweight[u1] += w[i];
@@ -874,10 +875,10 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
     // new vertices (scallop.cc:1753-1806) are appended at the end of the physical index space; the reference gives them the
     // indices m.. and moves the sink behind them -- same relative order, no edge has to move here
     int m = H.nv, nn = m;
-    for(int i = 0; i < nloc; i++) { if(mdeg[i] == 0) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; } if(mdeg[i] >= 2) evx[i] = nn++; }
+    for(int i = 0; i < nloc; i++) { if(ALD_UNLIKELY(mdeg[i] == 0)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; } if(mdeg[i] >= 2) evx[i] = nn++; }
     int newedges = 0;
     for(int i = 0; i < n; i++) { int u1 = PLOC(a[i]), u2 = PLOC(b[i]); if(mdeg[u1] == 1 && mdeg[u2] == 1) evx[u1] = nn++; else if(mdeg[u1] >= 2 && mdeg[u2] >= 2) newedges++; }
-    if(nn > MAXV || free_slots() < newedges) { fail(ALD_ST_CAPACITY); return; }
+    if(ALD_UNLIKELY(nn > MAXV || free_slots() < newedges)) { fail(ALD_ST_CAPACITY); return; }
     H.maybe_broken = 1; H.maybe_triv = 1;
     for(int i = m; i < nn; i++) { H.in_head[i] = NIL; H.out_head[i] = NIL; H.in_deg[i] = 0; H.out_deg[i] = 0; H.nz[i] = 1; C.vx[i].vw = 0; C.vx[i].lpos = 0; C.vx[i].rpos = 0; C.vx[i].vtype = -1; C.vx[i].v2v = -1; C.vx[i].memo = 0; }
     H.nv = nn;
@@ -900,7 +901,7 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
             if(rv >= 0) C.ed[e1].mask[(rv >> 6)] |= (1ull << (rv & 63));
             C.ed[e1].med += mweight[u1]; C.ed[e1].mei += rlen;
         } else if(mdeg[u2] == 1) {
-            if(evx[u1] < 0) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
+            if(ALD_UNLIKELY(evx[u1] < 0)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
             borrow_edge_strand(C, e2, e1);
             move_edge(e2, evx[u1], uni(H.ed[e2].lk.et));
             if(rv >= 0) C.ed[e2].mask[(rv >> 6)] |= (1ull << (rv & 63));
@@ -909,9 +910,9 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
             int z = add_edge(evx[u1], evx[u2]);
             if(z < 0) return;
             H.ed[z].w = ww;
-            if(!(C.ed[e1].ecount > 0 && uni(C.ed[e2].ecount) > 0)) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
+            if(ALD_UNLIKELY(!(C.ed[e1].ecount > 0 && uni(C.ed[e2].ecount) > 0))) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
             if(!intersect_samples(e1, e2, z)) return;
-            if(C.ed[z].ecount <= 0) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
+            if(ALD_UNLIKELY(C.ed[z].ecount <= 0)) { fail(ALD_ST_INVARIANT + ALD_INV_COUNT); return; }
             C.ed[z].econf = 0; C.ed[z].estrand = 0;
             for(int k = 0; k < NW; k++) C.ed[z].mask[k] = 0;
             if(rv >= 0) C.ed[z].mask[(rv >> 6)] |= (1ull << (rv & 63));
@@ -921,7 +922,7 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
             if(H.status) return;
         }
     }
-    if(H.in_deg[root] != 0 || uni(H.out_deg[root]) != 0) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }
+    if(ALD_UNLIKELY(H.in_deg[root] != 0 || uni(H.out_deg[root]) != 0)) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }
     H.nz[root] = 0;
     // scallop.cc:1976-1985 resolve_single_trivial_vertex(k, jump_ratio) on the new vertices: a no-op unless jump_ratio > 1
     double jump = H.p_ratio[7];
@@ -987,7 +988,7 @@ ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio)
     if(mixed_strand_vertex(i)) return false;
     if(classify_trivial_vertex(i, false) != 1) return false;
     bool ok; double r = compute_balance_ratio(i, ok);
-    if(!ok) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return false; }
+    if(ALD_UNLIKELY(!ok)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return false; }
     if(r >= jump_ratio) return false;
     trace(OP_TRIVIAL_FAST, vlog(i), 0, r);
     decompose_trivial_vertex(i);
@@ -1310,11 +1311,11 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     const Arena AR = arena_at(SMALL);
     const Pairs PW = pairs_at(SMALL, false);
     const int cap = AR.cap_i;
-    if(5 * n > cap) { fail(ALD_ST_CAPACITY); return false; }
+    if(ALD_UNLIKELY(5 * n > cap)) { fail(ALD_ST_CAPACITY); return false; }
     int32_t *u2e = AR.i;
     { int k = 0; for(int e = u_first_in(root); e >= 0; e = u_next_in(e)) { u2e[k++] = e; }
       for(int e = u_first_out(root); e >= 0; e = u_next_out(e)) { u2e[k++] = e; } }
-    if(mixed_strand_vertex(root)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }     // router.cc:71-76
+    if(ALD_UNLIKELY(mixed_strand_vertex(root))) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }     // router.cc:71-76
     // ---- routes from the phasing lists (hyper_set::get_routes, hyper_set.cc:553-571), gathered in the pair area
     const int half = PW.cap;
     int nr = 0;
@@ -1330,7 +1331,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
                 int f = -1;
                 for(int j = 0; j < nr; j++) if(ra[j] == x && rb[j] == y) { f = j; break; }
                 if(f >= 0) rc[f] += c;
-                else { if(nr >= half) { fail(ALD_ST_CAPACITY); return false; } ra[nr] = x; rb[nr] = y; rc[nr] = c; nr++; }
+                else { if(ALD_UNLIKELY(nr >= half)) { fail(ALD_ST_CAPACITY); return false; } ra[nr] = x; rb[nr] = y; rc[nr] = c; nr++; }
             }
         }
         sort_pairs(PW, nr);                    // MPII order == (id(e1), id(e2)) == creation order of the ug edges
@@ -1345,18 +1346,18 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     int32_t *us = AR.i + o; o += maxue;
     int32_t *ut = AR.i + o; o += maxue;
     int32_t *ualive = AR.i + o; o += maxue;
-    if(o > cap || 3 * n + maxue > AR.cap_d) { fail(ALD_ST_CAPACITY); return false; }
+    if(ALD_UNLIKELY(o > cap || 3 * n + maxue > AR.cap_d)) { fail(ALD_ST_CAPACITY); return false; }
     double *vw = AR.d, *uw = AR.d + n, *econf = AR.d + n + maxue;
     // ---- build_bipartite_graph (router.cc:250-325)
     int nue = 0;
     for(int i = 0; i < n; i++) { udeg[i] = 0; iso[i] = 0; }
     for(int j = 0; j < nr; j++) {
         int y = rb[j];
-        if(H.ed[y].lk.es == NIL || (int)uni(H.ed[y].lk.es) != root) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }   // assert(e2u.find(e2) != end)
+        if(ALD_UNLIKELY(H.ed[y].lk.es == NIL || (int)uni(H.ed[y].lk.es) != root)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }   // assert(e2u.find(e2) != end)
         int s = -1, t = -1;                       // local indices by search (routes exist only with phasing paths)
         for(int q = 0; q < nin; q++) if(u2e[q] == ra[j]) { s = q; break; }
         for(int q = nin; q < n; q++) if(u2e[q] == y) { t = q; break; }
-        if(s < 0 || t < 0) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
+        if(ALD_UNLIKELY(s < 0 || t < 0)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
         us[nue] = s; ut[nue] = t; uw[nue] = rc[j]; ualive[nue] = 1; udeg[s]++; udeg[t]++; nue++;
     }
     // isolated vertices attach to the best partner by shared sample abundance (router.cc:1010-1129).
@@ -1371,7 +1372,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
         if(udeg[v] != 0) continue;
         int partner = -1; double max_abd = 0.0, sum_abd = 0.0;
         for(int r = nin; r < n; r++) { if(iso[r] == 2) continue; double c = ALD_COMMON(v, r); sum_abd += c; if(c > max_abd) { max_abd = c; partner = r; } }
-        if(partner < 0) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
+        if(ALD_UNLIKELY(partner < 0)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
         us[nue] = v; ut[nue] = partner; uw[nue] = max_abd; ualive[nue] = 1; udeg[v]++; udeg[partner]++; nue++;
         iso[v] = 1; econf[v] = max_abd / sum_abd;        // the log is taken where it is used (end of build())
     }
@@ -1380,14 +1381,14 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
         if(udeg[v] != 0) continue;
         int partner = -1; double max_abd = 0.0, sum_abd = 0.0;
         for(int l = 0; l < nin; l++) { if(iso[l] == 2) continue; double c = ALD_COMMON(l, v); sum_abd += c; if(c > max_abd) { max_abd = c; partner = l; } }
-        if(partner < 0) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
+        if(ALD_UNLIKELY(partner < 0)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
         us[nue] = partner; ut[nue] = v; uw[nue] = max_abd; ualive[nue] = 1; udeg[v]++; udeg[partner]++; nue++;
         iso[v] = 1; econf[v] = max_abd / sum_abd;        // the log is taken where it is used (end of build())
     }
     // ---- classify_plain_vertex (router.cc:116-171)
     H.ro_npairs = 0; H.ro_ratio = 0;
     if(nin == 1 || nout == 1) { H.ro_type = T_TRIVIAL; H.ro_degree = n; return true; }
-    for(int i = 0; i < n; i++) if(udeg[i] < 1) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
+    for(int i = 0; i < n; i++) if(ALD_UNLIKELY(udeg[i] < 1)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
     int ncomp = 0;
     for(int i = 0; i < n; i++) comp[i] = -1;
     for(int i = 0; i < n; i++) {
@@ -1402,10 +1403,10 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
         bool b1 = true, b2 = true;             // one_side_connected (router.cc:173-191) -> assert(false)
         for(int i = 1; i < nin; i++) if(comp[i] != comp[0]) b1 = false;
         for(int i = nin + 1; i < n; i++) if(comp[i] != comp[nin]) b2 = false;
-        if(b1 || b2) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
+        if(ALD_UNLIKELY(b1 || b2)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
         int a = 0, b = 0;
         for(int c = 0; c < ncomp; c++) { int sz = 0; for(int i = 0; i < n; i++) if(comp[i] == c) sz++; if(sz == 1) a++; if(sz >= 2) b++; }
-        if(b < 1) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
+        if(ALD_UNLIKELY(b < 1)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
         rtype = T_SPLITTABLE_PURE; rdeg = b - 1 + (a + 1) / 2;
     }
     H.ro_type = rtype; H.ro_degree = rdeg;
@@ -1438,7 +1439,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
             if(udeg[s] == 1 && vw[s] <= vw[t]) { x = s; y = t; }
             else if(udeg[t] == 1 && vw[t] <= vw[s]) { x = t; y = s; }
             if(x < 0) continue;
-            if(np >= half) { fail(ALD_ST_CAPACITY); return false; }
+            if(ALD_UNLIKELY(np >= half)) { fail(ALD_ST_CAPACITY); return false; }
             pa[np] = PMAKE(u2e[s], s); pb[np] = PMAKE(u2e[t], t); pwt[np] = vw[x]; np++;
             for(int q = 0; q < nue; q++) if(ualive[q] && (us[q] == x || ut[q] == x)) { ualive[q] = 0; udeg[us[q]]--; udeg[ut[q]]--; live--; }   // clear_vertex
             vw[y] -= vw[x]; vw[x] = -1; b = true;
@@ -1450,11 +1451,11 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
         if(x == -1) break;
         double sum = 0;
         // out_edges(x) order: by the other endpoint, then creation (pairs are unique)
-        for(int t = 0; t < n; t++) for(int k = 0; k < nue; k++) { if(!ualive[k]) continue; int y = (us[k] == x) ? ut[k] : ((ut[k] == x) ? us[k] : -1); if(y != t) continue; sum += uw[k]; if(!(vw[t] >= vw[x])) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; } }
+        for(int t = 0; t < n; t++) for(int k = 0; k < nue; k++) { if(!ualive[k]) continue; int y = (us[k] == x) ? ut[k] : ((ut[k] == x) ? us[k] : -1); if(y != t) continue; sum += uw[k]; if(ALD_UNLIKELY(!(vw[t] >= vw[x]))) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; } }
         for(int t = 0; t < n; t++) for(int k = 0; k < nue; k++) {
             if(!ualive[k]) continue; int y = (us[k] == x) ? ut[k] : ((ut[k] == x) ? us[k] : -1); if(y != t) continue;
             double wgt = vw[x] * uw[k] / sum;
-            if(np >= half) { fail(ALD_ST_CAPACITY); return false; }
+            if(ALD_UNLIKELY(np >= half)) { fail(ALD_ST_CAPACITY); return false; }
             if(x < t) { pa[np] = PMAKE(u2e[x], x); pb[np] = PMAKE(u2e[t], t); } else { pa[np] = PMAKE(u2e[t], t); pb[np] = PMAKE(u2e[x], x); }
             pwt[np] = wgt; np++;
             vw[t] -= wgt;
@@ -1462,7 +1463,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
         vw[x] = -1;
         for(int q = 0; q < nue; q++) if(ualive[q] && (us[q] == x || ut[q] == x)) { ualive[q] = 0; udeg[us[q]]--; udeg[ut[q]]--; live--; }
     }
-    if(live != 0) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
+    if(ALD_UNLIKELY(live != 0)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
     double weight_remain = 0;
     for(int i = 0; i < n; i++) { if(vw[i] <= 0) continue; weight_remain += vw[i]; }
     H.ro_ratio = weight_remain / weight_sum;
@@ -1492,7 +1493,7 @@ ALD_FN void save_pairs(int n)
     n = uni(n);
     const bool lds = H.pw_lds != 0;
     const Pairs S = pairs_at(lds, false), D = pairs_at(lds, true);
-    if(n > D.cap) { fail(ALD_ST_CAPACITY); return; }
+    if(ALD_UNLIKELY(n > D.cap)) { fail(ALD_ST_CAPACITY); return; }
     for(int i = 0; i < n; i++) { D.a[i] = S.a[i]; D.b[i] = S.b[i]; D.w[i] = S.w[i]; }
     H.park_lds = lds ? 1 : 0;
 }
@@ -1587,13 +1588,13 @@ ALD_FN void collect_path(int e)
     int n = H.V0 - 1;                           // v2v[sink]: the sink's original index
     int cnt = 0, mi = 0; bool empty = false;
     for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.ed[e].mask[k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; cnt++; mi += uni(C.vx[x].rpos) - uni(C.vx[x].lpos); if(C.vx[x].vtype == K_EMPTY_VERTEX) empty = true; } }
-    if(C.ed[e].mei != mi || cnt == 0) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
+    if(ALD_UNLIKELY(C.ed[e].mei != mi || cnt == 0)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
     if(C.vx[0].vtype == K_EMPTY_VERTEX || uni(C.vx[n].vtype) == K_EMPTY_VERTEX) empty = true;
     if(!empty) {
         int nvp = cnt + 2;
         unsigned long long words = (unsigned long long)(REC_HDR_WORDS + nvp + ((REC_HDR_WORDS + nvp) & 1));
         unsigned long long o = atomic_add_u64(A->out.pool_used, words);
-        if(o + words > A->out.pool_cap) { fail(ALD_ST_CAPACITY); return; }
+        if(ALD_UNLIKELY(o + words > A->out.pool_cap)) { fail(ALD_ST_CAPACITY); return; }
         ALD_GLOBAL uint32_t *r = A->out.pool + o;
         int st = '.';
         if(C.ed[e].estrand == 1) st = '+';
@@ -1663,7 +1664,7 @@ ALD_FN double compute_maximum_path()
     int k = 0;
     while(k < qt) { int x = q[k++]; for(int e = u_first_out(x); e >= 0; e = u_next_out(e)) { int t = uni(H.ed[e].lk.et); if(--vd[t] == 0) q[qt++] = t; } }
     H.tmp0 = 0;
-    if(qt != n) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return -1; }
+    if(ALD_UNLIKELY(qt != n)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return -1; }
     int ssi = -1, tti = -1;
     for(int i = 0; i < n; i++) { if(q[i] == 0) ssi = i; if(q[i] == sinkp) tti = i; }
     table[0] = DBL_MAX;
@@ -1700,7 +1701,7 @@ ALD_FN void greedy_decompose()
     PROF_DECL;
     for(int rep = 0; rep < 2; rep++) for(int i = 1; i < H.nv; i++) { if(i == H.sinkp) continue; balance_vertex(i); if(H.status) return; }
     PROF_ADD(PF_G_BALANCE);
-    if(3 * H.nv > C.w_cap / 2) { fail(ALD_ST_CAPACITY); return; }
+    if(ALD_UNLIKELY(3 * H.nv > C.w_cap / 2)) { fail(ALD_ST_CAPACITY); return; }
     ALD_GLOBAL int32_t *path = C.wi + Cold::w_cap / 2;
     const double min_cov = H.p_min_cov;
     int guard = 4 * MAXE;
@@ -1713,14 +1714,14 @@ ALD_FN void greedy_decompose()
         if(w <= min_cov) break;
         if(tracing()) { int save = H.n_iters; trace(OP_GREEDY, plen, 0, w); H.n_iters = save; }
         if(plen == 0) break;
-        if(free_slots() < 2) { fail(ALD_ST_CAPACITY); return; }
+        if(ALD_UNLIKELY(free_slots() < 2)) { fail(ALD_ST_CAPACITY); return; }
         int ee = split_edge(path[0], w);
         for(int i = 1; i < plen && ee >= 0 && !H.status; i++) {
-            if(free_slots() < 2) { fail(ALD_ST_CAPACITY); return; }
+            if(ALD_UNLIKELY(free_slots() < 2)) { fail(ALD_ST_CAPACITY); return; }
             ee = merge_adjacent_edges(ee, path[i], w);     // split(path[i]) + merge with the (already equal) running edge
         }
         if(H.status) return;
-        if(ee < 0) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
+        if(ALD_UNLIKELY(ee < 0)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
         PROF_ADD(PF_G_SPLITMERGE);
         collect_path(ee);
         PROF_ADD(PF_G_COLLECT);
