@@ -40,6 +40,7 @@ struct HostBatch {
     rvec<int32_t> in_offset, in_edge;
     rvec<int32_t> phasing_offset, phasing_vertex, phasing_count; rvec<char> graph_strand;
     rvec<int32_t> edge_count;
+    std::vector<int32_t> cur_, perm_;          // scratch of add_graph, kept across calls
     std::string err;
 
     int n() const { return (int)g_nv.size(); }
@@ -62,7 +63,7 @@ struct HostBatch {
         for(int i = 0; i < V; i++) if(g.vertex_offset[i + 1] < g.vertex_offset[i]) { err = "vertex_offset not monotone"; return ALD_ERR_INVALID; }
         if(E > 0 && g.edge_sample_offset[0] != 0) { err = "edge_sample_offset[0] != 0"; return ALD_ERR_INVALID; }
         // ---- edges: per-row order by target (stable) ----
-        std::vector<int32_t> perm(E); std::iota(perm.begin(), perm.end(), 0);
+        std::vector<int32_t> &perm = perm_; perm.resize(E); std::iota(perm.begin(), perm.end(), 0);
         for(int s = 0; s < V; s++) {
             int a = g.vertex_offset[s], b = g.vertex_offset[s + 1];
             bool sorted = true;
@@ -70,6 +71,34 @@ struct HostBatch {
             if(!sorted) std::stable_sort(perm.begin() + a, perm.begin() + b, [&](int x, int y) { return g.edge_target[x] < g.edge_target[y]; });
         }
         size_t e0 = edge_target.size(), s0 = sample_id.size();
+        // canonical input (rows sorted, sample lists ascending, strands in range: what the reference's containers produce) is appended
+        // by ranges; anything else goes through the element-wise path below, which sorts and reports defects
+        bool canonical = true;
+        for(int k = 0; k < E && canonical; k++) if(perm[k] != k) canonical = false;
+        if(canonical && E > 0) {
+            const int32_t NS = g.edge_sample_offset[E];
+            if(NS < 0) canonical = false;
+            for(int k = 0; k < E && canonical; k++) {
+                const int a = g.edge_sample_offset[k], b = g.edge_sample_offset[k + 1];
+                if(b < a) { canonical = false; break; }
+                if(g.edge_strand && g.edge_strand[k] > 2) { canonical = false; break; }
+                if(g.edge_count && g.edge_count[k] < 0) { canonical = false; break; }
+                for(int j = a + 1; j < b; j++) if(g.sample_id[j - 1] >= g.sample_id[j]) { canonical = false; break; }
+            }
+        }
+        if(canonical && E > 0) {
+            const int32_t NS = g.edge_sample_offset[E];
+            edge_target.insert(edge_target.end(), g.edge_target, g.edge_target + E);
+            edge_weight.insert(edge_weight.end(), g.edge_weight, g.edge_weight + E);
+            if(g.edge_strand) edge_strand.insert(edge_strand.end(), g.edge_strand, g.edge_strand + E); else edge_strand.resize(e0 + E, 0);
+            sample_id.insert(sample_id.end(), g.sample_id, g.sample_id + NS);
+            sample_abd.insert(sample_abd.end(), g.sample_abd, g.sample_abd + NS);
+            edge_sample_offset.insert(edge_sample_offset.end(), g.edge_sample_offset, g.edge_sample_offset + E + 1);
+            if(g.edge_abd) edge_abd.insert(edge_abd.end(), g.edge_abd, g.edge_abd + E);
+            else { edge_abd.resize(e0 + E); for(int k = 0; k < E; k++) { double sum = 0; for(int j = g.edge_sample_offset[k]; j < g.edge_sample_offset[k + 1]; j++) sum += g.sample_abd[j]; edge_abd[e0 + k] = sum; } }
+            if(g.edge_count) edge_count.insert(edge_count.end(), g.edge_count, g.edge_count + E);
+            else { edge_count.resize(e0 + E); for(int k = 0; k < E; k++) edge_count[e0 + k] = g.edge_sample_offset[k + 1] - g.edge_sample_offset[k]; }
+        } else {
         edge_sample_offset.push_back(0);
         for(int k = 0; k < E; k++) {
             int q = perm[k];
@@ -92,7 +121,8 @@ struct HostBatch {
             edge_count.push_back(g.edge_count ? g.edge_count[q] : (int32_t)(b - a));
             edge_sample_offset.push_back((int32_t)(sample_id.size() - s0));
         }
-        for(int i = 0; i <= V; i++) vertex_offset.push_back(g.vertex_offset[i]);
+        }
+        vertex_offset.insert(vertex_offset.end(), g.vertex_offset, g.vertex_offset + V + 1);
         // ---- in-CSR: counting sort of edge ids by target; ids ascend within a target == (source, id) order ----
         {
             size_t b0 = in_offset.size(); in_offset.resize(b0 + V + 1, 0);
@@ -100,10 +130,11 @@ struct HostBatch {
             for(int k = 0; k < E; k++) io[edge_target[e0 + k] + 1]++;
             for(int i = 0; i < V; i++) io[i + 1] += io[i];
             size_t ie0 = in_edge.size(); in_edge.resize(ie0 + E);
-            std::vector<int32_t> cur(io, io + V);
-            for(int k = 0; k < E; k++) in_edge[ie0 + cur[edge_target[e0 + k]]++] = k;
+            cur_.assign(io, io + V);
+            for(int k = 0; k < E; k++) in_edge[ie0 + cur_[edge_target[e0 + k]]++] = k;
         }
-        for(int i = 0; i < V; i++) { vertex_weight.push_back(g.vertex_weight[i]); vertex_lpos.push_back(g.vertex_lpos[i]); vertex_rpos.push_back(g.vertex_rpos[i]); vertex_type.push_back(g.vertex_type ? g.vertex_type[i] : -1); }
+        vertex_weight.insert(vertex_weight.end(), g.vertex_weight, g.vertex_weight + V); vertex_lpos.insert(vertex_lpos.end(), g.vertex_lpos, g.vertex_lpos + V); vertex_rpos.insert(vertex_rpos.end(), g.vertex_rpos, g.vertex_rpos + V);
+        if(g.vertex_type) vertex_type.insert(vertex_type.end(), g.vertex_type, g.vertex_type + V); else vertex_type.resize(vertex_type.size() + V, -1);
         // ---- phasing lists -> the std::map `nodes` ----
         int np_kept = 0; size_t pv0 = phasing_vertex.size();
         phasing_offset.push_back(0);
