@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include "host_pack.h"
 #include <thread>
+#include <chrono>
 #include <iterator>
 #include "../host/transcript_sink.hpp"
 #include <mutex>
@@ -564,7 +565,9 @@ static size_t chain_hash(const std::vector<int32_t> &ex)
 int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int64_t tid_base, int32_t skip_single_exon)
 {
     if(!t || !b || !b->downloaded) return ALD_ERR_INVALID;
+    auto T0 = std::chrono::steady_clock::now();
     { int rc = ensure_index(b); if(rc != ALD_OK) return rc; }
+    auto T1 = std::chrono::steady_clock::now();
     const int n = b->hb.n();
     const int64_t np = (int64_t)b->res.paths.size();
     unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16;
@@ -583,26 +586,38 @@ int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int6
             bucket[(size_t)i] = (uint32_t)chain_hash(ex);                     // <= 2^31
         }
     });
-    // pass 2: thread th owns the tables th, th + nthr, ...; it walks the graphs in order and merges the per-graph set of its buckets
+    auto T2 = std::chrono::steady_clock::now();
+    // pass 2: thread th owns the tables th, th + nthr, ...; it walks the graphs in order and merges the per-graph set of its buckets.
+    // A graph that puts a single transcript into this thread's tables needs no per-graph set: merging a one-item set is the same as
+    // adding the item (transcript_set.cc:149-175).
     HostBatch::run_threads(nthr, [&](unsigned th) {
         std::vector<int32_t> ex;
+        auto mine = [&](uint32_t h) { return h != ALD_NO_BUCKET && (h % ALD_TSET_SHARDS) % nthr == th; };
+        auto make = [&](int g, int64_t i, aletsch::sink_transcript &x) {
+            const PathRec &p = b->res.paths[i];
+            join_exons(b, g, p, ex);
+            x.strand = p.strand; x.coverage = log(1.0 + p.weight); x.cov2 = x.coverage; x.conf = p.conf; x.abd = p.abd; x.count1 = p.count; x.count2 = 1;
+            x.tid = tid_base + (((int64_t)g << 20) | (int64_t)(i - b->res.path_begin[g]));
+            x.exons.clear(); x.exons.reserve(ex.size() / 2);
+            for(size_t k = 0; k + 1 < ex.size(); k += 2) x.exons.push_back(std::make_pair(ex[k], ex[k + 1]));
+        };
+        aletsch::sink_transcript x;
         for(int g = 0; g < n; g++) {
-            aletsch::transcript_sink ts(t->overlap); bool any = false;
-            for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++) {
-                const uint32_t h = bucket[(size_t)i];
-                if(h == ALD_NO_BUCKET || (h % ALD_TSET_SHARDS) % nthr != th) continue;
-                const PathRec &p = b->res.paths[i];
-                join_exons(b, g, p, ex);
-                aletsch::sink_transcript x;
-                x.strand = p.strand; x.coverage = log(1.0 + p.weight); x.cov2 = x.coverage; x.conf = p.conf; x.abd = p.abd; x.count1 = p.count; x.count2 = 1;
-                x.tid = tid_base + (((int64_t)g << 20) | (int64_t)(i - b->res.path_begin[g]));
-                x.exons.reserve(ex.size() / 2);
-                for(size_t k = 0; k + 1 < ex.size(); k += 2) x.exons.push_back(std::make_pair(ex[k], ex[k + 1]));
-                ts.add(x, 1, sid ? sid[g] : -1); any = true;                   // assembler.cc:1120
+            int cnt = 0; int64_t first = -1;
+            for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++) if(mine(bucket[(size_t)i])) { if(cnt++ == 0) first = i; }
+            if(cnt == 0) continue;
+            const int s_id = sid ? sid[g] : -1;
+            if(cnt == 1) { make(g, first, x); const uint32_t h = bucket[(size_t)first]; t->shard[h % ALD_TSET_SHARDS].add_hashed(x, h, 1, s_id); continue; }
+            aletsch::transcript_sink ts(t->overlap);
+            for(int64_t i = first; i < b->res.path_begin[g + 1]; i++) {
+                if(!mine(bucket[(size_t)i])) continue;
+                make(g, i, x);
+                ts.add_hashed(x, bucket[(size_t)i], 1, s_id);                   // assembler.cc:1120
             }
-            if(any) t->add(ts);                                                // assembler.cc:1130 (only tables this thread owns are touched)
+            t->add(ts);                                                        // assembler.cc:1130 (only tables this thread owns are touched)
         }
     });
+    if(getenv("ALD_SINK_PROF")) { auto T3 = std::chrono::steady_clock::now(); auto ms = [](auto a, auto b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); }; fprintf(stderr, "[sink] index %.1f ms, hash pass %.1f ms, merge pass %.1f ms (%u threads)\n", ms(T0, T1), ms(T1, T2), ms(T2, T3), nthr); }
     return ALD_OK;
 }
 

@@ -124,10 +124,11 @@ public:
 
     // transcript_set::add(t, count, sid) (transcript_set.cc:149-154) = a one-item set merged in.  merge_sorted_trans_items with a
     // single y walks the bucket while compare1 says "x first", then merges into the first equal item or inserts y right there.
-    void add(const sink_transcript &t, int count, int sid) {
+    void add(const sink_transcript &t, int count, int sid) { add_hashed(t, t.intron_chain_hashing(), count, sid); }
+    void add_hashed(const sink_transcript &t, size_t key, int count, int sid) {       // key == t.intron_chain_hashing(), computed by the caller
         sink_item y(t, count, sid);
-        auto z = mt.find(t.intron_chain_hashing());
-        if(z == mt.end()) { std::vector<sink_item> v; v.emplace_back(std::move(y)); mt.emplace(t.intron_chain_hashing(), std::move(v)); return; }
+        auto z = mt.find(key);
+        if(z == mt.end()) { std::vector<sink_item> v; v.emplace_back(std::move(y)); mt.emplace(key, std::move(v)); return; }
         std::vector<sink_item> &vx = z->second;
         size_t kx = 0; int b = +1;
         while(kx < vx.size() && (b = vx[kx].trst.compare1(y.trst, overlap_)) == +1) kx++;

@@ -1,0 +1,36 @@
+# Sustained host-arrays-in -> merged-transcript-set-out rate with the stages overlapped on host threads (ctypes drops the GIL):
+#   stage (add + upload)  |  kernel (run + download)  |  merge (sink.add_batch)      -- three batches in flight
+import sys, time, threading, queue, numpy as np
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import aletsch_amd as A
+n = 100000; rounds = 8
+pgs = [A.synth(seed=1002 + k, n_graphs=n, v_min=64, v_max=64, fixed_edges=256) for k in range(2)]
+sid = (np.arange(n) % 8).astype(np.int32)
+batches = [A.DecompBatch(0) for _ in range(3)]
+free = queue.Queue(); [free.put(b) for b in batches]
+staged = queue.Queue(maxsize=1); done = queue.Queue(maxsize=1)
+sink = A.TranscriptSink(0.8)
+tstage = tkern = tsink = 0.0
+def stage():
+    global tstage
+    for r in range(rounds):
+        b = free.get(); t = time.time(); b.clear(); b.add(pgs[r % 2]); b.upload(); tstage += time.time() - t; staged.put(b)
+    staged.put(None)
+def kern():
+    global tkern
+    while True:
+        b = staged.get()
+        if b is None: done.put(None); return
+        t = time.time(); b.run(); b.download(); tkern += time.time() - t; done.put(b)
+def merge():
+    global tsink
+    r = 0
+    while True:
+        b = done.get()
+        if b is None: return
+        t = time.time(); sink.add_batch(b, sid, tid_base=r << 44); tsink += time.time() - t; r += 1; free.put(b)
+# warm-up round (allocations), then the timed pipeline
+for b in batches: b.add(pgs[0]); b.upload(); b.run(); b.download(); b.clear()
+th = [threading.Thread(target=f) for f in (stage, kern, merge)]
+t0 = time.time(); [t.start() for t in th]; [t.join() for t in th]; el = time.time() - t0
+print("pipeline: %d batches x %d graphs in %.2f s -> %.0f graphs/s end to end (stage %.2f s, kernel+D2H %.2f s, merge %.2f s busy)" % (rounds, n, el, rounds * n / el, tstage, tkern, tsink), flush=True)
