@@ -399,38 +399,43 @@ struct HostResults {
         const size_t R = offs.size();
         unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16;
         if(R < 50000) nthr = 1;
-        std::vector<PathRec> tmp(R); std::vector<uint8_t> keep(R, 0); std::vector<int> bad(nthr, 0);
+        std::vector<uint8_t> keep(R, 0); std::vector<int> bad(nthr, 0);
         auto run = [&](unsigned nt, auto &&f) {
             if(nt <= 1) { f(0u); return; }
             std::vector<std::thread> th; for(unsigned t = 1; t < nt; t++) th.emplace_back([&f, t]() { f(t); });
             f(0u); for(auto &x : th) x.join();
         };
+        // which records count (final attempt of a graph that ended well), and how many per graph
+        std::vector<int64_t> cnt(n + 1, 0);
+        std::vector<std::vector<int32_t>> tcnt(nthr);
         run(nthr, [&](unsigned t) {
+            std::vector<int32_t> &c = tcnt[t]; c.assign(n, 0);
             for(size_t i = R * t / nthr; i < R * (t + 1) / nthr; i++) {
                 const uint32_t *r = pw + offs[i];
-                PathRec &p = tmp[i]; p.graph = (int32_t)r[0]; p.index = (int32_t)r[1]; p.nv = (int32_t)r[2]; p.length = (int32_t)r[3]; p.count = (int32_t)r[4];
-                p.strand = (char)(r[5] & 0xFF); p.attempt = (int)((r[5] >> 8) & 0xFF);
-                if(p.graph < 0 || p.graph >= n) { bad[t] = 1; return; }
-                memcpy(&p.weight, r + 6, 8); memcpy(&p.abd, r + 8, 8); memcpy(&p.conf, r + 10, 8); memcpy(&p.reads, r + 12, 8);
-                p.vert_off = offs[i] + REC_HDR_WORDS;
-                keep[i] = ((status[p.graph] == ALD_ST_OK || status[p.graph] == ALD_ST_SKIPPED_LARGE) && p.attempt == attempt[p.graph]) ? 1 : 0;
+                const int32_t g = (int32_t)r[0]; const int att = (int)((r[5] >> 8) & 0xFF);
+                if(g < 0 || g >= n) { bad[t] = 1; return; }
+                if((status[g] == ALD_ST_OK || status[g] == ALD_ST_SKIPPED_LARGE) && att == attempt[g]) { keep[i] = 1; c[g]++; }
             }
         });
         for(unsigned t = 0; t < nthr; t++) if(bad[t]) return -1;
-        std::vector<int64_t> cnt(n + 1, 0);
-        for(size_t i = 0; i < R; i++) if(keep[i]) cnt[tmp[i].graph + 1]++;
+        for(unsigned t = 0; t < nthr; t++) for(int g = 0; g < n; g++) cnt[g + 1] += tcnt[t][g];
         path_begin.assign(n + 1, 0);
         int64_t kept = 0;
         for(int g = 0; g < n; g++) { path_begin[g + 1] = path_begin[g] + cnt[g + 1]; kept += cnt[g + 1]; }
         paths.resize((size_t)kept);
+        // decode every kept record straight into its slot: (graph, index) is unique per kept record, so the writes are disjoint
         std::vector<int64_t> ob(nthr, 0);
-        for(unsigned t = 0; t < nthr; t++) bad[t] = 0;
         run(nthr, [&](unsigned t) {
             for(size_t i = R * t / nthr; i < R * (t + 1) / nthr; i++) {
                 if(!keep[i]) continue;
-                const PathRec &p = tmp[i];
-                if(p.index < 0 || p.index >= cnt[p.graph + 1]) { bad[t] = 2; return; }
-                paths[(size_t)(path_begin[p.graph] + p.index)] = p;            // (graph, index) is unique per kept record: disjoint writes
+                const uint32_t *r = pw + offs[i];
+                const int32_t g = (int32_t)r[0], idx = (int32_t)r[1];
+                if(idx < 0 || idx >= cnt[g + 1]) { bad[t] = 2; return; }
+                PathRec &p = paths[(size_t)(path_begin[g] + idx)];
+                p.graph = g; p.index = idx; p.nv = (int32_t)r[2]; p.length = (int32_t)r[3]; p.count = (int32_t)r[4];
+                p.strand = (char)(r[5] & 0xFF); p.attempt = (int)((r[5] >> 8) & 0xFF);
+                memcpy(&p.weight, r + 6, 8); memcpy(&p.abd, r + 8, 8); memcpy(&p.conf, r + 10, 8); memcpy(&p.reads, r + 12, 8);
+                p.vert_off = offs[i] + REC_HDR_WORDS;
                 ob[t] += 4ll * p.nv + 40;
             }
         });
