@@ -112,6 +112,28 @@ struct sink_item {                               // trans_item (transcript_set.h
         trst.count2 = (int)samples.size();
         for(auto &x : samples) { x.second.coverage = trst.coverage; x.second.count2 = (int)samples.size(); }
     }
+    // merge(sink_item(t, c, s)) without building the temporary item (what transcript_set::add(t, count, sid) amounts to when an equal
+    // transcript is already there)
+    void merge_transcript(const sink_transcript &t, int c, int s) {
+        if(trst.exons.size() >= 2) trst.coverage += t.coverage;
+        else if(trst.coverage < t.coverage) trst.coverage = t.coverage;
+        trst.extend_bounds(t);
+        count += c;
+        if(trst.cov2 < t.cov2) trst.cov2 = t.cov2;
+        if(trst.conf < t.conf) trst.conf = t.conf;
+        if(trst.abd < t.abd) trst.abd = t.abd;
+        if(trst.count1 < t.count1) trst.count1 = t.count1;
+        auto f = samples.find(s);
+        if(f == samples.end()) { sink_sample x; x.coverage = t.coverage; x.cov2 = t.cov2; x.conf = t.conf; x.abd = t.abd; x.count1 = t.count1; x.count2 = 1; samples.insert(std::make_pair(s, x)); }
+        else {
+            if(f->second.cov2 < t.cov2) f->second.cov2 = t.cov2;
+            if(f->second.conf < t.conf) f->second.conf = t.conf;
+            if(f->second.abd < t.abd) f->second.abd = t.abd;
+            if(f->second.count1 < t.count1) f->second.count1 = t.count1;
+        }
+        trst.count2 = (int)samples.size();
+        for(auto &x : samples) { x.second.coverage = trst.coverage; x.second.count2 = (int)samples.size(); }
+    }
 };
 
 class transcript_sink {                          // transcript_set (transcript_set.h:37-59), one chromosome / region per sink
@@ -126,14 +148,13 @@ public:
     // single y walks the bucket while compare1 says "x first", then merges into the first equal item or inserts y right there.
     void add(const sink_transcript &t, int count, int sid) { add_hashed(t, t.intron_chain_hashing(), count, sid); }
     void add_hashed(const sink_transcript &t, size_t key, int count, int sid) {       // key == t.intron_chain_hashing(), computed by the caller
-        sink_item y(t, count, sid);
         auto z = mt.find(key);
-        if(z == mt.end()) { std::vector<sink_item> v; v.emplace_back(std::move(y)); mt.emplace(key, std::move(v)); return; }
+        if(z == mt.end()) { std::vector<sink_item> v; v.emplace_back(t, count, sid); mt.emplace(key, std::move(v)); return; }
         std::vector<sink_item> &vx = z->second;
         size_t kx = 0; int b = +1;
-        while(kx < vx.size() && (b = vx[kx].trst.compare1(y.trst, overlap_)) == +1) kx++;
-        if(kx < vx.size() && b == 0) vx[kx].merge(y);
-        else vx.insert(vx.begin() + kx, std::move(y));
+        while(kx < vx.size() && (b = vx[kx].trst.compare1(t, overlap_)) == +1) kx++;
+        if(kx < vx.size() && b == 0) vx[kx].merge_transcript(t, count, sid);
+        else vx.insert(vx.begin() + kx, sink_item(t, count, sid));
     }
     void add(transcript_sink &ts) {              // transcript_set.cc:156-175
         for(auto &x : ts.mt) add_bucket(x.first, x.second);
