@@ -82,9 +82,20 @@ struct sink_transcript {
 struct sink_sample {                             // what the reference keeps of the per-sample transcript copy in trans_item::samples:
     double coverage = 0, cov2 = 0, conf = 0, abd = 0; int count1 = 0, count2 = 0;     // the fields merge() reads and writes (exons are those of trst)
 };
+// map<int, sink_sample> for a handful of samples: one sorted array (find / insert / ordered iteration as std::map gives them)
+struct sample_map {
+    typedef std::pair<int, sink_sample> value_type;
+    std::vector<value_type> v;
+    typedef std::vector<value_type>::iterator iterator;
+    iterator begin() { return v.begin(); } iterator end() { return v.end(); }
+    std::vector<value_type>::const_iterator begin() const { return v.begin(); } std::vector<value_type>::const_iterator end() const { return v.end(); }
+    size_t size() const { return v.size(); }
+    iterator find(int k) { iterator it = std::lower_bound(v.begin(), v.end(), k, [](const value_type &a, int key) { return a.first < key; }); return (it != v.end() && it->first == k) ? it : v.end(); }
+    void insert(const value_type &x) { iterator it = std::lower_bound(v.begin(), v.end(), x.first, [](const value_type &a, int key) { return a.first < key; }); if(it == v.end() || it->first != x.first) v.insert(it, x); }
+};
 struct sink_item {                               // trans_item (transcript_set.h:20-33)
     sink_transcript trst; int count = 0;
-    std::map<int, sink_sample> samples;
+    sample_map samples;
     sink_item() {}
     sink_item(const sink_transcript &t, int c, int s) : trst(t), count(c) {
         sink_sample x; x.coverage = t.coverage; x.cov2 = t.cov2; x.conf = t.conf; x.abd = t.abd; x.count1 = t.count1; x.count2 = 1;
