@@ -574,9 +574,13 @@ int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int6
     if(const char *ev = getenv("ALD_SINK_THREADS")) { int k = atoi(ev); if(k >= 1 && k <= 64) nthr = (unsigned)k; }
     else if(np < 20000) nthr = 1;
     if(nthr > ALD_TSET_SHARDS) nthr = ALD_TSET_SHARDS;
-    // pass 1: bucket of every transcript (hashes are below 2^31 + 1; ALD_NO_BUCKET = dropped)
+    // pass 1 (graphs split over the threads, everything local to a graph still in cache): joined exons of every transcript, kept in
+    // one array at a slot sized by its internal vertices, and its bucket (hashes are below 2^31 + 1; ALD_NO_BUCKET = dropped)
     const uint32_t ALD_NO_BUCKET = 0xFFFFFFFFu;
     std::vector<uint32_t> bucket((size_t)np, ALD_NO_BUCKET);
+    std::vector<int64_t> ex_off((size_t)np + 1, 0); std::vector<int32_t> ex_len((size_t)np, 0);
+    for(int64_t i = 0; i < np; i++) ex_off[(size_t)i + 1] = ex_off[(size_t)i] + 2 * (int64_t)(b->res.paths[(size_t)i].nv > 2 ? b->res.paths[(size_t)i].nv - 2 : 0);
+    rvec<int32_t> ex_all; ex_all.resize((size_t)ex_off[(size_t)np] + 2);
     HostBatch::run_threads(nthr, [&](unsigned th) {
         std::vector<int32_t> ex;
         const int g0 = (int)((int64_t)n * th / nthr), g1 = (int)((int64_t)n * (th + 1) / nthr);
@@ -584,6 +588,8 @@ int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int6
             join_exons(b, g, b->res.paths[i], ex);
             if(ex.size() <= 2 && skip_single_exon) continue;                 // assembler.cc:1117
             bucket[(size_t)i] = (uint32_t)chain_hash(ex);                     // <= 2^31
+            ex_len[(size_t)i] = (int32_t)ex.size();
+            if(!ex.empty()) memcpy(&ex_all[(size_t)ex_off[(size_t)i]], ex.data(), 4 * ex.size());
         }
     });
     auto T2 = std::chrono::steady_clock::now();
@@ -591,15 +597,14 @@ int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int6
     // A graph that puts a single transcript into this thread's tables needs no per-graph set: merging a one-item set is the same as
     // adding the item (transcript_set.cc:149-175).
     HostBatch::run_threads(nthr, [&](unsigned th) {
-        std::vector<int32_t> ex;
         auto mine = [&](uint32_t h) { return h != ALD_NO_BUCKET && (h % ALD_TSET_SHARDS) % nthr == th; };
         auto make = [&](int g, int64_t i, aletsch::sink_transcript &x) {
             const PathRec &p = b->res.paths[i];
-            join_exons(b, g, p, ex);
             x.strand = p.strand; x.coverage = log(1.0 + p.weight); x.cov2 = x.coverage; x.conf = p.conf; x.abd = p.abd; x.count1 = p.count; x.count2 = 1;
             x.tid = tid_base + (((int64_t)g << 20) | (int64_t)(i - b->res.path_begin[g]));
-            x.exons.clear(); x.exons.reserve(ex.size() / 2);
-            for(size_t k = 0; k + 1 < ex.size(); k += 2) x.exons.push_back(std::make_pair(ex[k], ex[k + 1]));
+            const int32_t *ex = &ex_all[(size_t)ex_off[(size_t)i]]; const int len = ex_len[(size_t)i];
+            x.exons.clear(); x.exons.reserve((size_t)len / 2);
+            for(int k = 0; k + 1 < len; k += 2) x.exons.push_back(std::make_pair(ex[k], ex[k + 1]));
         };
         aletsch::sink_transcript x;
         for(int g = 0; g < n; g++) {
