@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--graphs", type=int, default=100000, help="graphs per GPU (BASELINE configs[1]: 100k)")
     ap.add_argument("--vertices", type=int, default=64)
     ap.add_argument("--edges", type=int, default=256)
+    ap.add_argument("--weights", choices=("uniform", "int", "flow"), default="uniform",
+                    help="edge weights: uniform = U[1,100) f64 (BASELINE configs), flow = flow-conserving sums of s-t paths (SURVEY.md 8d's second distribution)")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="graphs in the bounded cpu_baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -66,7 +68,8 @@ def main():
 
     dev = local if dist_on else 0
     seed = 1002 if world == 1 else 1004 + rank          # SURVEY.md 8d seeds: cfg2 = 1002, cfg4 = 1004 + rank
-    pg = A.synth(seed=seed, n_graphs=args.graphs, v_min=args.vertices, v_max=args.vertices, fixed_edges=args.edges)
+    pg = A.synth(seed=seed, n_graphs=args.graphs, v_min=args.vertices, v_max=args.vertices, fixed_edges=args.edges,
+                 weight_mode={"uniform": 0, "int": 1, "flow": 2}[args.weights])
     # Two batch objects over the same resident input, used alternately: the D2H of batch k's path records (SDMA, own stream)
     # overlaps batch k+1's kernel.  Kernels never overlap each other (the previous one is synchronised before the next launch),
     # so the per-launch HIP-event time stays the time of ONE kernel on an otherwise idle GPU.
@@ -138,7 +141,7 @@ def main():
     traffic = None; traffic_src = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if tj.get("graphs_per_gpu") == args.graphs and tj.get("vertices") == args.vertices and tj.get("edges") == args.edges:
+        if tj.get("graphs_per_gpu") == args.graphs and tj.get("vertices") == args.vertices and tj.get("edges") == args.edges and args.weights == "uniform":
             traffic = tj["traffic_bytes_per_launch"]; traffic_src = tj.get("source")
     except (OSError, ValueError, KeyError):
         pass
@@ -152,7 +155,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.graphs} synthetic splice graphs per GPU, {args.vertices} vertices / {args.edges} edges each "
-                                   f"(BASELINE.json configs[1]; U[1,100) FP64 weights, 1 supporting sample per edge, no phasing paths)",
+                                   + ("(BASELINE.json configs[1]; U[1,100) FP64 weights, 1 supporting sample per edge, no phasing paths)" if args.weights == "uniform" else
+                                      f"(BASELINE.json configs[1] shape with {args.weights} weights -- secondary distribution, not the headline)"),
                        "graphs_per_gpu": args.graphs, "sharding": "independent graphs per rank, RCCL gather of path records to rank 0" if world > 1 else "single GPU",
                        "failed_graphs": n_bad, "paths_per_graph": float(len(res.weight)) / max(1, args.graphs),
                        "workgroups_per_cu": info["blocks_per_cu"], "grid": info["blocks_last_run"]},

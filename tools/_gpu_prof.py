@@ -5,9 +5,9 @@ import aletsch_amd as A
 names = ["load","broken","triv_eval","triv_mut","small_eval","small_mut","unsplit","collect0","g_balance","g_dp","g_splitmerge","g_collect","finish","T_balance","T_pairs","T_setup","M_load","M_add","M_isect","M_mask","M_sums","M_kill","T_hs","T_tail"]
 import os
 CFG = os.environ.get("PROF_CFG", "cfg2")
-for n in (20000 if CFG == "cfg2" else 600,):
-    pg = A.synth(seed=1002, n_graphs=n, v_min=64, v_max=64, fixed_edges=256) if CFG == "cfg2" else A.synth(seed=1003, n_graphs=n, v_min=400, v_max=512, edges_per_vertex=4)
-    with A.DecompBatch(0, trace_events=(600 if CFG == "cfg2" else 6000)) as b:
+for n in (20000 if CFG.startswith("cfg2") else 600,):
+    pg = A.synth(seed=1002, n_graphs=n, v_min=64, v_max=64, fixed_edges=256, weight_mode=(2 if CFG == "cfg2flow" else 0)) if CFG.startswith("cfg2") else A.synth(seed=1003, n_graphs=n, v_min=400, v_max=512, edges_per_vertex=4)
+    with A.DecompBatch(0, trace_events=(600 if CFG.startswith("cfg2") else 6000)) as b:
         b.add(pg); b.upload(); b.run(); b.download()
         tot = np.zeros(len(names)); cnt = 0
         for g in range(0, n, max(1, n // 200)):
