@@ -132,7 +132,6 @@ struct ColdLayoutT {
     static constexpr uint64_t ED_BYTES = (56 + 8ull * NW + 63) / 64 * 64;          // 4 f64 + mask[NW] + 5 i32 + strand, padded to whole lines
     static constexpr uint64_t o_vx = 0;
     static constexpr uint64_t o_ed = (o_vx + VX_BYTES * MAXV + 63) / 64 * 64;
-    static constexpr uint64_t o_mask = o_ed;                                        // (name kept for the next offset)
     static constexpr uint64_t o_spid = al(o_ed + ED_BYTES * MAXE);
     static constexpr uint64_t o_spabd = al(o_spid + 4ull * SP_CAP);
     static constexpr uint64_t o_hl = al(o_spabd + 8ull * SP_CAP);
