@@ -7,13 +7,16 @@
 // aletsch::gpu_assembly_queue keeps that call shape for the pool tasks -- submit(gx, hx, sid) where the reference has
 // `scallop sx(gx, hx, pa); sx.assemble(); ... tm.add(ts)` -- and batches ACROSS tasks and clusters:
 //
-//     pool threads --submit()--> filling batch --full--> [GPU thread: upload, kernel, download] --> [merge thread: ald_tset_add_batch]
+//   pool threads --submit()--> per-thread chunk --full--> ready chunks --> [pack thread: ald_batch_add_packed into a free batch]
+//        --> [GPU thread: upload, kernel, download] --> [merge thread: ald_tset_add_batch] --> sink
 //
-// `slots` batches rotate through the three stages, so staging (in the submitting threads), the kernel and the merge overlap.
-// Graphs are merged into the sink in ticket order (the order submit() calls took the queue's lock), batch after batch -- the
-// same per-bucket sequence of trans_item::merge calls as a serial run over the tickets, without `mylock` around the decomposition.
-// With one submitting thread the result is bit-identical to the serial loop; with several, the ticket order is whatever the pool
-// produced, exactly as the reference's merge order is whatever `mylock` produced.
+// A submitting thread converts its graph and appends it to ITS OWN chunk of packed arrays (no shared lock on that path); a full
+// chunk is handed over with one short critical section and gets the next run of tickets.  The pack thread gathers chunks into a
+// batch of `batch_graphs`; `slots` batches rotate through the pack, GPU and merge stages, so staging, kernel and merge overlap.  Graphs
+// are merged into the sink in ticket order, batch after batch -- the same per-bucket sequence of trans_item::merge calls as a
+// serial run over the tickets.  With one submitting thread tickets are the submission order and the result is bit-identical to
+// the serial loop; with several, chunks interleave as the pool produced them, exactly as the reference's merge order is whatever
+// `mylock` produced.
 //
 // C++11, header only; compiles inside the reference tree with its own types (see gpu_scallop.hpp for the members used).
 #pragma once
@@ -22,24 +25,59 @@
 #include <mutex>
 #include <condition_variable>
 #include <deque>
+#include <memory>
+#include <chrono>
 
 namespace aletsch {
+
+// many staged graphs back to back, in the layout of ald_batch_add_packed
+struct packed_chunk {
+    std::vector<int32_t> g_nv, g_ne, g_np, vertex_offset, edge_target, edge_sample_offset, sample_id, vertex_lpos, vertex_rpos, vertex_type,
+                         phasing_offset, phasing_vertex, phasing_count, edge_count, sid;
+    std::vector<double> edge_weight, edge_abd, sample_abd, vertex_weight; std::vector<uint8_t> edge_strand; std::vector<char> graph_strand;
+    long first = 0;                                               // ticket of the first graph, set when the chunk is handed over
+    int n() const { return (int)g_nv.size(); }
+    template<class T> static void cat(std::vector<T> &d, const std::vector<T> &s) { d.insert(d.end(), s.begin(), s.end()); }
+    void append(const staged_graph &s, int sample)
+    {
+        g_nv.push_back((int32_t)s.vertex_weight.size()); g_ne.push_back((int32_t)s.edge_target.size()); g_np.push_back((int32_t)s.phasing_count.size());
+        graph_strand.push_back(s.strand); sid.push_back((int32_t)sample);
+        cat(vertex_offset, s.vertex_offset); cat(edge_target, s.edge_target); cat(edge_weight, s.edge_weight); cat(edge_strand, s.edge_strand); cat(edge_abd, s.edge_abd);
+        cat(edge_sample_offset, s.edge_sample_offset); cat(sample_id, s.sample_id); cat(sample_abd, s.sample_abd);
+        cat(vertex_weight, s.vertex_weight); cat(vertex_lpos, s.vertex_lpos); cat(vertex_rpos, s.vertex_rpos); cat(vertex_type, s.vertex_type);
+        cat(phasing_offset, s.phasing_offset); cat(phasing_vertex, s.phasing_vertex); cat(phasing_count, s.phasing_count); cat(edge_count, s.edge_count);
+    }
+    int add_to(ald_batch *b) const
+    {
+        static const int32_t zero_i = 0; static const double zero_d = 0;     // empty arrays still need valid pointers
+        auto pi = [](const std::vector<int32_t> &v) { return v.empty() ? &zero_i : v.data(); };
+        auto pd = [](const std::vector<double> &v) { return v.empty() ? &zero_d : v.data(); };
+        return ald_batch_add_packed(b, n(), g_nv.data(), g_ne.data(), g_np.data(), vertex_offset.data(), pi(edge_target), pd(edge_weight),
+                                    edge_strand.empty() ? (const uint8_t*)&zero_i : edge_strand.data(), pd(edge_abd), edge_sample_offset.data(), pi(sample_id), pd(sample_abd),
+                                    pd(vertex_weight), pi(vertex_lpos), pi(vertex_rpos), pi(vertex_type), phasing_offset.data(), pi(phasing_vertex), pi(phasing_count),
+                                    graph_strand.data(), pi(edge_count));
+    }
+};
 
 template<class SpliceGraph, class HyperSet, class Parameters>
 class gpu_assembly_queue {
 public:
-    // sink: the shared result set (the reference's `tmerge`); skip_single_exon: cfg.skip_single_exon_transcripts (assembler.cc:1117)
-    gpu_assembly_queue(const Parameters &cfg, ald_tset *sink, bool skip_single_exon = false, int device = 0, int batch_graphs = 65536, int slots = 3)
+    // sink: the shared result set (the reference's `tmerge`); skip_single_exon: cfg.skip_single_exon_transcripts (assembler.cc:1117);
+    // chunk_graphs: graphs a submitting thread collects before it hands them over (capped by batch_graphs)
+    gpu_assembly_queue(const Parameters &cfg, ald_tset *sink, bool skip_single_exon = false, int device = 0, int batch_graphs = 65536, int slots = 4, int chunk_graphs = 2048)
         : sink_(sink), skip_(skip_single_exon), batch_graphs_(batch_graphs < 1 ? 1 : batch_graphs)
     {
         if(!sink) throw std::invalid_argument("gpu_assembly_queue: null sink");
         if(slots < 1) slots = 1;
+        chunk_graphs_ = chunk_graphs < 1 ? 1 : chunk_graphs; if(chunk_graphs_ > batch_graphs_) chunk_graphs_ = batch_graphs_;
+        ready_cap_ = (long)batch_graphs_ * (slots + 1);
         ald_params p = stage_params(cfg);
         slots_.resize((size_t)slots);
         for(auto &s : slots_) {
             int rc = ald_batch_create(&p, device, &s.b);
             if(rc != ALD_OK) { for(auto &q : slots_) if(q.b) ald_batch_destroy(q.b); throw gpu_error(rc, "ald_batch_create"); }
         }
+        pack_thread_ = std::thread([this] { pack_loop(); });
         gpu_thread_ = std::thread([this] { gpu_loop(); });
         merge_thread_ = std::thread([this] { merge_loop(); });
     }
@@ -47,77 +85,123 @@ public:
     {
         try { drain(); } catch(...) {}
         { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
-        cv_gpu_.notify_all(); cv_merge_.notify_all();
-        gpu_thread_.join(); merge_thread_.join();
+        cv_pack_.notify_all(); cv_gpu_.notify_all(); cv_merge_.notify_all();
+        pack_thread_.join(); gpu_thread_.join(); merge_thread_.join();
         for(auto &s : slots_) if(s.b) ald_batch_destroy(s.b);
     }
     gpu_assembly_queue(const gpu_assembly_queue &) = delete;
     gpu_assembly_queue &operator=(const gpu_assembly_queue &) = delete;
 
-    // Thread-safe.  Returns the graph's ticket; its transcripts carry tid = (ticket << 20) | path index.
-    long submit(SpliceGraph &gx, const HyperSet &hx, int sid)
+    // Thread-safe.  The graph's transcripts will carry tid = (ticket << 20) | path index, tickets being handed out chunk by chunk.
+    void submit(SpliceGraph &gx, const HyperSet &hx, int sid)
     {
-        staged_graph s = stage_graph(gx, hx);                     // the per-graph work stays in the calling thread, outside the lock
-        ald_graph_view g = s.view();
+        staged_graph s = stage_graph(gx, hx);                     // the per-graph work stays in the calling thread, outside any shared lock
+        lane *L = my_lane();
+        std::unique_lock<std::mutex> ll(L->m);
+        L->c.append(s, sid);
+        if(L->c.n() < chunk_graphs_) return;
+        packed_chunk full; std::swap(full, L->c);
+        ll.unlock();
         std::unique_lock<std::mutex> lk(m_);
-        for(;;) {
-            if(err_) throw gpu_error(err_, err_msg_.c_str());
-            if(fill_ >= 0) break;
-            for(size_t i = 0; i < slots_.size(); i++) if(slots_[i].state == FREE) { fill_ = (int)i; slots_[i].state = FILLING; slots_[i].first = next_; break; }
-            if(fill_ < 0) cv_free_.wait(lk);                      // every batch is in flight: the pool is ahead of the GPU
-        }
-        slot &S = slots_[(size_t)fill_];
-        int rc = ald_batch_add_graph(S.b, &g);
-        if(rc != ALD_OK) throw gpu_error(rc, "ald_batch_add_graph");
-        S.sid.push_back((int32_t)sid);
-        const long ticket = next_++;
-        if((int)S.sid.size() >= batch_graphs_) hand_over();
-        return ticket;
+        while(ready_graphs_ >= ready_cap_ && !err_) cv_space_.wait(lk);            // the pool is ahead of the GPU: hold the submitter back
+        if(err_) throw gpu_error(err_, err_msg_.c_str());
+        push_chunk(std::move(full));
     }
 
-    // Flushes the partial batch and returns when every submitted graph has been merged into the sink.
+    // Hands over every partial chunk and returns when every submitted graph has been merged into the sink.
     void drain()
     {
         std::unique_lock<std::mutex> lk(m_);
-        if(fill_ >= 0) {
-            if(slots_[(size_t)fill_].sid.empty()) { slots_[(size_t)fill_].state = FREE; fill_ = -1; }
-            else hand_over();
+        for(auto &kv : lanes_) {
+            std::lock_guard<std::mutex> ll(kv.second->m);
+            if(kv.second->c.n() > 0) { packed_chunk part; std::swap(part, kv.second->c); push_chunk(std::move(part)); }
         }
-        while(in_flight_ > 0) cv_done_.wait(lk);
+        flush_ = true; cv_pack_.notify_all();
+        while(!ready_.empty() || gathering_ || in_flight_ > 0) cv_done_.wait(lk);      // (after an error the stages still run dry: batches are dropped, not merged)
+        flush_ = false;
         if(err_) throw gpu_error(err_, err_msg_.c_str());
     }
 
-    long submitted() const { std::lock_guard<std::mutex> lk(m_); return next_; }
+    long submitted() const { std::lock_guard<std::mutex> lk(m_); return next_; }       // graphs handed over so far (all of them after drain())
     // graphs whose status word was not ALD_ST_OK (the reference would have aborted on an assert, or printed its own skip message)
     long failed_graphs() const { std::lock_guard<std::mutex> lk(m_); return failed_; }
     long batches() const { std::lock_guard<std::mutex> lk(m_); return batches_; }
+    // busy seconds of the stages so far: packing chunks into a batch / upload + kernel + download / merge into the sink
+    void stage_seconds(double &pack, double &gpu, double &merge) const { std::lock_guard<std::mutex> lk(m_); pack = t_pack_; gpu = t_gpu_; merge = t_merge_; }
 
 private:
-    enum { FREE, FILLING, QUEUED };
+    enum { FREE, BUSY };
     struct slot { ald_batch *b = nullptr; std::vector<int32_t> sid; long first = 0; int state = FREE; };
+    struct lane { std::mutex m; packed_chunk c; };
 
-    void hand_over()                                              // m_ held
+    lane *my_lane()
     {
-        slots_[(size_t)fill_].state = QUEUED; gpu_q_.push_back(fill_); fill_ = -1; in_flight_++; batches_++;
-        cv_gpu_.notify_one();
+        std::lock_guard<std::mutex> lk(m_);
+        std::unique_ptr<lane> &p = lanes_[std::this_thread::get_id()];
+        if(!p) p.reset(new lane());
+        return p.get();
+    }
+    void push_chunk(packed_chunk &&c)                             // m_ held
+    {
+        c.first = next_; next_ += c.n(); ready_graphs_ += c.n();
+        ready_.push_back(std::move(c));
+        if(ready_graphs_ >= batch_graphs_) cv_pack_.notify_one();
     }
     void fail(int rc, const char *what)                          // m_ held; the first error is kept
     {
         if(!err_) { err_ = rc; err_msg_ = std::string(what) + ": " + ald_last_error(); }
+        cv_space_.notify_all();
     }
-    void gpu_loop()
+    void pack_loop()                                              // gathers handed-over chunks into a free batch
     {
         for(;;) {
-            int i;
-            { std::unique_lock<std::mutex> lk(m_); while(gpu_q_.empty() && !stop_) cv_gpu_.wait(lk); if(gpu_q_.empty()) return; i = gpu_q_.front(); gpu_q_.pop_front(); }
-            ald_batch *b = slots_[(size_t)i].b;
-            int rc; const char *what = "ald_batch_upload";
-            if((rc = ald_batch_upload(b)) == ALD_OK) { what = "ald_batch_run"; rc = ald_batch_run(b); }
-            if(rc == ALD_OK) { what = "ald_batch_download"; rc = ald_batch_download(b); }
+            std::vector<packed_chunk> take; int i = -1;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                for(;;) {
+                    const bool work = ready_graphs_ >= batch_graphs_ || (flush_ && !ready_.empty());
+                    if(work) { for(size_t k = 0; k < slots_.size(); k++) if(slots_[k].state == FREE) { i = (int)k; break; } if(i >= 0) break; }
+                    else if(stop_) return;
+                    cv_pack_.wait(lk);
+                }
+                long got = 0;
+                while(!ready_.empty() && got < batch_graphs_) { got += ready_.front().n(); take.push_back(std::move(ready_.front())); ready_.pop_front(); }
+                ready_graphs_ -= got; gathering_ = true; slots_[(size_t)i].state = BUSY; batches_++;
+                cv_space_.notify_all();
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            slot &S = slots_[(size_t)i];
+            S.first = take.front().first; S.sid.clear();
+            int rc = ALD_OK;
+            for(auto &c : take) { if(rc == ALD_OK) rc = c.add_to(S.b); S.sid.insert(S.sid.end(), c.sid.begin(), c.sid.end()); }
+            take.clear();
+            const auto t1 = std::chrono::steady_clock::now();
+            std::lock_guard<std::mutex> lk(m_);
+            if(rc != ALD_OK) fail(rc, "ald_batch_add_packed");
+            t_pack_ += std::chrono::duration<double>(t1 - t0).count();
+            gathering_ = false; in_flight_++;
+            gpu_q_.push_back(i); cv_gpu_.notify_one();
+        }
+    }
+    void gpu_loop()                                               // upload, kernel, download of one batch at a time
+    {
+        for(;;) {
+            int i; bool ok;
+            { std::unique_lock<std::mutex> lk(m_); while(gpu_q_.empty() && !stop_) cv_gpu_.wait(lk); if(gpu_q_.empty()) return; i = gpu_q_.front(); gpu_q_.pop_front(); ok = !err_; }
+            slot &S = slots_[(size_t)i];
+            const auto t1 = std::chrono::steady_clock::now();
+            int rc = ALD_OK; const char *what = "ald_batch_upload";
+            if(ok) {
+                rc = ald_batch_upload(S.b);
+                if(rc == ALD_OK) { what = "ald_batch_run"; rc = ald_batch_run(S.b); }
+                if(rc == ALD_OK) { what = "ald_batch_download"; rc = ald_batch_download(S.b); }
+            }
             long bad = 0;
-            if(rc == ALD_OK) { const int n = (int)slots_[(size_t)i].sid.size(); ald_result_view r; for(int g = 0; g < n; g++) if(ald_batch_get_result(b, g, &r) == ALD_OK && r.status != ALD_ST_OK) bad++; }
+            if(ok && rc == ALD_OK) { const int n = (int)S.sid.size(); ald_result_view r; for(int g = 0; g < n; g++) if(ald_batch_get_result(S.b, g, &r) == ALD_OK && r.status != ALD_ST_OK) bad++; }
+            const auto t2 = std::chrono::steady_clock::now();
             std::lock_guard<std::mutex> lk(m_);
             if(rc != ALD_OK) fail(rc, what);
+            t_gpu_ += std::chrono::duration<double>(t2 - t1).count();
             failed_ += bad;
             merge_q_.push_back(i); cv_merge_.notify_one();
         }
@@ -129,22 +213,27 @@ private:
             { std::unique_lock<std::mutex> lk(m_); while(merge_q_.empty() && !stop_) cv_merge_.wait(lk); if(merge_q_.empty()) return; i = merge_q_.front(); merge_q_.pop_front(); ok = !err_; }
             slot &S = slots_[(size_t)i];
             int rc = ALD_OK;
+            const auto t0 = std::chrono::steady_clock::now();
             if(ok) rc = ald_tset_add_batch(sink_, S.b, S.sid.data(), (int64_t)S.first << 20, skip_ ? 1 : 0);      // assembler.cc:1105-1133 for the whole batch
             ald_batch_clear(S.b);
+            const auto t1 = std::chrono::steady_clock::now();
             std::lock_guard<std::mutex> lk(m_);
+            t_merge_ += std::chrono::duration<double>(t1 - t0).count();
             if(rc != ALD_OK) fail(rc, "ald_tset_add_batch");
-            S.sid.clear(); S.state = FREE; in_flight_--;
-            cv_free_.notify_all(); cv_done_.notify_all();
+            S.state = FREE; in_flight_--;
+            cv_pack_.notify_all(); cv_done_.notify_all();
         }
     }
 
-    ald_tset *sink_; bool skip_; int batch_graphs_;
+    ald_tset *sink_; bool skip_; int batch_graphs_, chunk_graphs_ = 1; long ready_cap_ = 0;
     mutable std::mutex m_;
-    std::condition_variable cv_free_, cv_gpu_, cv_merge_, cv_done_;
-    std::vector<slot> slots_; std::deque<int> gpu_q_, merge_q_;
-    int fill_ = -1; long next_ = 0, failed_ = 0, batches_ = 0; int in_flight_ = 0; bool stop_ = false;
+    std::condition_variable cv_pack_, cv_gpu_, cv_merge_, cv_done_, cv_space_;
+    std::vector<slot> slots_; std::deque<int> gpu_q_, merge_q_; std::deque<packed_chunk> ready_;
+    std::map<std::thread::id, std::unique_ptr<lane>> lanes_;
+    long next_ = 0, failed_ = 0, batches_ = 0, ready_graphs_ = 0; int in_flight_ = 0; bool stop_ = false, flush_ = false, gathering_ = false;
+    double t_pack_ = 0, t_gpu_ = 0, t_merge_ = 0;
     int err_ = 0; std::string err_msg_;
-    std::thread gpu_thread_, merge_thread_;
+    std::thread pack_thread_, gpu_thread_, merge_thread_;
 };
 
 } // namespace aletsch
