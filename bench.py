@@ -53,6 +53,10 @@ def main():
                     help="edge weights: uniform = U[1,100) f64 (BASELINE configs), flow = flow-conserving sums of s-t paths (SURVEY.md 8d's second distribution)")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="graphs in the bounded cpu_baseline sample (0 = skip)")
     args = ap.parse_args()
+    # stdout carries exactly one line, the JSON: libraries that write banners to file descriptor 1 (RCCL prints its version block
+    # there at init) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    real_stdout = os.dup(1); os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
@@ -177,7 +181,9 @@ def main():
             line["cpu_baseline"] = {"value": v, "unit": "bundles/s", "cores": cores, "kind": "port",
                                     "sample": f"first {sample.n} graphs of the same workload, oracle/ (CPU restatement of the reference scallop core), "
                                               f"{cores} threads over independent graphs, {cpu_sec:.2f} s"}
+        sys.stdout.flush(); os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     for b in batches:
         b.close()
     if dist_on:
