@@ -69,3 +69,18 @@ def test_synth_is_deterministic_and_well_formed():
         assert (t > src).all() and not ((src == 0) & (t == 63)).any()
         indeg = np.bincount(t, minlength=64); outdeg = np.diff(vo)
         assert (indeg[1:63] >= 1).all() and (outdeg[1:63] >= 1).all()
+
+
+def test_host_adapters_compile_as_cxx11_against_the_header():
+    """The reference builds with -std=c++11: both adapter programs (gpu_scallop.hpp, gpu_dispatch.hpp over include/aletsch_decomp.h,
+    instantiated with mock types carrying the reference's member names) must compile and link against the in-tree library without a
+    warning.  They are RUN by the GPU tier (tests/test_gpu_adapter.py); here only the build is checked."""
+    import subprocess
+    ROOT = common.ROOT
+    lib = os.path.join(ROOT, "aletsch_amd", "lib")
+    out = os.path.join(ROOT, "tests", "_build"); os.makedirs(out, exist_ok=True)
+    for src in ("adapter_test.cc", "dispatch_test.cc"):
+        r = subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", "host_adapter", src), "-o", os.path.join(out, src[:-3] + "_cpu_check"),
+                            "-L" + lib, "-laletsch_decomp", "-Wl,-rpath," + lib], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
