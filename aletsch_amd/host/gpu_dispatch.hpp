@@ -47,6 +47,14 @@ struct packed_chunk {
         cat(vertex_weight, s.vertex_weight); cat(vertex_lpos, s.vertex_lpos); cat(vertex_rpos, s.vertex_rpos); cat(vertex_type, s.vertex_type);
         cat(phasing_offset, s.phasing_offset); cat(phasing_vertex, s.phasing_vertex); cat(phasing_count, s.phasing_count); cat(edge_count, s.edge_count);
     }
+    void reserve_like(const packed_chunk &o)                      // the next chunk of a thread is about as large as its last one
+    {
+        g_nv.reserve(o.g_nv.size()); g_ne.reserve(o.g_ne.size()); g_np.reserve(o.g_np.size()); graph_strand.reserve(o.graph_strand.size()); sid.reserve(o.sid.size());
+        vertex_offset.reserve(o.vertex_offset.size()); edge_target.reserve(o.edge_target.size()); edge_weight.reserve(o.edge_weight.size()); edge_strand.reserve(o.edge_strand.size());
+        edge_abd.reserve(o.edge_abd.size()); edge_sample_offset.reserve(o.edge_sample_offset.size()); sample_id.reserve(o.sample_id.size()); sample_abd.reserve(o.sample_abd.size());
+        vertex_weight.reserve(o.vertex_weight.size()); vertex_lpos.reserve(o.vertex_lpos.size()); vertex_rpos.reserve(o.vertex_rpos.size()); vertex_type.reserve(o.vertex_type.size());
+        phasing_offset.reserve(o.phasing_offset.size()); phasing_vertex.reserve(o.phasing_vertex.size()); phasing_count.reserve(o.phasing_count.size()); edge_count.reserve(o.edge_count.size());
+    }
     int add_to(ald_batch *b) const
     {
         static const int32_t zero_i = 0; static const double zero_d = 0;     // empty arrays still need valid pointers
@@ -100,7 +108,7 @@ public:
         std::unique_lock<std::mutex> ll(L->m);
         L->c.append(s, sid);
         if(L->c.n() < chunk_graphs_) return;
-        packed_chunk full; std::swap(full, L->c);
+        packed_chunk full; std::swap(full, L->c); L->c.reserve_like(full);
         ll.unlock();
         std::unique_lock<std::mutex> lk(m_);
         while(ready_graphs_ >= ready_cap_ && !err_) cv_space_.wait(lk);            // the pool is ahead of the GPU: hold the submitter back

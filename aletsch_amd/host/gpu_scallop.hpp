@@ -58,12 +58,16 @@ staged_graph stage_graph(SpliceGraph &gr, const HyperSet &hs)
     const int V = (int)gr.num_vertices();
     typedef typename std::decay<decltype(*gr.edges().first)>::type edge_t;     // edge_descriptor
     struct E { int src, dst, ord; edge_t e; };
-    std::vector<E> es;
+    std::vector<E> es; es.reserve(256);
     { auto pe = gr.edges(); int k = 0; for(auto it = pe.first; it != pe.second; ++it, ++k) es.push_back(E{(*it)->source(), (*it)->target(), k, *it}); }
     std::stable_sort(es.begin(), es.end(), [](const E &a, const E &b) { return a.src != b.src ? a.src < b.src : (a.dst != b.dst ? a.dst < b.dst : a.ord < b.ord); });
     s.vertex_offset.assign(V + 1, 0);
     for(const E &x : es) s.vertex_offset[x.src + 1]++;
     for(int i = 0; i < V; i++) s.vertex_offset[i + 1] += s.vertex_offset[i];
+    { const size_t ne = es.size();                              // one allocation per array instead of a doubling series
+      s.edge_target.reserve(ne); s.edge_weight.reserve(ne); s.edge_strand.reserve(ne); s.edge_abd.reserve(ne); s.edge_count.reserve(ne);
+      s.edge_sample_offset.reserve(ne + 1); s.sample_id.reserve(ne); s.sample_abd.reserve(ne);
+      s.vertex_weight.reserve((size_t)V); s.vertex_lpos.reserve((size_t)V); s.vertex_rpos.reserve((size_t)V); s.vertex_type.reserve((size_t)V); }
     s.edge_sample_offset.push_back(0);
     for(const E &x : es) {
         const auto &ei = gr.get_edge_info(x.e);
