@@ -55,7 +55,32 @@ struct HostBatch {
         err.clear();
     }
 
+    // sizes of every array: a rejected graph must leave the batch exactly as it found it (the element-wise path appends while it checks)
+    struct Mark { size_t a[27]; };
+    Mark mark() const
+    {
+        Mark m = {{ g_nv.size(), g_ne.size(), g_np.size(), off_v.size(), off_e.size(), off_s.size(), off_p.size(), off_pv.size(),
+                    vertex_offset.size(), edge_target.size(), edge_weight.size(), edge_strand.size(), edge_abd.size(), edge_sample_offset.size(), sample_id.size(), sample_abd.size(),
+                    vertex_weight.size(), vertex_lpos.size(), vertex_rpos.size(), vertex_type.size(), in_offset.size(), in_edge.size(),
+                    phasing_offset.size(), phasing_vertex.size(), phasing_count.size(), graph_strand.size(), edge_count.size() }};
+        return m;
+    }
+    void rollback(const Mark &m)
+    {
+        g_nv.resize(m.a[0]); g_ne.resize(m.a[1]); g_np.resize(m.a[2]); off_v.resize(m.a[3]); off_e.resize(m.a[4]); off_s.resize(m.a[5]); off_p.resize(m.a[6]); off_pv.resize(m.a[7]);
+        vertex_offset.resize(m.a[8]); edge_target.resize(m.a[9]); edge_weight.resize(m.a[10]); edge_strand.resize(m.a[11]); edge_abd.resize(m.a[12]); edge_sample_offset.resize(m.a[13]);
+        sample_id.resize(m.a[14]); sample_abd.resize(m.a[15]); vertex_weight.resize(m.a[16]); vertex_lpos.resize(m.a[17]); vertex_rpos.resize(m.a[18]); vertex_type.resize(m.a[19]);
+        in_offset.resize(m.a[20]); in_edge.resize(m.a[21]); phasing_offset.resize(m.a[22]); phasing_vertex.resize(m.a[23]); phasing_count.resize(m.a[24]); graph_strand.resize(m.a[25]);
+        edge_count.resize(m.a[26]);
+    }
     int add_graph(const ald_graph_view &g)
+    {
+        const Mark m = mark();
+        const int rc = add_graph_body(g);
+        if(rc != ALD_OK) rollback(m);
+        return rc;
+    }
+    int add_graph_body(const ald_graph_view &g)
     {
         const int V = g.num_vertices, E = g.num_edges, P = g.num_phasing;
         if(V < 2 || E < 0 || P < 0 || !g.vertex_offset || (E > 0 && (!g.edge_target || !g.edge_weight || !g.edge_sample_offset)) || !g.vertex_weight || !g.vertex_lpos || !g.vertex_rpos) { err = "null or negative field"; return ALD_ERR_INVALID; }
@@ -67,7 +92,7 @@ struct HostBatch {
         for(int s = 0; s < V; s++) {
             int a = g.vertex_offset[s], b = g.vertex_offset[s + 1];
             bool sorted = true;
-            for(int k = a; k < b; k++) { int t = g.edge_target[k]; if(t < 0 || t >= V || t == s) { err = "edge target out of range"; return ALD_ERR_INVALID; } if(k > a && g.edge_target[k - 1] > t) sorted = false; }
+            for(int k = a; k < b; k++) { int t = g.edge_target[k]; if(t <= s || t >= V) { err = "edge target out of range (edges go from a lower to a higher vertex index, below V)"; return ALD_ERR_INVALID; } if(k > a && g.edge_target[k - 1] > t) sorted = false; }
             if(!sorted) std::stable_sort(perm.begin() + a, perm.begin() + b, [&](int x, int y) { return g.edge_target[x] < g.edge_target[y]; });
         }
         size_t e0 = edge_target.size(), s0 = sample_id.size();
@@ -169,6 +194,7 @@ struct HostBatch {
                    const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand, const int32_t *ecount = nullptr)
     {
         int64_t ov = 0, ovo = 0, oe = 0, oeo = 0, os = 0, op = 0, opo = 0, opv = 0;
+        const Mark m0 = mark();                     // all or nothing: a defect in graph i also takes graphs 0..i-1 of this call back out
         for(int i = 0; i < n; i++) {
             ald_graph_view g; memset(&g, 0, sizeof(g));
             int V = nv[i], E = ne[i], P = np ? np[i] : 0;
@@ -178,10 +204,10 @@ struct HostBatch {
             g.vertex_weight = vw + ov; g.vertex_lpos = lpos + ov; g.vertex_rpos = rpos + ov; g.vertex_type = vtype ? vtype + ov : nullptr;
             g.phasing_offset = poff ? poff + opo : nullptr; g.phasing_vertex = pv ? pv + opv : nullptr; g.phasing_count = pc ? pc + op : nullptr;
             g.strand = gstrand ? gstrand[i] : '.'; g.edge_count = ecount ? ecount + oe : nullptr;
-            if(V < 2 || E < 0) { err = "bad graph size"; return ALD_ERR_INVALID; }
+            if(V < 2 || E < 0) { err = "bad graph size"; rollback(m0); return ALD_ERR_INVALID; }
             int64_t ns = E > 0 ? g.edge_sample_offset[E] : 0, npv = (P > 0 && poff) ? g.phasing_offset[P] : 0;
             int rc = add_graph(g);
-            if(rc != ALD_OK) return rc;
+            if(rc != ALD_OK) { rollback(m0); err = "graph " + std::to_string(i) + " of the call: " + err; return rc; }
             ov += V; ovo += V + 1; oe += E; oeo += E + 1; os += ns; op += P; opo += P + 1; opv += npv;
         }
         return ALD_OK;
@@ -226,7 +252,7 @@ struct HostBatch {
                 if(vo[0] != 0 || vo[V] != E || (E > 0 && so[0] != 0)) { worst = 2; break; }
                 for(int s = 0; s < V && worst < 2; s++) {
                     if(vo[s + 1] < vo[s]) { worst = 2; break; }
-                    for(int k = vo[s]; k < vo[s + 1]; k++) { int t2 = tg[k]; if(t2 < 0 || t2 >= V || t2 == s) { worst = 2; break; } if(k > vo[s] && tg[k - 1] > t2) worst = 1; }
+                    for(int k = vo[s]; k < vo[s + 1]; k++) { int t2 = tg[k]; if(t2 <= s || t2 >= V) { worst = 2; break; } if(k > vo[s] && tg[k - 1] > t2) worst = 1; }
                 }
                 for(int k = 0; k < E && worst < 2; k++) {
                     if(so[k + 1] < so[k]) { worst = 2; break; }

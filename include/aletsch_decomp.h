@@ -113,7 +113,10 @@ int  ald_batch_create(const ald_params *p, int device, ald_batch **out);
 int  ald_batch_destroy(ald_batch *b);
 int  ald_batch_clear(ald_batch *b);                       /* forget graphs, keep buffers */
 
-/* ---- staging: copy one graph / many packed graphs into the pinned wire buffer ---- */
+/* ---- staging: copy one graph / many packed graphs into the pinned wire buffer ----
+ * A malformed graph (edge not from a lower to a higher vertex index below V, offsets that do not span their arrays, strand
+ * outside 0..2, negative count, duplicate sample id on an edge) is refused with ALD_ERR_INVALID and a message in ald_last_error();
+ * the batch is left exactly as it was -- for the bulk form all or nothing: no graph of a refused call is added. */
 int  ald_batch_add_graph(ald_batch *b, const ald_graph_view *g);
 /* Bulk form for n graphs concatenated: every per-vertex / per-edge / per-sample array is the
  * concatenation over graphs; g_nv[n], g_ne[n], g_np[n] give sizes; vertex_offset, edge_sample_offset

@@ -259,3 +259,53 @@ def test_record_exchange_from_device_memory():
             assert [r["graph"] for r in recs] == [r["graph"] + 1000 for r in local] and [r["v"] for r in recs] == [r["v"] for r in local]
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rejected_graphs_leave_the_batch_intact():
+    """Error behaviour of the staging calls: a malformed graph is refused with ALD_ERR_INVALID and a message, and the batch stays
+    exactly as it was -- also when the defect is only found after part of the graph (or earlier graphs of the same bulk call) had
+    been appended.  The graphs staged before and after the refused calls decompose as if nothing had happened."""
+    import copy
+    from aletsch_amd.native import DecompError
+    pg = A.synth(seed=77, n_graphs=24, v_min=10, v_max=40, edges_per_vertex=3, n_samples=3, phasing_per_graph=4, weight_mode=1)
+    want = common.oracle_run(pg)[0]
+    first, second = pg.select(np.arange(0, 12)), pg.select(np.arange(12, 24))
+
+    def broken(kind):
+        bad = copy.deepcopy(pg.select(np.arange(3, 6)))           # three graphs in one bulk call; the defect sits in the LAST one
+        sl = bad.graph_slices(); g = 2
+        e0 = int(sl["e"][g]); vo0 = int(sl["vo"][g]); V = int(bad.g_nv[g])
+        row = next(s for s in range(V) if bad.vertex_offset[vo0 + s + 1] - bad.vertex_offset[vo0 + s] >= 2)
+        k = e0 + int(bad.vertex_offset[vo0 + row])
+        if kind == "backward edge":
+            s = next(s for s in range(2, V) if bad.vertex_offset[vo0 + s + 1] > bad.vertex_offset[vo0 + s])
+            bad.edge_target[e0 + int(bad.vertex_offset[vo0 + s])] = s - 1
+        elif kind == "self loop":
+            bad.edge_target[k] = row
+        elif kind == "strand out of range":
+            bad.edge_strand[k + 1] = 3
+        elif kind == "strand out of range, unsorted row":          # the element-wise path appends edges before it meets the defect
+            bad.edge_target[k], bad.edge_target[k + 1] = bad.edge_target[k + 1], bad.edge_target[k]
+            bad.edge_strand[k + 1] = 3
+        elif kind == "negative edge count":
+            bad.edge_count = bad.sample_counts().astype(np.int32); bad.edge_count[k] = -1
+        elif kind == "vertex_offset does not span":
+            bad.vertex_offset[vo0 + V] += 1
+        elif kind == "two vertices at least":
+            bad.g_nv[g] = 1
+        return bad
+
+    with A.DecompBatch(0) as b:
+        b.add(first)
+        for kind in ("backward edge", "self loop", "strand out of range", "strand out of range, unsorted row", "negative edge count",
+                     "vertex_offset does not span", "two vertices at least"):
+            with pytest.raises(DecompError) as ei:
+                b.add(broken(kind))
+            assert ei.value.code == -1, (kind, ei.value)                       # ALD_ERR_INVALID
+            assert b.n == first.n, kind
+        b.add(second)
+        assert b.n == pg.n
+        b.upload(); b.run(); b.download()
+        got = b.result()
+    assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
