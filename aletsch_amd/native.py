@@ -180,7 +180,7 @@ class DecompBatch:
         return int(p.value or 0), int(n.value)
 
     def result(self) -> DecompResult:
-        return export_via(self._lib.ald_batch_export, self._h, self.n)
+        return export_via(self._lib.ald_batch_export, self._h, self.n, check=_check)
 
     def transcripts(self):
         """(coverage[paths], exon_offset[paths+1], exons[n,2]): scallop::build_transcripts without the ML features."""

@@ -177,11 +177,13 @@ class DecompResult:
         return out
 
 
-def export_via(fn, handle, n: int) -> DecompResult:
-    """Drive an ``ald_batch_export``-shaped C function (two-pass: sizes, then fill)."""
+def export_via(fn, handle, n: int, check=None) -> DecompResult:
+    """Drive an ``ald_batch_export``-shaped C function (two-pass: sizes, then fill); ``check(rc)`` may raise the caller's own error."""
     tp = C.c_int64(0); tv = C.c_int64(0)
     nul = None
     rc = fn(handle, C.byref(tp), C.byref(tv), nul, nul, nul, nul, nul, nul, nul, nul, nul, nul, nul)
+    if rc != 0 and check is not None:
+        check(rc)
     if rc != 0:
         raise RuntimeError(f"export(sizes) failed rc={rc}")
     P, TV = tp.value, tv.value

@@ -309,3 +309,25 @@ def test_rejected_graphs_leave_the_batch_intact():
         b.upload(); b.run(); b.download()
         got = b.result()
     assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
+
+
+@pytest.mark.gpu
+def test_calls_out_of_order_are_refused():
+    """run before upload, download before run, results before download: ALD_ERR_STATE with a message, never a crash or stale data;
+    staging another graph invalidates what was uploaded."""
+    from aletsch_amd.native import DecompError
+    pg = A.synth(seed=78, n_graphs=8, v_min=8, v_max=20, edges_per_vertex=3)
+    with A.DecompBatch(0) as b:
+        b.add(pg)
+        for call in (b.run, b.download, b.result):
+            with pytest.raises(DecompError) as ei:
+                call()
+            assert ei.value.code == -4, ei.value                               # ALD_ERR_STATE
+        b.upload()
+        with pytest.raises(DecompError):
+            b.download()
+        b.add(pg.select(np.arange(2)))                                         # the wire buffer on the device is stale now
+        with pytest.raises(DecompError):
+            b.run()
+        b.upload(); b.run(); b.download()
+        assert (b.result().status == 0).all() and b.n == 10
