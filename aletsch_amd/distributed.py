@@ -35,9 +35,9 @@ class RecordGatherer:
     needs no size exchange and NOTHING in it blocks the host: the gather is only enqueued, the next batch's kernel is launched
     right behind it and the two share the GPU, and on rank 0 the gathered streams go to pinned host memory by async copies that
     the copy engine performs meanwhile.  Graph ids stay local in the stream; each rank's `graph_offset` rides in the header, so
-    rank 0 makes them global when it consumes a stream (`aletsch_amd.records_add_graph_offset`, a C loop).  A stream that
-    outgrows the capacity triggers a new agreement (every rank sees the overflow flag of every other rank one step late, so a
-    varying workload should call `renegotiate()` itself whenever its batch shape changes).
+    rank 0 makes them global when it consumes a stream (`aletsch_amd.records_add_graph_offset`, a C loop).  The agreement is a
+    collective, so it is never entered by one rank alone: a stream that outgrows the capacity raises, and a workload whose batch
+    shape changes calls `renegotiate()` on every rank at that point (the capacity carries 3 % head-room over the largest stream).
     """
     HDR = 4
 
@@ -70,8 +70,12 @@ class RecordGatherer:
         CPU) that is reached once `words` has been read -- the caller waits for it before it lets anything overwrite `words`."""
         dev = self.device
         n = int(words.numel())
-        if self.cap == 0 or self.HDR + n > self.cap:
-            self.renegotiate(n)                                           # collective: every rank of a fixed-shape workload gets here together
+        if self.cap == 0:
+            self.renegotiate(n)                                           # collective: on first use every rank gets here together
+        elif self.HDR + n > self.cap:
+            # never enter a collective alone: the other ranks are about to enqueue the gather of this step
+            raise ValueError(f"record stream of {n} words exceeds the capacity agreed by all ranks ({self.cap - self.HDR}): "
+                             "call renegotiate() on EVERY rank when the batch shape changes")
         if self._done is not None:
             self._done.synchronize()                                      # the previous step's host copies must be out of the buffers
         pad = self._pad

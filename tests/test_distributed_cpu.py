@@ -38,6 +38,38 @@ WORKER = textwrap.dedent('''
             assert all(abs(r["reads"] - 3.25 * g) < 1e-12 for r in mine)
         print("GATHER_OK", len(allrec))
     dist.barrier()
+    # the persistent form bench.py uses: one gatherer, several steps of differently sized streams inside the agreed capacity, a
+    # renegotiation entered by both ranks when the shape grows, and a loud error instead of a lone collective on overflow
+    from aletsch_amd.distributed import RecordGatherer
+    def stream(n_rec, tag):
+        out = []
+        for k in range(n_rec):
+            hdr = np.zeros(REC_HDR_WORDS, np.uint32); hdr[0] = k; hdr[1] = 0; hdr[2] = 2; hdr[4] = tag; hdr[5] = ord(".")
+            out.append(np.concatenate([hdr, np.array([0, 1], np.uint32), np.zeros(REC_HDR_WORDS & 1, np.uint32)]))
+        return np.concatenate(out) if out else np.zeros(0, np.uint32)
+    G = RecordGatherer(torch.device("cpu"))
+    for step, n_rec in enumerate((40 + 3 * rank, 41, 0, 43 - rank)):
+        w = stream(n_rec, 10 * step + rank)
+        G.gather(torch.from_numpy(w.view(np.int32).copy()), graph_offset=1000 * rank)
+        if rank == 0:
+            st = G.streams()
+            assert [off for _, off in st] == [0, 1000]
+            want = [(40, 41, 0, 43)[step], (43, 41, 0, 42)[step]]
+            for r, (words, off) in enumerate(st):
+                recs = parse_records(words.copy())
+                assert len(recs) == want[r] and all(x["count"] == 10 * step + r for x in recs), (step, r, len(recs))
+    big = stream(400, 7)
+    try:
+        G.gather(torch.from_numpy(big.view(np.int32).copy()))
+        raise SystemExit("overflow was not refused")
+    except ValueError:
+        pass
+    G.renegotiate(big.size)                      # both ranks
+    G.gather(torch.from_numpy(big.view(np.int32).copy()), graph_offset=5 * rank)
+    if rank == 0:
+        assert [len(parse_records(wd.copy())) for wd, _ in G.streams()] == [400, 400]
+        print("STEPS_OK")
+    dist.barrier()
     dist.destroy_process_group()
 ''') % ROOT
 
@@ -49,7 +81,7 @@ def test_gloo_world2_gather(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29517", str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "GATHER_OK 28" in r.stdout
+    assert "GATHER_OK 28" in r.stdout and "STEPS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_shard_range_partitions():
