@@ -3,6 +3,8 @@
 // Reads a tiny text graph from stdin, decomposes it on the GPU, prints the paths.  Driven by tests/test_gpu_adapter.py.
 #include "../../aletsch_amd/host/gpu_scallop.hpp"
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <set>
 #include <unordered_map>
 
@@ -23,19 +25,46 @@ struct mock_hyper_set { std::map<std::vector<int>, int> nodes; };
 struct mock_parameters { double max_decompose_error_ratio[8] = {0.30, 0.00, 1.10, 1.10, 0.75, 0.30, 0.00, 1.00}; double min_guaranteed_edge_weight = 0.01, min_transcript_coverage = 2.0; int max_num_exons = 10000; };
 struct mock_path { std::vector<int> v; std::vector<std::pair<int, int>> junc; int length = 0; double abd = 0, weight = 0, conf = 0, reads = 0; char strand = '.'; int count = 0; };
 
-int main()
+static bool read_graph(mock_graph &g, mock_hyper_set &hs)
 {
     int V, E, P;
-    if(scanf("%d %d %d", &V, &E, &P) != 3) return 2;
-    mock_graph g; mock_hyper_set hs; mock_parameters cfg;
-    for(int i = 0; i < V; i++) { double w; int l, r; if(scanf("%lf %d %d", &w, &l, &r) != 3) return 2; g.vw.push_back(w); mock_vertex_info vi; vi.lpos = l; vi.rpos = r; g.vi.push_back(vi); }
-    for(int k = 0; k < E; k++) { int s, t; double w; if(scanf("%d %d %lf", &s, &t, &w) != 3) return 2; g.es.push_back(new mock_edge{s, t}); g.ew.push_back(w); mock_edge_info ei; ei.count = 1; ei.abd = w; ei.samples.insert(0); ei.spAbd[0] = w; g.ei.push_back(ei); }
-    for(int p = 0; p < P; p++) { int len, c; if(scanf("%d %d", &len, &c) != 2) return 2; std::vector<int> v(len); for(int &x : v) if(scanf("%d", &x) != 1) return 2; hs.nodes[v] += c; }
+    if(scanf("%d %d %d", &V, &E, &P) != 3) return false;
+    for(int i = 0; i < V; i++) { double w; int l, r; if(scanf("%lf %d %d", &w, &l, &r) != 3) return false; g.vw.push_back(w); mock_vertex_info vi; vi.lpos = l; vi.rpos = r; g.vi.push_back(vi); }
+    for(int k = 0; k < E; k++) { int s, t; double w; if(scanf("%d %d %lf", &s, &t, &w) != 3) return false; g.es.push_back(new mock_edge{s, t}); g.ew.push_back(w); mock_edge_info ei; ei.count = 1; ei.abd = w; ei.samples.insert(0); ei.spAbd[0] = w; g.ei.push_back(ei); }
+    for(int p = 0; p < P; p++) { int len, c; if(scanf("%d %d", &len, &c) != 2) return false; std::vector<int> v(len); for(int &x : v) if(scanf("%d", &x) != 1) return false; hs.nodes[v] += c; }
+    return true;
+}
+static void print_paths(int status, const std::vector<mock_path> &paths)
+{
+    printf("status %d paths %zu\n", status, paths.size());
+    for(auto &p : paths) { printf("%.17g %.17g %.17g %d %d %c %zu :", p.weight, p.abd, p.reads, p.length, p.count, p.strand, p.junc.size()); for(int x : p.v) printf(" %d", x); printf("\n"); }
+}
+
+// no argument: one graph through aletsch::gpu_scallop (ctor + assemble() + .paths);
+// "batch N": N graphs through aletsch::gpu_scallop_batch -- enqueue all, ONE flush, paths(i) per ticket, then clear() and a second round
+int main(int argc, char **argv)
+{
+    mock_parameters cfg;
     try {
+        if(argc >= 3 && std::string(argv[1]) == "batch") {
+            const int N = atoi(argv[2]);
+            std::vector<mock_graph> gs((size_t)N); std::vector<mock_hyper_set> hs((size_t)N);
+            for(int n = 0; n < N; n++) if(!read_graph(gs[(size_t)n], hs[(size_t)n])) return 2;
+            aletsch::gpu_scallop_batch<mock_graph, mock_hyper_set, mock_parameters, mock_path> batch(cfg, 0);
+            for(int round = 0; round < 2; round++) {
+                std::vector<int> ticket;
+                for(int n = 0; n < N; n++) ticket.push_back(batch.enqueue(gs[(size_t)n], hs[(size_t)n]));
+                batch.flush();
+                if(round == 1) for(int n = 0; n < N; n++) print_paths(batch.status(ticket[(size_t)n]), batch.paths(ticket[(size_t)n]));
+                batch.clear();
+            }
+            return 0;
+        }
+        mock_graph g; mock_hyper_set hs;
+        if(!read_graph(g, hs)) return 2;
         aletsch::gpu_scallop<mock_graph, mock_hyper_set, mock_parameters, mock_path> sx(g, hs, cfg, false);
         sx.assemble();
-        printf("status %d paths %zu\n", sx.status, sx.paths.size());
-        for(auto &p : sx.paths) { printf("%.17g %.17g %.17g %d %d %c %zu :", p.weight, p.abd, p.reads, p.length, p.count, p.strand, p.junc.size()); for(int x : p.v) printf(" %d", x); printf("\n"); }
+        print_paths(sx.status, sx.paths);
     } catch(const std::exception &e) { printf("EXCEPTION %s\n", e.what()); return 1; }
     return 0;
 }

@@ -136,3 +136,26 @@ def test_dispatch_queue_matches_the_serial_merge():
         assert g["count"] == w["count"] and g["count2"] == w["count2"]
         assert np.isclose(g["coverage"], w["coverage"], rtol=1e-12) and np.isclose(g["cov2"], w["cov2"], rtol=1e-12)
         assert sorted(s["sid"] for s in g["samples"]) == sorted(s["sid"] for s in w["samples"])
+
+
+@pytest.mark.gpu
+def test_batched_adapter_enqueue_flush_paths():
+    """aletsch::gpu_scallop_batch (INTEGRATION.md section 2): many graphs enqueued, ONE flush, `paths(ticket)` per graph; the batch
+    object is cleared and reused for a second round, whose output is the one compared -- graph by graph against the oracle."""
+    build()
+    pg = A.synth(seed=64, n_graphs=40, v_min=8, v_max=60, edges_per_vertex=3, phasing_per_graph=5, weight_mode=1)
+    pg.sample_id[:] = 0; pg.sample_abd[:] = pg.edge_weight; pg.edge_abd[:] = pg.edge_weight
+    want = common.oracle_run(pg)[0]
+    text = "".join(graph_text(pg.select(np.array([g])), 9 if g % 2 else None) for g in range(pg.n))
+    out = subprocess.run([BIN, "batch", str(pg.n)], input=text, capture_output=True, text=True, check=True).stdout.splitlines()
+    pos = 0
+    for g in range(pg.n):
+        head = out[pos].split(); pos += 1
+        a, b = int(want.path_offset[g]), int(want.path_offset[g + 1])
+        assert head[0] == "status" and int(head[1]) == int(want.status[g]) and int(head[3]) == b - a, (g, head)
+        for i in range(a, b):
+            f, vs = out[pos].split(" :"); f = f.split(); pos += 1
+            assert float(f[0]) == want.weight[i] and float(f[1]) == want.abd[i] and float(f[2]) == want.reads[i]
+            assert int(f[3]) == want.length[i] and int(f[4]) == want.count[i] and f[5] == chr(want.strand[i])
+            assert [int(x) for x in vs.split()] == [int(x) for x in want.path_vertices[want.pv_offset[i]:want.pv_offset[i + 1]]]
+    assert pos == len(out)
