@@ -144,7 +144,7 @@ int stage_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], i
         if(const char *ov = getenv("ALD_WG_PER_CU")) { int k = atoi(ov); if(k >= 1 && k < per_cu) per_cu = k; }     // tuning knob: cap the persistent grid
         int want = b->n_cus * per_cu;
         const uint64_t stride = ci.slab_bytes + k_hot[c]();           // catch-all class: hot state + cold state per wave
-        if(c >= ALD_FIRST_GLOBAL_CLASS && want > b->n_cus) want = b->n_cus;      // ~13 MB per wave: one wave per CU is plenty
+        if(c == ALD_CATCH_ALL_CLASS && want > b->n_cus) want = b->n_cus;      // ~13 MB per wave: one wave per CU is plenty
         if((size_t)want > work[c].size()) want = (int)work[c].size();
         if(want < 1) want = 1;
         if(b->d_slabs[c].ensure((size_t)want * stride)) return set_err(ALD_ERR_NOMEM, "class slab");
@@ -333,6 +333,18 @@ int ald_batch_upload(ald_batch *b)
             b->cls0[g] = c;
             if(c >= 0) work[c].push_back(g);
         }
+        // More graphs of a class than its LDS form can run at once: they go to the slab-resident twin (twelve workgroups per CU instead
+        // of three, no LDS taken from the other classes).  Fewer: the LDS form finishes each of them 2-3 times sooner.
+        // ALD_DEBUG_TWIN=1 / 0 forces / forbids the move (tests, A/B runs).
+        for(int c = 0; c < ALD_NUM_PICK_CLASSES; c++) {
+            const int tw = class_twin(c);
+            if(tw < 0 || work[c].empty()) continue;
+            bool move = (int64_t)work[c].size() > (int64_t)b->n_cus * occupancy_for(b, c);
+            if(const char *ev = getenv("ALD_DEBUG_TWIN")) move = atoi(ev) != 0;
+            if(!move) continue;
+            for(int32_t g : work[c]) b->cls0[g] = tw;
+            work[tw].swap(work[c]);
+        }
         for(int c = 0; c < ALD_NUM_CLASSES; c++)
             std::stable_sort(work[c].begin(), work[c].end(), [&](int32_t x, int32_t y) { return b->hb.g_ne[x] > b->hb.g_ne[y]; });
         if(!b->pass0) b->pass0 = new StagedPass();
@@ -390,7 +402,7 @@ int ald_batch_download(ald_batch *b)
             if(b->attempt[g] != pass) continue;                 // not part of this pass
             b->status[g] = st[g];
             if(st[g] == ALD_ST_CAPACITY && getenv("ALD_DEBUG_RETRY")) fprintf(stderr, "[ald] graph %d (V=%d E=%d) overflowed class %d in pass %d\n", g, b->hb.g_nv[g], b->hb.g_ne[g], b->cls[g], pass);
-            if(st[g] == ALD_ST_CAPACITY && b->cls[g] + 1 < ALD_NUM_CLASSES) { b->cls[g]++; b->attempt[g] = pass + 1; work[b->cls[g]].push_back(g); any = true; }
+            if(st[g] == ALD_ST_CAPACITY && class_retry_up(b->cls[g]) >= 0) { b->cls[g] = class_retry_up(b->cls[g]); b->attempt[g] = pass + 1; work[b->cls[g]].push_back(g); any = true; }
         }
         if(!any) break;
         int rc = launch_pass(b, work, pass + 1);

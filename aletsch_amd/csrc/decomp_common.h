@@ -102,8 +102,15 @@ struct KernelArgs {                               // lives in device memory; eve
 // ---- size classes ----
 // Geometric-ish ladder: a graph pays for the LDS of its class for as long as it runs, and a mixed batch is bound by exactly that
 // product (LDS bytes x time), so the steps are fine where the time is spent (257..512 vertices in cfg3).
-#define ALD_NUM_CLASSES 11
-#define ALD_FOR_EACH_CLASS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+// Classes 0..10 are what pick_class() chooses from.  Classes 11 and 12 are TWINS of 7 and 8 (same capacities) that keep the hot state in
+// the wave's HBM slab instead of LDS: a graph runs 2-3 times longer there, but twelve workgroups fit a CU instead of three and none
+// of them takes LDS away from the other classes -- the host moves a class's graphs to its twin when there are more of them than the
+// LDS form can hold at once (ald_abi.cpp: ald_batch_upload).
+#define ALD_NUM_PICK_CLASSES 11
+#define ALD_NUM_CLASSES 13
+#define ALD_CATCH_ALL_CLASS 10
+#define ALD_FOR_EACH_PICK_CLASS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#define ALD_FOR_EACH_CLASS(X) ALD_FOR_EACH_PICK_CLASS(X) X(11) X(12)
 template<int ID> struct ClassDims;
 template<> struct ClassDims<0>  { enum { MAXV = 64,   MAXE = 160,  NW = 1 }; };     // V <= 32
 template<> struct ClassDims<1>  { enum { MAXV = 128,  MAXE = 288,  NW = 1 }; };     // V <= 64   (the bench workload: 20 workgroups per CU)
@@ -116,7 +123,18 @@ template<> struct ClassDims<7>  { enum { MAXV = 896,  MAXE = 2000, NW = 7 }; }; 
 template<> struct ClassDims<8>  { enum { MAXV = 1024, MAXE = 2280, NW = 8 }; };     // V <= 512  (2280 edges: three workgroups per CU; holds E <= 2052)
 template<> struct ClassDims<9>  { enum { MAXV = 2048, MAXE = 6600, NW = 32 }; };    // one workgroup per CU: 145 KB of its 160 KB LDS; V <= 1024, E <= 5940
 template<> struct ClassDims<10> { enum { MAXV = 4096, MAXE = 16384, NW = 64 }; };   // catch-all: hot state in the wave's HBM slab, not LDS
-#define ALD_FIRST_GLOBAL_CLASS 10
+template<> struct ClassDims<11> { enum { MAXV = 896,  MAXE = 2000, NW = 7 }; };     // twin of class 7, hot state in the slab
+template<> struct ClassDims<12> { enum { MAXV = 1024, MAXE = 2280, NW = 8 }; };     // twin of class 8, hot state in the slab
+static inline int class_twin(int c) { return c == 7 ? 11 : c == 8 ? 12 : -1; }       // slab-resident twin of an LDS class (-1: none)
+static inline int class_retry_up(int c)                                              // where a graph goes when its working set overflowed class c
+{
+    if(c == 11) return 12;
+    if(c == 12) return 9;
+    return c + 1 < ALD_NUM_PICK_CLASSES ? c + 1 : -1;
+}
+#ifndef ALD_FIRST_GLOBAL_CLASS
+#define ALD_FIRST_GLOBAL_CLASS 10     /* classes from here on keep the Hot struct in the wave's HBM slab (overridable for experiments) */
+#endif
 
 // per-wave HBM slab, laid out at compile time (so that cold pointers cost no registers)
 template<int MAXV, int MAXE, int NW>
@@ -160,7 +178,7 @@ static inline ClassInfo class_info(int c)
 // plus the intersections created by merges.
 static inline int pick_class(int V, int E, int64_t n_samples, int64_t n_phasing_vertices, int first = 0)
 {
-    for(int c = first < 0 ? 0 : first; c < ALD_NUM_CLASSES; c++) {
+    for(int c = first < 0 ? 0 : first; c < ALD_NUM_PICK_CLASSES; c++) {
         ClassInfo k = class_info(c);
         if(V <= k.nw * 64 && 2 * V <= k.maxv && E + k.maxe / 10 <= k.maxe && 2 * n_samples <= (int64_t)k.sp_cap && 4 * n_phasing_vertices <= (int64_t)k.hl_cap) return c;
     }

@@ -9,7 +9,7 @@
 
 extern "C" {
 #define ALD_DECL(ID) void emu_run_class_##ID(const ald::KernelArgs *);
-ALD_FOR_EACH_CLASS(ALD_DECL)
+ALD_FOR_EACH_PICK_CLASS(ALD_DECL)
 #undef ALD_DECL
 }
 using namespace ald;
@@ -44,7 +44,7 @@ int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_
     A.out.pool_used = &pool_used; A.out.pool = pool.data(); A.out.pool_cap = pool_cap;
     A.out.trace_cap = trace_cap; A.out.trace_n = E->trace_n.data(); A.out.trace_codes = E->trace_codes.data(); A.out.trace_vals = E->trace_vals.data();
     std::vector<int32_t> cls(n), attempt(n, 0);
-    std::vector<int32_t> work[ALD_NUM_CLASSES];
+    std::vector<int32_t> work[ALD_NUM_PICK_CLASSES];
     for(int g = 0; g < n; g++) {
         int64_t ns = B.off_s[g + 1] - B.off_s[g], npv = B.off_pv[g + 1] - B.off_pv[g];
         cls[g] = debug_underclass(pick_class(B.g_nv[g], B.g_ne[g], ns, npv, force_class));
@@ -52,11 +52,11 @@ int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_
     }
     typedef void (*run_fn)(const KernelArgs *);
 #define ALD_R(ID) emu_run_class_##ID,
-    run_fn runs[ALD_NUM_CLASSES] = { ALD_FOR_EACH_CLASS(ALD_R) };
+    run_fn runs[ALD_NUM_PICK_CLASSES] = { ALD_FOR_EACH_PICK_CLASS(ALD_R) };
 #undef ALD_R
-    for(int pass = 0; pass < ALD_NUM_CLASSES + 1; pass++) {
+    for(int pass = 0; pass < ALD_NUM_PICK_CLASSES + 1; pass++) {
         bool any = false;
-        for(int c = 0; c < ALD_NUM_CLASSES; c++) {
+        for(int c = 0; c < ALD_NUM_PICK_CLASSES; c++) {
             if(work[c].empty()) continue;
             any = true;
             ClassInfo ci = class_info(c);
@@ -66,12 +66,12 @@ int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_
             runs[c](&A);
         }
         if(!any) break;
-        std::vector<int32_t> next[ALD_NUM_CLASSES];
-        for(int c = 0; c < ALD_NUM_CLASSES; c++) for(int g : work[c]) {
+        std::vector<int32_t> next[ALD_NUM_PICK_CLASSES];
+        for(int c = 0; c < ALD_NUM_PICK_CLASSES; c++) for(int g : work[c]) {
             attempt[g] = pass;
-            if(status[g] == ALD_ST_CAPACITY && c + 1 < ALD_NUM_CLASSES) { cls[g] = c + 1; next[c + 1].push_back(g); }
+            if(status[g] == ALD_ST_CAPACITY && c + 1 < ALD_NUM_PICK_CLASSES) { cls[g] = c + 1; next[c + 1].push_back(g); }
         }
-        for(int c = 0; c < ALD_NUM_CLASSES; c++) work[c].swap(next[c]);
+        for(int c = 0; c < ALD_NUM_PICK_CLASSES; c++) work[c].swap(next[c]);
     }
     E->R.status = status; E->R.n_iters = n_iters; E->R.attempt = attempt;
     E->R.pool.assign(pool.begin(), pool.begin() + pool_used);

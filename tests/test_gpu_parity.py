@@ -331,3 +331,27 @@ def test_calls_out_of_order_are_refused():
             b.run()
         b.upload(); b.run(); b.download()
         assert (b.result().status == 0).all() and b.n == 10
+
+
+@pytest.mark.gpu
+def test_slab_twins_of_the_large_lds_classes(monkeypatch):
+    """Classes 11 / 12 are the twins of 7 / 8 with the hot state in the wave's HBM slab (chosen when a batch holds more graphs of the
+    class than its LDS form runs at once).  Forced on and forced off, the records are the same and equal the oracle's; a graph that
+    outgrows a twin is retried through twin 12 and then class 9."""
+    pg = A.synth(seed=93, n_graphs=60, v_min=390, v_max=512, edges_per_vertex=4, phasing_per_graph=6, n_samples=2, weight_mode=1)
+    want = common.oracle_run(pg, threads=8)[0]
+    for force in ("1", "0"):
+        monkeypatch.setenv("ALD_DEBUG_TWIN", force)
+        with A.DecompBatch(0) as b:
+            b.add(pg); b.upload(); b.run(); b.download()
+            got = b.result()
+            used = {c: b.class_info(c)["n_graphs"] for c in range(13) if b.class_info(c)["n_graphs"]}
+        assert not common.compare_results(want, got, pg.n, conf_tol=1e-9), force
+        assert (set(used) <= {11, 12, 9}) if force == "1" else (set(used) <= {7, 8, 9}), (force, used)
+    monkeypatch.setenv("ALD_DEBUG_TWIN", "1"); monkeypatch.setenv("ALD_DEBUG_UNDERCLASS", "1")
+    small = pg.select(np.arange(12))
+    with A.DecompBatch(0) as b:                               # started one class too low: overflow -> the next twin / class 9
+        b.add(small); b.upload(); b.run(); b.download()
+        got = b.result()
+    w2 = common.oracle_run(small, threads=8)[0]
+    assert not common.compare_results(w2, got, small.n, conf_tol=1e-9)

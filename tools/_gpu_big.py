@@ -11,6 +11,6 @@ for kw in (dict(seed=301, n_graphs=200, v_min=600, v_max=1500, edges_per_vertex=
     t0 = time.time(); want = common.oracle_run(pg, threads=thr)[0]; t1 = time.time()
     with A.DecompBatch(0) as b:
         b.add(pg); b.upload(); b.run(); b.download(); got = b.result(); ms = b.kernel_ms()
-        cls = [(c, b.class_info(c)["n_graphs"]) for c in range(11) if b.class_info(c)["n_graphs"]]
+        cls = [(c, b.class_info(c)["n_graphs"]) for c in range(13) if b.class_info(c)["n_graphs"]]
     bad = common.compare_results(want, got, pg.n, conf_tol=1e-9)
     print(kw, "classes", cls, "oracle %.1f s, kernel %.0f ms" % (t1 - t0, ms), "status!=0", int((want.status != 0).sum()), "MISMATCH " + str(bad[:3]) if bad else "ok", flush=True)

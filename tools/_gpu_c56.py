@@ -8,4 +8,4 @@ for name, kw in (("c5 (LDS, V 700..1000)", dict(seed=311, n_graphs=256, v_min=70
         b.add(pg); b.upload(); ms = []
         for rep in range(2):
             b.run(); b.download(); ms.append(b.kernel_ms())
-        print(name, "graphs", pg.n, "kernel_ms %.0f" % min(ms), [(c, b.class_info(c)["n_graphs"]) for c in range(11) if b.class_info(c)["n_graphs"]], flush=True)
+        print(name, "graphs", pg.n, "kernel_ms %.0f" % min(ms), [(c, b.class_info(c)["n_graphs"]) for c in range(13) if b.class_info(c)["n_graphs"]], flush=True)

@@ -10,7 +10,7 @@ def run(sel, name):
         b.add(sub); b.upload(); ms = []
         for rep in range(2):
             b.run(); b.download(); ms.append(b.kernel_ms())
-        info = [(c, b.class_info(c)["n_graphs"], b.class_info(c)["blocks_per_cu"]) for c in range(11) if b.class_info(c)["n_graphs"]]
+        info = [(c, b.class_info(c)["n_graphs"], b.class_info(c)["blocks_per_cu"]) for c in range(13) if b.class_info(c)["n_graphs"]]
         print(name, "graphs", sub.n, "kernel_ms %.1f" % min(ms), "classes(n, wg/cu)", info, flush=True)
 run(V <= 32, "V<=32")
 run((V > 32) & (V <= 64), "33..64")

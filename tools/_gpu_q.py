@@ -10,4 +10,4 @@ for name, kw in (("cfg2", dict(seed=1002, n_graphs=100000, v_min=64, v_max=64, f
         for rep in range(3):
             b.run(); b.download(); ms.append(b.kernel_ms())
         r = b.result()
-        print(name, "kernel_ms", ["%.2f" % x for x in ms], "graphs/s %.0f" % (pg.n / (min(ms) / 1e3)), "bad", int((r.status != 0).sum()), "grids", [b.class_info(c)["blocks_last_run"] for c in range(11)], "paths", len(r.weight), [b.class_info(c)["blocks_per_cu"] for c in range(11)], flush=True)
+        print(name, "kernel_ms", ["%.2f" % x for x in ms], "graphs/s %.0f" % (pg.n / (min(ms) / 1e3)), "bad", int((r.status != 0).sum()), "grids", [b.class_info(c)["blocks_last_run"] for c in range(13)], "paths", len(r.weight), [b.class_info(c)["blocks_per_cu"] for c in range(13)], flush=True)
