@@ -333,17 +333,28 @@ int ald_batch_upload(ald_batch *b)
             b->cls0[g] = c;
             if(c >= 0) work[c].push_back(g);
         }
-        // More graphs of a class than its LDS form can run at once: they go to the slab-resident twin (twelve workgroups per CU instead
-        // of three, no LDS taken from the other classes).  Fewer: the LDS form finishes each of them 2-3 times sooner.
-        // ALD_DEBUG_TWIN=1 / 0 forces / forbids the move (tests, A/B runs).
-        for(int c = 0; c < ALD_NUM_PICK_CLASSES; c++) {
-            const int tw = class_twin(c);
-            if(tw < 0 || work[c].empty()) continue;
-            bool move = (int64_t)work[c].size() > (int64_t)b->n_cus * occupancy_for(b, c);
+        // LDS form or slab-resident twin for the large classes?  The LDS-hungry classes of a batch (16 KB per workgroup and up) serialise --
+        // each holds its CU's LDS for as long as it runs -- so the batch takes about the SUM of their times; the twins take no LDS and run beside them, 12 workgroups per CU
+        // instead of 3, but a graph takes 2-3 times longer there and the first result comes after ~90 ms.  Estimate both (constants
+        // from tools/_gpu_twin.py and the per-class times of cfg3, DESIGN.md section 5: one round of a class takes about MAXE / 60 ms,
+        // the twins 90 ms + 19 us per graph) and move the graphs when the twins win.  ALD_DEBUG_TWIN=1 / 0 forces / forbids the move.
+        {
+            double others = 0, mine = 0; int64_t n_tw = 0;
+            for(int c = 0; c < ALD_NUM_PICK_CLASSES; c++) {
+                if(work[c].empty() || c == ALD_CATCH_ALL_CLASS) continue;
+                const double cap = (double)b->n_cus * std::max(1, occupancy_for(b, c));
+                const double t = std::max(1.0, (double)work[c].size() / cap) * class_info(c).maxe / 60.0;
+                if(class_twin(c) >= 0) { mine += t; n_tw += (int64_t)work[c].size(); }
+                else if(class_info(c).maxe >= 640) others += t;      // the small classes (8 KB of LDS and less per workgroup) fit beside anything and do not serialise
+            }
+            bool move = n_tw > 0 && std::max(1.1 * others, 90.0 + 0.019 * (double)n_tw) < others + mine;
             if(const char *ev = getenv("ALD_DEBUG_TWIN")) move = atoi(ev) != 0;
-            if(!move) continue;
-            for(int32_t g : work[c]) b->cls0[g] = tw;
-            work[tw].swap(work[c]);
+            if(move) for(int c = 0; c < ALD_NUM_PICK_CLASSES; c++) {
+                const int tw = class_twin(c);
+                if(tw < 0 || work[c].empty()) continue;
+                for(int32_t g : work[c]) b->cls0[g] = tw;
+                work[tw].swap(work[c]);
+            }
         }
         for(int c = 0; c < ALD_NUM_CLASSES; c++)
             std::stable_sort(work[c].begin(), work[c].end(), [&](int32_t x, int32_t y) { return b->hb.g_ne[x] > b->hb.g_ne[y]; });
