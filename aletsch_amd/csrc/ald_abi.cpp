@@ -90,6 +90,8 @@ struct ald_batch {
     HostResults res;
     int passes = 0;
     bool indexed = false;
+    const void *launched_slab[ALD_NUM_CLASSES] = {};      // test hook (ald_batch_debug_slab)
+    rvec<uint32_t> tstream;                                // last transcript stream built from this batch (ald_batch_transcript_stream)
 };
 
 namespace {
@@ -181,6 +183,20 @@ int stage_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], i
     return push_pass(b, P);
 }
 
+// Buffers that a retry pass or a pool growth may have moved since pass 0 was staged (DevBuf::ensure frees and reallocates): the
+// class slabs and the record pool.  Pass 0's arguments are brought up to date before they are used again.
+bool refresh_pass_args(ald_batch *b, StagedPass &P)
+{
+    bool changed = false;
+    for(int c = 0; c < ALD_NUM_CLASSES; c++) {
+        if(P.nblk[c] == 0 || P.args.empty()) continue;
+        KernelArgs &A = P.args[c];
+        if(A.slabs != (uint8_t*)b->d_slabs[c].p) { A.slabs = (uint8_t*)b->d_slabs[c].p; changed = true; }
+        if(A.out.pool != (uint32_t*)b->d_pool.p || A.out.pool_cap != b->pool_cap_words) { A.out.pool = (uint32_t*)b->d_pool.p; A.out.pool_cap = b->pool_cap_words; changed = true; }
+    }
+    return changed;
+}
+
 int fire_pass(ald_batch *b, const StagedPass &P)          // fork on the side streams behind ev0, join on the batch stream before ev1
 {
     if(P.tot == 0) return ALD_OK;
@@ -188,7 +204,7 @@ int fire_pass(ald_batch *b, const StagedPass &P)          // fork on the side st
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     for(int k = 0; k < P.nord; k++) {
         const int c = P.order[k], st = P.stream_of[c];
-        b->blocks[c] = P.nblk[c];
+        b->blocks[c] = P.nblk[c]; b->launched_slab[c] = P.args[c].slabs;
         HIPCHK(hipStreamWaitEvent(b->cstream[st], b->ev0, 0));
         if(k_launch[c]((const KernelArgs*)b->d_args.p + c, P.nblk[c], b->cstream[st]) != 0) return set_err(ALD_ERR_HIP, "kernel launch failed");
         HIPCHK(hipEventRecord(b->cdone[c], b->cstream[st]));
@@ -282,12 +298,13 @@ int ald_batch_add_packed(ald_batch *b, int32_t n, const int32_t *g_nv, const int
                          const int32_t *vertex_offset, const int32_t *edge_target, const double *edge_weight, const uint8_t *edge_strand, const double *edge_abd,
                          const int32_t *edge_sample_offset, const int32_t *sample_id, const double *sample_abd,
                          const double *vertex_weight, const int32_t *vertex_lpos, const int32_t *vertex_rpos, const int32_t *vertex_type,
-                         const int32_t *phasing_offset, const int32_t *phasing_vertex, const int32_t *phasing_count, const char *graph_strand, const int32_t *edge_count)
+                         const int32_t *phasing_offset, const int32_t *phasing_vertex, const int32_t *phasing_count, const char *graph_strand, const int32_t *edge_count,
+                         const int32_t *edge_creation_rank)
 {
     if(!b || n < 0 || !g_nv || !g_ne) return ALD_ERR_INVALID;
     b->uploaded = b->ran = b->downloaded = false;
     int rc = b->hb.add_packed(n, g_nv, g_ne, g_np, vertex_offset, edge_target, edge_weight, edge_strand, edge_abd, edge_sample_offset, sample_id, sample_abd,
-                              vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand, edge_count);
+                              vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand, edge_count, edge_creation_rank);
     if(rc != ALD_OK) return set_err(rc, b->hb.err);
     return ALD_OK;
 }
@@ -312,7 +329,10 @@ int ald_batch_upload(ald_batch *b)
     b->hb.pack_into((uint8_t*)b->pin_in.p, b->sec);
     HIPCHK(hipMemcpyAsync(b->d_in.p, b->pin_in.p, b->in_bytes, hipMemcpyHostToDevice, b->stream));    // ONE coalesced H2D copy
     // outputs
+    // a heuristic, not a bound (one graph can need about (E - V + 2) * (V + 14) words): a graph that finds the pool full reports
+    // ALD_ST_POOL_FULL and ald_batch_download grows the pool.  ALD_DEBUG_POOL_WORDS starts it small so that tests reach that path.
     uint64_t pool = 0; for(int g = 0; g < n; g++) pool += 16ull * b->hb.g_ne[g] + 256;
+    if(const char *ev = getenv("ALD_DEBUG_POOL_WORDS")) { const long long k = atoll(ev); if(k > 0 && (uint64_t)k < pool) pool = (uint64_t)k; }
     b->pool_cap_words = pool;
     if(b->d_status.ensure(4 * (size_t)n + 4) || b->d_npaths.ensure(4 * (size_t)n + 4) || b->d_niters.ensure(4 * (size_t)n + 4) || b->d_pool.ensure(4 * pool + 64) || b->d_poolused.ensure(64))
         return set_err(ALD_ERR_NOMEM, "device output buffers");
@@ -367,17 +387,24 @@ int ald_batch_upload(ald_batch *b)
     return ALD_OK;
 }
 
+static int start_run(ald_batch *b);
 int ald_batch_run(ald_batch *b)
 {
     if(!b) return ALD_ERR_INVALID;
     if(!b->uploaded || !b->pass0) return set_err(ALD_ERR_STATE, "ald_batch_run before ald_batch_upload");
+    b->kernel_ms = 0;
+    return start_run(b);
+}
+static int start_run(ald_batch *b)
+{
     HIPCHK(hipSetDevice(b->device));
     const int n = b->hb.n();
     HIPCHK(hipMemsetAsync(b->d_poolused.p, 0, 64, b->stream));
     HIPCHK(hipMemsetAsync(b->d_status.p, 0, 4 * (size_t)n + 4, b->stream));
     HIPCHK(hipMemsetAsync(b->d_npaths.p, 0, 4 * (size_t)n + 4, b->stream));
     b->cls = b->cls0; b->attempt.assign(n, 0); b->status.assign(n, 0);
-    b->passes = 0; b->kernel_ms = 0;
+    b->passes = 0;
+    if(refresh_pass_args(b, *b->pass0)) b->pass0_on_device = false;      // a slab or the pool moved since pass 0 was staged (stale slab pointers)
     if(!b->pass0_on_device) { int rc = push_pass(b, *b->pass0); if(rc != ALD_OK) return rc; b->pass0_on_device = true; }      // a retry pass of the last run used the buffers
     int rc = fire_pass(b, *b->pass0);
     if(rc != ALD_OK) return rc;
@@ -401,6 +428,9 @@ int ald_batch_download(ald_batch *b)
     const int n = b->hb.n();
     b->n_paths.assign(n, 0); b->n_iters.assign(n, 0);
     std::vector<int32_t> st(n);
+    unsigned long long used = 0;
+  for(int regrow = 0; ; regrow++) {
+    bool pool_full = false;
     for(int pass = 0; pass <= ALD_NUM_CLASSES; pass++) {
         HIPCHK(hipStreamSynchronize(b->stream));
         float ms = 0; if(hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->kernel_ms += ms;
@@ -412,15 +442,27 @@ int ald_batch_download(ald_batch *b)
             if(b->cls[g] < 0) { b->status[g] = ALD_ST_CAPACITY; continue; }
             if(b->attempt[g] != pass) continue;                 // not part of this pass
             b->status[g] = st[g];
+            if(st[g] == ALD_ST_POOL_FULL) pool_full = true;
             if(st[g] == ALD_ST_CAPACITY && getenv("ALD_DEBUG_RETRY")) fprintf(stderr, "[ald] graph %d (V=%d E=%d) overflowed class %d in pass %d\n", g, b->hb.g_nv[g], b->hb.g_ne[g], b->cls[g], pass);
             if(st[g] == ALD_ST_CAPACITY && class_retry_up(b->cls[g]) >= 0) { b->cls[g] = class_retry_up(b->cls[g]); b->attempt[g] = pass + 1; work[b->cls[g]].push_back(g); any = true; }
         }
-        if(!any) break;
+        if(!any || pool_full) break;
         int rc = launch_pass(b, work, pass + 1);
         if(rc != ALD_OK) return rc;
     }
-    unsigned long long used = 0;
     HIPCHK(hipMemcpy(&used, b->d_poolused.p, 8, hipMemcpyDeviceToHost));
+    if(!pool_full) break;
+    // Some graph found the record pool full.  Records behind the first refused one may be missing (the bump pointer moved, nothing was
+    // written), so the stream of this run is unusable as a whole: the pool grows -- `used` counts every request made, a lower bound
+    // of the need -- and the batch is decomposed again from pass 0.  Rare by construction (single-graph batches of long sparse graphs
+    // with many isoforms), so the cost of the second run does not matter.
+    if(regrow >= 8) break;                                 // gives up: the graphs keep ALD_ST_POOL_FULL
+    uint64_t want = std::max<uint64_t>(2 * b->pool_cap_words, used + used / 4 + 4096);
+    if(b->d_pool.ensure(4 * want + 64)) return set_err(ALD_ERR_NOMEM, "record pool");
+    b->pool_cap_words = want;
+    int rc = start_run(b);
+    if(rc != ALD_OK) return rc;
+  }
     if(used > b->pool_cap_words) used = b->pool_cap_words;
     b->res.clear();
     // the records land in a pinned buffer (kept across runs) through an async copy on the batch stream: the copy engine moves them
@@ -460,6 +502,14 @@ int ald_batch_get_result(const ald_batch *b, int32_t graph, ald_result_view *out
     { int rc = ensure_index(b); if(rc != ALD_OK) return rc; }
     out->status = b->res.status[graph]; out->num_paths = (int32_t)(b->res.path_begin[graph + 1] - b->res.path_begin[graph]);
     out->num_iterations = b->res.n_iters[graph]; out->reserved = 0;
+    return ALD_OK;
+}
+
+int ald_batch_export_iterations(const ald_batch *b, int32_t *num_iterations)
+{
+    if(!b || !num_iterations) return ALD_ERR_INVALID;
+    if(!b->downloaded) return set_err(ALD_ERR_STATE, "ald_batch_export_iterations before ald_batch_download");
+    for(int g = 0; g < b->hb.n(); g++) num_iterations[g] = b->n_iters[g];
     return ALD_OK;
 }
 
@@ -561,9 +611,9 @@ int ald_tset_add(ald_tset *t, int32_t n_groups, const int64_t *group_offset, con
         aletsch::transcript_sink ts(t->overlap);
         for(int64_t i = group_offset[g]; i < group_offset[g + 1]; i++) {
             aletsch::sink_transcript x;
-            x.strand = strand[i]; x.coverage = coverage[i]; x.cov2 = coverage[i]; x.conf = conf[i]; x.abd = abd[i]; x.count1 = count1[i]; x.count2 = 1; x.tid = tid[i];
-            for(int64_t k = exon_offset[i]; k < exon_offset[i + 1]; k++) x.exons.push_back(std::make_pair(exon_lr[2 * k], exon_lr[2 * k + 1]));
-            if(x.exons.size() <= 1 && skip_single_exon) continue;           // assembler.cc:1117
+            x.strand = strand[i]; x.coverage = coverage[i]; x.top.cov2 = coverage[i]; x.top.conf = conf[i]; x.top.abd = abd[i]; x.top.count1 = count1[i]; x.count2 = 1; x.tid = tid[i];
+            x.xs.assign(exon_lr + 2 * exon_offset[i], exon_lr + 2 * exon_offset[i + 1]);
+            if(x.n_exons() <= 1 && skip_single_exon) continue;               // assembler.cc:1117
             ts.add(x, 1, group_sid[g]);                                      // assembler.cc:1120
         }
         t->add(ts);                                                          // assembler.cc:1130
@@ -571,20 +621,68 @@ int ald_tset_add(ald_tset *t, int32_t n_groups, const int64_t *group_offset, con
     return ALD_OK;
 }
 
-// transcript::get_intron_chain_hashing (gtf/transcript.cc:183-201) over the flat exon list of join_exons
-static size_t chain_hash(const std::vector<int32_t> &ex)
+} // extern "C"  (the helpers below are templates / C++ types)
+static void join_exons(const ald_batch *b, int32_t graph, const PathRec &p, std::vector<int32_t> &ex);
+namespace {
+unsigned sink_threads(int64_t n_transcripts)
 {
-    const size_t ne = ex.size() / 2;
-    if(ne == 0) return 0;
-    if(ne == 1) return (size_t)((ex[0] + ex[1]) / 10000) + 1;
-    size_t seed = 2 * (ne - 1);
-    for(size_t k = 1; k < 2 * ne - 1; k++) seed ^= (size_t)(ex[k]) + 0x9e3779b9 + (seed << 6) + (seed >> 2);      // r0, l1, r1, l2, ..., l_last
-    return (seed & 0x7FFFFFFF) + 1;
+    unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16;
+    if(const char *ev = getenv("ALD_SINK_THREADS")) { int k = atoi(ev); if(k >= 1 && k <= 64) nthr = (unsigned)k; }
+    else if(n_transcripts < 20000) nthr = 1;
+    if(nthr > ALD_TSET_SHARDS) nthr = ALD_TSET_SHARDS;
+    return nthr;
+}
+const uint32_t ALD_NO_BUCKET = 0xFFFFFFFFu;       // hashes are below 2^31 + 1
+
+// The merge of many graphs' transcripts.  Buckets never interact, so they are dealt to the host threads by hash: every thread walks
+// the groups (graphs) in ascending order, builds the per-graph set of ITS buckets and merges it -- the same sequence of
+// trans_item::merge calls per bucket as the serial loop of assembler.cc:1105-1133, hence the same result, without `mylock`.
+// `make(i, x)` fills x from transcript i; grp[k] .. grp[k+1] are the transcripts of group k; bucket[i] = its chain key or ALD_NO_BUCKET.
+template<class Make> void merge_groups(ald_tset *t, unsigned nthr, int64_t n_groups, const int64_t *grp, const int32_t *grp_sid, const uint32_t *bucket, Make make)
+{
+    HostBatch::run_threads(nthr, [&](unsigned th) {
+        auto mine = [&](uint32_t h) { return h != ALD_NO_BUCKET && (h % ALD_TSET_SHARDS) % nthr == th; };
+        aletsch::sink_transcript x;
+        for(int64_t g = 0; g < n_groups; g++) {
+            int cnt = 0; int64_t first = -1;
+            for(int64_t i = grp[g]; i < grp[g + 1]; i++) if(mine(bucket[(size_t)i])) { if(cnt++ == 0) first = i; }
+            if(cnt == 0) continue;
+            const int s_id = grp_sid ? grp_sid[g] : -1;
+            // a graph that puts a single transcript into this thread's tables needs no per-graph set: merging a one-item set is the same
+            // as adding the item (transcript_set.cc:149-175)
+            if(cnt == 1) { make(first, x); const uint32_t h = bucket[(size_t)first]; t->shard[h % ALD_TSET_SHARDS].add_hashed(x, h, 1, s_id); continue; }
+            aletsch::transcript_sink ts(t->overlap);
+            for(int64_t i = first; i < grp[g + 1]; i++) {
+                if(!mine(bucket[(size_t)i])) continue;
+                make(i, x);
+                ts.add_hashed(x, bucket[(size_t)i], 1, s_id);                  // assembler.cc:1120
+            }
+            t->add(ts);                                                        // assembler.cc:1130 (only tables this thread owns are touched)
+        }
+    });
 }
 
-// The merge of a whole batch.  Buckets (intron-chain hashes) never interact, so they are dealt to the host threads by hash: every
-// thread walks the graphs in ascending order, builds the per-graph set of ITS buckets and merges it -- the same sequence of
-// trans_item::merge calls per bucket as the serial loop of assembler.cc:1105-1133, hence the same result, without `mylock`.
+// joined exons of every path of a downloaded batch, one slot per path sized by its internal vertices (pass 1 of both consumers below)
+struct JoinedExons { std::vector<int64_t> off; std::vector<int32_t> len; rvec<int32_t> words; };
+void join_all(const ald_batch *b, unsigned nthr, JoinedExons &J)
+{
+    const int n = b->hb.n(); const int64_t np = (int64_t)b->res.paths.size();
+    J.off.assign((size_t)np + 1, 0); J.len.assign((size_t)np, 0);
+    for(int64_t i = 0; i < np; i++) J.off[(size_t)i + 1] = J.off[(size_t)i] + 2 * (int64_t)(b->res.paths[(size_t)i].nv > 2 ? b->res.paths[(size_t)i].nv - 2 : 0);
+    J.words.resize((size_t)J.off[(size_t)np] + 2);
+    HostBatch::run_threads(nthr, [&](unsigned th) {
+        std::vector<int32_t> ex;
+        const int g0 = (int)((int64_t)n * th / nthr), g1 = (int)((int64_t)n * (th + 1) / nthr);
+        for(int g = g0; g < g1; g++) for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++) {
+            join_exons(b, g, b->res.paths[i], ex);
+            J.len[(size_t)i] = (int32_t)ex.size();
+            if(!ex.empty()) memcpy(&J.words[(size_t)J.off[(size_t)i]], ex.data(), 4 * ex.size());
+        }
+    });
+}
+} // namespace
+
+extern "C" {
 int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int64_t tid_base, int32_t skip_single_exon)
 {
     if(!t || !b || !b->downloaded) return ALD_ERR_INVALID;
@@ -593,59 +691,92 @@ int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int6
     auto T1 = std::chrono::steady_clock::now();
     const int n = b->hb.n();
     const int64_t np = (int64_t)b->res.paths.size();
-    unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16;
-    if(const char *ev = getenv("ALD_SINK_THREADS")) { int k = atoi(ev); if(k >= 1 && k <= 64) nthr = (unsigned)k; }
-    else if(np < 20000) nthr = 1;
-    if(nthr > ALD_TSET_SHARDS) nthr = ALD_TSET_SHARDS;
-    // pass 1 (graphs split over the threads, everything local to a graph still in cache): joined exons of every transcript, kept in
-    // one array at a slot sized by its internal vertices, and its bucket (hashes are below 2^31 + 1; ALD_NO_BUCKET = dropped)
-    const uint32_t ALD_NO_BUCKET = 0xFFFFFFFFu;
+    const unsigned nthr = sink_threads(np);
+    // pass 1 (graphs split over the threads, everything local to a graph still in cache): joined exons and bucket of every transcript
+    JoinedExons J; join_all(b, nthr, J);
     std::vector<uint32_t> bucket((size_t)np, ALD_NO_BUCKET);
-    std::vector<int64_t> ex_off((size_t)np + 1, 0); std::vector<int32_t> ex_len((size_t)np, 0);
-    for(int64_t i = 0; i < np; i++) ex_off[(size_t)i + 1] = ex_off[(size_t)i] + 2 * (int64_t)(b->res.paths[(size_t)i].nv > 2 ? b->res.paths[(size_t)i].nv - 2 : 0);
-    rvec<int32_t> ex_all; ex_all.resize((size_t)ex_off[(size_t)np] + 2);
     HostBatch::run_threads(nthr, [&](unsigned th) {
-        std::vector<int32_t> ex;
-        const int g0 = (int)((int64_t)n * th / nthr), g1 = (int)((int64_t)n * (th + 1) / nthr);
-        for(int g = g0; g < g1; g++) for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++) {
-            join_exons(b, g, b->res.paths[i], ex);
-            if(ex.size() <= 2 && skip_single_exon) continue;                 // assembler.cc:1117
-            bucket[(size_t)i] = (uint32_t)chain_hash(ex);                     // <= 2^31
-            ex_len[(size_t)i] = (int32_t)ex.size();
-            if(!ex.empty()) memcpy(&ex_all[(size_t)ex_off[(size_t)i]], ex.data(), 4 * ex.size());
+        for(int64_t i = np * th / nthr; i < np * (th + 1) / nthr; i++) {
+            if(J.len[(size_t)i] <= 2 && skip_single_exon) continue;            // assembler.cc:1117
+            bucket[(size_t)i] = (uint32_t)aletsch::sink_transcript::chain_key(&J.words[(size_t)J.off[(size_t)i]], (size_t)J.len[(size_t)i]);
         }
     });
     auto T2 = std::chrono::steady_clock::now();
-    // pass 2: thread th owns the tables th, th + nthr, ...; it walks the graphs in order and merges the per-graph set of its buckets.
-    // A graph that puts a single transcript into this thread's tables needs no per-graph set: merging a one-item set is the same as
-    // adding the item (transcript_set.cc:149-175).
-    HostBatch::run_threads(nthr, [&](unsigned th) {
-        auto mine = [&](uint32_t h) { return h != ALD_NO_BUCKET && (h % ALD_TSET_SHARDS) % nthr == th; };
-        auto make = [&](int g, int64_t i, aletsch::sink_transcript &x) {
-            const PathRec &p = b->res.paths[i];
-            x.strand = p.strand; x.coverage = log(1.0 + p.weight); x.cov2 = x.coverage; x.conf = p.conf; x.abd = p.abd; x.count1 = p.count; x.count2 = 1;
-            x.tid = tid_base + (((int64_t)g << 20) | (int64_t)(i - b->res.path_begin[g]));
-            const int32_t *ex = &ex_all[(size_t)ex_off[(size_t)i]]; const int len = ex_len[(size_t)i];
-            x.exons.clear(); x.exons.reserve((size_t)len / 2);
-            for(int k = 0; k + 1 < len; k += 2) x.exons.push_back(std::make_pair(ex[k], ex[k + 1]));
-        };
-        aletsch::sink_transcript x;
-        for(int g = 0; g < n; g++) {
-            int cnt = 0; int64_t first = -1;
-            for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++) if(mine(bucket[(size_t)i])) { if(cnt++ == 0) first = i; }
-            if(cnt == 0) continue;
-            const int s_id = sid ? sid[g] : -1;
-            if(cnt == 1) { make(g, first, x); const uint32_t h = bucket[(size_t)first]; t->shard[h % ALD_TSET_SHARDS].add_hashed(x, h, 1, s_id); continue; }
-            aletsch::transcript_sink ts(t->overlap);
-            for(int64_t i = first; i < b->res.path_begin[g + 1]; i++) {
-                if(!mine(bucket[(size_t)i])) continue;
-                make(g, i, x);
-                ts.add_hashed(x, bucket[(size_t)i], 1, s_id);                   // assembler.cc:1120
-            }
-            t->add(ts);                                                        // assembler.cc:1130 (only tables this thread owns are touched)
-        }
+    // pass 2: thread th owns the tables th, th + nthr, ...
+    std::vector<int32_t> graph_of((size_t)np);
+    for(int g = 0; g < n; g++) for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++) graph_of[(size_t)i] = g;
+    merge_groups(t, nthr, n, b->res.path_begin.data(), sid, bucket.data(), [&](int64_t i, aletsch::sink_transcript &x) {
+        const PathRec &p = b->res.paths[(size_t)i]; const int g = graph_of[(size_t)i];
+        x.strand = p.strand; x.coverage = log(1.0 + p.weight); x.top.cov2 = x.coverage; x.top.conf = p.conf; x.top.abd = p.abd; x.top.count1 = p.count; x.count2 = 1;
+        x.tid = tid_base + (((int64_t)g << 20) | (int64_t)(i - b->res.path_begin[g]));
+        const int32_t *ex = &J.words[(size_t)J.off[(size_t)i]];
+        x.xs.assign(ex, ex + J.len[(size_t)i]);
     });
     if(getenv("ALD_SINK_PROF")) { auto T3 = std::chrono::steady_clock::now(); auto ms = [](auto a, auto b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); }; fprintf(stderr, "[sink] index %.1f ms, hash pass %.1f ms, merge pass %.1f ms (%u threads)\n", ms(T0, T1), ms(T1, T2), ms(T2, T3), nthr); }
+    return ALD_OK;
+}
+
+/* ---- finished transcripts as ONE self-contained stream: what ranks exchange in the multi-GPU gather and what a device list merges ----
+ * 4-byte words, transcripts in ascending (graph, path index) order:
+ *   [graph, path, sid, strand, count1, n_exons, weight f64, conf f64, abd f64, (l, r) * n_exons]        TS_HDR + 2 * n_exons words
+ * Records of abandoned attempts and of graphs that did not end well are already gone (HostResults::build), exons are joined. */
+enum { TS_HDR = 12 };
+int ald_batch_transcript_stream(const ald_batch *cb, const int32_t *sid, int32_t skip_single_exon, const uint32_t **words, int64_t *n_words)
+{
+    if(!cb || !words || !n_words) return ALD_ERR_INVALID;
+    if(!cb->downloaded) return set_err(ALD_ERR_STATE, "ald_batch_transcript_stream before ald_batch_download");
+    { int rc = ensure_index(cb); if(rc != ALD_OK) return rc; }
+    ald_batch *b = const_cast<ald_batch*>(cb);
+    const int n = b->hb.n(); const int64_t np = (int64_t)b->res.paths.size();
+    const unsigned nthr = sink_threads(np);
+    JoinedExons J; join_all(b, nthr, J);
+    std::vector<int64_t> at((size_t)np + 1, 0);
+    for(int64_t i = 0; i < np; i++) at[(size_t)i + 1] = at[(size_t)i] + ((J.len[(size_t)i] <= 2 && skip_single_exon) ? 0 : TS_HDR + J.len[(size_t)i]);
+    b->tstream.resize((size_t)at[(size_t)np] + 2);
+    uint32_t *out = b->tstream.data();
+    HostBatch::run_threads(nthr, [&](unsigned th) {
+        const int g0 = (int)((int64_t)n * th / nthr), g1 = (int)((int64_t)n * (th + 1) / nthr);
+        for(int g = g0; g < g1; g++) for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++) {
+            if(at[(size_t)i + 1] == at[(size_t)i]) continue;
+            const PathRec &p = b->res.paths[(size_t)i]; uint32_t *w = out + at[(size_t)i];
+            w[0] = (uint32_t)g; w[1] = (uint32_t)(i - b->res.path_begin[g]); w[2] = (uint32_t)(sid ? sid[g] : -1); w[3] = (uint32_t)(unsigned char)p.strand;
+            w[4] = (uint32_t)p.count; w[5] = (uint32_t)(J.len[(size_t)i] / 2);
+            memcpy(w + 6, &p.weight, 8); memcpy(w + 8, &p.conf, 8); memcpy(w + 10, &p.abd, 8);
+            if(J.len[(size_t)i]) memcpy(w + TS_HDR, &J.words[(size_t)J.off[(size_t)i]], 4 * (size_t)J.len[(size_t)i]);
+        }
+    });
+    *words = out; *n_words = at[(size_t)np];
+    return ALD_OK;
+}
+
+int ald_tset_add_stream(ald_tset *t, const uint32_t *words, int64_t n_words, int32_t graph_offset, int64_t tid_base)
+{
+    if(!t || n_words < 0 || (n_words > 0 && !words)) return ALD_ERR_INVALID;
+    // record boundaries and groups (one serial walk: the lengths are in the records)
+    std::vector<int64_t> offs, grp; std::vector<int32_t> grp_sid;
+    int64_t last_graph = -1;
+    for(int64_t o = 0; o < n_words; ) {
+        if(o + TS_HDR > n_words) return set_err(ALD_ERR_INVALID, "malformed transcript stream");
+        const int64_t len = TS_HDR + 2 * (int64_t)words[o + 5];
+        if(o + len > n_words || (int32_t)words[o + 5] < 0) return set_err(ALD_ERR_INVALID, "malformed transcript stream");
+        const int64_t g = (int64_t)words[o];
+        if(g < last_graph) return set_err(ALD_ERR_INVALID, "transcript stream not in ascending graph order");
+        if(g != last_graph) { grp.push_back((int64_t)offs.size()); grp_sid.push_back((int32_t)words[o + 2]); last_graph = g; }
+        offs.push_back(o); o += len;
+    }
+    const int64_t nt = (int64_t)offs.size(); grp.push_back(nt);
+    const unsigned nthr = sink_threads(nt);
+    std::vector<uint32_t> bucket((size_t)nt);
+    HostBatch::run_threads(nthr, [&](unsigned th) {
+        for(int64_t i = nt * th / nthr; i < nt * (th + 1) / nthr; i++) { const uint32_t *w = words + offs[(size_t)i]; bucket[(size_t)i] = (uint32_t)aletsch::sink_transcript::chain_key((const int32_t*)(w + TS_HDR), 2 * (size_t)w[5]); }
+    });
+    merge_groups(t, nthr, (int64_t)grp_sid.size(), grp.data(), grp_sid.data(), bucket.data(), [&](int64_t i, aletsch::sink_transcript &x) {
+        const uint32_t *w = words + offs[(size_t)i];
+        double weight, conf, abd; memcpy(&weight, w + 6, 8); memcpy(&conf, w + 8, 8); memcpy(&abd, w + 10, 8);
+        x.strand = (char)w[3]; x.coverage = log(1.0 + weight); x.top.cov2 = x.coverage; x.top.conf = conf; x.top.abd = abd; x.top.count1 = (int32_t)w[4]; x.count2 = 1;
+        x.tid = tid_base + ((((int64_t)w[0] + graph_offset) << 20) | (int64_t)w[1]);
+        x.xs.assign((const int32_t*)(w + TS_HDR), (const int32_t*)(w + TS_HDR) + 2 * (size_t)w[5]);
+    });
     return ALD_OK;
 }
 
@@ -653,7 +784,7 @@ int ald_tset_size(const ald_tset *t, int64_t *n_items, int64_t *n_exons, int64_t
 {
     if(!t) return ALD_ERR_INVALID;
     int64_t a = 0, e = 0, s = 0;
-    for(auto &sh : t->shard) for(auto &x : sh.mt) for(auto &z : x.second) { a++; e += (int64_t)z.trst.exons.size(); s += (int64_t)z.samples.size(); }
+    for(auto &sh : t->shard) for(auto &x : sh.mt) for(auto &z : x.second) { a++; e += (int64_t)z.trst.n_exons(); s += (int64_t)z.samples.size(); }
     if(n_items) *n_items = a; if(n_exons) *n_exons = e; if(n_samples) *n_samples = s;
     return ALD_OK;
 }
@@ -668,10 +799,10 @@ int ald_tset_export(const ald_tset *t, uint64_t *hash, int32_t *count, char *str
     std::sort(keys.begin(), keys.end());
     for(size_t key : keys) for(auto &z : t->shard[key % ALD_TSET_SHARDS].mt.find(key)->second) {        // the reference's iteration order: ascending hash
         const aletsch::sink_transcript &r = z.trst;
-        hash[i] = (uint64_t)key; count[i] = z.count; strand[i] = r.strand; coverage[i] = r.coverage; cov2[i] = r.cov2; conf[i] = r.conf; abd[i] = r.abd;
-        count1[i] = r.count1; count2[i] = r.count2; tid[i] = r.tid; exon_offset[i] = e; sample_offset[i] = s;
-        for(auto &q : r.exons) { exon_lr[2 * e] = q.first; exon_lr[2 * e + 1] = q.second; e++; }
-        for(auto &q : z.samples) { sample_sid[s] = q.first; sample_cov2[s] = q.second.cov2; sample_conf[s] = q.second.conf; sample_abd[s] = q.second.abd; sample_count1[s] = q.second.count1; s++; }
+        hash[i] = (uint64_t)key; count[i] = z.count; strand[i] = r.strand; coverage[i] = r.coverage; cov2[i] = r.top.cov2; conf[i] = r.top.conf; abd[i] = r.top.abd;
+        count1[i] = r.top.count1; count2[i] = r.count2; tid[i] = r.tid; exon_offset[i] = e; sample_offset[i] = s;
+        memcpy(exon_lr + 2 * e, r.xs.data(), 4 * r.xs.size()); e += (int64_t)r.n_exons();
+        for(auto &q : z.samples) { sample_sid[s] = q.first; sample_cov2[s] = q.second.top.cov2; sample_conf[s] = q.second.top.conf; sample_abd[s] = q.second.top.abd; sample_count1[s] = q.second.top.count1; s++; }
         i++;
     }
     exon_offset[i] = e; sample_offset[i] = s;
@@ -704,6 +835,14 @@ int ald_batch_raw_records(const ald_batch *b, const uint32_t **words, int64_t *n
 {
     if(!b || !b->downloaded || !words || !n_words) return ALD_ERR_INVALID;
     *words = b->res.pool_data(); *n_words = (int64_t)b->res.pool_size();
+    return ALD_OK;
+}
+
+int ald_batch_debug_slab(const ald_batch *b, int32_t cls, const void **launched_with, const void **owned)
+{
+    if(!b || cls < 0 || cls >= ALD_NUM_CLASSES) return ALD_ERR_INVALID;
+    if(launched_with) *launched_with = b->launched_slab[cls];
+    if(owned) *owned = b->d_slabs[cls].p;
     return ALD_OK;
 }
 

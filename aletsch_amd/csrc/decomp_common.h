@@ -84,6 +84,7 @@ struct BatchIn {
     ALD_GLOBAL const int32_t *phasing_offset, *phasing_vertex, *phasing_count;
     ALD_GLOBAL const char    *graph_strand;
     ALD_GLOBAL const int32_t *edge_count;                               // edge_info.count at hand-over (not always |samples|)
+    ALD_GLOBAL const int32_t *edge_rank;                                // creation rank (scallop edge index) of every input edge, or null: CSR position
 };
 struct BatchOut {
     ALD_GLOBAL int32_t *status, *n_paths, *n_iters;        // [n]

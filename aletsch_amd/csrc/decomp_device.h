@@ -1594,7 +1594,7 @@ ALD_FN void collect_path(int e)
         int nvp = cnt + 2;
         unsigned long long words = (unsigned long long)(REC_HDR_WORDS + nvp + ((REC_HDR_WORDS + nvp) & 1));
         unsigned long long o = atomic_add_u64(A->out.pool_used, words);
-        if(ALD_UNLIKELY(o + words > A->out.pool_cap)) { fail(ALD_ST_CAPACITY); return; }
+        if(ALD_UNLIKELY(o + words > A->out.pool_cap)) { fail(ALD_ST_POOL_FULL); return; }     // not this graph's class that is too small: the host grows the pool
         ALD_GLOBAL uint32_t *r = A->out.pool + o;
         int st = '.';
         if(C.ed[e].estrand == 1) st = '+';
@@ -1762,8 +1762,9 @@ ALD_FN bool load_graph()
     }
     bool strand = false;
     ALD_GLOBAL const int32_t *so = A->in.edge_sample_offset + oeo;
+    ALD_GLOBAL const int32_t *rank = A->in.edge_rank;      // scallop::scallop -> get_edge_indices (scallop.cc:24, graph_base.cc:139-153): e2i of the input edges
     for(int k = lane; k < E; k += ALD_WAVE) {
-        H.ed[k].lk.et = (IDX)A->in.edge_target[oe + k]; H.ed[k].w = A->in.edge_weight[oe + k]; H.eid[k] = (uint16_t)k; H.hflag[k] = 0;
+        H.ed[k].lk.et = (IDX)A->in.edge_target[oe + k]; H.ed[k].w = A->in.edge_weight[oe + k]; H.eid[k] = rank ? (uint16_t)rank[oe + k] : (uint16_t)k; H.hflag[k] = 0;
         uint8_t st = A->in.edge_strand[oe + k]; C.ed[k].estrand = st; if(st) strand = true;
         C.ed[k].med = 0; C.ed[k].mei = 0; C.ed[k].econf = 0; C.ed[k].eabd = A->in.edge_abd[oe + k];
         C.ed[k].sp_off = (uint32_t)so[k]; C.ed[k].sp_len = (uint32_t)(so[k + 1] - so[k]); C.ed[k].ecount = A->in.edge_count[oe + k];

@@ -40,7 +40,8 @@ struct HostBatch {
     rvec<int32_t> in_offset, in_edge;
     rvec<int32_t> phasing_offset, phasing_vertex, phasing_count; rvec<char> graph_strand;
     rvec<int32_t> edge_count;
-    std::vector<int32_t> cur_, perm_;          // scratch of add_graph, kept across calls
+    rvec<int32_t> edge_rank; bool has_rank = false;   // creation rank of every input edge (optional: empty until a caller supplies one, then identity-filled for the rest)
+    std::vector<int32_t> cur_, perm_; std::vector<uint8_t> seen_;          // scratch of add_graph, kept across calls
     std::string err;
 
     int n() const { return (int)g_nv.size(); }
@@ -51,18 +52,18 @@ struct HostBatch {
         vertex_offset.clear(); edge_target.clear(); edge_weight.clear(); edge_strand.clear(); edge_abd.clear();
         edge_sample_offset.clear(); sample_id.clear(); sample_abd.clear();
         vertex_weight.clear(); vertex_lpos.clear(); vertex_rpos.clear(); vertex_type.clear();
-        in_offset.clear(); in_edge.clear(); phasing_offset.clear(); phasing_vertex.clear(); phasing_count.clear(); graph_strand.clear(); edge_count.clear();
+        in_offset.clear(); in_edge.clear(); phasing_offset.clear(); phasing_vertex.clear(); phasing_count.clear(); graph_strand.clear(); edge_count.clear(); edge_rank.clear(); has_rank = false;
         err.clear();
     }
 
     // sizes of every array: a rejected graph must leave the batch exactly as it found it (the element-wise path appends while it checks)
-    struct Mark { size_t a[27]; };
+    struct Mark { size_t a[28]; bool has_rank; };
     Mark mark() const
     {
         Mark m = {{ g_nv.size(), g_ne.size(), g_np.size(), off_v.size(), off_e.size(), off_s.size(), off_p.size(), off_pv.size(),
                     vertex_offset.size(), edge_target.size(), edge_weight.size(), edge_strand.size(), edge_abd.size(), edge_sample_offset.size(), sample_id.size(), sample_abd.size(),
                     vertex_weight.size(), vertex_lpos.size(), vertex_rpos.size(), vertex_type.size(), in_offset.size(), in_edge.size(),
-                    phasing_offset.size(), phasing_vertex.size(), phasing_count.size(), graph_strand.size(), edge_count.size() }};
+                    phasing_offset.size(), phasing_vertex.size(), phasing_count.size(), graph_strand.size(), edge_count.size(), edge_rank.size() }, has_rank};
         return m;
     }
     void rollback(const Mark &m)
@@ -71,7 +72,21 @@ struct HostBatch {
         vertex_offset.resize(m.a[8]); edge_target.resize(m.a[9]); edge_weight.resize(m.a[10]); edge_strand.resize(m.a[11]); edge_abd.resize(m.a[12]); edge_sample_offset.resize(m.a[13]);
         sample_id.resize(m.a[14]); sample_abd.resize(m.a[15]); vertex_weight.resize(m.a[16]); vertex_lpos.resize(m.a[17]); vertex_rpos.resize(m.a[18]); vertex_type.resize(m.a[19]);
         in_offset.resize(m.a[20]); in_edge.resize(m.a[21]); phasing_offset.resize(m.a[22]); phasing_vertex.resize(m.a[23]); phasing_count.resize(m.a[24]); graph_strand.resize(m.a[25]);
-        edge_count.resize(m.a[26]);
+        edge_count.resize(m.a[26]); edge_rank.resize(m.a[27]); has_rank = m.has_rank;
+    }
+    // the first graph that brings a creation rank turns the column on: every edge staged before it gets its CSR position
+    void enable_rank()
+    {
+        if(has_rank) return;
+        has_rank = true; edge_rank.resize(edge_target.size());
+        for(int g = 0; g < n(); g++) { const int64_t o = off_e[g]; for(int k = 0; k < g_ne[g]; k++) edge_rank[o + k] = k; }
+    }
+    // is r[0..E) a permutation of 0..E-1 ?
+    bool rank_is_permutation(const int32_t *r, int E, std::vector<uint8_t> &seen) const
+    {
+        seen.assign((size_t)E, 0);
+        for(int k = 0; k < E; k++) { const int32_t x = r[k]; if(x < 0 || x >= E || seen[x]) return false; seen[x] = 1; }
+        return true;
     }
     int add_graph(const ald_graph_view &g)
     {
@@ -89,12 +104,18 @@ struct HostBatch {
         if(E > 0 && g.edge_sample_offset[0] != 0) { err = "edge_sample_offset[0] != 0"; return ALD_ERR_INVALID; }
         // ---- edges: per-row order by target (stable) ----
         std::vector<int32_t> &perm = perm_; perm.resize(E); std::iota(perm.begin(), perm.end(), 0);
+        const int32_t *rk = g.edge_creation_rank;
+        if(rk && E > 0 && !rank_is_permutation(rk, E, seen_)) { err = "edge_creation_rank is not a permutation of 0..E-1"; return ALD_ERR_INVALID; }
+        if(rk) { bool ident = true; for(int k = 0; k < E && ident; k++) ident = rk[k] == k; if(ident) rk = nullptr; }     // the default order: nothing to carry
         for(int s = 0; s < V; s++) {
             int a = g.vertex_offset[s], b = g.vertex_offset[s + 1];
             bool sorted = true;
-            for(int k = a; k < b; k++) { int t = g.edge_target[k]; if(t <= s || t >= V) { err = "edge target out of range (edges go from a lower to a higher vertex index, below V)"; return ALD_ERR_INVALID; } if(k > a && g.edge_target[k - 1] > t) sorted = false; }
-            if(!sorted) std::stable_sort(perm.begin() + a, perm.begin() + b, [&](int x, int y) { return g.edge_target[x] < g.edge_target[y]; });
+            for(int k = a; k < b; k++) { int t = g.edge_target[k]; if(t <= s || t >= V) { err = "edge target out of range (edges go from a lower to a higher vertex index, below V)"; return ALD_ERR_INVALID; }
+                                         if(k > a && (g.edge_target[k - 1] > t || (rk && g.edge_target[k - 1] == t && rk[k - 1] > rk[k]))) sorted = false; }
+            // parallel edges iterate in creation order (graph/edge_base.h:35-45): by rank when the caller gives one, else by position
+            if(!sorted) std::stable_sort(perm.begin() + a, perm.begin() + b, [&](int x, int y) { return g.edge_target[x] != g.edge_target[y] ? g.edge_target[x] < g.edge_target[y] : (rk ? rk[x] < rk[y] : false); });
         }
+        if(rk) enable_rank();
         size_t e0 = edge_target.size(), s0 = sample_id.size();
         // canonical input (rows sorted, sample lists ascending, strands in range: what the reference's containers produce) is appended
         // by ranges; anything else goes through the element-wise path below, which sorts and reports defects
@@ -123,6 +144,7 @@ struct HostBatch {
             else { edge_abd.resize(e0 + E); for(int k = 0; k < E; k++) { double sum = 0; for(int j = g.edge_sample_offset[k]; j < g.edge_sample_offset[k + 1]; j++) sum += g.sample_abd[j]; edge_abd[e0 + k] = sum; } }
             if(g.edge_count) edge_count.insert(edge_count.end(), g.edge_count, g.edge_count + E);
             else { edge_count.resize(e0 + E); for(int k = 0; k < E; k++) edge_count[e0 + k] = g.edge_sample_offset[k + 1] - g.edge_sample_offset[k]; }
+            if(has_rank) { if(rk) edge_rank.insert(edge_rank.end(), rk, rk + E); else { edge_rank.resize(e0 + E); for(int k = 0; k < E; k++) edge_rank[e0 + k] = k; } }
         } else {
         edge_sample_offset.push_back(0);
         for(int k = 0; k < E; k++) {
@@ -144,6 +166,7 @@ struct HostBatch {
             edge_abd.push_back(g.edge_abd ? g.edge_abd[q] : sum);
             if(g.edge_count && g.edge_count[q] < 0) { err = "negative edge count"; return ALD_ERR_INVALID; }
             edge_count.push_back(g.edge_count ? g.edge_count[q] : (int32_t)(b - a));
+            if(has_rank) edge_rank.push_back(rk ? rk[q] : k);
             edge_sample_offset.push_back((int32_t)(sample_id.size() - s0));
         }
         }
@@ -191,7 +214,7 @@ struct HostBatch {
                    const int32_t *voff, const int32_t *etgt, const double *ew, const uint8_t *estrand, const double *eabd,
                    const int32_t *esoff, const int32_t *sid, const double *sabd,
                    const double *vw, const int32_t *lpos, const int32_t *rpos, const int32_t *vtype,
-                   const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand, const int32_t *ecount = nullptr)
+                   const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand, const int32_t *ecount = nullptr, const int32_t *erank = nullptr)
     {
         int64_t ov = 0, ovo = 0, oe = 0, oeo = 0, os = 0, op = 0, opo = 0, opv = 0;
         const Mark m0 = mark();                     // all or nothing: a defect in graph i also takes graphs 0..i-1 of this call back out
@@ -203,7 +226,7 @@ struct HostBatch {
             g.edge_sample_offset = esoff + oeo; g.sample_id = sid + os; g.sample_abd = sabd + os;
             g.vertex_weight = vw + ov; g.vertex_lpos = lpos + ov; g.vertex_rpos = rpos + ov; g.vertex_type = vtype ? vtype + ov : nullptr;
             g.phasing_offset = poff ? poff + opo : nullptr; g.phasing_vertex = pv ? pv + opv : nullptr; g.phasing_count = pc ? pc + op : nullptr;
-            g.strand = gstrand ? gstrand[i] : '.'; g.edge_count = ecount ? ecount + oe : nullptr;
+            g.strand = gstrand ? gstrand[i] : '.'; g.edge_count = ecount ? ecount + oe : nullptr; g.edge_creation_rank = erank ? erank + oe : nullptr;
             if(V < 2 || E < 0) { err = "bad graph size"; rollback(m0); return ALD_ERR_INVALID; }
             int64_t ns = E > 0 ? g.edge_sample_offset[E] : 0, npv = (P > 0 && poff) ? g.phasing_offset[P] : 0;
             int rc = add_graph(g);
@@ -222,7 +245,7 @@ struct HostBatch {
                    const int32_t *voff, const int32_t *etgt, const double *ew, const uint8_t *estrand, const double *eabd,
                    const int32_t *esoff, const int32_t *sid, const double *sabd,
                    const double *vw, const int32_t *lpos, const int32_t *rpos, const int32_t *vtype,
-                   const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand, const int32_t *ecount = nullptr)
+                   const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand, const int32_t *ecount = nullptr, const int32_t *erank = nullptr)
     {
         if(n <= 0) return ALD_OK;
         // offsets of every graph inside the caller's concatenated arrays
@@ -243,17 +266,20 @@ struct HostBatch {
         if((int64_t)nthr > (TE >> 16) + 1) nthr = (unsigned)((TE >> 16) + 1);                      // not worth a thread below ~64k edges
         // ---- pass 1 (parallel): is every graph canonical and valid?
         std::vector<int> verdict(nthr, 0);           // 0 ok, 1 not canonical, 2 invalid
+        std::vector<int> permuted(nthr, 0);          // some graph of the slice carries a creation rank other than the CSR position
         auto check = [&](unsigned t) {
             const int g0 = (int)((int64_t)n * t / nthr), g1 = (int)((int64_t)n * (t + 1) / nthr);
-            int worst = 0;
+            int worst = 0; std::vector<uint8_t> seen;
             for(int g = g0; g < g1 && worst < 2; g++) {
                 const int V = nv[g], E = ne[g], P = np ? np[g] : 0;
                 const int32_t *vo = voff + iv[g] + g, *tg = etgt + ie[g], *so = esoff + ie[g] + g;
                 if(vo[0] != 0 || vo[V] != E || (E > 0 && so[0] != 0)) { worst = 2; break; }
                 for(int s = 0; s < V && worst < 2; s++) {
                     if(vo[s + 1] < vo[s]) { worst = 2; break; }
-                    for(int k = vo[s]; k < vo[s + 1]; k++) { int t2 = tg[k]; if(t2 <= s || t2 >= V) { worst = 2; break; } if(k > vo[s] && tg[k - 1] > t2) worst = 1; }
+                    for(int k = vo[s]; k < vo[s + 1]; k++) { int t2 = tg[k]; if(t2 <= s || t2 >= V) { worst = 2; break; } if(k > vo[s] && (tg[k - 1] > t2 || (erank && tg[k - 1] == t2 && erank[ie[g] + k - 1] > erank[ie[g] + k]))) worst = 1; }
                 }
+                if(erank && worst < 2 && E > 0 && !rank_is_permutation(erank + ie[g], E, seen)) { worst = 2; break; }
+                if(erank && !permuted[t]) for(int k = 0; k < E; k++) if(erank[ie[g] + k] != k) { permuted[t] = 1; break; }
                 for(int k = 0; k < E && worst < 2; k++) {
                     if(so[k + 1] < so[k]) { worst = 2; break; }
                     if(estrand && estrand[ie[g] + k] > 2) { worst = 2; break; }
@@ -274,8 +300,10 @@ struct HostBatch {
         };
         run_threads(nthr, check);
         int worst = 0; for(unsigned t = 0; t < nthr; t++) worst = std::max(worst, verdict[t]);
+        if(erank && worst == 0) { bool any = false; for(unsigned t = 0; t < nthr; t++) any = any || permuted[t]; if(!any) erank = nullptr; }     // identity everywhere: nothing to carry
         if(worst != 0)      // the per-graph path normalises, or names the defect
-            return add_packed_serial(n, nv, ne, np, voff, etgt, ew, estrand, eabd, esoff, sid, sabd, vw, lpos, rpos, vtype, poff, pv, pc, gstrand, ecount);
+            return add_packed_serial(n, nv, ne, np, voff, etgt, ew, estrand, eabd, esoff, sid, sabd, vw, lpos, rpos, vtype, poff, pv, pc, gstrand, ecount, erank);
+        if(erank) enable_rank();
         // ---- pass 2: size everything once, then fill disjoint ranges in parallel
         const size_t n0 = g_nv.size(), v0 = vertex_weight.size(), vo0 = vertex_offset.size(), e0 = edge_target.size(), eo0 = edge_sample_offset.size(), s0 = sample_id.size(),
                      p0 = phasing_count.size(), po0 = phasing_offset.size(), pv0 = phasing_vertex.size();
@@ -285,7 +313,7 @@ struct HostBatch {
         off_v.resize(n0 + n + 1); off_e.resize(n0 + n + 1); off_s.resize(n0 + n + 1); off_p.resize(n0 + n + 1); off_pv.resize(n0 + n + 1);
         for(int i = 0; i < n; i++) { off_v[n0 + i + 1] = off_v[n0] + iv[i + 1]; off_e[n0 + i + 1] = off_e[n0] + ie[i + 1]; off_s[n0 + i + 1] = off_s[n0] + is[i + 1]; off_p[n0 + i + 1] = off_p[n0] + ip[i + 1]; off_pv[n0 + i + 1] = off_pv[n0] + ipv[i + 1]; }
         vertex_offset.resize(vo0 + TV + n); in_offset.resize(vo0 + TV + n);
-        edge_target.resize(e0 + TE); edge_weight.resize(e0 + TE); edge_strand.resize(e0 + TE); edge_abd.resize(e0 + TE); edge_count.resize(e0 + TE); in_edge.resize(e0 + TE);
+        edge_target.resize(e0 + TE); edge_weight.resize(e0 + TE); edge_strand.resize(e0 + TE); edge_abd.resize(e0 + TE); edge_count.resize(e0 + TE); in_edge.resize(e0 + TE); if(has_rank) edge_rank.resize(e0 + TE);
         edge_sample_offset.resize(eo0 + TE + n); sample_id.resize(s0 + TS); sample_abd.resize(s0 + TS);
         vertex_weight.resize(v0 + TV); vertex_lpos.resize(v0 + TV); vertex_rpos.resize(v0 + TV); vertex_type.resize(v0 + TV);
         phasing_offset.resize(po0 + TP + n); phasing_vertex.resize(pv0 + TPV); phasing_count.resize(p0 + TP);
@@ -301,6 +329,7 @@ struct HostBatch {
                 if(estrand) memcpy(&edge_strand[e0 + a_e], estrand + a_e, (size_t)(b_e - a_e)); else memset(&edge_strand[e0 + a_e], 0, (size_t)(b_e - a_e));
                 if(eabd) memcpy(&edge_abd[e0 + a_e], eabd + a_e, 8 * (size_t)(b_e - a_e));
                 if(ecount) memcpy(&edge_count[e0 + a_e], ecount + a_e, 4 * (size_t)(b_e - a_e));
+                if(has_rank && erank) memcpy(&edge_rank[e0 + a_e], erank + a_e, 4 * (size_t)(b_e - a_e));
             }
             if(b_s > a_s) { memcpy(&sample_id[s0 + a_s], sid + a_s, 4 * (size_t)(b_s - a_s)); memcpy(&sample_abd[s0 + a_s], sabd + a_s, 8 * (size_t)(b_s - a_s)); }
             memcpy(&vertex_weight[v0 + a_v], vw + a_v, 8 * (size_t)(b_v - a_v)); memcpy(&vertex_lpos[v0 + a_v], lpos + a_v, 4 * (size_t)(b_v - a_v)); memcpy(&vertex_rpos[v0 + a_v], rpos + a_v, 4 * (size_t)(b_v - a_v));
@@ -315,6 +344,7 @@ struct HostBatch {
                 const int32_t *so = esoff + ie[g] + g, *tg = etgt + ie[g];
                 if(!eabd) for(int k = 0; k < E; k++) { double sum = 0; for(int j = so[k]; j < so[k + 1]; j++) sum += sabd[is[g] + j]; edge_abd[e0 + ie[g] + k] = sum; }
                 if(!ecount) for(int k = 0; k < E; k++) edge_count[e0 + ie[g] + k] = so[k + 1] - so[k];
+                if(has_rank && !erank) for(int k = 0; k < E; k++) edge_rank[e0 + ie[g] + k] = k;
                 int32_t *io = &in_offset[vo0 + iv[g] + g]; int32_t *ied = E > 0 ? &in_edge[e0 + ie[g]] : nullptr;
                 for(int i = 0; i <= V; i++) io[i] = 0;
                 for(int k = 0; k < E; k++) io[tg[k] + 1]++;
@@ -338,7 +368,7 @@ struct HostBatch {
     // ---- one contiguous buffer; section offsets are 256-byte aligned ----
     struct Section { const void *src; uint64_t bytes; uint64_t off; };
     enum { S_NV, S_NE, S_NP, S_OFFV, S_OFFE, S_OFFS, S_OFFP, S_OFFPV, S_VOFF, S_ETGT, S_EW, S_ESTRAND, S_EABD, S_ESOFF, S_SID, S_SABD,
-           S_VW, S_LPOS, S_RPOS, S_VTYPE, S_INOFF, S_INEDGE, S_POFF, S_PV, S_PC, S_GSTRAND, S_ECOUNT, S_COUNT };
+           S_VW, S_LPOS, S_RPOS, S_VTYPE, S_INOFF, S_INEDGE, S_POFF, S_PV, S_PC, S_GSTRAND, S_ECOUNT, S_ERANK, S_COUNT };
     uint64_t layout(Section sec[S_COUNT]) const
     {
         auto set = [&](int i, const void *p, uint64_t b) { sec[i].src = p; sec[i].bytes = b; };
@@ -352,6 +382,7 @@ struct HostBatch {
         set(S_VTYPE, vertex_type.data(), 4ull * vertex_type.size()); set(S_INOFF, in_offset.data(), 4ull * in_offset.size()); set(S_INEDGE, in_edge.data(), 4ull * in_edge.size());
         set(S_POFF, phasing_offset.data(), 4ull * phasing_offset.size()); set(S_PV, phasing_vertex.data(), 4ull * phasing_vertex.size()); set(S_PC, phasing_count.data(), 4ull * phasing_count.size());
         set(S_GSTRAND, graph_strand.data(), graph_strand.size()); set(S_ECOUNT, edge_count.data(), 4ull * edge_count.size());
+        set(S_ERANK, edge_rank.data(), has_rank ? 4ull * edge_rank.size() : 0);      // travels only when some caller supplied a creation rank
         uint64_t o = 0;
         for(int i = 0; i < S_COUNT; i++) { sec[i].off = o; o = (o + sec[i].bytes + 255) / 256 * 256; }
         return o < 256 ? 256 : o;
@@ -384,6 +415,7 @@ struct HostBatch {
         b.vertex_weight = ALD_P(double, S_VW); b.vertex_lpos = ALD_P(int32_t, S_LPOS); b.vertex_rpos = ALD_P(int32_t, S_RPOS); b.vertex_type = ALD_P(int32_t, S_VTYPE);
         b.in_offset = ALD_P(int32_t, S_INOFF); b.in_edge = ALD_P(int32_t, S_INEDGE);
         b.phasing_offset = ALD_P(int32_t, S_POFF); b.phasing_vertex = ALD_P(int32_t, S_PV); b.phasing_count = ALD_P(int32_t, S_PC); b.graph_strand = ALD_P(char, S_GSTRAND); b.edge_count = ALD_P(int32_t, S_ECOUNT);
+        b.edge_rank = has_rank ? ALD_P(int32_t, S_ERANK) : nullptr;
 #undef ALD_P
         return b;
     }

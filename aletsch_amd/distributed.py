@@ -1,7 +1,11 @@
 """Multi-GPU plumbing: bundles shard embarrassingly (one process per GPU, no data-path collective); the only exchange
-is the final gather of the packed path records to rank 0 -- the analogue of the reference's per-graph
+is the final gather of every rank's FINISHED transcripts to rank 0 -- the analogue of the reference's per-graph
 ``tm.add(ts, ...)`` under ``mylock`` (meta/assembler.cc:1127-1132), done once per batch over RCCL (backend "nccl")
-or gloo (CPU tests).  Merge order on rank 0 is ascending global graph id, independent of the number of ranks."""
+or gloo (CPU tests).  What travels is the self-contained transcript stream of ``ald_batch_transcript_stream``
+(records of abandoned capacity attempts and of failed graphs already dropped, exons already joined), so rank 0 needs
+nothing else from the sender to merge it: ``ald_tset_add_stream`` in rank order == ascending global graph id,
+independent of the number of ranks.  The raw record pool can be gathered too (same gatherer: any
+int32 stream), but it is only meaningful together with the sender's status / attempt arrays and vertex coordinates."""
 from __future__ import annotations
 
 import numpy as np
@@ -27,8 +31,8 @@ def _device_words(ptr: int, n_words: int, device: torch.device) -> torch.Tensor:
     return torch.as_tensor(sp, device=device)[: int(n_words)]
 
 
-class RecordGatherer:
-    """The one exchange step of the multi-GPU path: every rank's packed path records -> rank 0.
+class StreamGatherer:
+    """The one exchange step of the multi-GPU path: every rank's word stream (finished transcripts) -> rank 0.
 
     Every rank sends a fixed-capacity buffer [n_words, graph_offset, 0, 0, records...] through a `gather` (RCCL when the tensors
     are on the GPU, gloo on CPU).  The capacity is agreed once (all_gather of the first step's sizes, plus head-room), so a step
@@ -105,6 +109,17 @@ class RecordGatherer:
         return out
 
 
+RecordGatherer = StreamGatherer          # round-1 name
+
+
+def merge_streams(sink, streams, tid_base: int = 0):
+    """Rank 0: merge gathered transcript streams [(words, graph_offset)] in rank order (== ascending global graph id) into a
+    ``TranscriptSink``; the result equals the single-rank merge of the unsharded batch."""
+    for words, off in streams:
+        sink.add_stream(np.ascontiguousarray(words, dtype=np.uint32), graph_offset=int(off), tid_base=tid_base)
+    return sink
+
+
 def gather_records(rec, device: torch.device, graph_offset: int = 0):
     """One-shot form: `rec` is a uint32 numpy stream (or an int32 tensor already on `device`).  Returns on rank 0 the list of
     per-rank streams with GLOBAL graph ids (copies), None elsewhere."""
@@ -112,7 +127,7 @@ def gather_records(rec, device: torch.device, graph_offset: int = 0):
         t = torch.from_numpy(np.ascontiguousarray(rec, dtype=np.uint32).view(np.int32)).to(device)
     else:
         t = rec
-    g = RecordGatherer(device)
+    g = StreamGatherer(device)
     g.gather(t, graph_offset)
     st = g.streams()
     if st is None:

@@ -33,7 +33,7 @@ namespace aletsch {
 // many staged graphs back to back, in the layout of ald_batch_add_packed
 struct packed_chunk {
     std::vector<int32_t> g_nv, g_ne, g_np, vertex_offset, edge_target, edge_sample_offset, sample_id, vertex_lpos, vertex_rpos, vertex_type,
-                         phasing_offset, phasing_vertex, phasing_count, edge_count, sid;
+                         phasing_offset, phasing_vertex, phasing_count, edge_count, edge_rank, sid;
     std::vector<double> edge_weight, edge_abd, sample_abd, vertex_weight; std::vector<uint8_t> edge_strand; std::vector<char> graph_strand;
     long first = 0;                                               // ticket of the first graph, set when the chunk is handed over
     int n() const { return (int)g_nv.size(); }
@@ -45,7 +45,7 @@ struct packed_chunk {
         cat(vertex_offset, s.vertex_offset); cat(edge_target, s.edge_target); cat(edge_weight, s.edge_weight); cat(edge_strand, s.edge_strand); cat(edge_abd, s.edge_abd);
         cat(edge_sample_offset, s.edge_sample_offset); cat(sample_id, s.sample_id); cat(sample_abd, s.sample_abd);
         cat(vertex_weight, s.vertex_weight); cat(vertex_lpos, s.vertex_lpos); cat(vertex_rpos, s.vertex_rpos); cat(vertex_type, s.vertex_type);
-        cat(phasing_offset, s.phasing_offset); cat(phasing_vertex, s.phasing_vertex); cat(phasing_count, s.phasing_count); cat(edge_count, s.edge_count);
+        cat(phasing_offset, s.phasing_offset); cat(phasing_vertex, s.phasing_vertex); cat(phasing_count, s.phasing_count); cat(edge_count, s.edge_count); cat(edge_rank, s.edge_rank);
     }
     void reserve_like(const packed_chunk &o)                      // the next chunk of a thread is about as large as its last one
     {
@@ -53,7 +53,7 @@ struct packed_chunk {
         vertex_offset.reserve(o.vertex_offset.size()); edge_target.reserve(o.edge_target.size()); edge_weight.reserve(o.edge_weight.size()); edge_strand.reserve(o.edge_strand.size());
         edge_abd.reserve(o.edge_abd.size()); edge_sample_offset.reserve(o.edge_sample_offset.size()); sample_id.reserve(o.sample_id.size()); sample_abd.reserve(o.sample_abd.size());
         vertex_weight.reserve(o.vertex_weight.size()); vertex_lpos.reserve(o.vertex_lpos.size()); vertex_rpos.reserve(o.vertex_rpos.size()); vertex_type.reserve(o.vertex_type.size());
-        phasing_offset.reserve(o.phasing_offset.size()); phasing_vertex.reserve(o.phasing_vertex.size()); phasing_count.reserve(o.phasing_count.size()); edge_count.reserve(o.edge_count.size());
+        phasing_offset.reserve(o.phasing_offset.size()); phasing_vertex.reserve(o.phasing_vertex.size()); phasing_count.reserve(o.phasing_count.size()); edge_count.reserve(o.edge_count.size()); edge_rank.reserve(o.edge_rank.size());
     }
     int add_to(ald_batch *b) const
     {
@@ -63,7 +63,7 @@ struct packed_chunk {
         return ald_batch_add_packed(b, n(), g_nv.data(), g_ne.data(), g_np.data(), vertex_offset.data(), pi(edge_target), pd(edge_weight),
                                     edge_strand.empty() ? (const uint8_t*)&zero_i : edge_strand.data(), pd(edge_abd), edge_sample_offset.data(), pi(sample_id), pd(sample_abd),
                                     pd(vertex_weight), pi(vertex_lpos), pi(vertex_rpos), pi(vertex_type), phasing_offset.data(), pi(phasing_vertex), pi(phasing_count),
-                                    graph_strand.data(), pi(edge_count));
+                                    graph_strand.data(), pi(edge_count), edge_rank.size() == edge_target.size() && !edge_rank.empty() ? edge_rank.data() : nullptr);
     }
 };
 

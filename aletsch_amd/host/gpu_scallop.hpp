@@ -20,8 +20,10 @@
 //   Parameters:  .max_decompose_error_ratio[8], .min_guaranteed_edge_weight, .min_transcript_coverage, .max_num_exons
 //   Path:        .v, .junc, .length, .abd, .weight, .conf, .reads, .strand, .count      (rnacore/path.h)
 //
-// Canonical edge order: the reference's order is raw-pointer order; the adapter defines it as
-// (source, target, position in gr.edges()), which is the order each vertex's out-edge set iterates in.
+// Canonical edge order: the reference's order is raw-pointer order, which is what gr.edges() iterates in and what
+// scallop's ctor turns into edge indices (scallop.cc:24, graph_base.cc:139-153).  The adapter lays the edges out as CSR by
+// (source, target, position in gr.edges()) -- the order each vertex's out-edge set iterates in -- and hands the position in
+// gr.edges() over as ald_graph_view.edge_creation_rank, so that the kernel's edge ids ARE the reference's e2i values.
 // The consumed-input contract is relaxed: gx / hx are left untouched (the reference empties them; its callers never read
 // them again: assembler.cc:346-355).
 #pragma once
@@ -37,7 +39,7 @@
 namespace aletsch {
 
 struct staged_graph {                       // owning arrays behind one ald_graph_view
-    std::vector<int32_t> vertex_offset, edge_target, edge_sample_offset, sample_id, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, edge_count;
+    std::vector<int32_t> vertex_offset, edge_target, edge_sample_offset, sample_id, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, edge_count, edge_rank;
     std::vector<double> edge_weight, edge_abd, sample_abd, vertex_weight; std::vector<uint8_t> edge_strand; char strand = '.';
     ald_graph_view view() const {
         ald_graph_view g{};
@@ -46,7 +48,7 @@ struct staged_graph {                       // owning arrays behind one ald_grap
         g.edge_sample_offset = edge_sample_offset.data(); g.sample_id = sample_id.data(); g.sample_abd = sample_abd.data();
         g.vertex_weight = vertex_weight.data(); g.vertex_lpos = vertex_lpos.data(); g.vertex_rpos = vertex_rpos.data(); g.vertex_type = vertex_type.data();
         g.num_phasing = (int32_t)phasing_count.size(); g.phasing_offset = phasing_offset.data(); g.phasing_vertex = phasing_vertex.data(); g.phasing_count = phasing_count.data();
-        g.strand = strand; g.edge_count = edge_count.data();
+        g.strand = strand; g.edge_count = edge_count.data(); g.edge_creation_rank = edge_rank.empty() ? nullptr : edge_rank.data();
         return g;
     }
 };
@@ -65,7 +67,7 @@ staged_graph stage_graph(SpliceGraph &gr, const HyperSet &hs)
     for(const E &x : es) s.vertex_offset[x.src + 1]++;
     for(int i = 0; i < V; i++) s.vertex_offset[i + 1] += s.vertex_offset[i];
     { const size_t ne = es.size();                              // one allocation per array instead of a doubling series
-      s.edge_target.reserve(ne); s.edge_weight.reserve(ne); s.edge_strand.reserve(ne); s.edge_abd.reserve(ne); s.edge_count.reserve(ne);
+      s.edge_target.reserve(ne); s.edge_weight.reserve(ne); s.edge_strand.reserve(ne); s.edge_abd.reserve(ne); s.edge_count.reserve(ne); s.edge_rank.reserve(ne);
       s.edge_sample_offset.reserve(ne + 1); s.sample_id.reserve(ne); s.sample_abd.reserve(ne);
       s.vertex_weight.reserve((size_t)V); s.vertex_lpos.reserve((size_t)V); s.vertex_rpos.reserve((size_t)V); s.vertex_type.reserve((size_t)V); }
     s.edge_sample_offset.push_back(0);
@@ -75,6 +77,7 @@ staged_graph stage_graph(SpliceGraph &gr, const HyperSet &hs)
         // edge_info.count travels as its own field: it starts as the number of supporting samples (meta/assembler.cc:202-231) but
         // group_start_boundaries ADDS counts along a grouped boundary (graph_reviser.cc:965-975) without touching the sample sets
         s.edge_count.push_back((int32_t)ei.count);
+        s.edge_rank.push_back((int32_t)x.ord);          // scallop's edge index of this edge: get_edge_indices numbers gr.edges() in iteration order (graph_base.cc:139-153)
         for(int sp : ei.samples) { s.sample_id.push_back(sp); auto f = ei.spAbd.find(sp); s.sample_abd.push_back(f == ei.spAbd.end() ? 0.0 : f->second); }
         s.edge_sample_offset.push_back((int32_t)s.sample_id.size());
     }

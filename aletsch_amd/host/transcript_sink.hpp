@@ -1,197 +1,176 @@
-// transcript_sink.hpp -- host-side result sink: the reference's transcript_set (rnacore/transcript_set.cc:38-175) restated over
-// plain records.  Transcripts are bucketed by intron-chain hash (gtf/transcript.cc:183-201, util/util.cc:38-46), each bucket is
-// kept sorted by transcript::compare1 (gtf/transcript.cc:269-300), equal transcripts merge (trans_item::merge,
-// transcript_set.cc:38-81: multi-exon coverage adds, single-exon takes the max, bounds widen, per-sample records merge,
-// count2 = number of samples).  Quirks are kept: intron_chain_compare skips the last-but-one exon (transcript.cc:236-245),
-// the first inserted transcript keeps its id.
+// transcript_sink.hpp -- host-side result sink with the merge semantics of the reference's transcript_set
+// (rnacore/transcript_set.cc:38-175; ordering and hashing from gtf/transcript.cc:183-308, util/util.cc:38-46).
+//
+// Layout is this library's own: a transcript's exons are ONE flat coordinate list (l0 r0 l1 r1 ...), the same words the record
+// and transcript streams carry, so hashing and comparing walk a contiguous span; the numeric attributes that a merge only ever
+// raises live in one `peak` block with a single raise(); per-sample state is a small sorted array.  What is dictated by bit-exact
+// parity, and therefore kept: which coordinates a comparison looks at (the reference never looks at the last-but-one exon of a
+// multi-exon chain, transcript.cc:236-245), the FORWARD walk of a bucket merge (the single-exon overlap test is not transitive,
+// so the sequence of comparisons is behaviour), coverage adding for multi-exon and taking the maximum for single-exon
+// transcripts, the first inserted transcript keeping its id.
 //
 // Pinned against the reference's own transcript_set.cc built from source (oracle/_ref/ref_tset, tests/golden/ref_tset.json).
-// In the multi-GPU flow rank 0 feeds the gathered records in ascending global graph id, so the result does not depend on the
-// number of ranks.
+// In the multi-GPU flow rank 0 feeds the gathered transcript streams in ascending global graph id, so the result does not depend
+// on the number of ranks.
 #pragma once
 #include <vector>
-#include <map>
 #include <unordered_map>
 #include <algorithm>
 #include <cstdint>
 #include <cstddef>
 #include <utility>
+#include <iterator>
 
 namespace aletsch {
 
+// attributes a merge can only raise (trans_item::merge takes the maximum of each: transcript_set.cc:47-50, 63-66)
+struct peak {
+    double cov2 = 0, conf = 0, abd = 0; int count1 = 0;
+    void raise(const peak &o) { if(cov2 < o.cov2) cov2 = o.cov2; if(conf < o.conf) conf = o.conf; if(abd < o.abd) abd = o.abd; if(count1 < o.count1) count1 = o.count1; }
+};
+
+// the reference's comparators answer +1 when the left operand sorts first, -1 when the right one does
+template<class T> inline int first_is(const T &a, const T &b) { return a < b ? +1 : (b < a ? -1 : 0); }
+
 struct sink_transcript {
     char strand = '.';
-    double coverage = 0, cov2 = 0, conf = 0, abd = 0;
-    int count1 = 0, count2 = 0;
-    int64_t tid = 0;                            // transcript_id (the reference keeps a string "chr<chrm>.<gid>.<i>")
-    std::vector<std::pair<int32_t, int32_t>> exons;
+    double coverage = 0;
+    peak top;                                    // cov2 / conf / abd / count1
+    int count2 = 0;
+    int64_t tid = 0;                             // transcript_id (the reference keeps a string "chr<chrm>.<gid>.<i>")
+    std::vector<int32_t> xs;                     // exon coordinates, flat: l0 r0 l1 r1 ...
 
-    int length() const { int s = 0; for(auto &e : exons) s += e.second - e.first; return s; }
-    size_t intron_chain_hashing() const {       // transcript.cc:183-201 + util.cc:38-46 (vector_hash)
-        if(exons.empty()) return 0;
-        if(exons.size() == 1) { size_t p = (size_t)((exons[0].first + exons[0].second) / 10000); return p + 1; }
-        std::vector<int32_t> vv;
-        int32_t p = exons[0].second;
-        for(size_t k = 1; k < exons.size(); k++) { vv.push_back(p); vv.push_back(exons[k].first); p = exons[k].second; }
-        size_t seed = vv.size();
-        for(size_t i = 0; i < vv.size(); i++) seed ^= (size_t)(vv[i]) + 0x9e3779b9 + (seed << 6) + (seed >> 2);
-        return (seed & 0x7FFFFFFF) + 1;
+    size_t n_exons() const { return xs.size() / 2; }
+    void add_exon(int32_t l, int32_t r) { xs.push_back(l); xs.push_back(r); }
+    int32_t span_len() const { int32_t s = 0; for(size_t k = 0; k + 1 < xs.size(); k += 2) s += xs[k + 1] - xs[k]; return s; }
+
+    // bucket key (transcript.cc:183-201 over util.cc:38-46): single exon -> its mid-point bin; otherwise a boost-style hash_combine
+    // over the inner coordinates r0 l1 r1 ... l_last, i.e. the flat list without its first and last word
+    static size_t chain_key(const int32_t *x, size_t n_words) {
+        if(n_words < 2) return 0;
+        if(n_words == 2) return (size_t)((x[0] + x[1]) / 10000) + 1;
+        size_t h = n_words - 2;
+        for(size_t k = 1; k + 1 < n_words; k++) h ^= (size_t)(x[k]) + 0x9e3779b9 + (h << 6) + (h >> 2);
+        return (h & 0x7FFFFFFF) + 1;
     }
-    int intron_chain_compare(const sink_transcript &t) const {      // transcript.cc:226-246
-        if(exons.size() < t.exons.size()) return +1;
-        if(exons.size() > t.exons.size()) return -1;
-        if(exons.size() <= 1) return 0;
-        int n = (int)exons.size() - 1;
-        if(exons[0].second < t.exons[0].second) return +1;
-        if(exons[0].second > t.exons[0].second) return -1;
-        for(int k = 1; k < n - 1; k++) {
-            if(exons[k].first < t.exons[k].first) return +1;
-            if(exons[k].first > t.exons[k].first) return -1;
-            if(exons[k].second < t.exons[k].second) return +1;
-            if(exons[k].second > t.exons[k].second) return -1;
+    size_t chain_key() const { return chain_key(xs.data(), xs.size()); }
+
+    // transcript::compare1 (transcript.cc:269-300) for one seqname.  Coordinates looked at for a chain of m >= 2 exons, in this
+    // order: word 1, words 2 .. 2m-5, word 2m-2 -- the reference's loop stops one exon early (transcript.cc:236-245).
+    int order_against(const sink_transcript &o, double single_exon_overlap) const {
+        if(int c = first_is(xs.size(), o.xs.size())) return c;
+        if(int c = first_is(strand, o.strand)) return c;
+        const size_t w = xs.size();
+        if(w < 2) return 0;
+        if(w == 2) {
+            const int32_t lo = std::max(xs[0], o.xs[0]), hi = std::min(xs[1], o.xs[1]);
+            const int32_t shared = hi - lo;
+            if(shared >= single_exon_overlap * span_len() || shared >= single_exon_overlap * o.span_len()) return 0;
+            if(int c = first_is(xs[0], o.xs[0])) return c;
+            return first_is(xs[1], o.xs[1]);
         }
-        if(exons[n].first < t.exons[n].first) return +1;
-        if(exons[n].first > t.exons[n].first) return -1;
-        return 0;
+        if(int c = first_is(xs[1], o.xs[1])) return c;
+        for(size_t k = 2; k + 5 <= w; k++) if(int c = first_is(xs[k], o.xs[k])) return c;
+        return first_is(xs[w - 2], o.xs[w - 2]);
     }
-    int compare1(const sink_transcript &t, double single_exon_overlap) const {     // transcript.cc:269-300 (one seqname per sink)
-        if(exons.size() < t.exons.size()) return +1;
-        if(exons.size() > t.exons.size()) return -1;
-        if(strand < t.strand) return +1;
-        if(strand > t.strand) return -1;
-        if(exons.size() == 1) {
-            int32_t p2 = exons[0].first < t.exons[0].first ? t.exons[0].first : exons[0].first;
-            int32_t q2 = exons[0].second > t.exons[0].second ? t.exons[0].second : exons[0].second;
-            int32_t overlap = q2 - p2;
-            if(overlap >= single_exon_overlap * length()) return 0;
-            if(overlap >= single_exon_overlap * t.length()) return 0;
-            if(exons[0].first < t.exons[0].first) return +1;
-            if(exons[0].first > t.exons[0].first) return -1;
-            if(exons[0].second < t.exons[0].second) return +1;
-            if(exons[0].second > t.exons[0].second) return -1;
-        }
-        return intron_chain_compare(t);
-    }
-    void extend_bounds(const sink_transcript &t) {                  // transcript.cc:302-308
-        if(exons.empty()) return;
-        if(t.exons.front().first < exons.front().first) exons.front().first = t.exons.front().first;
-        if(t.exons.back().second > exons.back().second) exons.back().second = t.exons.back().second;
+    void widen_to(const sink_transcript &o) {    // transcript::extend_bounds (transcript.cc:302-308)
+        if(xs.empty()) return;
+        xs.front() = std::min(xs.front(), o.xs.front());
+        xs.back() = std::max(xs.back(), o.xs.back());
     }
 };
 
-struct sink_sample {                             // what the reference keeps of the per-sample transcript copy in trans_item::samples:
-    double coverage = 0, cov2 = 0, conf = 0, abd = 0; int count1 = 0, count2 = 0;     // the fields merge() reads and writes (exons are those of trst)
-};
-// map<int, sink_sample> for a handful of samples: one sorted array (find / insert / ordered iteration as std::map gives them)
+struct sink_sample { double coverage = 0; peak top; int count2 = 0; };    // the fields of trans_item::samples[sid] that a merge reads or writes
+
+// a handful of samples per item: sorted array with the find / insert / ordered walk a std::map<int, ...> gives
 struct sample_map {
     typedef std::pair<int, sink_sample> value_type;
     std::vector<value_type> v;
-    typedef std::vector<value_type>::iterator iterator;
-    iterator begin() { return v.begin(); } iterator end() { return v.end(); }
-    std::vector<value_type>::const_iterator begin() const { return v.begin(); } std::vector<value_type>::const_iterator end() const { return v.end(); }
     size_t size() const { return v.size(); }
-    iterator find(int k) { iterator it = std::lower_bound(v.begin(), v.end(), k, [](const value_type &a, int key) { return a.first < key; }); return (it != v.end() && it->first == k) ? it : v.end(); }
-    void insert(const value_type &x) { iterator it = std::lower_bound(v.begin(), v.end(), x.first, [](const value_type &a, int key) { return a.first < key; }); if(it == v.end() || it->first != x.first) v.insert(it, x); }
+    std::vector<value_type>::iterator begin() { return v.begin(); }
+    std::vector<value_type>::iterator end() { return v.end(); }
+    std::vector<value_type>::const_iterator begin() const { return v.begin(); }
+    std::vector<value_type>::const_iterator end() const { return v.end(); }
+    // the slot of sample `sid`, created from `fresh` when absent; `was_new` tells which
+    sink_sample &slot(int sid, const sink_sample &fresh, bool &was_new) {
+        auto it = std::lower_bound(v.begin(), v.end(), sid, [](const value_type &a, int key) { return a.first < key; });
+        was_new = (it == v.end() || it->first != sid);
+        if(was_new) it = v.insert(it, value_type(sid, fresh));
+        return it->second;
+    }
 };
+
 struct sink_item {                               // trans_item (transcript_set.h:20-33)
     sink_transcript trst; int count = 0;
     sample_map samples;
     sink_item() {}
-    sink_item(const sink_transcript &t, int c, int s) : trst(t), count(c) {
-        sink_sample x; x.coverage = t.coverage; x.cov2 = t.cov2; x.conf = t.conf; x.abd = t.abd; x.count1 = t.count1; x.count2 = 1;
-        samples.insert(std::make_pair(s, x));
-    }
-    void merge(sink_item &ti) {                  // TRANSCRIPT_COUNT_ADD_COVERAGE_ADD (transcript_set.cc:38-75)
-        if(trst.exons.size() >= 2) trst.coverage += ti.trst.coverage;
-        else if(trst.coverage < ti.trst.coverage) trst.coverage = ti.trst.coverage;
-        trst.extend_bounds(ti.trst);
-        count += ti.count;
-        if(trst.cov2 < ti.trst.cov2) trst.cov2 = ti.trst.cov2;
-        if(trst.conf < ti.trst.conf) trst.conf = ti.trst.conf;
-        if(trst.abd < ti.trst.abd) trst.abd = ti.trst.abd;
-        if(trst.count1 < ti.trst.count1) trst.count1 = ti.trst.count1;
-        for(auto &x : ti.samples) {
-            auto f = samples.find(x.first);
-            if(f == samples.end()) samples.insert(x);
-            else {
-                if(f->second.cov2 < x.second.cov2) f->second.cov2 = x.second.cov2;
-                if(f->second.conf < x.second.conf) f->second.conf = x.second.conf;
-                if(f->second.abd < x.second.abd) f->second.abd = x.second.abd;
-                if(f->second.count1 < x.second.count1) f->second.count1 = x.second.count1;
-            }
-        }
-        trst.count2 = (int)samples.size();
-        for(auto &x : samples) { x.second.coverage = trst.coverage; x.second.count2 = (int)samples.size(); }
-    }
-    // merge(sink_item(t, c, s)) without building the temporary item (what transcript_set::add(t, count, sid) amounts to when an equal
-    // transcript is already there)
-    void merge_transcript(const sink_transcript &t, int c, int s) {
-        if(trst.exons.size() >= 2) trst.coverage += t.coverage;
-        else if(trst.coverage < t.coverage) trst.coverage = t.coverage;
-        trst.extend_bounds(t);
+    sink_item(const sink_transcript &t, int c, int sid) : trst(t), count(c) { bool fresh; samples.slot(sid, as_sample(t), fresh); }
+
+    static sink_sample as_sample(const sink_transcript &t) { sink_sample s; s.coverage = t.coverage; s.top = t.top; s.count2 = 1; return s; }
+
+    // trans_item::merge in TRANSCRIPT_COUNT_ADD_COVERAGE_ADD mode (transcript_set.cc:38-75), as two steps shared by both entry points
+    void absorb_head(const sink_transcript &t, int c) {
+        if(trst.n_exons() >= 2) trst.coverage += t.coverage;
+        else trst.coverage = std::max(trst.coverage, t.coverage);
+        trst.widen_to(t);
         count += c;
-        if(trst.cov2 < t.cov2) trst.cov2 = t.cov2;
-        if(trst.conf < t.conf) trst.conf = t.conf;
-        if(trst.abd < t.abd) trst.abd = t.abd;
-        if(trst.count1 < t.count1) trst.count1 = t.count1;
-        auto f = samples.find(s);
-        if(f == samples.end()) { sink_sample x; x.coverage = t.coverage; x.cov2 = t.cov2; x.conf = t.conf; x.abd = t.abd; x.count1 = t.count1; x.count2 = 1; samples.insert(std::make_pair(s, x)); }
-        else {
-            if(f->second.cov2 < t.cov2) f->second.cov2 = t.cov2;
-            if(f->second.conf < t.conf) f->second.conf = t.conf;
-            if(f->second.abd < t.abd) f->second.abd = t.abd;
-            if(f->second.count1 < t.count1) f->second.count1 = t.count1;
-        }
-        trst.count2 = (int)samples.size();
-        for(auto &x : samples) { x.second.coverage = trst.coverage; x.second.count2 = (int)samples.size(); }
+        trst.top.raise(t.top);
     }
+    void absorb_sample(int sid, const sink_sample &s) { bool fresh; sink_sample &mine = samples.slot(sid, s, fresh); if(!fresh) mine.top.raise(s.top); }
+    void settle() {                              // every per-sample copy mirrors the merged coverage and the number of samples
+        const int k = (int)samples.size();
+        trst.count2 = k;
+        for(auto &x : samples) { x.second.coverage = trst.coverage; x.second.count2 = k; }
+    }
+    void merge(const sink_item &o) { absorb_head(o.trst, o.count); for(const auto &x : o.samples) absorb_sample(x.first, x.second); settle(); }
+    // == merge(sink_item(t, c, sid)) without the temporary (what transcript_set::add(t, count, sid) does when an equal item exists)
+    void merge_transcript(const sink_transcript &t, int c, int sid) { absorb_head(t, c); absorb_sample(sid, as_sample(t)); settle(); }
 };
 
 class transcript_sink {                          // transcript_set (transcript_set.h:37-59), one chromosome / region per sink
 public:
+    typedef std::vector<sink_item> bucket;
     explicit transcript_sink(double single_exon_overlap = 0.8) : overlap_(single_exon_overlap) {}
     // the reference's map<size_t, vector<trans_item>> (transcript_set.h:43) is only ever probed by key and walked in key order at the
     // end: a hash table for the probes (a million buckets make every tree descent a chain of cache misses), keys sorted on demand
-    std::unordered_map<size_t, std::vector<sink_item>> mt;
+    std::unordered_map<size_t, bucket> mt;
     std::vector<size_t> sorted_keys() const { std::vector<size_t> k; k.reserve(mt.size()); for(auto &x : mt) k.push_back(x.first); std::sort(k.begin(), k.end()); return k; }
 
-    // transcript_set::add(t, count, sid) (transcript_set.cc:149-154) = a one-item set merged in.  merge_sorted_trans_items with a
-    // single y walks the bucket while compare1 says "x first", then merges into the first equal item or inserts y right there.
-    void add(const sink_transcript &t, int count, int sid) { add_hashed(t, t.intron_chain_hashing(), count, sid); }
-    void add_hashed(const sink_transcript &t, size_t key, int count, int sid) {       // key == t.intron_chain_hashing(), computed by the caller
-        auto z = mt.find(key);
-        if(z == mt.end()) { std::vector<sink_item> v; v.emplace_back(t, count, sid); mt.emplace(key, std::move(v)); return; }
-        std::vector<sink_item> &vx = z->second;
-        size_t kx = 0; int b = +1;
-        while(kx < vx.size() && (b = vx[kx].trst.compare1(t, overlap_)) == +1) kx++;
-        if(kx < vx.size() && b == 0) vx[kx].merge_transcript(t, count, sid);
-        else vx.insert(vx.begin() + kx, sink_item(t, count, sid));
+    // transcript_set::add(t, count, sid) (transcript_set.cc:149-154): a one-item set merged in -- walk the bucket while its items sort
+    // first, then merge into the item that compares equal or insert right there
+    void add(const sink_transcript &t, int count, int sid) { add_hashed(t, t.chain_key(), count, sid); }
+    void add_hashed(const sink_transcript &t, size_t key, int count, int sid) {       // key == t.chain_key(), computed by the caller
+        bucket &b = mt[key];
+        size_t at = 0; int c = +1;
+        while(at < b.size() && (c = b[at].trst.order_against(t, overlap_)) == +1) at++;
+        if(at < b.size() && c == 0) b[at].merge_transcript(t, count, sid);
+        else b.emplace(b.begin() + at, t, count, sid);
     }
-    void add(transcript_sink &ts) {              // transcript_set.cc:156-175
-        for(auto &x : ts.mt) add_bucket(x.first, x.second);
-    }
-    void add_bucket(size_t key, std::vector<sink_item> &vy) {       // one iteration of that loop
+    void add(transcript_sink &ts) { for(auto &x : ts.mt) add_bucket(x.first, x.second); }      // transcript_set.cc:156-175
+    void add_bucket(size_t key, bucket &incoming) {                                           // one iteration of that loop
         auto z = mt.find(key);
-        if(z == mt.end()) mt.emplace(key, std::move(vy));
-        else merge_sorted(z->second, vy);
+        if(z == mt.end()) mt.emplace(key, std::move(incoming));
+        else zip(z->second, incoming);
     }
     size_t size() const { size_t n = 0; for(auto &x : mt) n += x.second.size(); return n; }
     void clear() { mt.clear(); }
     double single_exon_overlap() const { return overlap_; }
 private:
     double overlap_;
-    void merge_sorted(std::vector<sink_item> &vx, std::vector<sink_item> &vy) {    // transcript_set.cc:83-120
-        std::vector<sink_item> vz; vz.reserve(vx.size() + vy.size());
-        size_t kx = 0, ky = 0;
-        while(kx < vx.size() && ky < vy.size()) {
-            int b = vx[kx].trst.compare1(vy[ky].trst, overlap_);
-            if(b == 0) { vx[kx].merge(vy[ky]); vz.emplace_back(std::move(vx[kx])); kx++; ky++; }
-            else if(b == 1) { vz.emplace_back(std::move(vx[kx])); kx++; }
-            else { vz.emplace_back(std::move(vy[ky])); ky++; }
+    bucket zipped_;                              // scratch of zip(), kept across calls
+    // merge_sorted_trans_items (transcript_set.cc:83-120): forward walk of both sorted buckets; equal heads fuse into `mine`'s item
+    void zip(bucket &mine, bucket &theirs) {
+        bucket &out = zipped_; out.clear(); out.reserve(mine.size() + theirs.size());
+        size_t i = 0, j = 0;
+        while(i < mine.size() && j < theirs.size()) {
+            const int c = mine[i].trst.order_against(theirs[j].trst, overlap_);
+            if(c == -1) { out.push_back(std::move(theirs[j++])); continue; }
+            if(c == 0) mine[i].merge(theirs[j++]);
+            out.push_back(std::move(mine[i++]));
         }
-        for(size_t i = kx; i < vx.size(); i++) vz.emplace_back(std::move(vx[i]));
-        for(size_t i = ky; i < vy.size(); i++) vz.emplace_back(std::move(vy[i]));
-        vx.swap(vz);
+        std::move(mine.begin() + i, mine.end(), std::back_inserter(out));
+        std::move(theirs.begin() + j, theirs.end(), std::back_inserter(out));
+        mine.swap(out);
     }
 };
 

@@ -70,6 +70,9 @@ def load_library():
     lib.ald_tset_add.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 10 + [C.c_int32]
     lib.ald_tset_add_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     lib.ald_tset_size.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 3
+    lib.ald_batch_transcript_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]
+    lib.ald_tset_add_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64]
+    lib.ald_batch_export_iterations.argtypes = [C.c_void_p, C.c_void_p]
     lib.ald_tset_export.argtypes = [C.c_void_p] * 19
     _LIB = lib
     return lib
@@ -193,11 +196,22 @@ class DecompBatch:
         return cov, eo, lr[:2 * te.value].reshape(-1, 2)
 
     def iterations(self) -> np.ndarray:
-        out = np.zeros(self.n, np.int32); rv = _ResultView()
-        for g in range(self.n):
-            _check(self._lib.ald_batch_get_result(self._h, g, C.byref(rv)))
-            out[g] = rv.num_iterations
-        return out
+        """main-loop rule firings per graph (the `steps` of SURVEY.md 8d's steps/s/CU)"""
+        out = np.zeros(max(self.n, 1), np.int32)
+        _check(self._lib.ald_batch_export_iterations(self._h, C.c_void_p(out.ctypes.data)))
+        return out[:self.n]
+
+    def transcript_stream(self, sid=None, skip_single_exon: bool = False) -> np.ndarray:
+        """Finished transcripts of the downloaded batch as one self-contained uint32 stream (copy): what ranks exchange in the
+        multi-GPU gather and what TranscriptSink.add_stream merges."""
+        sp = None
+        if sid is not None:
+            sid = np.ascontiguousarray(sid, np.int32); assert len(sid) == self.n; sp = C.c_void_p(sid.ctypes.data)
+        w = C.POINTER(C.c_uint32)(); n = C.c_int64()
+        _check(self._lib.ald_batch_transcript_stream(self._h, sp, C.c_int32(int(skip_single_exon)), C.byref(w), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, np.uint32)
+        return np.ctypeslib.as_array(w, shape=(n.value,)).copy()
 
     def trace(self, g: int):
         n = C.c_int32(); codes = C.POINTER(C.c_int32)(); vals = C.POINTER(C.c_double)()
@@ -251,6 +265,11 @@ class TranscriptSink:
         if sid is not None:
             sid = np.ascontiguousarray(sid, np.int32); assert len(sid) == batch.n; sp = C.c_void_p(sid.ctypes.data)
         _check(self._lib.ald_tset_add_batch(self._h, batch._h, sp, C.c_int64(tid_base), C.c_int32(int(skip_single_exon))))
+
+    def add_stream(self, words: np.ndarray, graph_offset: int = 0, tid_base: int = 0):
+        """Merge a transcript stream (DecompBatch.transcript_stream, possibly gathered from another rank) graph by graph."""
+        words = np.ascontiguousarray(words, np.uint32)
+        _check(self._lib.ald_tset_add_stream(self._h, C.c_void_p(words.ctypes.data), C.c_int64(words.size), C.c_int32(int(graph_offset)), C.c_int64(int(tid_base))))
 
     def items(self):
         """List of dicts in the reference's iteration order (bucket hash ascending, then bucket order)."""

@@ -41,6 +41,7 @@ class PackedGraphs:
     phasing_count: np.ndarray   # [sum P] int32
     graph_strand: np.ndarray    # [n] int8 ('+', '-', '.')
     edge_count: Optional[np.ndarray] = None   # [sum E] int32 edge_info.count at hand-over; None => the number of supporting samples
+    edge_rank: Optional[np.ndarray] = None    # [sum E] int32 creation rank (scallop edge index) per graph: a permutation of 0..E-1; None => CSR position
 
     @property
     def n(self) -> int:
@@ -52,6 +53,11 @@ class PackedGraphs:
         d = np.diff(self.edge_sample_offset.astype(np.int64))
         keep = np.ones(d.shape[0], bool); keep[eo[1:-1] - 1] = False            # drop the differences across graph borders
         return d[keep].astype(np.int32)
+
+    def identity_rank(self) -> np.ndarray:
+        """[sum E] the default creation rank: every edge's CSR position inside its graph."""
+        E = self.g_ne.astype(np.int64)
+        return (np.arange(int(E.sum()), dtype=np.int64) - np.repeat(np.concatenate([[0], np.cumsum(E)[:-1]]), E)).astype(np.int32)
 
     def c_args(self):
         """Pointers in the argument order shared by ald_batch_add_packed / ora_run_packed."""
@@ -68,6 +74,7 @@ class PackedGraphs:
             p(self.phasing_offset, C.c_int32), p(self.phasing_vertex, C.c_int32), p(self.phasing_count, C.c_int32),
             p(self.graph_strand, C.c_char),
             p(np.ascontiguousarray(self.edge_count, np.int32), C.c_int32) if self.edge_count is not None else None,
+            p(np.ascontiguousarray(self.edge_rank, np.int32), C.c_int32) if self.edge_rank is not None else None,
         )
 
     def graph_slices(self):
@@ -105,20 +112,23 @@ class PackedGraphs:
             phasing_offset=cat(self.phasing_offset, o["po"], P + 1), phasing_vertex=cat(self.phasing_vertex, o["pv"], npv),
             phasing_count=cat(self.phasing_count, o["p"], P), graph_strand=self.graph_strand[idx].copy(),
             edge_count=None if self.edge_count is None else cat(self.edge_count, o["e"], E),
+            edge_rank=None if self.edge_rank is None else cat(self.edge_rank, o["e"], E),
         )
 
     @staticmethod
     def concat(parts) -> "PackedGraphs":
-        kw = {f.name: np.concatenate([getattr(p, f.name) for p in parts]) for f in fields(PackedGraphs) if f.name != "edge_count"}
+        kw = {f.name: np.concatenate([getattr(p, f.name) for p in parts]) for f in fields(PackedGraphs) if f.name not in ("edge_count", "edge_rank")}
         if any(p.edge_count is not None for p in parts):
             kw["edge_count"] = np.concatenate([p.edge_count if p.edge_count is not None else p.sample_counts() for p in parts]).astype(np.int32)
+        if any(p.edge_rank is not None for p in parts):
+            kw["edge_rank"] = np.concatenate([p.edge_rank if p.edge_rank is not None else p.identity_rank() for p in parts]).astype(np.int32)
         return PackedGraphs(**kw)
 
     @staticmethod
     def from_graphs(graphs) -> "PackedGraphs":
         """Build from a list of dicts: V, edges=[(s,t,w[,strand[,{sid:abd}]])], vw, lpos, rpos,
         optional vtype, phasing=[([v...], count)], strand.  Edges are sorted into CSR order."""
-        acc = {f.name: [] for f in fields(PackedGraphs) if f.name != "edge_count"}
+        acc = {f.name: [] for f in fields(PackedGraphs) if f.name not in ("edge_count", "edge_rank")}
         for g in graphs:
             V = int(g["V"]); edges = sorted(g["edges"], key=lambda e: (e[0], e[1]))
             voff = np.zeros(V + 1, _I32)

@@ -1,64 +1,165 @@
 #!/usr/bin/env python3
-"""bench.py -- bundles/sec of the MI355X splice-graph decomposition path (BASELINE.json metric).
+"""bench.py -- bundles/sec of the MI355X splice-graph decomposition path (BASELINE.json metric, SURVEY.md 8d).
 
-One "step" = one pass of the hot path over one batch of synthetic splice graphs that is already resident in HBM:
-kernel launch(es) on the batch's HIP stream, D2H of the status words + packed path records and, at N > 1, the
-RCCL gather of the records to rank 0 (the path's only exchange step: SURVEY.md 8e).
+One "step" = one pass of the hot path over one batch of synthetic splice graphs, host arrays in -> host results out:
+pack into the pinned wire buffer (ald_batch_add_packed) + ONE H2D copy + the decomposition kernels + D2H of the status words and
+packed path records (+ at N > 1 the RCCL gather of the finished transcripts to rank 0, the path's only exchange step: SURVEY.md 8e).
+Three batch objects rotate so that staging and H2D of batch k+1 run on a host thread / the copy engine while the kernel of
+batch k runs; kernels never overlap each other, so the per-launch HIP-event time is that of one kernel on an otherwise idle GPU.
+`value` is that H2D-inclusive rate (SURVEY.md 8d's definition of the metric); `value_resident` is the rate of a second timed loop
+over batches that are already resident in HBM (kernel + D2H only), the figure round 1 reported.
 
 Workload (N=1): BASELINE.json configs[1] -- 100k synthetic splice graphs, 64 vertices / 256 edges each.
 N > 1: bundles shard embarrassingly; every rank decomposes its own 100k-graph shard (weak scaling, seed 1004+rank).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--graphs G]
+        (--gpus N > 1 without a launcher's WORLD_SIZE in the environment: this process starts the N ranks itself, as
+         `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...`, before it touches the GPU,
+         relays rank 0's JSON line and exits with the launcher's code)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  `roofline.achieved` = algorithmic bytes per launch (packed input +
-packed path records) / mean kernel duration measured with HIP events on the launch stream.  `cpu_baseline` = the
-oracle (CPU restatement of the reference, oracle/) on a bounded sample of the same workload, all host cores.
+Prints ONE JSON line on rank 0.  `roofline.achieved` = algorithmic bytes per launch (packed input + packed path
+records) / mean kernel duration measured with HIP events on the launch stream over the timed region.  `cpu_baseline` = the oracle
+(CPU restatement of the reference, oracle/) on a bounded sample of the same workload on the host cores, 1 thread and all cores.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import queue
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+N_CUS = 256
 
 
-def cpu_baseline(pg_sample, cores: int):
-    """The oracle ("port": our CPU restatement of the reference algorithm) on the GPU box's host cores."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import common
-    t0 = time.time()
-    _, _, sec, _ = common.oracle_run(pg_sample, threads=cores)
-    wall = time.time() - t0
-    return pg_sample.n / sec, sec, wall
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graphs", type=int, default=100000, help="graphs per GPU (BASELINE configs[1]: 100k)")
     ap.add_argument("--vertices", type=int, default=64)
     ap.add_argument("--edges", type=int, default=256)
     ap.add_argument("--weights", choices=("uniform", "int", "flow"), default="uniform",
                     help="edge weights: uniform = U[1,100) f64 (BASELINE configs), flow = flow-conserving sums of s-t paths (SURVEY.md 8d's second distribution)")
-    ap.add_argument("--cpu-sample", type=int, default=8192, help="graphs in the bounded cpu_baseline sample (0 = skip)")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-sample", type=int, default=32768, help="graphs in the bounded all-cores cpu_baseline sample (0 = skip both CPU legs)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 / flow-weight kernel timings (the `secondary` block)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: CPU rehearsal of the multi-rank plumbing (needs --dry-run)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: every rank stages its shard and enters the exchange with an empty stream (CPU tier)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args) -> int:
+    """--gpus N without a launcher: start the N ranks as fresh child processes (this process has not touched torch or HIP yet and
+    never will), relay rank 0's JSON line, propagate the launcher's exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        print(line, flush=True)
+    if r.returncode == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited cleanly but rank 0 printed no result line\n")
+        return 1
+    return r.returncode
+
+
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_legs(pg, n_all: int):
+    """The oracle ("port": our CPU restatement of the reference algorithm) on the GPU box's host cores: one thread, and all the
+    cores this process may run on, over bounded samples of the same workload."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import common
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))                       # the GPU box gives each GPU a 16-core share of the host
+    n_all = min(n_all, pg.n); n_one = max(256, min(pg.n, n_all // 12))
+    s_all = pg.select(np.arange(n_all)); s_one = pg.select(np.arange(n_one))
+    _, _, sec_all, _ = common.oracle_run(s_all, threads=cores)
+    _, _, sec_one, _ = common.oracle_run(s_one, threads=1)
+    model = cpu_model()
+    note = ("oracle/ = CPU restatement of the reference scallop core (container-based port; the survey's probe of the reference itself "
+            "measured 157-206 graphs/s per thread on these graphs, BASELINE.md section 2)")
+    allc = {"value": s_all.n / sec_all, "unit": "bundles/s", "cores": cores, "kind": "port", "cpu_model": model,
+            "sample": f"first {s_all.n} graphs of the same workload, {cores} threads over independent graphs, {sec_all:.2f} s; {note}"}
+    one = {"value": s_one.n / sec_one, "unit": "bundles/s", "cores": 1, "kind": "port", "cpu_model": model,
+           "sample": f"first {s_one.n} graphs of the same workload, 1 thread, {sec_one:.2f} s"}
+    return allc, one
+
+
+def committed_pmc(args):
+    """HBM traffic and instruction counts of the dominant kernel: PMC counters cannot be read from inside the process, so the figures
+    come from the committed summary of separate `rocprofv3 --pmc` passes over this same command (profiles/summarize.py); they are only
+    quoted when they were collected on this exact workload, else null."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if tj.get("graphs_per_gpu") == args.graphs and tj.get("vertices") == args.vertices and tj.get("edges") == args.edges and args.weights == "uniform":
+            return tj
+    except (OSError, ValueError, KeyError):
+        pass
+    return {}
+
+
+def kernel_only(A, dev, pg, reps=2):
+    """upload once, run `reps` times, -> (best kernel ms, failed graphs, per-class graph counts)"""
+    with A.DecompBatch(dev) as b:
+        b.add(pg); b.upload()
+        best = None
+        for _ in range(reps):
+            b.run(); b.download()
+            ms = b.kernel_ms(); best = ms if best is None else min(best, ms)
+        bad = int((b.result().status != 0).sum())
+        classes = {str(c): b.class_info(c)["n_graphs"] for c in range(13) if b.class_info(c)["n_graphs"]}
+    return best, bad, classes
+
+
+def main() -> int:
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        return launch_ranks(args)                        # before any torch / HIP call in this process
+    rank = int(os.environ.get("RANK", "0")); world = int(world_env or "1"); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks\n")
+        return 2
+    if args.dry_run != (args.backend == "gloo"):
+        sys.stderr.write("bench.py: --backend gloo and --dry-run go together (the CPU rehearsal of the multi-rank plumbing)\n")
+        return 2
     # stdout carries exactly one line, the JSON: libraries that write banners to file descriptor 1 (RCCL prints its version block
     # there at init) are sent to stderr for the duration of the run
     sys.stdout.flush()
     real_stdout = os.dup(1); os.dup2(2, 1)
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
     import torch
     import torch.distributed as dist
     dist_on = world > 1 or bool(os.environ.get("ALD_BENCH_FORCE_DIST"))      # the override runs the exchange path with one rank (rehearsal on a 1-GPU box)
@@ -66,129 +167,174 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", str(rank)); os.environ.setdefault("WORLD_SIZE", str(world))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend="gloo")
     import aletsch_amd as A
+    from aletsch_amd.distributed import StreamGatherer
 
     dev = local if dist_on else 0
+    tdev = torch.device("cpu") if args.dry_run else torch.device("cuda", dev)
     seed = 1002 if world == 1 else 1004 + rank          # SURVEY.md 8d seeds: cfg2 = 1002, cfg4 = 1004 + rank
     pg = A.synth(seed=seed, n_graphs=args.graphs, v_min=args.vertices, v_max=args.vertices, fixed_edges=args.edges,
                  weight_mode={"uniform": 0, "int": 1, "flow": 2}[args.weights])
-    # Two batch objects over the same resident input, used alternately: the D2H of batch k's path records (SDMA, own stream)
-    # overlaps batch k+1's kernel.  Kernels never overlap each other (the previous one is synchronised before the next launch),
-    # so the per-launch HIP-event time stays the time of ONE kernel on an otherwise idle GPU.
-    batches = [A.DecompBatch(dev), A.DecompBatch(dev)]
-    for b in batches:
-        b.add(pg)
-        b.upload()                                      # inputs resident in HBM before the timed region
-    batch = batches[0]
+    gatherer = StreamGatherer(tdev) if dist_on else None
 
-    from aletsch_amd.distributed import RecordGatherer, _device_words
-    gatherer = RecordGatherer(torch.device("cuda", dev)) if dist_on else None
+    def emit(line):
+        sys.stdout.flush(); os.dup2(real_stdout, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
 
-    pool_read = {}                                       # batch -> event reached once the exchange has read its record pool
+    if args.dry_run:
+        # CPU rehearsal: no kernel exists here, so every rank stages its shard (host code of the product) and goes through the same
+        # exchange step with a stream that only says who it is; rank 0 reports the world the collective actually saw
+        me = np.array([rank, pg.n, int(pg.g_ne.sum())], np.int32)
+        gatherer.gather(torch.from_numpy(me), graph_offset=rank * args.graphs)
+        if rank == 0:
+            st = gatherer.streams()
+            seen = sorted(int(w.view(np.int32)[0]) for w, _ in st)
+            emit({"metric": "bundles/sec", "value": None, "unit": "bundles/s", "n_gpus": len(st), "dry_run": True, "backend": "gloo",
+                  "ranks_in_gather": seen, "graph_offsets": [int(o) for _, o in st], "graphs_staged": [int(w.view(np.int32)[1]) for w, _ in st]})
+        dist.barrier(); dist.destroy_process_group()
+        return 0
 
-    def gather_records(b):
-        """RCCL gather of the packed path records to rank 0, straight from the batch's record pool in HBM (no host round trip);
+    NB = 3
+    batches = [A.DecompBatch(dev) for _ in range(NB)]
+    stream_read = {}                                     # batch -> event reached once the exchange has read what it sent
+
+    def exchange(b):
+        """RCCL gather of this batch's finished transcripts (filtered records, joined exons: ald_batch_transcript_stream) to rank 0;
         only enqueued: the next kernel is launched behind it and the host never waits for a collective"""
-        ptr, n = b.device_records()
-        pool_read[id(b)] = gatherer.gather(_device_words(ptr, n, torch.device("cuda", dev)), graph_offset=rank * args.graphs)
+        w = b.transcript_stream()
+        t = torch.from_numpy(w.view(np.int32)).to(tdev, non_blocking=True)
+        stream_read[id(b)] = gatherer.gather(t, graph_offset=rank * args.graphs)
 
     def finish(b):
         b.download()                                    # stream sync + D2H of status / packed records (+ class retries)
         if dist_on:
-            gather_records(b)
+            exchange(b)
         return b.kernel_ms()
 
-    def run_steps(k):
-        """k complete passes (kernel + results on the host); returns the per-launch kernel times"""
-        ms = []; prev = None
-        for i in range(k):
-            cur = batches[i % 2]
+    def run_steps(k, staged):
+        """k complete passes.  staged=True: host arrays in -> host results out (a host thread packs and uploads batch i+1 while the
+        kernel of batch i runs); staged=False: the batches are resident, kernel + D2H only.  Returns the per-launch kernel times."""
+        ms = []
+        if k <= 0:
+            return ms
+        ready = queue.Queue(); free = queue.Queue()
+        for b in batches:
+            free.put(b)
+        err = []
+
+        def stager():
+            try:
+                for _ in range(k):
+                    b = free.get()
+                    if staged:
+                        b.clear(); b.add(pg); b.upload()         # pack into the pinned wire buffer + ONE H2D copy + first-pass work lists
+                    ready.put(b)
+            except BaseException as e:                           # surface the failure in the main thread instead of a hang
+                err.append(e); ready.put(None)
+        th = threading.Thread(target=stager, daemon=True); th.start()
+        prev = None
+        for _ in range(k):
+            cur = ready.get()
+            if cur is None:
+                raise err[0]
             if prev is not None:
                 prev.sync()                             # the previous kernel is done ...
-            ev = pool_read.pop(id(cur), None)
+            ev = stream_read.pop(id(cur), None)
             if ev is not None:
-                ev.synchronize()                        # (the exchange of this batch's previous records has read its pool)
+                ev.synchronize()
             cur.run()                                   # ... the next one starts ...
             if prev is not None:
-                ms.append(finish(prev))                 # ... while the previous records travel to the host
+                ms.append(finish(prev)); free.put(prev)  # ... while the previous records travel to the host
             prev = cur
-        if prev is not None:
-            ms.append(finish(prev))
+        ms.append(finish(prev)); free.put(prev)
+        th.join()
         return ms
 
-    run_steps(args.warmup)
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    kms = run_steps(args.steps)
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev}")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    def timed(k, staged):
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kms = run_steps(k, staged)
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist_on:
+            te = torch.tensor([el], dtype=torch.float64, device=tdev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        return el, kms
 
+    run_steps(max(args.warmup, NB), True)                # warm-up (at least one pass per batch object: pinned / device buffers allocated)
+    elapsed, kms = timed(args.steps, True)               # THE timed region: K steps, host arrays in -> host results out
+    elapsed_res, kms_res = timed(args.steps, False)      # the same K steps over resident inputs (round 1's figure)
+
+    batch = batches[0]
     res = batch.result()
     n_bad = int((res.status != 0).sum())
     in_b, out_b = batch.algorithmic_bytes()
     k_ms = float(np.mean(kms))
     info = batch.class_info(1)
-
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the figure comes from the committed
-    # summary of separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (profiles/summarize.py);
-    # it is only quoted when it was collected on this exact workload, else null
-    traffic = None; traffic_src = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if tj.get("graphs_per_gpu") == args.graphs and tj.get("vertices") == args.vertices and tj.get("edges") == args.edges and args.weights == "uniform":
-            traffic = tj["traffic_bytes_per_launch"]; traffic_src = tj.get("source")
-    except (OSError, ValueError, KeyError):
-        pass
+    iters = int(batch.iterations().astype(np.int64).sum())
+    pmc = committed_pmc(args)
+    traffic = pmc.get("traffic_bytes_per_launch")
 
     if rank == 0:
-        total_graphs = args.graphs * world * args.steps
-        value = total_graphs / elapsed
+        value = args.graphs * world * args.steps / elapsed
         achieved = (in_b + out_b) / (k_ms / 1e3) / 1e9
         line = {
             "metric": "bundles/sec", "value": value, "unit": "bundles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "timed_step": "ald_batch_add_packed (pack into the pinned wire buffer) + H2D + decomposition kernels + D2H of status / path records"
+                          + (" + RCCL gather of the finished transcripts to rank 0" if dist_on else "") + "; staging of batch k+1 overlaps the kernel of batch k (3 batch objects)",
+            "value_resident": args.graphs * world * args.steps / elapsed_res, "ms_per_step_resident": elapsed_res / args.steps * 1e3,
             "config": {"workload": f"{args.graphs} synthetic splice graphs per GPU, {args.vertices} vertices / {args.edges} edges each "
                                    + ("(BASELINE.json configs[1]; U[1,100) FP64 weights, 1 supporting sample per edge, no phasing paths)" if args.weights == "uniform" else
                                       f"(BASELINE.json configs[1] shape with {args.weights} weights -- secondary distribution, not the headline)"),
-                       "graphs_per_gpu": args.graphs, "sharding": "independent graphs per rank, RCCL gather of path records to rank 0" if world > 1 else "single GPU",
+                       "graphs_per_gpu": args.graphs, "sharding": "independent graphs per rank, RCCL gather of finished transcripts to rank 0" if world > 1 else "single GPU",
                        "failed_graphs": n_bad, "paths_per_graph": float(len(res.weight)) / max(1, args.graphs),
                        "workgroups_per_cu": info["blocks_per_cu"], "grid": info["blocks_last_run"]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": pmc.get("source"),
                          "traffic_gbs": (traffic / (k_ms / 1e3) / 1e9) if traffic else None,      # measured HBM traffic over this run's kernel time
-                         "kernel": "ald_decomp_kernel_c1", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": in_b + out_b,
-                         "bytes_per_graph": (in_b + out_b) / args.graphs, "kernel_graphs_per_s": args.graphs / (k_ms / 1e3)},
+                         "kernel": "ald_decomp_kernel_c1", "kernel_ms": k_ms, "kernel_ms_resident_loop": float(np.mean(kms_res)),
+                         "algorithmic_bytes_per_launch": in_b + out_b, "bytes_per_graph": (in_b + out_b) / args.graphs,
+                         "kernel_graphs_per_s": args.graphs / (k_ms / 1e3),
+                         # what actually bounds this kernel (SURVEY.md 8d: dependent mutate-and-rescan steps, not bytes)
+                         "steps_per_graph": iters / max(1, args.graphs), "steps_per_s_per_cu": iters / (k_ms / 1e3) / N_CUS,
+                         "instr_per_graph": pmc.get("instr_per_graph"), "lds_bytes_per_workgroup": pmc.get("lds_bytes_per_workgroup")},
         }
+        if world == 1 and not args.no_secondary:
+            # the other single-GPU shapes of BASELINE.json / SURVEY.md 8d, kernel time only (parity for them: tests/test_gpu_parity.py)
+            sec = {}
+            cfg3 = A.synth(seed=1003, n_graphs=10000, v_min=8, v_max=512, edges_per_vertex=4)
+            ms3, bad3, cls3 = kernel_only(A, dev, cfg3)
+            sec["cfg3_mixed"] = {"workload": "BASELINE.json configs[2]: 10000 graphs, V ~ U{8..512}, E = 4V, seed 1003", "kernel_ms": ms3,
+                                 "bundles_per_s": 10000 / (ms3 / 1e3), "failed_graphs": bad3, "graphs_per_class": cls3}
+            if args.weights == "uniform":
+                flow = A.synth(seed=seed, n_graphs=args.graphs, v_min=args.vertices, v_max=args.vertices, fixed_edges=args.edges, weight_mode=2)
+                msf, badf, clsf = kernel_only(A, dev, flow)
+                sec["flow_weights"] = {"workload": f"{args.graphs} x {args.vertices}v/{args.edges}e, flow-conserving weights (SURVEY.md 8d's second distribution)",
+                                       "kernel_ms": msf, "bundles_per_s": args.graphs / (msf / 1e3), "failed_graphs": badf, "graphs_per_class": clsf}
+            line["secondary"] = sec
         if args.cpu_sample > 0 and world == 1:           # reported at N = 1 only
-            # the GPU box gives each GPU a share of the host (16 cores per GPU): use the cores this process may actually run on
-            try:
-                cores = len(os.sched_getaffinity(0))
-            except AttributeError:
-                cores = os.cpu_count() or 1
-            cores = max(1, min(cores, 16 * max(1, world)))
-            sample = pg.select(np.arange(min(args.cpu_sample, pg.n)))
-            v, cpu_sec, wall = cpu_baseline(sample, cores)
-            line["cpu_baseline"] = {"value": v, "unit": "bundles/s", "cores": cores, "kind": "port",
-                                    "sample": f"first {sample.n} graphs of the same workload, oracle/ (CPU restatement of the reference scallop core), "
-                                              f"{cores} threads over independent graphs, {cpu_sec:.2f} s"}
-        sys.stdout.flush(); os.dup2(real_stdout, 1)
-        print(json.dumps(line), flush=True)
-        os.dup2(2, 1)
+            line["cpu_baseline"], line["cpu_baseline_1t"] = cpu_baseline_legs(pg, args.cpu_sample)
+        emit(line)
     for b in batches:
         b.close()
     if dist_on:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -14,8 +14,11 @@
  * violation becomes a per-graph status word, see ALD_ST_*).
  *
  * Canonical order: the reference orders edges by raw
- * pointer value; this ABI defines the order as "edge creation sequence", and
- * the creation sequence of the input edges is their CSR position.
+ * pointer value; this ABI defines the order as "edge creation sequence".  The
+ * caller may hand over the creation sequence of the input edges explicitly
+ * (ald_graph_view.edge_creation_rank: the position of each edge in the
+ * reference's gr.edges() / get_edge_indices order, graph/graph_base.cc:139-153);
+ * without it the creation sequence is the CSR position.
  */
 #ifndef ALETSCH_DECOMP_H
 #define ALETSCH_DECOMP_H
@@ -39,6 +42,8 @@ extern "C" {
 #define ALD_ST_OK              0
 #define ALD_ST_SKIPPED_LARGE   1   /* the rule loop left through |V| > max_num_exons (scallop.cc:49: at once, or after the graph grew past it); greedy still ran */
 #define ALD_ST_CAPACITY        2   /* device working-set capacity exceeded after all retries  */
+#define ALD_ST_POOL_FULL       3   /* the batch's path-record pool was exhausted while this graph emitted a path; ald_batch_download grows the pool
+                                      and decomposes the batch again, so a caller only sees this word if the device cannot hold a larger pool */
 #define ALD_ST_INVARIANT     100   /* 100+n: the reference would have hit assert class n      */
 
 /* assert classes (status = ALD_ST_INVARIANT + class) */
@@ -83,6 +88,10 @@ typedef struct ald_graph_view {
     char           strand;              /* splice_graph::strand '+','-','.'              */
     const int32_t *edge_count;          /* [E]   edge_info.count; NULL => number of supporting samples.  The callers of assemble() hand over graphs
                                           *       whose counts were ADDED along grouped boundaries (graph_reviser.cc:965-975): count != |samples| there */
+    const int32_t *edge_creation_rank;  /* [E]   a permutation of 0..E-1: the scallop edge index e2i of each edge, i.e. its position in the reference's
+                                          *       gr.edges() (get_edge_indices walks `se` in pointer order, graph/graph_base.cc:139-153, scallop.cc:24).
+                                          *       Ids are behaviour: pe2w / routes are ordered by (id, id) (router.h:23), parallel edges and
+                                          *       thread_leaf's scan by id (graph/edge_base.h:35-45, router.cc:861).  NULL => CSR position */
 } ald_graph_view;
 
 /* One decomposed s-t path (reference rnacore/path.h:14-35, scallop.cc:2766-2834). */
@@ -118,7 +127,8 @@ int  ald_batch_clear(ald_batch *b);                       /* forget graphs, keep
  * outside 0..2, negative count, duplicate sample id on an edge) is refused with ALD_ERR_INVALID and a message in ald_last_error();
  * the batch is left exactly as it was -- for the bulk form all or nothing: no graph of a refused call is added. */
 int  ald_batch_add_graph(ald_batch *b, const ald_graph_view *g);
-/* Bulk form for n graphs concatenated: every per-vertex / per-edge / per-sample array is the
+/* (A malformed edge_creation_rank -- not a permutation of 0..E-1 -- is refused the same way.)
+ * Bulk form for n graphs concatenated: every per-vertex / per-edge / per-sample array is the
  * concatenation over graphs; g_nv[n], g_ne[n], g_np[n] give sizes; vertex_offset, edge_sample_offset
  * and phasing_offset are per-graph LOCAL (each restarts at 0; lengths V+1, E+1, P+1). */
 int  ald_batch_add_packed(ald_batch *b, int32_t n,
@@ -129,7 +139,8 @@ int  ald_batch_add_packed(ald_batch *b, int32_t n,
                           const double *vertex_weight, const int32_t *vertex_lpos, const int32_t *vertex_rpos,
                           const int32_t *vertex_type,
                           const int32_t *phasing_offset, const int32_t *phasing_vertex, const int32_t *phasing_count,
-                          const char *graph_strand, const int32_t *edge_count /* NULL => per-edge sample count */);
+                          const char *graph_strand, const int32_t *edge_count /* NULL => per-edge sample count */,
+                          const int32_t *edge_creation_rank /* NULL => CSR position; else per graph a permutation of 0..E-1 */);
 int  ald_batch_num_graphs(const ald_batch *b);
 
 /* ---- execution (replaces `sx.assemble()`, scallop.cc:38-188) ---- */
@@ -145,6 +156,7 @@ int  ald_batch_algorithmic_bytes(const ald_batch *b, int64_t *in_bytes, int64_t 
 /* ---- results (replaces reading sx.paths, scallop.h:50) ---- */
 int  ald_batch_get_result(const ald_batch *b, int32_t graph, ald_result_view *out);
 int  ald_batch_get_path(const ald_batch *b, int32_t graph, int32_t path, ald_path_view *out);
+int  ald_batch_export_iterations(const ald_batch *b, int32_t *num_iterations /* [graphs] */);
 /* Bulk export: fills caller arrays. path_offset[n+1] (paths per graph prefix), then per path the
  * scalar fields and pv_offset[num_paths_total+1] into path_vertices. Pass NULL to query sizes. */
 int  ald_batch_export(const ald_batch *b, int64_t *total_paths, int64_t *total_path_vertices,
@@ -183,6 +195,15 @@ int  ald_tset_add(ald_tset *t, int32_t n_groups, const int64_t *group_offset, co
 /* every graph of a downloaded batch, ascending graph id; sid[graphs] gives each graph's sample id (NULL => -1);
  * tid = tid_base + (graph << 20 | path index) */
 int  ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int64_t tid_base, int32_t skip_single_exon);
+/* Finished transcripts of a downloaded batch as ONE self-contained stream -- what ranks exchange in the multi-GPU gather and
+ * what a host driving several devices merges.  4-byte words, transcripts in ascending (graph, path index) order:
+ *   [graph, path index, sid, strand, count1, n_exons, weight f64, conf f64, abd f64, (l, r) * n_exons]
+ * Only graphs that ended ALD_ST_OK / ALD_ST_SKIPPED_LARGE contribute, records of abandoned capacity attempts are gone, exons are joined,
+ * single-exon transcripts are left out when skip_single_exon (assembler.cc:1117).  Valid until the next call on this batch. */
+int  ald_batch_transcript_stream(const ald_batch *b, const int32_t *sid, int32_t skip_single_exon, const uint32_t **words, int64_t *n_words);
+/* Merge such a stream, graph by graph in stream order (assembler.cc:1105-1133): coverage = log(1 + weight) is taken here, on the host;
+ * tid = tid_base + ((graph + graph_offset) << 20 | path index), i.e. what ald_tset_add_batch gives the same graph in an unsharded batch */
+int  ald_tset_add_stream(ald_tset *t, const uint32_t *words, int64_t n_words, int32_t graph_offset, int64_t tid_base);
 int  ald_tset_size(const ald_tset *t, int64_t *n_items, int64_t *n_exons, int64_t *n_samples);
 /* items in the reference's iteration order (hash ascending, then bucket order) */
 int  ald_tset_export(const ald_tset *t, uint64_t *hash, int32_t *count, char *strand, double *coverage, double *cov2, double *conf, double *abd,
@@ -202,6 +223,9 @@ int  ald_batch_raw_records(const ald_batch *b, const uint32_t **words, int64_t *
 /* diagnostics: size class `cls` (0..4): capacities, resident workgroups per CU, grid of the last run, graphs assigned */
 int  ald_batch_class_info(ald_batch *b, int32_t cls, int32_t *maxv, int32_t *maxe, int32_t *blocks_per_cu, int32_t *blocks_last_run,
                           int64_t *slab_bytes, int32_t *n_graphs);
+
+/* test hook: the slab address class `cls` was launched with in the last run, and the address of the slab buffer the batch owns now */
+int  ald_batch_debug_slab(const ald_batch *b, int32_t cls, const void **launched_with, const void **owned);
 
 /* optional per-graph operation trace (debug builds of the parity tests): rule id, vertex/edge, ratio */
 int  ald_batch_enable_trace(ald_batch *b, int32_t max_events_per_graph);

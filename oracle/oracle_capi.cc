@@ -29,7 +29,7 @@ struct Packed {
     const int32_t *vertex_offset, *edge_target; const double *edge_weight; const uint8_t *edge_strand; const double *edge_abd;
     const int32_t *edge_sample_offset, *sample_id; const double *sample_abd;
     const double *vertex_weight; const int32_t *vertex_lpos, *vertex_rpos, *vertex_type;
-    const int32_t *phasing_offset, *phasing_vertex, *phasing_count; const char *graph_strand; const int32_t *edge_count;
+    const int32_t *phasing_offset, *phasing_vertex, *phasing_count; const char *graph_strand; const int32_t *edge_count, *edge_rank;
 };
 
 struct Offsets { int64_t v, vo, e, eo, s, p, po, pv; };
@@ -46,7 +46,13 @@ void run_one(const Packed &P, const Offsets &o, int g, const ora::Params &cfg, b
         gr.vinf[i].type = P.vertex_type ? P.vertex_type[o.v + i] : -1;
     }
     const int32_t *vo = P.vertex_offset + o.vo; const int32_t *so = P.edge_sample_offset + o.eo;
-    for(int s = 0; s < V; s++) for(int k = vo[s]; k < vo[s + 1]; k++) {
+    // edges are created in the order of their creation rank (the reference's gr.edges() order: graph_base.cc:139-153 assigns the
+    // scallop edge indices by walking `se`); without a rank that order is the CSR position
+    std::vector<int> src_of(E), order(E);
+    for(int s = 0; s < V; s++) for(int k = vo[s]; k < vo[s + 1]; k++) src_of[k] = s;
+    for(int k = 0; k < E; k++) order[P.edge_rank ? P.edge_rank[o.e + k] : k] = k;
+    for(int q = 0; q < E; q++) {
+        const int k = order[q], s = src_of[k];
         int e = gr.add_edge(s, P.edge_target[o.e + k]);
         gr.ewrt[e] = P.edge_weight[o.e + k];
         ora::EdgeInfo &ei = gr.einf[e];
@@ -95,11 +101,11 @@ int ora_run_packed(int32_t n,
                    const double *vertex_weight, const int32_t *vertex_lpos, const int32_t *vertex_rpos,
                    const int32_t *vertex_type,
                    const int32_t *phasing_offset, const int32_t *phasing_vertex, const int32_t *phasing_count,
-                   const char *graph_strand, const int32_t *edge_count,
+                   const char *graph_strand, const int32_t *edge_count, const int32_t *edge_rank,
                    const ald_params *prm, int32_t n_threads, int32_t want_trace, ora_result **out)
 {
     Packed P{n, g_nv, g_ne, g_np, vertex_offset, edge_target, edge_weight, edge_strand, edge_abd, edge_sample_offset, sample_id, sample_abd,
-             vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand, edge_count};
+             vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand, edge_count, edge_rank};
     ora::Params cfg;
     if(prm) {
         for(int i = 0; i < 8; i++) cfg.max_decompose_error_ratio[i] = prm->max_decompose_error_ratio[i];

@@ -142,3 +142,33 @@ PARITY_CONFIGS = {
     "phasing": dict(seed=15, n_graphs=150, v_min=10, v_max=60, edges_per_vertex=3, phasing_per_graph=12, weight_mode=2),
     "everything": dict(seed=16, n_graphs=150, v_min=6, v_max=100, edges_per_vertex=3, phasing_per_graph=20, weight_mode=1, n_samples=4, strand_mode=1, layout_mode=1),
 }
+
+
+def transcript_stream_from_result(pg: PackedGraphs, res: DecompResult, sid=None, skip_single_exon: bool = False) -> np.ndarray:
+    """Test-side restatement of ald_batch_transcript_stream (include/aletsch_decomp.h) over any DecompResult -- e.g. the single-lane
+    emulation's, so that the CPU tier can drive the multi-rank exchange and the stream merge without a GPU.  Exons: the path's
+    internal vertices' [lpos, rpos) with touching intervals joined (essential.cc:719-748)."""
+    sl = pg.graph_slices(); out = []
+    for g in range(pg.n):
+        if int(res.status[g]) not in (0, 1):
+            continue
+        ov = int(sl["v"][g])
+        for k, p in enumerate(range(int(res.path_offset[g]), int(res.path_offset[g + 1]))):
+            v = res.path_vertices[int(res.pv_offset[p]):int(res.pv_offset[p + 1])]
+            ex = []
+            for x in v[1:-1]:
+                l, r = int(pg.vertex_lpos[ov + x]), int(pg.vertex_rpos[ov + x])
+                if l >= r:
+                    continue
+                if ex and ex[-1] == l:
+                    ex[-1] = r
+                else:
+                    ex += [l, r]
+            if len(ex) <= 2 and skip_single_exon:
+                continue
+            hdr = np.zeros(12, np.uint32)
+            hdr[0] = g; hdr[1] = k; hdr[2] = np.array([-1 if sid is None else int(sid[g])], np.int32).view(np.uint32)[0]
+            hdr[3] = int(res.strand[p]) & 0xFF; hdr[4] = int(res.count[p]); hdr[5] = len(ex) // 2
+            hdr[6:12] = np.array([res.weight[p], res.conf[p], res.abd[p]], np.float64).view(np.uint32)
+            out.append(hdr); out.append(np.array(ex, np.int32).view(np.uint32))
+    return np.concatenate(out) if out else np.zeros(0, np.uint32)

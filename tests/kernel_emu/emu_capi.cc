@@ -22,11 +22,11 @@ int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_
                    const int32_t *voff, const int32_t *etgt, const double *ew, const uint8_t *estrand, const double *eabd,
                    const int32_t *esoff, const int32_t *sid, const double *sabd,
                    const double *vw, const int32_t *lpos, const int32_t *rpos, const int32_t *vtype,
-                   const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand, const int32_t *ecount,
+                   const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand, const int32_t *ecount, const int32_t *erank,
                    const ald_params *prm, int32_t trace_cap, int32_t force_class, emu_result **out)
 {
     HostBatch B;
-    int rc = B.add_packed(n, nv, ne, np, voff, etgt, ew, estrand, eabd, esoff, sid, sabd, vw, lpos, rpos, vtype, poff, pv, pc, gstrand, ecount);
+    int rc = B.add_packed(n, nv, ne, np, voff, etgt, ew, estrand, eabd, esoff, sid, sabd, vw, lpos, rpos, vtype, poff, pv, pc, gstrand, ecount, erank);
     if(rc != ALD_OK) { fprintf(stderr, "emu: add_packed failed: %s\n", B.err.c_str()); return rc; }
     HostBatch::Section sec[HostBatch::S_COUNT];
     uint64_t bytes = B.layout(sec);
@@ -37,6 +37,7 @@ int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_
     params_from_abi(prm, A.prm);
     std::vector<int32_t> status(n, 0), n_paths(n, 0), n_iters(n, 0);
     uint64_t pool_cap = 0; for(int g = 0; g < n; g++) pool_cap += 16ull * B.g_ne[g] + 256;
+    if(const char *ev = getenv("ALD_DEBUG_POOL_WORDS")) { const long long k = atoll(ev); if(k > 0 && (uint64_t)k < pool_cap) pool_cap = (uint64_t)k; }     // same knob as ald_batch_upload
     std::vector<uint32_t> pool(pool_cap); unsigned long long pool_used = 0;
     emu_result *E = new emu_result(); E->n = n; E->trace_cap = trace_cap;
     if(trace_cap > 0) { E->trace_n.assign(n, 0); E->trace_codes.assign(3ull * n * trace_cap, 0); E->trace_vals.assign((size_t)n * trace_cap, 0); }
@@ -44,7 +45,10 @@ int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_
     A.out.pool_used = &pool_used; A.out.pool = pool.data(); A.out.pool_cap = pool_cap;
     A.out.trace_cap = trace_cap; A.out.trace_n = E->trace_n.data(); A.out.trace_codes = E->trace_codes.data(); A.out.trace_vals = E->trace_vals.data();
     std::vector<int32_t> cls(n), attempt(n, 0);
+  for(int regrow = 0; ; regrow++) {          // the host policy of ald_batch_download: a full record pool grows and the batch runs again
     std::vector<int32_t> work[ALD_NUM_PICK_CLASSES];
+    std::fill(status.begin(), status.end(), 0); std::fill(n_paths.begin(), n_paths.end(), 0); std::fill(attempt.begin(), attempt.end(), 0); pool_used = 0;
+    if(trace_cap > 0) std::fill(E->trace_n.begin(), E->trace_n.end(), 0);
     for(int g = 0; g < n; g++) {
         int64_t ns = B.off_s[g + 1] - B.off_s[g], npv = B.off_pv[g + 1] - B.off_pv[g];
         cls[g] = debug_underclass(pick_class(B.g_nv[g], B.g_ne[g], ns, npv, force_class));
@@ -73,8 +77,13 @@ int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_
         }
         for(int c = 0; c < ALD_NUM_PICK_CLASSES; c++) work[c].swap(next[c]);
     }
+    bool pool_full = false; for(int g = 0; g < n; g++) if(status[g] == ALD_ST_POOL_FULL) pool_full = true;
+    if(!pool_full || regrow >= 8) break;
+    pool_cap = std::max<uint64_t>(2 * pool_cap, pool_used + pool_used / 4 + 4096); pool.assign(pool_cap, 0);
+    A.out.pool = pool.data(); A.out.pool_cap = pool_cap;
+  }
     E->R.status = status; E->R.n_iters = n_iters; E->R.attempt = attempt;
-    E->R.pool.assign(pool.begin(), pool.begin() + pool_used);
+    E->R.pool.assign(pool.begin(), pool.begin() + std::min<uint64_t>(pool_used, pool_cap));
     E->cls = cls;
     rc = E->R.build(n, n_paths);
     if(rc != 0) { fprintf(stderr, "emu: record parse failed rc=%d\n", rc); delete E; return ALD_ERR_STATE; }

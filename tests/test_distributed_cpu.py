@@ -93,3 +93,92 @@ def test_shard_range_partitions():
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
+
+
+SHARD_WORKER = textwrap.dedent('''
+    import os, sys, json, numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+    import aletsch_amd as A, common
+    from aletsch_amd.distributed import StreamGatherer, merge_streams, shard_range
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    spec = json.loads(os.environ["ALD_TEST_SPEC"])
+    pg = A.synth(**spec)                                   # every rank knows the whole batch and takes its block of it
+    sid = (np.arange(pg.n) %% 4).astype(np.int32)
+    lo, hi = shard_range(pg.n, rank, world)
+    mine = pg.select(np.arange(lo, hi))
+    res, _, _ = common.emu_run(mine)                       # the engine (single-lane emulation of the HIP kernels) on this rank's shard
+    words = common.transcript_stream_from_result(mine, res, sid[lo:hi])
+    G = StreamGatherer(torch.device("cpu"))
+    G.gather(torch.from_numpy(words.view(np.int32).copy()), graph_offset=lo)
+    if rank == 0:
+        sink = merge_streams(A.TranscriptSink(0.8), G.streams())
+        json.dump(sink.items(), open(os.environ["ALD_TEST_OUT"], "w"))
+        print("MERGED", len(sink.items()))
+    dist.barrier()
+    dist.destroy_process_group()
+''') % (ROOT, ROOT)
+
+
+def test_sharded_batch_merges_to_the_single_rank_result(tmp_path):
+    """SURVEY.md 8e's determinism rule, tested: a real batch is sharded over two gloo ranks, every rank decomposes its block with the
+    engine (emulated), the finished transcript streams are gathered and merged on rank 0 in ascending global graph id -- and the
+    merged transcript set (every field of every item, tids included) equals the one-rank merge of the unsharded batch, which in turn
+    equals the same transcripts fed through the reference-pinned ald_tset_add."""
+    import json
+    import numpy as np
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import aletsch_amd as A
+    import common
+    spec = dict(seed=71, n_graphs=90, v_min=8, v_max=60, edges_per_vertex=3, layout_mode=1, weight_mode=2, phasing_per_graph=3, strand_mode=1)
+    pg = A.synth(**spec)
+    sid = (np.arange(pg.n) % 4).astype(np.int32)
+    res, _, _ = common.emu_run(pg)
+    single = A.TranscriptSink(0.8); single.add_stream(common.transcript_stream_from_result(pg, res, sid))
+    want = single.items()
+    assert len(want) > 50
+    # the stream merge against the per-group entry point whose rules are pinned to the reference's transcript_set.cc
+    groups = []
+    import math
+    sl = pg.graph_slices()
+    for g in range(pg.n):
+        ts = []
+        for k, p in enumerate(range(int(res.path_offset[g]), int(res.path_offset[g + 1]))):
+            v = res.path_vertices[int(res.pv_offset[p]):int(res.pv_offset[p + 1])]; ex = []
+            for x in v[1:-1]:
+                l, r = int(pg.vertex_lpos[sl["v"][g] + x]), int(pg.vertex_rpos[sl["v"][g] + x])
+                if l >= r: continue
+                if ex and ex[-1][1] == l: ex[-1] = (ex[-1][0], r)
+                else: ex.append((l, r))
+            ts.append((chr(int(res.strand[p])), math.log(1.0 + float(res.weight[p])), float(res.conf[p]), float(res.abd[p]), int(res.count[p]), (g << 20) | k, ex))
+        groups.append((int(sid[g]), ts))
+    pinned = A.TranscriptSink(0.8); pinned.add_groups(groups)
+    assert pinned.items() == want
+    out = tmp_path / "merged.json"
+    script = tmp_path / "shard_worker.py"; script.write_text(SHARD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", ALD_TEST_SPEC=json.dumps(spec), ALD_TEST_OUT=str(out))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = json.load(open(out))
+    for x in got:
+        x["exons"] = [tuple(e) for e in x["exons"]]
+    assert got == want
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (fresh child processes, before any GPU call), relays rank
+    0's JSON line and reports the world the collective actually saw; here as a CPU / gloo dry run of that plumbing"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run", "--graphs", "300"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_in_gather"] == [0, 1] and d["graph_offsets"] == [0, 300] and d["graphs_staged"] == [300, 300]
+    # a launcher world that contradicts --gpus is refused
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run"], capture_output=True, text=True, timeout=120, env=env2)
+    assert r2.returncode == 2 and "WORLD_SIZE=1" in r2.stderr

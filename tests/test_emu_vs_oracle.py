@@ -167,3 +167,49 @@ def test_max_num_exons_skips_the_cascade():
     assert big.any() and (~big).any()
     assert (want.status[big] == 1).all() and (want.status[~big] == 0).any() and (want.status[~big] == 1).any()     # some grow past the limit mid-run
     assert (np.diff(want.path_offset)[big] > 0).any()
+
+
+def permuted_rank(pg, seed):
+    """A random creation rank per graph (a permutation of 0..E-1), as a reference heap layout other than creation order would give."""
+    rng = np.random.default_rng(seed)
+    out = np.empty(int(pg.g_ne.sum()), np.int32); o = 0
+    for e in pg.g_ne:
+        out[o:o + e] = rng.permutation(int(e)).astype(np.int32); o += int(e)
+    return out
+
+
+def test_edge_creation_rank_crosses_the_boundary():
+    """ald_graph_view.edge_creation_rank: the scallop edge index (position in the reference's gr.edges(), graph_base.cc:139-153) of
+    every input edge.  Ids are behaviour (pe2w / route order, parallel edges, thread_leaf's scan): a permuted rank changes some
+    decompositions, identically in the engine and the oracle; the identity rank reproduces the default (CSR position) bit for bit."""
+    import copy
+    pg = A.synth(seed=21, n_graphs=300, v_min=10, v_max=70, edges_per_vertex=3, phasing_per_graph=10, weight_mode=1, n_samples=3)
+    base_o = common.oracle_run(pg)[0]
+    ident = copy.copy(pg); ident.edge_rank = pg.identity_rank()
+    assert not common.compare_results(base_o, common.oracle_run(ident)[0], pg.n)
+    assert not common.compare_results(base_o, common.emu_run(ident)[0], pg.n)
+    perm = copy.copy(pg); perm.edge_rank = permuted_rank(pg, 5)
+    want, st, _, _ = common.oracle_run(perm)
+    got, it, _ = common.emu_run(perm)
+    assert not common.compare_results(want, got, pg.n)
+    assert np.array_equal(it, st[:, 3])
+    changed = [g for g in range(pg.n) if want.paths_of(g) != base_o.paths_of(g)]
+    assert changed, "a permuted creation rank should change at least one decomposition (integer weights give ties)"
+    # sub-batches and concatenations carry the column along
+    sub = perm.select(np.arange(50, 120))
+    assert not common.compare_results(common.oracle_run(sub)[0], common.emu_run(sub)[0], sub.n)
+    from aletsch_amd.packed import PackedGraphs
+    mix = PackedGraphs.concat([pg.select(np.arange(10)), sub])          # graphs without a rank in front of graphs with one
+    assert not common.compare_results(common.oracle_run(mix)[0], common.emu_run(mix)[0], mix.n)
+
+
+def test_full_record_pool_grows_and_the_batch_runs_again(monkeypatch):
+    """ALD_ST_POOL_FULL is its own status (not the class-overflow code): the host grows the pool and decomposes the batch again
+    instead of walking the graph up through every larger class"""
+    pg = A.synth(seed=33, n_graphs=60, v_min=20, v_max=90, edges_per_vertex=4)
+    want = common.oracle_run(pg)[0]
+    _, _, cl_plain = common.emu_run(pg)
+    monkeypatch.setenv("ALD_DEBUG_POOL_WORDS", "900")
+    got, _, cl = common.emu_run(pg)
+    assert not common.compare_results(want, got, pg.n)
+    assert np.array_equal(cl, cl_plain)                  # nobody changed class because of the pool

@@ -214,8 +214,17 @@ def test_capacity_retry_on_gpu():
     try:
         with A.DecompBatch(0) as b:
             b.add(pg); b.upload()
+            import ctypes as C
             for rep in range(2):
-                b.run(); b.download()
+                b.run()
+                # the retry passes of the previous download regrew class slabs (hipFree + hipMalloc): the first pass of this run must
+                # have been launched with the buffers the batch owns NOW, not the addresses staged at upload time
+                for c in range(13):
+                    if b.class_info(c)["blocks_last_run"] > 0:
+                        used, owned = C.c_void_p(), C.c_void_p()
+                        assert b._lib.ald_batch_debug_slab(b._h, c, C.byref(used), C.byref(owned)) == 0
+                        assert used.value == owned.value, (rep, c)
+                b.download()
                 assert not common.compare_results(want, b.result(), pg.n, conf_tol=1e-9)
     finally:
         del os.environ["ALD_DEBUG_UNDERCLASS"]
@@ -355,3 +364,143 @@ def test_slab_twins_of_the_large_lds_classes(monkeypatch):
         got = b.result()
     w2 = common.oracle_run(small, threads=8)[0]
     assert not common.compare_results(w2, got, small.n, conf_tol=1e-9)
+
+
+def _host_threads():
+    import os
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+def test_cfg3_mixed_batch_at_spec():
+    """BASELINE.json configs[2] at spec: 10 000 graphs, V ~ U{8..512}, E = 4V (seed 1003) -- the one place where nine
+    size classes, three side streams and the LDS / slab-twin choice run together -- compared with the oracle graph by graph"""
+    pg = A.synth(seed=1003, n_graphs=10000, v_min=8, v_max=512, edges_per_vertex=4)
+    want = common.oracle_run(pg, threads=_host_threads())[0]
+    with A.DecompBatch(0) as b:
+        b.add(pg); b.upload(); b.run(); b.download()
+        got = b.result()
+        used = {c: b.class_info(c)["n_graphs"] for c in range(13) if b.class_info(c)["n_graphs"]}
+    assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
+    assert (got.status == 0).all() and len(used) >= 8, used
+
+
+def test_flow_weights_at_full_size():
+    """SURVEY.md 8d's second weight distribution at the bench size: 100 000 x 64v/256e with flow-conserving weights (sums of random s-t
+    paths); twice the unsplittable vertices and router runs of the uniform batch, and at least one graph outgrows its class and is
+    retried one class up"""
+    n = 100000
+    pg = A.synth(seed=1002, n_graphs=n, v_min=64, v_max=64, fixed_edges=256, weight_mode=2)
+    want = common.oracle_run(pg, threads=_host_threads())[0]
+    with A.DecompBatch(0) as b:
+        b.add(pg); b.upload(); b.run(); b.download()
+        got = b.result()
+        classes = {c: b.class_info(c)["n_graphs"] for c in range(13) if b.class_info(c)["n_graphs"]}
+    assert not common.compare_results(want, got, n, conf_tol=1e-9)
+    assert (got.status == 0).all()
+    assert set(classes) - {1}, f"expected at least one capacity retry out of class 1: {classes}"
+
+
+def test_fuzz_slice():
+    """A fixed-seed slice of the randomized GPU-vs-oracle sweep (60 s; profiles/r01/fuzz_parity.txt holds the long runs): sizes 4..520,
+    2..5 edges per vertex, three weight modes, 1..4 samples, 0..25 phasing paths, strands, touching exons, non-default ratios,
+    coverage threshold and max_num_exons, explicit edge counts, permuted creation ranks"""
+    import time
+    rng = np.random.default_rng(20260)
+    thr = _host_threads()
+    t_end = time.time() + 60.0; ntot = 0; k = 0
+    while time.time() < t_end:
+        k += 1
+        vmin = int(rng.choice([4, 8, 16, 32, 64, 100])); vmax = int(min(520, vmin * rng.choice([1, 2, 4])))
+        kw = dict(seed=int(rng.integers(1, 1 << 30)), v_min=vmin, v_max=vmax, edges_per_vertex=int(rng.choice([2, 3, 4, 5])),
+                  weight_mode=int(rng.choice([0, 1, 2])), n_samples=int(rng.choice([1, 1, 2, 4])), phasing_per_graph=int(rng.choice([0, 0, 3, 10, 25])),
+                  strand_mode=int(rng.choice([0, 0, 1])), layout_mode=int(rng.choice([0, 1])))
+        kw["n_graphs"] = int(max(50, min(20000, 2.5e6 / ((vmin + vmax) / 2 * kw["edges_per_vertex"]))))
+        p = A.default_params()
+        if rng.random() < 0.3: p.max_decompose_error_ratio[7] = float(rng.choice([1.2, 1.5, 3.0]))
+        if rng.random() < 0.3: p.max_decompose_error_ratio[0] = float(rng.choice([0.1, 0.2, 0.5]))
+        if rng.random() < 0.2: p.min_transcript_coverage = float(rng.choice([0.5, 5.0]))
+        if rng.random() < 0.2: p.max_num_exons = int(rng.choice([12, 40, 150]))
+        pg = A.synth(**kw)
+        if rng.random() < 0.3:
+            pg.edge_count = (pg.sample_counts() + rng.integers(0, 3, pg.edge_target.size)).astype(np.int32)
+        if rng.random() < 0.3:
+            r = np.empty(pg.edge_target.size, np.int32); o = 0
+            for e in pg.g_ne:
+                r[o:o + e] = rng.permutation(int(e)); o += int(e)
+            pg.edge_rank = r
+        want = common.oracle_run(pg, params=p, threads=thr)[0]
+        got = A.decompose(pg, device=0, params=p)
+        bad = common.compare_results(want, got, pg.n, conf_tol=1e-9)
+        assert not bad, (k, kw, list(p.max_decompose_error_ratio), p.min_transcript_coverage, p.max_num_exons, bad[:3])
+        ntot += pg.n
+    assert k >= 3 and ntot >= 1000, (k, ntot)
+
+
+def test_edge_creation_rank_on_gpu():
+    """the caller's edge order (position in gr.edges()) as the kernel's initial edge ids: permuted ranks change router / pe2w outcomes
+    identically in HIP and oracle; the identity rank is the default"""
+    import copy
+    pg = A.synth(seed=21, n_graphs=2000, v_min=10, v_max=140, edges_per_vertex=3, phasing_per_graph=10, weight_mode=1, n_samples=3)
+    base = A.decompose(pg, 0)
+    ident = copy.copy(pg); ident.edge_rank = pg.identity_rank()
+    assert not common.compare_results(base, A.decompose(ident, 0), pg.n)
+    perm = copy.copy(pg); r = np.empty(pg.edge_target.size, np.int32); o = 0; rng = np.random.default_rng(8)
+    for e in pg.g_ne:
+        r[o:o + e] = rng.permutation(int(e)); o += int(e)
+    perm.edge_rank = r
+    want = common.oracle_run(perm, threads=_host_threads())[0]
+    got = A.decompose(perm, 0)
+    assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
+    assert common.compare_results(base, got, pg.n), "a permuted creation rank should change some decomposition"
+    # a rank that is not a permutation is refused, the batch stays usable
+    from aletsch_amd.native import DecompError
+    bad = copy.copy(pg.select(np.arange(4))); bad.edge_rank = bad.identity_rank(); bad.edge_rank[1] = bad.edge_rank[0]
+    with A.DecompBatch(0) as b:
+        with pytest.raises(DecompError):
+            b.add(bad)
+        assert b.n == 0
+
+
+def test_record_pool_regrow_on_gpu(monkeypatch):
+    """a record pool that is too small: ALD_ST_POOL_FULL -> the pool grows, the batch runs again (no walk through the larger classes);
+    a second run of the same resident batch uses the grown pool"""
+    pg = A.synth(seed=33, n_graphs=600, v_min=20, v_max=90, edges_per_vertex=4)
+    want = common.oracle_run(pg, threads=4)[0]
+    plain = {}
+    with A.DecompBatch(0) as b:
+        b.add(pg); b.upload(); b.run(); b.download()
+        plain = {c: b.class_info(c)["n_graphs"] for c in range(13)}
+    monkeypatch.setenv("ALD_DEBUG_POOL_WORDS", "5000")
+    with A.DecompBatch(0) as b:
+        b.add(pg); b.upload()
+        for rep in range(2):
+            b.run(); b.download()
+            assert not common.compare_results(want, b.result(), pg.n, conf_tol=1e-9)
+            assert {c: b.class_info(c)["n_graphs"] for c in range(13)} == plain
+
+
+def test_transcript_stream_and_its_merge():
+    """ald_batch_transcript_stream: the finished transcripts of a batch as one self-contained stream (what ranks exchange) --
+    word for word the test-side restatement over the exported results; merging it (ald_tset_add_stream) gives the same set as
+    ald_tset_add_batch, also when the batch is cut into two "ranks" whose streams are merged with their graph offsets"""
+    pg = A.synth(seed=45, n_graphs=400, v_min=8, v_max=60, edges_per_vertex=3, layout_mode=1, weight_mode=2, phasing_per_graph=2, strand_mode=1)
+    sid = (np.arange(pg.n) % 5).astype(np.int32)
+    with A.DecompBatch(0) as b:
+        b.add(pg); b.upload(); b.run(); b.download()
+        r = b.result()
+        for skip in (False, True):
+            w = b.transcript_stream(sid, skip_single_exon=skip)
+            assert np.array_equal(w, common.transcript_stream_from_result(pg, r, sid, skip_single_exon=skip))
+        w = b.transcript_stream(sid)
+        direct = A.TranscriptSink(0.8); direct.add_batch(b, sid, tid_base=7 << 44)
+    via = A.TranscriptSink(0.8); via.add_stream(w, tid_base=7 << 44)
+    assert via.items() == direct.items() and len(via.items()) > 100
+    cut = 170
+    parts = []
+    for lo, hi in ((0, cut), (cut, pg.n)):
+        with A.DecompBatch(0) as b:
+            b.add(pg.select(np.arange(lo, hi))); b.upload(); b.run(); b.download()
+            parts.append((b.transcript_stream(sid[lo:hi]), lo))
+    from aletsch_amd.distributed import merge_streams
+    two = merge_streams(A.TranscriptSink(0.8), parts, tid_base=7 << 44)
+    assert two.items() == direct.items()
