@@ -4,8 +4,7 @@
 // copy, launches the per-size-class persistent kernels (decomp_class.hip) on the batch's stream, and parses the
 // packed path records that come back.  There is NO CPU compute path here: without a HIP device every compute
 // entry point fails with ALD_ERR_NO_DEVICE.
-#include <hip/hip_runtime.h>
-#include "host_pack.h"
+#include "ald_internal.h"
 #include <thread>
 #include <chrono>
 #include <iterator>
@@ -15,8 +14,6 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cmath>
-
-using namespace ald;
 
 extern "C" {
 #define ALD_DECL(ID) int ald_launch_c##ID(const KernelArgs *, int, hipStream_t); int ald_occupancy_c##ID(); unsigned long long ald_hot_slab_bytes_c##ID();
@@ -43,56 +40,7 @@ const hot_fn k_hot[ALD_NUM_CLASSES] = { ALD_FOR_EACH_CLASS(ALD_H) };
 #undef ALD_O
 #undef ALD_H
 
-struct DevBuf {
-    void *p = nullptr; size_t cap = 0;
-    int ensure(size_t bytes) { if(bytes <= cap) return 0; if(p) hipFree(p); p = nullptr; cap = 0; size_t want = bytes + bytes / 4 + 256; if(hipMalloc(&p, want) != hipSuccess) return -1; cap = want; return 0; }
-    void release() { if(p) hipFree(p); p = nullptr; cap = 0; }
-};
-struct PinBuf {
-    void *p = nullptr; size_t cap = 0;
-    int ensure(size_t bytes) { if(bytes <= cap) return 0; if(p) hipHostFree(p); p = nullptr; cap = 0; size_t want = bytes + bytes / 4 + 256; if(hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return -1; cap = want; return 0; }
-    void release() { if(p) hipHostFree(p); p = nullptr; cap = 0; }
-};
-
 } // namespace
-
-enum { ALD_SIDE_STREAMS = 3 };
-// one pass of a batch, staged: work lists, kernel arguments, grid sizes, stream assignment (see stage_pass)
-struct StagedPass {
-    std::vector<int32_t> flat; std::vector<KernelArgs> args;
-    int nblk[ALD_NUM_CLASSES]; int order[ALD_NUM_CLASSES]; int stream_of[ALD_NUM_CLASSES]; int nord = 0; size_t tot = 0;
-};
-
-struct ald_batch {
-    int device = 0; int n_cus = 0;
-    Params prm;
-    HostBatch hb;
-    HostBatch::Section sec[HostBatch::S_COUNT];
-    uint64_t in_bytes = 0;
-    hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // the size classes run concurrently on a few side streams.  Not one per class: a process only gets a handful of hardware queues
-    // (4 by default) and streams beyond that share them in creation order, which can put the two heaviest classes behind each other
-    hipStream_t cstream[ALD_SIDE_STREAMS] = {};
-    hipEvent_t cdone[ALD_NUM_CLASSES] = {};
-    PinBuf pin_in, pin_out;
-    DevBuf d_in, d_status, d_npaths, d_niters, d_pool, d_poolused, d_trace_n, d_trace_codes, d_trace_vals, d_work, d_counter, d_args;
-    DevBuf d_slabs[ALD_NUM_CLASSES];
-    int blocks[ALD_NUM_CLASSES] = {};
-    int occ[ALD_NUM_CLASSES]; ald_batch() { for(int c = 0; c < ALD_NUM_CLASSES; c++) occ[c] = -1; }
-    StagedPass *pass0 = nullptr; bool pass0_on_device = false; std::vector<int32_t> cls0;      // first pass of the uploaded batch, staged at upload time
-    uint64_t pool_cap_words = 0;
-    int trace_cap = 0;
-    bool uploaded = false, ran = false, downloaded = false;
-    double kernel_ms = -1;
-    // per-graph scheduling state
-    std::vector<int32_t> cls, attempt, status, n_paths, n_iters;
-    std::vector<int32_t> trace_n, trace_codes; std::vector<double> trace_vals;
-    HostResults res;
-    int passes = 0;
-    bool indexed = false;
-    const void *launched_slab[ALD_NUM_CLASSES] = {};      // test hook (ald_batch_debug_slab)
-    rvec<uint32_t> tstream;                                // last transcript stream built from this batch (ald_batch_transcript_stream)
-};
 
 namespace {
 
@@ -107,6 +55,11 @@ int ensure_index(const ald_batch *cb)
     b->indexed = true;
     return ALD_OK;
 }
+
+} // namespace
+int ald_ensure_index(const ald_batch *b) { return ensure_index(b); }
+int ald_set_err(int code, const std::string &msg) { return set_err(code, msg); }
+namespace {
 
 int occupancy_for(ald_batch *b, int c)
 {

@@ -36,6 +36,40 @@ class SynthSpec(C.Structure):
                 ("layout_mode", C.c_int32)]
 
 
+_I, _D = C.c_int32, C.c_double
+FEATURE_FIELDS = [("gr_vertices", _I), ("gr_edges", _I), ("gr_reads", _I), ("gr_subgraph", _I), ("num_vertices", _I), ("num_edges", _I), ("junc_ratio", _D),
+                  ("max_mid_exon_len", _I), ("start_loss1", _D), ("start_loss2", _D), ("start_loss3", _D), ("end_loss1", _D), ("end_loss2", _D), ("end_loss3", _D),
+                  ("start_merged_loss", _D), ("end_merged_loss", _D), ("introns", _I), ("start_introns", _I), ("end_introns", _I), ("intron_ratio", _D),
+                  ("start_intron_ratio", _D), ("end_intron_ratio", _D), ("uni_junc", _I), ("seq_min_wt", _D), ("seq_min_cnt", _I), ("seq_min_abd", _D),
+                  ("seq_min_ratio", _D), ("seq_max_wt", _D), ("seq_max_cnt", _I), ("seq_max_abd", _D), ("seq_max_ratio", _D),
+                  ("unbridge_start_coming_count", _I), ("unbridge_start_coming_ratio", _D), ("unbridge_end_leaving_count", _I), ("unbridge_end_leaving_ratio", _D),
+                  ("start_cnt", _I), ("start_weight", _D), ("start_abd", _D), ("end_cnt", _I), ("end_weight", _D), ("end_abd", _D)]
+
+
+class TrstFeatures(C.Structure):
+    """ald_trst_features == transcript::TrstFeatures (gtf/transcript.h:60-104)"""
+    _fields_ = FEATURE_FIELDS
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in FEATURE_FIELDS}
+
+
+class GraphExtras(C.Structure):
+    """ald_graph_extras: what only the feature block reads (vertex_info's boundary / unbridged fields, splice_graph::reads / subgraph)"""
+    _fields_ = [("boundary_loss1", C.POINTER(_D)), ("boundary_loss2", C.POINTER(_D)), ("boundary_loss3", C.POINTER(_D)), ("boundary_merged_loss", C.POINTER(_D)),
+                ("unbridge_leaving_count", C.POINTER(_I)), ("unbridge_leaving_ratio", C.POINTER(_D)), ("unbridge_coming_count", C.POINTER(_I)),
+                ("unbridge_coming_ratio", C.POINTER(_D)), ("gr_reads", _I), ("gr_subgraph", _I)]
+
+    @classmethod
+    def from_arrays(cls, gr_reads=0, gr_subgraph=0, **arrays):
+        x = cls(); x.gr_reads = gr_reads; x.gr_subgraph = gr_subgraph; x._keep = []
+        for name, a in arrays.items():
+            t = dict(cls._fields_)[name]._type_
+            a = np.ascontiguousarray(a, np.int32 if t is _I else np.float64); x._keep.append(a)
+            setattr(x, name, a.ctypes.data_as(C.POINTER(t)))
+        return x
+
+
 class _ResultView(C.Structure):
     _fields_ = [("status", C.c_int32), ("num_paths", C.c_int32), ("num_iterations", C.c_int32), ("reserved", C.c_int32)]
 
@@ -73,6 +107,13 @@ def load_library():
     lib.ald_batch_transcript_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]
     lib.ald_tset_add_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64]
     lib.ald_batch_export_iterations.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ald_batch_features.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ald_gtf_format_transcript.restype = C.c_int64
+    lib.ald_gtf_format_transcript.argtypes = [C.c_char_p, C.c_int64] + [C.c_char_p] * 6 + [C.c_char, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_void_p]
+    lib.ald_gtf_format_features.restype = C.c_int64
+    lib.ald_gtf_format_features.argtypes = [C.c_char_p, C.c_int64, C.c_int32] + [C.c_char_p] * 3 + [C.c_double] * 4 + [C.c_int32] * 3 + [C.c_void_p]
+    lib.ald_transcript_id.restype = C.c_int64
+    lib.ald_transcript_id.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_int32]
     lib.ald_tset_export.argtypes = [C.c_void_p] * 19
     _LIB = lib
     return lib
@@ -201,6 +242,17 @@ class DecompBatch:
         _check(self._lib.ald_batch_export_iterations(self._h, C.c_void_p(out.ctypes.data)))
         return out[:self.n]
 
+    def features(self, graph: int, extras: Optional["GraphExtras"] = None):
+        """-> (features: list of TrstFeatures, complete: int32 array, rc): scallop::update_trst_features for every path of `graph`;
+        rc > 0 where the reference would have asserted."""
+        rv = _ResultView(); _check(self._lib.ald_batch_get_result(self._h, graph, C.byref(rv)))
+        k = max(rv.num_paths, 1)
+        f = (TrstFeatures * k)(); comp = np.zeros(k, np.int32)
+        rc = self._lib.ald_batch_features(self._h, graph, C.byref(extras) if extras is not None else None, C.byref(f), C.c_void_p(comp.ctypes.data))
+        if rc < 0:
+            _check(rc)
+        return [f[i] for i in range(rv.num_paths)], comp[:rv.num_paths], rc
+
     def transcript_stream(self, sid=None, skip_single_exon: bool = False) -> np.ndarray:
         """Finished transcripts of the downloaded batch as one self-contained uint32 stream (copy): what ranks exchange in the
         multi-GPU gather and what TranscriptSink.add_stream merges."""
@@ -287,6 +339,30 @@ class TranscriptSink:
                             count1=int(c1[i]), count2=int(c2[i]), tid=int(tid[i]), exons=[(int(lr[2 * k]), int(lr[2 * k + 1])) for k in range(eo[i], eo[i + 1])],
                             samples=[dict(sid=int(ssid[k]), cov2=float(scov2[k]), conf=float(sconf[k]), abd=float(sabd[k]), count1=int(sc1[k])) for k in range(so[i], so[i + 1])]))
         return out
+
+
+def _two_pass(fn, *args) -> str:
+    n = fn(None, 0, *args)
+    buf = C.create_string_buffer(int(n) + 1)
+    fn(buf, int(n) + 1, *args)
+    return buf.value.decode()
+
+
+def format_transcript(seqname, source, gene_id, transcript_id, strand, coverage, exons, cov2=-1.0, count=-1, gene_type="", transcript_type="") -> str:
+    """transcript::write (gtf/transcript.cc:318-360): the GTF records of one transcript; exons = [(l, r), ...]"""
+    lr = np.ascontiguousarray(np.array(exons, np.int32).reshape(-1))
+    return _two_pass(load_library().ald_gtf_format_transcript, seqname.encode(), source.encode(), gene_id.encode(), transcript_id.encode(), gene_type.encode(),
+                     transcript_type.encode(), strand.encode(), float(coverage), float(cov2), int(count), len(exons), C.c_void_p(lr.ctypes.data) if len(exons) else None)
+
+
+def format_features(transcript_id, meta_tid, seqname, coverage, cov2, abd, conf, count1, count2, n_exons, features: "TrstFeatures", fixed2=False) -> str:
+    """transcript::write_features (gtf/transcript.cc:362-494): one row of *.trstFeature.csv; fixed2 = the file form (2 decimals)"""
+    return _two_pass(load_library().ald_gtf_format_features, int(bool(fixed2)), transcript_id.encode(), meta_tid.encode(), seqname.encode(), float(coverage), float(cov2),
+                     float(abd), float(conf), int(count1), int(count2), int(n_exons), C.byref(features))
+
+
+def transcript_id(chrm: str, gid: str, path_index: int) -> str:
+    return _two_pass(load_library().ald_transcript_id, chrm.encode(), gid.encode(), int(path_index))
 
 
 def records_add_graph_offset(words: np.ndarray, graph_offset: int):

@@ -168,7 +168,7 @@ int  ald_batch_export(const ald_batch *b, int64_t *total_paths, int64_t *total_p
 /* ---- transcripts (replaces scallop::build_transcripts -> build_transcript, scallop.cc:3250-3266, rnacore/essential.cc:719-748) ----
  * One transcript per path: exons = the path's internal vertices' [lpos, rpos) intervals with touching intervals joined (the
  * reference's Boost.ICL join_interval_map), coverage = log(1 + path.weight).  The ML feature block of update_trst_features
- * (scallop.cc:3268-3451) is NOT produced here. */
+ * (scallop.cc:3268-3451) comes from ald_batch_features below. */
 typedef struct ald_transcript_view {
     int32_t        num_exons;
     const int32_t *exons;          /* 2 * num_exons values: l0, r0, l1, r1, ...; valid until the next call on this thread */
@@ -180,6 +180,54 @@ typedef struct ald_transcript_view {
 int  ald_batch_get_transcript(const ald_batch *b, int32_t graph, int32_t path, ald_transcript_view *out);
 /* bulk: coverage[total_paths], exon_offset[total_paths+1], exon_lr[2*total_exons]; pass NULL arrays to query *total_exons */
 int  ald_batch_export_transcripts(const ald_batch *b, int64_t *total_exons, double *coverage, int64_t *exon_offset, int32_t *exon_lr);
+
+/* ---- transcript features (replaces scallop::update_trst_features, scallop.cc:3268-3451, and unique_junc, :3472-3497) ----
+ * Host side, read from the ORIGINAL graph as staged (the reference's gr_ori copy, scallop.cc:42,179) and the graph's path set.
+ * Fields and order are transcript::TrstFeatures (gtf/transcript.h:60-104). */
+typedef struct ald_trst_features {
+    int32_t gr_vertices, gr_edges, gr_reads, gr_subgraph;
+    int32_t num_vertices, num_edges;
+    double  junc_ratio;
+    int32_t max_mid_exon_len;
+    double  start_loss1, start_loss2, start_loss3, end_loss1, end_loss2, end_loss3, start_merged_loss, end_merged_loss;
+    int32_t introns, start_introns, end_introns;
+    double  intron_ratio, start_intron_ratio, end_intron_ratio;
+    int32_t uni_junc;
+    double  seq_min_wt; int32_t seq_min_cnt; double seq_min_abd, seq_min_ratio;
+    double  seq_max_wt; int32_t seq_max_cnt; double seq_max_abd, seq_max_ratio;
+    int32_t unbridge_start_coming_count; double unbridge_start_coming_ratio;
+    int32_t unbridge_end_leaving_count;  double unbridge_end_leaving_ratio;
+    int32_t start_cnt; double start_weight, start_abd;
+    int32_t end_cnt;   double end_weight, end_abd;
+} ald_trst_features;
+/* what the features read beyond the decomposition's own inputs: vertex_info's boundary / unbridged-read fields (rnacore/vertex_info.h:35-42)
+ * and splice_graph::reads / subgraph; every array is [V] of the graph and may be NULL (= zeros) */
+typedef struct ald_graph_extras {
+    const double  *boundary_loss1, *boundary_loss2, *boundary_loss3, *boundary_merged_loss;
+    const int32_t *unbridge_leaving_count; const double *unbridge_leaving_ratio;
+    const int32_t *unbridge_coming_count;  const double *unbridge_coming_ratio;
+    int32_t gr_reads, gr_subgraph;
+} ald_graph_extras;
+/* features[k] for every path k of `graph` (ald_batch_get_result(...).num_paths entries); complete[k] = 1 when every field was set, 0 for a
+ * path without a junction (single exon): the reference leaves all but the first seven fields of such a transcript indeterminate (it
+ * never writes them: incubator.cc:781,813), here they are zero.  Returns ALD_OK, or ALD_ST_INVARIANT + ALD_INV_OTHER (> 0) where the
+ * reference would have hit one of the asserts of update_trst_features (an edge it looks up does not exist in the original graph). */
+int  ald_batch_features(const ald_batch *b, int32_t graph, const ald_graph_extras *extras, ald_trst_features *features, int32_t *complete);
+
+/* ---- GTF / feature-table writers (replace transcript::write, gtf/transcript.cc:318-360, and transcript::write_features, :362-494) ----
+ * snprintf-style: write at most cap bytes (NUL-terminated when cap > 0), return the number of bytes the full text needs.
+ * Byte for byte what the reference's writers put on their streams (pinned: oracle/_ref/ref_gtf, tests/golden/ref_gtf.json). */
+int64_t ald_gtf_format_transcript(char *buf, int64_t cap, const char *seqname, const char *source, const char *gene_id, const char *transcript_id,
+                                  const char *gene_type /* "" or NULL: omitted */, const char *transcript_type, char strand,
+                                  double coverage, double cov2 /* < -0.5: omitted */, int32_t count /* < 0: omitted */,
+                                  int32_t n_exons, const int32_t *exon_lr);
+/* one row of *.trstFeature.csv; fixed2 = 0: the stream form (default ostream state, 6 significant digits: incubator.cc:781),
+ * fixed2 = 1: the file form (fixed, 2 decimals: transcript.cc:430-434, incubator.cc:813) */
+int64_t ald_gtf_format_features(char *buf, int64_t cap, int32_t fixed2, const char *transcript_id, const char *meta_tid, const char *seqname,
+                                double coverage, double cov2, double abd, double conf, int32_t count1, int32_t count2, int32_t n_exons,
+                                const ald_trst_features *f);
+/* "chr<chrm>.<gid>.<path index>" (scallop.cc:3258) */
+int64_t ald_transcript_id(char *buf, int64_t cap, const char *chrm, const char *gid, int32_t path_index);
 
 /* ---- result sink (replaces transcript_set::add / trans_item::merge, rnacore/transcript_set.cc:38-175) ----
  * Host-side: hash-bucketed merge of transcripts across graphs / samples, as assembler::assemble does with `ts` / `tm`

@@ -21,6 +21,7 @@ struct GraphResult {
     std::vector<ora::Transcript> trsts;
     std::vector<ora::TraceEvent> trace;
     ora::Stats st;
+    int feature_assert = 0;
 };
 
 struct Packed {
@@ -30,6 +31,7 @@ struct Packed {
     const int32_t *edge_sample_offset, *sample_id; const double *sample_abd;
     const double *vertex_weight; const int32_t *vertex_lpos, *vertex_rpos, *vertex_type;
     const int32_t *phasing_offset, *phasing_vertex, *phasing_count; const char *graph_strand; const int32_t *edge_count, *edge_rank;
+    const ald_graph_extras *extras;            // [n] or null: what only the feature block reads
 };
 
 struct Offsets { int64_t v, vo, e, eo, s, p, po, pv; };
@@ -44,6 +46,16 @@ void run_one(const Packed &P, const Offsets &o, int g, const ora::Params &cfg, b
         gr.vwrt[i] = P.vertex_weight[o.v + i];
         gr.vinf[i].lpos = P.vertex_lpos[o.v + i]; gr.vinf[i].rpos = P.vertex_rpos[o.v + i];
         gr.vinf[i].type = P.vertex_type ? P.vertex_type[o.v + i] : -1;
+    }
+    if(P.extras) {
+        const ald_graph_extras &X = P.extras[g]; gr.reads = X.gr_reads; gr.subgraph = X.gr_subgraph;
+        for(int i = 0; i < V; i++) {
+            ora::VertexInfo &vi = gr.vinf[i];
+            if(X.boundary_loss1) vi.boundary_loss1 = X.boundary_loss1[i]; if(X.boundary_loss2) vi.boundary_loss2 = X.boundary_loss2[i]; if(X.boundary_loss3) vi.boundary_loss3 = X.boundary_loss3[i];
+            if(X.boundary_merged_loss) vi.boundary_merged_loss = X.boundary_merged_loss[i];
+            if(X.unbridge_leaving_count) vi.unbridge_leaving_count = X.unbridge_leaving_count[i]; if(X.unbridge_leaving_ratio) vi.unbridge_leaving_ratio = X.unbridge_leaving_ratio[i];
+            if(X.unbridge_coming_count) vi.unbridge_coming_count = X.unbridge_coming_count[i]; if(X.unbridge_coming_ratio) vi.unbridge_coming_ratio = X.unbridge_coming_ratio[i];
+        }
     }
     const int32_t *vo = P.vertex_offset + o.vo; const int32_t *so = P.edge_sample_offset + o.eo;
     // edges are created in the order of their creation rank (the reference's gr.edges() order: graph_base.cc:139-153 assigns the
@@ -75,7 +87,7 @@ void run_one(const Packed &P, const Offsets &o, int g, const ora::Params &cfg, b
         ora::Scallop sc(gr, hs, cfg);
         if(want_trace) sc.trace = &out.trace;
         sc.assemble();
-        out.paths = sc.paths; out.trsts = sc.trsts; out.st = sc.st; out.iterations = sc.st.iterations;
+        out.paths = sc.paths; out.trsts = sc.trsts; out.st = sc.st; out.iterations = sc.st.iterations; out.feature_assert = sc.feature_assert;
         if(sc.st.cut_short) out.status = ALD_ST_SKIPPED_LARGE;        // the loop left through `num_vertices() > max_num_exons` (scallop.cc:49), at the start or after growing
     } catch(const ora::AssertFail &a) {
         out.status = ALD_ST_INVARIANT + a.cls;
@@ -93,6 +105,9 @@ struct ora_result {
 
 extern "C" {
 
+static const ald_graph_extras *g_next_extras = nullptr;      // consumed by the next ora_run_packed (keeps the argument list shared with ald_batch_add_packed)
+void ora_set_extras(const ald_graph_extras *per_graph) { g_next_extras = per_graph; }
+
 int ora_run_packed(int32_t n,
                    const int32_t *g_nv, const int32_t *g_ne, const int32_t *g_np,
                    const int32_t *vertex_offset, const int32_t *edge_target,
@@ -105,7 +120,8 @@ int ora_run_packed(int32_t n,
                    const ald_params *prm, int32_t n_threads, int32_t want_trace, ora_result **out)
 {
     Packed P{n, g_nv, g_ne, g_np, vertex_offset, edge_target, edge_weight, edge_strand, edge_abd, edge_sample_offset, sample_id, sample_abd,
-             vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand, edge_count, edge_rank};
+             vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand, edge_count, edge_rank, g_next_extras};
+    g_next_extras = nullptr;
     ora::Params cfg;
     if(prm) {
         for(int i = 0; i < 8; i++) cfg.max_decompose_error_ratio[i] = prm->max_decompose_error_ratio[i];
@@ -182,6 +198,28 @@ int ora_result_export_transcripts(const ora_result *R, int64_t *total_exons, dou
     }
     exon_offset[it] = ie;
     return 0;
+}
+
+/* feature block of every transcript of one graph (scallop.cc:3268-3451); returns 0, or 1 when an assert of update_trst_features fired */
+int ora_result_features(const ora_result *R, int32_t graph, ald_trst_features *out, int32_t *complete)
+{
+    const GraphResult &G = R->gr[graph];
+    for(size_t k = 0; k < G.trsts.size(); k++) {
+        const ora::Features &f = G.trsts[k].features; ald_trst_features &o = out[k];
+        o.gr_vertices = f.gr_vertices; o.gr_edges = f.gr_edges; o.gr_reads = f.gr_reads; o.gr_subgraph = f.gr_subgraph; o.num_vertices = f.num_vertices; o.num_edges = f.num_edges;
+        o.junc_ratio = f.junc_ratio; o.max_mid_exon_len = f.max_mid_exon_len;
+        o.start_loss1 = f.start_loss1; o.start_loss2 = f.start_loss2; o.start_loss3 = f.start_loss3; o.end_loss1 = f.end_loss1; o.end_loss2 = f.end_loss2; o.end_loss3 = f.end_loss3;
+        o.start_merged_loss = f.start_merged_loss; o.end_merged_loss = f.end_merged_loss;
+        o.introns = f.introns; o.start_introns = f.start_introns; o.end_introns = f.end_introns; o.intron_ratio = f.intron_ratio; o.start_intron_ratio = f.start_intron_ratio; o.end_intron_ratio = f.end_intron_ratio;
+        o.uni_junc = f.uni_junc;
+        o.seq_min_wt = f.seq_min_wt; o.seq_min_cnt = f.seq_min_cnt; o.seq_min_abd = f.seq_min_abd; o.seq_min_ratio = f.seq_min_ratio;
+        o.seq_max_wt = f.seq_max_wt; o.seq_max_cnt = f.seq_max_cnt; o.seq_max_abd = f.seq_max_abd; o.seq_max_ratio = f.seq_max_ratio;
+        o.unbridge_start_coming_count = f.unbridge_start_coming_count; o.unbridge_start_coming_ratio = f.unbridge_start_coming_ratio;
+        o.unbridge_end_leaving_count = f.unbridge_end_leaving_count; o.unbridge_end_leaving_ratio = f.unbridge_end_leaving_ratio;
+        o.start_cnt = f.start_cnt; o.start_weight = f.start_weight; o.start_abd = f.start_abd; o.end_cnt = f.end_cnt; o.end_weight = f.end_weight; o.end_abd = f.end_abd;
+        if(complete) complete[k] = f.complete ? 1 : 0;
+    }
+    return G.feature_assert ? 1 : 0;
 }
 
 /* per-graph diagnostics: [max_live_edges, max_vertices, total_edge_ids, iterations, router_builds, max_mev] */

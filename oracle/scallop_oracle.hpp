@@ -67,7 +67,11 @@ struct EdgeInfo {                               // rnacore/edge_info.h:14-35 (fi
     std::map<int, double> spAbd;
 };
 
-struct VertexInfo { int32_t lpos = 0, rpos = 0; int type = -1; };  // rnacore/vertex_info.cc:10-33
+struct VertexInfo {                             // rnacore/vertex_info.h:20-42 (fields the path touches; the last eight only feed the feature block)
+    int32_t lpos = 0, rpos = 0; int type = -1;
+    double boundary_loss1 = 0, boundary_loss2 = 0, boundary_loss3 = 0, boundary_merged_loss = 0;
+    int unbridge_leaving_count = 0; double unbridge_leaving_ratio = 0; int unbridge_coming_count = 0; double unbridge_coming_ratio = 0;
+};
 
 typedef std::tuple<int, int, int> EKey;        // (source, target, creation id): graph/edge_base.h:35-45
 
@@ -83,6 +87,7 @@ struct Graph {
     std::vector<double> vwrt;
     std::vector<VertexInfo> vinf;
     char strand = '.';
+    int reads = 0, subgraph = 0;               // splice_graph::reads / subgraph (feature block only)
 
     int num_vertices() const { return (int)si.size(); }
     int num_edges() const { return (int)se.size(); }
@@ -573,9 +578,19 @@ struct Path {                                   // rnacore/path.h
     std::vector<int> v; std::vector<std::pair<int, int>> junc;
     int length = 0; double abd = 0, weight = 0, conf = 0, reads = 0; char strand = '.'; int count = 0;
 };
+struct Features {                               // transcript::TrstFeatures (gtf/transcript.h:60-104), same order
+    int gr_vertices = 0, gr_edges = 0, gr_reads = 0, gr_subgraph = 0, num_vertices = 0, num_edges = 0; double junc_ratio = 0; int max_mid_exon_len = 0;
+    double start_loss1 = 0, start_loss2 = 0, start_loss3 = 0, end_loss1 = 0, end_loss2 = 0, end_loss3 = 0, start_merged_loss = 0, end_merged_loss = 0;
+    int introns = 0, start_introns = 0, end_introns = 0; double intron_ratio = 0, start_intron_ratio = 0, end_intron_ratio = 0; int uni_junc = 0;
+    double seq_min_wt = 0; int seq_min_cnt = 0; double seq_min_abd = 0, seq_min_ratio = 0, seq_max_wt = 0; int seq_max_cnt = 0; double seq_max_abd = 0, seq_max_ratio = 0;
+    int unbridge_start_coming_count = 0; double unbridge_start_coming_ratio = 0; int unbridge_end_leaving_count = 0; double unbridge_end_leaving_ratio = 0;
+    int start_cnt = 0; double start_weight = 0, start_abd = 0; int end_cnt = 0; double end_weight = 0, end_abd = 0;
+    bool complete = false;                      // false: the reference returned early (no junction) and left the rest indeterminate
+};
 struct Transcript {                             // the fields build_transcript fills (essential.cc:719-748)
     double coverage = 0, conf = 0, abd = 0; int count1 = 0; char strand = '.';
     std::vector<std::pair<int32_t, int32_t>> exons;
+    Features features;
 };
 struct TraceEvent { int code, a, b; double val; };
 enum { OP_BROKEN = 1, OP_TRIVIAL_FAST = 2, OP_TRIVIAL_NOW = 3, OP_TRIVIAL_BEST = 4, OP_SMALL_NOW = 5, OP_SMALLEST = 6,
@@ -593,6 +608,7 @@ struct Scallop {
     std::vector<Path> paths; std::vector<Transcript> trsts;
     std::vector<TraceEvent> *trace = nullptr; Stats st;
     Graph gr_ori;
+    int feature_assert = 0;                     // line of the first assert update_trst_features would have hit (0: none); the paths stand either way
 
     Scallop(Graph &g, HyperSet &h, const Params &c) : cfg(c), gr(g), hs(h) {       // scallop.cc:19-32
         hs.build(gr);
@@ -1029,10 +1045,81 @@ struct Scallop {
             track();
         }
     }
-    void build_transcripts() {                  // scallop.cc:3250-3266 + essential.cc:719-748 (exon join; features are out of round-1 scope)
+    // scallop::unique_junc (scallop.cc:3472-3497)
+    int unique_junc(int i) const {
+        std::map<std::pair<int, int>, int> juncUni;
+        for(size_t idx = 0; idx < paths.size(); ++idx) for(const auto &pr : paths[idx].junc) {
+            if(juncUni.find(pr) == juncUni.end()) juncUni[pr] = (int)idx;
+            else if(juncUni[pr] != (int)idx && juncUni[pr] != -1) juncUni[pr] = -1;
+        }
+        int uniqueCount = 0;
+        for(const auto &pr : paths[i].junc) if(juncUni.find(pr) != juncUni.end() && juncUni[pr] == i) uniqueCount++;
+        return uniqueCount;
+    }
+    // scallop::update_trst_features (scallop.cc:3268-3451) on the pre-decomposition copy of the graph
+    void update_trst_features(const Graph &g, Features &f, int pid) {
+        const Path &p = paths[pid];
+        int n = (int)p.v.size();
+        ORA_ASSERT(INV_OTHER, n >= 3);
+        f.num_vertices = n - 2; f.num_edges = n - 3; f.gr_vertices = g.num_vertices(); f.gr_edges = g.num_edges(); f.gr_reads = g.reads; f.gr_subgraph = g.subgraph;
+        f.max_mid_exon_len = 0;
+        int junc = (int)p.junc.size();
+        if(junc == 0) return;                   // ignore single exon
+        int start_splicing_v = p.junc.front().first, end_splicing_v = p.junc.back().second;
+        auto it_s = std::lower_bound(p.v.begin(), p.v.end(), start_splicing_v), it_t = std::lower_bound(p.v.begin(), p.v.end(), end_splicing_v);
+        ORA_ASSERT(INV_OTHER, !(it_s == p.v.end() || *it_s != start_splicing_v || it_t == p.v.end() || *it_t != end_splicing_v));
+        f.junc_ratio = 1.0 * junc / (it_t - it_s);
+        for(int i = 1; i < junc; i++) { int exon_len = g.vinf[p.junc[i].first].rpos - g.vinf[p.junc[i - 1].second].lpos; f.max_mid_exon_len = std::max(f.max_mid_exon_len, exon_len); }
+        const VertexInfo &svi = g.vinf[p.v[1]], &evi = g.vinf[p.v[n - 2]];
+        f.start_loss1 = svi.boundary_loss1; f.start_loss2 = svi.boundary_loss2; f.start_loss3 = svi.boundary_loss3;
+        f.end_loss1 = evi.boundary_loss1; f.end_loss2 = evi.boundary_loss2; f.end_loss3 = evi.boundary_loss3;
+        f.start_merged_loss = svi.boundary_merged_loss; f.end_merged_loss = evi.boundary_merged_loss;
+        f.uni_junc = unique_junc(pid);
+        auto ratio = [&](int v1, int v2) {      // the three edge lookups the reference asserts on, then junction weight / smaller flank
+            int e = g.edge(v1, v2), e1 = g.edge(v1, v1 + 1), e2 = g.edge(v2 - 1, v2);
+            ORA_ASSERT(INV_OTHER, e >= 0); ORA_ASSERT(INV_OTHER, e1 >= 0); ORA_ASSERT(INV_OTHER, e2 >= 0);
+            return g.ewrt[e] / std::min(g.ewrt[e1], g.ewrt[e2]);
+        };
+        for(int o = 0; o < (int)paths.size(); o++) {
+            if(o == pid) continue;
+            const std::vector<std::pair<int, int>> &junc1 = p.junc, junc2 = paths[o].junc;
+            if(junc1.size() < 2 || junc2.size() < 1) continue;
+            int intron_cnt = 0, start_intron = 0, end_intron = 0;
+            for(size_t i = 0; i < junc1.size(); ++i) for(size_t j = 0; j < junc2.size(); ++j) {
+                if(i == 0) {
+                    if(junc2[j].first >= p.v[1] && junc2[j].second <= junc1[0].first) { start_intron++; f.start_intron_ratio = std::max(f.start_intron_ratio, ratio(junc2[j].first, junc2[j].second)); }
+                }
+                else if(junc2[j].second <= junc1[i].first && junc2[j].first >= junc1[i - 1].second) { intron_cnt++; f.intron_ratio = std::max(f.intron_ratio, ratio(junc2[j].first, junc2[j].second)); }
+                if(i == junc1.size() - 1) {
+                    if(junc2[j].first >= junc1[i].second && junc2[j].second <= p.v[n - 2]) { end_intron++; f.end_intron_ratio = std::max(f.end_intron_ratio, ratio(junc2[j].first, junc2[j].second)); }
+                }
+            }
+            f.introns = std::max(f.introns, intron_cnt); f.start_introns = std::max(f.start_introns, start_intron); f.end_introns = std::max(f.end_introns, end_intron);
+        }
+        f.seq_min_wt = DBL_MAX; f.seq_min_cnt = INT_MAX; f.seq_min_abd = DBL_MAX; f.seq_min_ratio = 1.0;
+        f.seq_max_wt = 0; f.seq_max_cnt = 0; f.seq_max_abd = 0; f.seq_max_ratio = 0;
+        for(int i = 1; i < n; i++) {
+            int v1 = p.v[i - 1], v2 = p.v[i];
+            int e = g.edge(v1, v2);
+            ORA_ASSERT(INV_OTHER, e >= 0);
+            const EdgeInfo &ei = g.einf[e]; const VertexInfo &vi2 = g.vinf[v2];
+            double w = g.ewrt[e], r = w / std::max(g.get_in_weights(v2), g.get_out_weights(v1));
+            f.seq_min_wt = std::min(f.seq_min_wt, w); f.seq_min_cnt = std::min(f.seq_min_cnt, ei.count); f.seq_min_abd = std::min(f.seq_min_abd, ei.abd); f.seq_min_ratio = std::min(f.seq_min_ratio, r);
+            f.seq_max_wt = std::max(f.seq_max_wt, w); f.seq_max_cnt = std::max(f.seq_max_cnt, ei.count); f.seq_max_abd = std::max(f.seq_max_abd, ei.abd); f.seq_max_ratio = std::max(f.seq_max_ratio, r);
+            if(i == 1) { f.unbridge_start_coming_count = vi2.unbridge_coming_count; f.unbridge_start_coming_ratio = vi2.unbridge_coming_ratio; f.start_cnt = ei.count; f.start_weight = w; f.start_abd = ei.abd; }
+            else if(i == n - 2) { f.unbridge_end_leaving_count = vi2.unbridge_leaving_count; f.unbridge_end_leaving_ratio = vi2.unbridge_leaving_ratio; }
+            else if(i == n - 1) { f.end_cnt = ei.count; f.end_weight = w; f.end_abd = ei.abd; }
+        }
+        f.complete = true;
+    }
+    void build_transcripts() {                  // scallop.cc:3250-3266 + essential.cc:719-748 (features first, then the exon join)
         trsts.clear();
-        for(const Path &p : paths) {
+        for(size_t pi = 0; pi < paths.size(); pi++) {
+            const Path &p = paths[pi];
             Transcript t;
+            // the reference would abort on an assert in here; the oracle records it and keeps the decomposition (the product computes
+            // the features in a separate, optional call)
+            try { update_trst_features(gr_ori, t.features, (int)pi); } catch(const AssertFail &a) { if(!feature_assert) feature_assert = a.line; }
             t.coverage = log(1.0 + p.weight); t.strand = p.strand; t.conf = p.conf; t.abd = p.abd; t.count1 = p.count;
             // join_interval_map: add [lpos,rpos) with value 1; touching equal-valued intervals join, empty intervals vanish
             for(size_t k = 1; k + 1 < p.v.size(); k++) {

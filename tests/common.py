@@ -172,3 +172,27 @@ def transcript_stream_from_result(pg: PackedGraphs, res: DecompResult, sid=None,
             hdr[6:12] = np.array([res.weight[p], res.conf[p], res.abd[p]], np.float64).view(np.uint32)
             out.append(hdr); out.append(np.array(ex, np.int32).view(np.uint32))
     return np.concatenate(out) if out else np.zeros(0, np.uint32)
+
+
+def oracle_features(pg: PackedGraphs, extras=None):
+    """scallop::update_trst_features restated in the oracle (unpinned: scallop.cc needs Boost/htslib to build) ->
+    per graph (list of feature dicts, complete flags, asserted?); extras: list of aletsch_amd.GraphExtras, one per graph, or None"""
+    from aletsch_amd.native import TrstFeatures, GraphExtras
+    O = oracle_lib()
+    arr = None
+    if extras is not None:
+        arr = (GraphExtras * pg.n)()
+        for g, x in enumerate(extras):
+            C.memmove(C.byref(arr[g]), C.byref(x), C.sizeof(GraphExtras))
+        O.ora_set_extras(arr)
+    h = C.c_void_p()
+    assert O.ora_run_packed(*pg.c_args(), None, C.c_int32(1), C.c_int32(0), C.byref(h)) == 0
+    r = export_via(O.ora_result_export, h, pg.n)
+    out = []
+    for g in range(pg.n):
+        k = int(r.path_offset[g + 1] - r.path_offset[g])
+        f = (TrstFeatures * max(k, 1))(); comp = np.zeros(max(k, 1), np.int32)
+        bad = O.ora_result_features(h, g, C.byref(f), C.c_void_p(comp.ctypes.data))
+        out.append(([f[i].as_dict() for i in range(k)], comp[:k].copy(), bool(bad)))
+    O.ora_result_free(h)
+    return r, out

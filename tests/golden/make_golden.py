@@ -11,7 +11,12 @@
   ref_tset.json       transcript groups + the merged set produced by oracle/_ref/ref_tset (the REFERENCE's
                       rnacore/transcript_set.cc + gtf/transcript.cc)  -> pins the result sink (ald_tset_*)
 
+  ref_gtf.json        transcripts (+ feature blocks) and the bytes the REFERENCE's writers emit for them: transcript::write,
+                      write_features(ostream), write_features(int) (gtf/transcript.cc:318-494, oracle/_ref/ref_gtf)
+                      -> pins ald_gtf_format_transcript / ald_gtf_format_features
+
 Needs /root/reference (for the _ref binaries); run from the repo root:  python tests/golden/make_golden.py
+(`python tests/golden/make_golden.py gtf` regenerates ref_gtf.json only)
 """
 import json
 import os
@@ -93,8 +98,74 @@ def tset_parse(out):
     return items
 
 
+FEATURE_ORDER = ["gr_vertices", "gr_edges", "gr_reads", "gr_subgraph", "num_vertices", "num_edges", "junc_ratio", "max_mid_exon_len", "start_loss1", "start_loss2",
+                 "start_loss3", "end_loss1", "end_loss2", "end_loss3", "start_merged_loss", "end_merged_loss", "introns", "start_introns", "end_introns", "intron_ratio",
+                 "start_intron_ratio", "end_intron_ratio", "uni_junc", "seq_min_wt", "seq_min_cnt", "seq_min_abd", "seq_min_ratio", "seq_max_wt", "seq_max_cnt",
+                 "seq_max_abd", "seq_max_ratio", "unbridge_start_coming_count", "unbridge_start_coming_ratio", "unbridge_end_leaving_count",
+                 "unbridge_end_leaving_ratio", "start_cnt", "start_weight", "start_abd", "end_cnt", "end_weight", "end_abd"]    # transcript.h:60-104
+INT_FEATURES = {"gr_vertices", "gr_edges", "gr_reads", "gr_subgraph", "num_vertices", "num_edges", "max_mid_exon_len", "introns", "start_introns", "end_introns", "uni_junc",
+                "seq_min_cnt", "seq_max_cnt", "unbridge_start_coming_count", "unbridge_end_leaving_count", "start_cnt", "end_cnt"}
+
+
+def gtf_cases(rng, n):
+    """transcripts with every kind of number the writers meet: rounding ties at 4 / 2 decimals, six-significant-digit switches to
+    exponent form, huge and tiny magnitudes, DBL_MAX / INT_MAX sentinels, zeros, omitted cov2 / count, optional gene / transcript types"""
+    def num():
+        k = rng.randrange(10)
+        if k == 0: return 0.0
+        if k == 1: return float(rng.randrange(1, 2000))
+        if k == 2: return rng.choice([0.00005, 0.00015, 0.12345, 0.123449999, 2.675, 1.005, 0.125, 0.375, 999999.5, 1234567.0, 0.000123456, 1e-7, 123456.5])
+        if k == 3: return 1.7976931348623157e308
+        if k == 4: return rng.uniform(0, 1)
+        if k == 5: return rng.uniform(0, 1e6)
+        if k == 6: return 10.0 ** rng.uniform(-9, 12)
+        return round(rng.uniform(0, 500), rng.randrange(0, 6))
+    cases = []
+    for t in range(n):
+        ne = rng.choice([1, 2, 2, 3, 5, 12]); x = rng.randrange(0, 3000000); ex = []
+        for _ in range(ne):
+            l = x + rng.randrange(1, 5000); r = l + rng.randrange(1, 3000); ex.append([l, r]); x = r
+        f = {k: (rng.choice([0, 1, 7, 2147483647, rng.randrange(0, 100000)]) if k in INT_FEATURES else num()) for k in FEATURE_ORDER}
+        c = dict(seqname=rng.choice(["1", "chr1", "X", "GL000194.1"]), source="aletsch", gene_id=rng.choice(["gene.12.0", "g", "bundle.7.3.0"]),
+                 transcript_id="chr1.gene.%d.%d" % (t, rng.randrange(40)), meta_tid=rng.choice(["chr1.m.%d" % t, "x"]),
+                 gene_type=rng.choice(["", "", "protein_coding"]), transcript_type=rng.choice(["", "", "lncRNA"]), strand=rng.choice("+-."),
+                 coverage=num(), cov2=num(), conf=num(), abd=num(), count1=rng.randrange(0, 50), count2=rng.randrange(0, 50),
+                 w_cov2=rng.choice([-1.0, -1.0, num()]), w_count=rng.choice([-1, -1, 0, rng.randrange(1, 60)]), exons=ex, features=f)
+        cases.append(c)
+    return cases
+
+
+def gtf_text(cases):
+    out = ["%d" % len(cases)]
+    e = lambda s: s if s else "-"
+    for c in cases:
+        out.append(" ".join([e(c["seqname"]), e(c["source"]), e(c["gene_id"]), e(c["transcript_id"]), e(c["meta_tid"]), e(c["gene_type"]), e(c["transcript_type"]), c["strand"],
+                             repr(c["coverage"]), repr(c["cov2"]), repr(c["conf"]), repr(c["abd"]), str(c["count1"]), str(c["count2"]), repr(c["w_cov2"]), str(c["w_count"]),
+                             str(len(c["exons"]))] + ["%d %d" % tuple(x) for x in c["exons"]]))
+        out.append(" ".join(repr(c["features"][k]) for k in FEATURE_ORDER))
+    return "\n".join(out) + "\n"
+
+
+def make_gtf():
+    import tempfile
+    rng = random.Random(318360)
+    cases = gtf_cases(rng, 120)
+    with tempfile.TemporaryDirectory() as tmp:
+        out = subprocess.run([os.path.join(ROOT, "oracle/_ref/ref_gtf"), tmp], input=gtf_text(cases), capture_output=True, text=True, check=True).stdout
+    blocks = out.split("@T\n")[1:]
+    assert len(blocks) == len(cases)
+    for c, b in zip(cases, blocks):
+        t, rest = b.split("@F\n"); f, g = rest.split("@G\n")
+        c["T"], c["F"], c["G"] = t, f, g
+    json.dump(cases, open(os.path.join(HERE, "ref_gtf.json"), "w"))
+    return len(cases)
+
+
 def main():
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
+    if len(sys.argv) > 1 and sys.argv[1] == "gtf":
+        print("ref_gtf.json:", make_gtf(), "transcripts")
+        return
     rng = random.Random(20250211)
     # ---- graph layer ----
     cases = []
@@ -125,6 +196,7 @@ def main():
         out = subprocess.run([os.path.join(ROOT, "oracle/_ref/ref_tset")], input=tset_text(groups), capture_output=True, text=True, check=True).stdout
         tcases.append({"groups": groups, "items": tset_parse(out)})
     json.dump(tcases, open(os.path.join(HERE, "ref_tset.json"), "w"))
+    make_gtf()
     # ---- oracle regression fixture ----
     import aletsch_amd as A
     import common

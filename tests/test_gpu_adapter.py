@@ -25,9 +25,25 @@ def build():
                     "-o", BIN, "-L" + lib, "-laletsch_decomp", "-Wl,-rpath," + lib], check=True)
 
 
+def shuffled_rank(one, shuffle_seed):
+    """creation rank of every CSR edge of a single-graph batch when the caller's gr.edges() lists the edges in the scrambled order of
+    graph_text(one, shuffle_seed): the adapter hands the position in gr.edges() over as edge_creation_rank"""
+    V, E = int(one.g_nv[0]), int(one.g_ne[0])
+    keys = [(s, int(one.edge_target[k])) for s in range(V) for k in range(one.vertex_offset[s], one.vertex_offset[s + 1])]
+    perm = np.random.default_rng(shuffle_seed).permutation(E)
+    slots = {}
+    for pos, k in enumerate(perm):
+        slots.setdefault(keys[k], []).append(pos)
+    rank = np.zeros(E, np.int32); nxt = {}
+    for k in range(E):
+        j = nxt.get(keys[k], 0); nxt[keys[k]] = j + 1
+        rank[k] = slots[keys[k]][j]
+    return rank
+
+
 def graph_text(one, shuffle_seed=None):
-    """a single-graph batch in adapter_test's stdin format; edges optionally in scrambled order (the adapter must restore the
-    canonical (source, target, position in gr.edges()) order itself)"""
+    """a single-graph batch in adapter_test's stdin format; edges optionally in scrambled order: the adapter lays them out as CSR by
+    (source, target, position in gr.edges()) and hands the position in gr.edges() over as the creation rank (= scallop's edge index)"""
     V, E, P = int(one.g_nv[0]), int(one.g_ne[0]), int(one.g_np[0])
     lines = ["%d %d %d" % (V, E, P)]
     for i in range(V):
@@ -62,11 +78,17 @@ def test_adapter_matches_abi_and_oracle(cfg):
     want = common.oracle_run(pg)[0]
     got = A.decompose(pg, device=0)
     assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
+    whole = want
     for g in range(pg.n):
         for seed in (None, 5):
-            out = subprocess.run([BIN], input=graph_text(pg.select(np.array([g])), seed), capture_output=True, text=True, check=True).stdout.splitlines()
-            head = out[0].split(); assert head[0] == "status" and int(head[1]) == int(want.status[g])
-            a, b = int(want.path_offset[g]), int(want.path_offset[g + 1])
+            one = pg.select(np.array([g]))
+            out = subprocess.run([BIN], input=graph_text(one, seed), capture_output=True, text=True, check=True).stdout.splitlines()
+            if seed is None:
+                want = whole; gg = g
+            else:                                   # a caller whose gr.edges() iterates in another order: the ids differ, and so may the paths
+                one.edge_rank = shuffled_rank(one, seed); want = common.oracle_run(one)[0]; gg = 0
+            head = out[0].split(); assert head[0] == "status" and int(head[1]) == int(want.status[gg])
+            a, b = int(want.path_offset[gg]), int(want.path_offset[gg + 1])
             assert int(head[3]) == b - a
             for k, line in enumerate(out[1:]):
                 f, vs = line.split(" :"); f = f.split(); i = a + k
@@ -145,7 +167,11 @@ def test_batched_adapter_enqueue_flush_paths():
     build()
     pg = A.synth(seed=64, n_graphs=40, v_min=8, v_max=60, edges_per_vertex=3, phasing_per_graph=5, weight_mode=1)
     pg.sample_id[:] = 0; pg.sample_abd[:] = pg.edge_weight; pg.edge_abd[:] = pg.edge_weight
-    want = common.oracle_run(pg)[0]
+    from aletsch_amd.packed import PackedGraphs
+    ones = []
+    for g in range(pg.n):
+        one = pg.select(np.array([g])); one.edge_rank = shuffled_rank(one, 9) if g % 2 else one.identity_rank(); ones.append(one)
+    want = common.oracle_run(PackedGraphs.concat(ones))[0]
     text = "".join(graph_text(pg.select(np.array([g])), 9 if g % 2 else None) for g in range(pg.n))
     out = subprocess.run([BIN, "batch", str(pg.n)], input=text, capture_output=True, text=True, check=True).stdout.splitlines()
     pos = 0

@@ -504,3 +504,46 @@ def test_transcript_stream_and_its_merge():
     from aletsch_amd.distributed import merge_streams
     two = merge_streams(A.TranscriptSink(0.8), parts, tid_base=7 << 44)
     assert two.items() == direct.items()
+
+
+def test_transcript_features_match_oracle():
+    """ald_batch_features = scallop::update_trst_features + unique_junc (scallop.cc:3268-3497) read from the staged (original) graph:
+    every one of the 41 fields of every transcript equals the oracle's container-based restatement bit for bit; single-exon paths are
+    flagged incomplete on both sides; where the reference would have asserted (an intron of another path inside an exon whose
+    flanking within-exon edges do not exist) both sides say so.  layout_mode=1 makes consecutive vertices touch, so exons span
+    several vertices and retained introns do occur."""
+    pg = A.synth(seed=52, n_graphs=300, v_min=8, v_max=70, edges_per_vertex=3, layout_mode=1, weight_mode=2, phasing_per_graph=3, n_samples=3)
+    rng = np.random.default_rng(3)
+    pg.edge_count = (pg.sample_counts() + rng.integers(0, 3, pg.edge_target.size)).astype(np.int32)
+    extras = []
+    for V in pg.g_nv:
+        V = int(V)
+        extras.append(A.GraphExtras.from_arrays(gr_reads=int(rng.integers(1, 10000)), gr_subgraph=int(rng.integers(0, 4)),
+                                                boundary_loss1=rng.random(V), boundary_loss2=rng.random(V), boundary_loss3=rng.random(V), boundary_merged_loss=rng.random(V),
+                                                unbridge_leaving_count=rng.integers(0, 9, V), unbridge_leaving_ratio=rng.random(V),
+                                                unbridge_coming_count=rng.integers(0, 9, V), unbridge_coming_ratio=rng.random(V)))
+    want_r, want = common.oracle_features(pg, extras)
+    n_complete = n_single = n_assert = n_intron = 0
+    with A.DecompBatch(0) as b:
+        b.add(pg); b.upload(); b.run(); b.download()
+        assert not common.compare_results(want_r, b.result(), pg.n, conf_tol=1e-9)
+        for g in range(pg.n):
+            feats, comp, rc = b.features(g, extras[g])
+            wf, wc, wbad = want[g]
+            assert (rc != 0) == wbad, (g, rc, wbad)
+            if wbad:
+                n_assert += 1; continue                     # the reference would have aborted here: partial values mean nothing
+            assert np.array_equal(comp, wc), g
+            for k, f in enumerate(feats):
+                d = f.as_dict()
+                if comp[k]:
+                    assert d == wf[k], (g, k, {x: (d[x], wf[k][x]) for x in d if d[x] != wf[k][x]})
+                    n_complete += 1; n_intron += int(d["introns"] + d["start_introns"] + d["end_introns"] > 0)
+                else:                                        # no junction: only the graph / path counts are defined
+                    for x in ("gr_vertices", "gr_edges", "gr_reads", "gr_subgraph", "num_vertices", "num_edges", "max_mid_exon_len"):
+                        assert d[x] == wf[k][x]
+                    n_single += 1
+        # without extras the boundary / unbridged fields read as zero
+        f0, _, _ = b.features(0)
+        assert all(f.start_loss1 == 0 and f.gr_reads == 0 for f in f0)
+    assert n_complete > 500 and n_single > 0 and n_intron > 0, (n_complete, n_single, n_assert, n_intron)
