@@ -1023,7 +1023,7 @@ ALD_INL int eval_smallest(int i, double &r)
 
 // ---------------------------------------------------------------- wave-level sweeps
 // scallop::resolve_broken_vertex (scallop.cc:190-236)
-ALD_FN bool resolve_broken_vertex()
+ALD_INL bool resolve_broken_vertex()
 {
     if(!uni(H.maybe_broken)) return false;
     const int lane = lane_id();
@@ -1105,7 +1105,7 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
     wsync();
     return code;
 }
-ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
+ALD_INL bool sweep_trivial(int mode, int type, double jump_ratio)
 {
     mode = uni(mode); type = uni(type); jump_ratio = uni(jump_ratio);
     const int lane = lane_id();
@@ -1163,7 +1163,7 @@ ALD_FN bool sweep_trivial(int mode, int type, double jump_ratio)
 // only change with hs_dirty), so after a removal just those two lanes evaluate again.  And while nothing else can fire -- no
 // broken vertex, no type-1 trivial vertex, phasing flags untouched: exactly what R1..R3 would find out -- the next sweep of the
 // reference's outer loop (scallop.cc:38-188) starts right here instead of going back through the cascade.
-ALD_FN bool sweep_smallest(double max_ratio)
+ALD_INL bool sweep_smallest(double max_ratio)
 {
     max_ratio = uni(max_ratio);
     const int lane = lane_id();
@@ -1506,7 +1506,7 @@ ALD_FN void restore_pairs(int n)
     for(int i = 0; i < n; i++) { D.a[i] = S.a[i]; D.b[i] = S.b[i]; D.w[i] = S.w[i]; }
 }
 // scallop::resolve_unsplittable_vertex (scallop.cc:1004-1060)
-ALD_FN bool sweep_unsplittable(int type, int degree, double max_ratio)
+ALD_INL bool sweep_unsplittable(int type, int degree, double max_ratio)
 {
 #ifdef ALD_EMU_COUNT
     g_cnt_unsweep++;
@@ -1630,7 +1630,7 @@ ALD_FN void materialize_special()
 // scallop::collect_existing_st_paths (scallop.cc:2742-2752): ascending edge index == ascending creation id.
 // out(0) / in(sink) are not linked at this point (see link_out): the source->sink edges are picked out of the slot array by the
 // whole wave and ordered by id on lane 0; collect_path's remove_edge then only counts.  Called by ALL lanes.
-ALD_FN void collect_existing_st_paths()
+ALD_INL void collect_existing_st_paths()
 {
     COLD;
     const int lane = lane_id();
@@ -1730,7 +1730,7 @@ ALD_FN void greedy_decompose()
 }
 
 // ---------------------------------------------------------------- load: packed wire arrays -> working state (wave-parallel)
-ALD_FN bool load_graph()
+ALD_INL bool load_graph()
 {
     COLD;
     const int lane = lane_id();
@@ -1803,7 +1803,7 @@ ALD_FN bool load_graph()
     return H.status == 0;
 }
 
-ALD_FN void finish_graph()
+ALD_INL void finish_graph()
 {
     if(lane_id() == 0) {
         ALD_GLOBAL const KernelArgs *A = H.args; const int g = H.g;
@@ -1817,7 +1817,7 @@ ALD_FN void finish_graph()
 }
 
 // ---------------------------------------------------------------- scallop::assemble (scallop.cc:38-188)
-ALD_FN void run_graph()
+ALD_INL void run_graph()
 {
     PROF_DECL;
 #ifdef ALD_PROF
