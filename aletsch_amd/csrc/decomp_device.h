@@ -297,6 +297,45 @@ ALD_INL void relink_out(int v, int e, uint32_t kt)         // kt already mapped 
     if(pe < 0) H.out_head[v] = nxe; else H.ed[pe].lk.onx = nxe;
     if(ip < 0) { H.ed[e].lk.onx = uni(H.out_head[v]); H.out_head[v] = (IDX)e; } else { H.ed[e].lk.onx = uni(H.ed[ip].lk.onx); H.ed[ip].lk.onx = (IDX)e; }
 }
+// The same two moves for the lane-parallel star: every lane works on ITS OWN vertex / edge (distinct vertices -> disjoint lists), so
+// nothing here may be routed through the scalar unit.
+ALD_INL void relink_in_lane(int v, int e, uint32_t ks)
+{
+    if(v == H.sinkp && !H.special_linked) return;
+    int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
+    int guard = MAXE;
+    for(int cur = first_in(v); cur >= 0 && guard-- > 0; ) {
+        const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; const int nx = lk_next((uint32_t)((w >> 32) & 0xFFFF));
+        if(cur == e) { pe = last; seen = true; if(placed) break; }
+        else { if(!placed && (uint32_t)(w & 0xFFFF) > ks) { ip = last; placed = true; if(seen) break; } last = cur; }
+        cur = nx;
+    }
+    if(ALD_UNLIKELY(!seen)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
+    if(!placed) ip = last;
+    if(ip == pe) return;
+    const IDX nxe = H.ed[e].lk.inx;
+    if(pe < 0) H.in_head[v] = nxe; else H.ed[pe].lk.inx = nxe;
+    if(ip < 0) { H.ed[e].lk.inx = H.in_head[v]; H.in_head[v] = (IDX)e; } else { H.ed[e].lk.inx = H.ed[ip].lk.inx; H.ed[ip].lk.inx = (IDX)e; }
+}
+ALD_INL void relink_out_lane(int v, int e, uint32_t kt)    // kt already mapped by tkey()
+{
+    if(v == 0 && !H.special_linked) return;
+    const uint32_t sk = (uint32_t)H.sinkp;
+    int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
+    int guard = MAXE;
+    for(int cur = first_out(v); cur >= 0 && guard-- > 0; ) {
+        const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; const int nx = lk_next((uint32_t)(w >> 48));
+        if(cur == e) { pe = last; seen = true; if(placed) break; }
+        else { uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu; if(!placed && ct > kt) { ip = last; placed = true; if(seen) break; } last = cur; }
+        cur = nx;
+    }
+    if(ALD_UNLIKELY(!seen)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
+    if(!placed) ip = last;
+    if(ip == pe) return;
+    const IDX nxe = H.ed[e].lk.onx;
+    if(pe < 0) H.out_head[v] = nxe; else H.ed[pe].lk.onx = nxe;
+    if(ip < 0) { H.ed[e].lk.onx = H.out_head[v]; H.out_head[v] = (IDX)e; } else { H.ed[e].lk.onx = H.ed[ip].lk.onx; H.ed[ip].lk.onx = (IDX)e; }
+}
 ALD_INL int free_slots() { return uni(H.free_cnt) + (MAXE - uni(H.slot_hw)); }
 // directed_graph::add_edge (directed_graph.cc:38-48) + i2e.push_back: the new id is the largest
 ALD_INL int add_edge_i(int s, int t)
@@ -839,6 +878,241 @@ ALD_FN void decompose_trivial_vertex(int x)
 
 ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio);
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same decomposition (scallop.cc:2144-2167 -> 2486-2576, 2009-2142, 2394-2484, 2242-2378) executed by the WHOLE WAVE, one fan
+// edge per lane.  What the merges of one star depend on each other through is small and numeric:
+//   * what is left of c after every cut             -- a recurrence over the pair weights in creation-id order
+//   * the ids handed out                            -- a running count of the cuts
+//   * the weight of vertex x, reduced merge by merge -- a chain of multiply / divide / subtract
+//   * the sum of the not yet merged fan weights      -- per merge, over the fan in list order
+// Every lane replays the first two up to its own merge (a few arithmetic steps each), computes its own fan sum, ONE lane runs the
+// vertex-weight chain over the per-merge sums left in LDS, and then every lane finishes its own merged edge: the cold record (one
+// round of global loads and stores for the whole fan instead of one per merge), the new id / weight / endpoint, and its place in
+// the far list of ITS other endpoint (distinct vertices -> disjoint lists; a fan with two edges to the same vertex takes the
+// sequential walk).  Only the insertions into the ONE list all merged edges share (far's), the phasing-list edits and multi-sample
+// support intersections (pool allocation) stay sequential, in creation order.  Every floating-point operation is the one the
+// sequential form performs, on the same operands in the same order.  Called by ALL lanes; cross-lane values travel through the LDS
+// scratch (so the single-lane emulation runs the phases as loops).
+enum { SW_N = 128, SW_C, SW_FAR, SW_FAIL, SW_FAILQ, SW_SERIAL };          // context words in scr_i behind fe / ord / inv / oth (32 each)
+template<bool A> ALD_INL void star_wave_body(int x)
+{
+    COLD;
+    PROF_DECL;
+    const int lane = lane_id();
+    const double mw = H.p_min_w;
+    int32_t *fe = (int32_t*)H.scr_i, *ord = fe + STAR_MAX, *inv = fe + 2 * STAR_MAX, *oth = fe + 3 * STAR_MAX, *ctx = (int32_t*)H.scr_i;
+    double *fw = (double*)H.scr_d, *sq = fw + STAR_MAX;                  // pair weights (list order) / per merge: (sum, later r1), in merge order
+    double *dctx = fw + 2 * STAR_MAX;                                      // [0] = weight c starts with, [1] = vertex weight of x
+    // ---- phase 0 (lane 0): gather the fan, balance_vertex(x) on the gathered weights, pair weights -- as in the sequential form
+    if(lane == 0) {
+        const int c = A ? u_first_in(x) : u_first_out(x);
+        int n = 0; double wcen = H.ed[c].w; int bad = 0;
+        if(ALD_UNLIKELY(uni(!(wcen >= mw - kSMIN)))) bad = ALD_ST_INVARIANT + ALD_INV_WEIGHT;
+        double sfan0 = 0;
+        for(int e = A ? u_first_out(x) : u_first_in(x); e >= 0 && n < STAR_MAX; e = A ? u_next_out(e) : u_next_in(e)) {
+            double w2 = H.ed[e].w; if(ALD_UNLIKELY(uni(!(w2 >= mw - kSMIN)))) bad = ALD_ST_INVARIANT + ALD_INV_WEIGHT;
+            fe[n] = e; fw[n] = w2; sfan0 += w2; n++;
+        }
+        if(!bad) {
+            double scen0 = 0; scen0 += wcen;
+            const double w_in = A ? scen0 : sfan0, w_out = A ? sfan0 : scen0;
+            const double bw = sqrt(w_in * w_out);
+            const double r_in = bw / w_in, r_out = bw / w_out;
+            double m_cen = 0, m_fan = 0;
+            { double wy = wcen * (A ? r_in : r_out); if(wy < mw) { m_cen += mw - wy; wy = mw; } wcen = wy; }
+            for(int j = 0; j < n; j++) { double wy = fw[j] * (A ? r_out : r_in); if(wy < mw) { m_fan += mw - wy; wy = mw; } fw[j] = wy; }
+            const double m1 = A ? m_cen : m_fan, m2 = A ? m_fan : m_cen;
+            if(m1 > m2) { if(A) fw[0] = fw[0] + m1 - m2; else wcen = wcen + m1 - m2; }
+            else if(m1 < m2) { if(A) wcen = wcen + m2 - m1; else fw[0] = fw[0] + m2 - m1; }
+            const double wc = wcen;
+            for(int j = 0; j < n; j++) { double w2 = fw[j]; fw[j] = A ? (wc <= w2 ? wc : w2) : (w2 <= wc ? w2 : wc); }
+        }
+        ctx[SW_N] = n; ctx[SW_C] = c; ctx[SW_FAR] = A ? (int)uni(H.ed[c].lk.es) : (int)uni(H.ed[c].lk.et); ctx[SW_FAIL] = bad; ctx[SW_FAILQ] = -1; ctx[SW_SERIAL] = 0;
+    }
+    wsync();
+    const int n = uni(ctx[SW_N]), c = uni(ctx[SW_C]), far = uni(ctx[SW_FAR]);
+    if(uni(ctx[SW_FAIL])) { if(lane == 0) fail(ctx[SW_FAIL]); wsync(); return; }
+    PROF_ADD(PF_T_BALANCE);
+    // ---- phase 1 (lane j): rank of fan edge j by creation id -> ord (merge order) and its inverse
+    for(int j = lane; j < n; j += ALD_WAVE) {
+        const uint32_t id = H.eid[fe[j]]; int r = 0;
+        for(int k = 0; k < n; k++) r += ((uint32_t)H.eid[fe[k]] < id) ? 1 : 0;
+        ord[r] = j; inv[j] = r;
+    }
+    wsync();
+    // ---- phase 2 (lane 0): weight of c = sum of its pair weights in merge order; the fan edges take their pair weight
+    if(lane == 0) {
+        double mdc = 0; int bad = 0;
+        for(int q = 0; q < n; q++) { double w = fw[ord[q]]; if(ALD_UNLIKELY(!(w >= mw - kSMIN))) bad = ALD_ST_INVARIANT + ALD_INV_WEIGHT; mdc = (q == 0) ? w : mdc + w; }
+        dctx[0] = mdc; dctx[1] = C.vx[x].vw;
+        if(bad) ctx[SW_FAIL] = bad;
+    }
+    for(int j = lane; j < n; j += ALD_WAVE) H.ed[fe[j]].w = fw[j];
+    wsync();
+    if(uni(ctx[SW_FAIL])) { if(lane == 0) fail(ctx[SW_FAIL]); wsync(); return; }
+    PROF_ADD(PF_T_SETUP);
+    const int id0 = uni(H.next_id);
+    const double medc = C.ed[c].med, cc = C.ed[c].econf;
+    const int meic = uni(C.ed[c].mei), cntc = uni(C.ed[c].ecount), stc = uni(C.ed[c].estrand);
+    const uint32_t nsc = uni(C.ed[c].sp_len); const int idc = uni(C.ed[c].s0id); const double abc = C.ed[c].s0abd;
+    const int lt = uni(C.vx[x].lpos), rt = uni(C.vx[x].rpos), ov = uni(C.vx[x].v2v);
+    // what is left of c before merge q, whether merge q cuts a piece off, the id of its merged edge: replayed by lane q
+    #define SW_REPLAY(q_, wcur_, sc_, rem_, nid_, dead_) \
+        double wcur_ = dctx[0], rem_ = 0; bool sc_ = false, dead_ = false; int nid_ = id0; \
+        for(int qq = 0; qq <= (q_); qq++) { \
+            if(qq > 0) { if(!sc_) dead_ = true; wcur_ = rem_; nid_ += 1; } \
+            const double w2_ = fw[ord[qq]]; \
+            sc_ = !(fabs(wcur_ - w2_) <= kSMIN); \
+            rem_ = wcur_; if(sc_) { nid_ += 1; rem_ = wcur_ - w2_; if(rem_ <= mw) rem_ = mw; } \
+        }
+    // ---- phase 3 (lane q): the two weight sums around x at merge q, left in LDS for the vertex-weight chain
+    for(int q = lane; q < n; q += ALD_WAVE) {
+        SW_REPLAY(q, wcur, sc, rem, nid, dead);
+        const int j = ord[q]; const double ww = fw[j];
+        int bad = 0;
+        if(dead) bad = ALD_ST_INVARIANT + ALD_INV_OTHER;                      // the sequential form would be handed a dead edge here
+        else if(nid - (sc ? 1 : 0) >= 0xFFF0) bad = ALD_ST_CAPACITY;          // the id counter as merge q finds it
+        else if(!(cntc > 0 && C.ed[fe[j]].ecount > 0)) bad = ALD_ST_INVARIANT + ALD_INV_COUNT;
+        if(ALD_UNLIKELY(bad)) { ctx[SW_FAIL] = bad; }                          // (any failing lane: the graph is abandoned with one of the statuses the sequence would raise; see below)
+        double sfan = 0;
+        for(int k = 0; k < n; k++) if(inv[k] >= q) sfan += fw[k];             // not merged yet, list order
+        double sc_side = 0; sc_side += sc ? rem : wcur; if(sc) sc_side += ww;
+        sq[q] = A ? (sc_side + sfan) * 0.5 : (sfan + sc_side) * 0.5;
+        oth[q] = A ? (int)H.ed[fe[j]].lk.et : (int)H.ed[fe[j]].lk.es;
+    }
+    wsync();
+    // which failure the sequence meets first: the smallest q that has one
+    if(uni(ctx[SW_FAIL])) {
+        int code = 0;
+        if(lane == 0) {
+            double wcur = dctx[0]; int nid = id0; bool dead = false;
+            for(int q = 0; q < n && !code; q++) {
+                const double ww = fw[ord[q]]; const bool sc = !(fabs(wcur - ww) <= kSMIN);
+                if(dead) code = ALD_ST_INVARIANT + ALD_INV_OTHER;
+                else if(nid >= 0xFFF0) code = ALD_ST_CAPACITY;
+                else if(!(cntc > 0 && C.ed[fe[ord[q]]].ecount > 0)) code = ALD_ST_INVARIANT + ALD_INV_COUNT;
+                if(sc) { nid++; double rem = wcur - ww; if(rem <= mw) rem = mw; wcur = rem; } else dead = true;
+                nid++;
+            }
+            fail(code ? code : ctx[SW_FAIL]);
+        }
+        wsync();
+        return;
+    }
+    PROF_ADD(PF_T_MERGE_LOAD);
+    // ---- phase 4 (lane 0): the weight of x, merge by merge; sq[q] becomes r1 of merge q
+    if(lane == 0) {
+        double vwt = dctx[1], wcur = dctx[0]; bool sc = false;
+        for(int q = 0; q < n; q++) {
+            const double ww = fw[ord[q]];
+            sc = !(fabs(wcur - ww) <= kSMIN);                                     // split_edge(c, ww) cuts a piece off (scallop.cc:2433-2484)
+            const double wc0 = sc ? ww : wcur;
+            const double r1 = A ? vwt * (wc0 + ww) * 0.5 / sq[q] : vwt * (ww + wc0) * 0.5 / sq[q];
+            vwt = vwt - r1; sq[q] = r1;
+            if(sc) { double rem = wcur - ww; if(rem <= mw) rem = mw; wcur = rem; }
+        }
+        C.vx[x].vw = vwt;
+        ctx[SW_SERIAL] = sc ? 0 : 1;                                              // the last merge consumed c
+    }
+    wsync();
+    PROF_ADD(PF_T_MERGE_SUMS);
+    // ---- phase 5 (lane q): the merged edge takes over the fan edge's slot -- cold record, id, weight, endpoint, place in the far
+    // list of its other endpoint
+    bool dup = false;
+    for(int q = lane; q < n; q += ALD_WAVE) { const int o = oth[q]; for(int k = 0; k < q; k++) if(oth[k] == o) dup = true; }
+    const bool any_dup = wballot(dup) != 0;
+    bool multi = false;
+    for(int q = lane; q < n; q += ALD_WAVE) {
+        SW_REPLAY(q, wcur, sc, rem, nid, dead);
+        (void)rem; (void)dead;
+        const int j = ord[q], f = fe[j]; const double ww = fw[j];
+        const double wc0 = sc ? ww : wcur;
+        const double medc1 = sc ? medc * ww / wcur : medc;
+        const double r1 = sq[q];
+        const double medf = C.ed[f].med, cf = C.ed[f].econf;
+        const int meif = C.ed[f].mei, stf = C.ed[f].estrand;
+        const uint32_t nsf = C.ed[f].sp_len; const int idf = C.ed[f].s0id; const double abf = C.ed[f].s0abd;
+        if(nsc == 1 && nsf == 1) {
+            if(idf == idc) { const double xa = A ? abc : abf, ya = A ? abf : abc; const double mn = (ya < xa) ? ya : xa; C.ed[f].sp_off = 0; C.ed[f].ecount = 1; C.ed[f].eabd = 0.0 + mn; C.ed[f].s0abd = mn; }
+            else { C.ed[f].sp_off = 0; C.ed[f].sp_len = 0; C.ed[f].ecount = 0; C.ed[f].eabd = 0; C.ed[f].s0id = 0; C.ed[f].s0abd = 0; }
+        } else multi = true;                                                  // pool allocation: sequential, below
+        C.ed[f].econf = A ? cc + cf : cf + cc;
+        { const int sty = A ? stf : stc, stx = A ? stc : stf; C.ed[f].estrand = (uint8_t)(sty != 0 ? sty : stx); }
+        for(int k = 0; k < NW; k++) { uint64_t mk = C.ed[c].mask[k] | C.ed[f].mask[k]; if(ov >= 0 && (ov >> 6) == k) mk |= (1ull << (ov & 63)); C.ed[f].mask[k] = mk; }
+        const int mi = A ? rt - lt + meic + meif : rt - lt + meif + meic;
+        C.ed[f].med = A ? mi * r1 + medc1 + medf : mi * r1 + medf + medc1; C.ed[f].mei = mi;
+        H.eid[f] = (uint16_t)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
+        if(A) H.ed[f].lk.es = (IDX)far; else H.ed[f].lk.et = (IDX)far;
+        if(!any_dup) { if(A) relink_in_lane(oth[q], f, (uint32_t)far); else relink_out_lane(oth[q], f, tkey((uint32_t)far)); }
+    }
+    const bool any_multi = wballot(multi) != 0;
+    // far's list: c leaves it now (lane 0, while nothing else touches a list of that kind), the merged edges enter it below
+    const bool counted = A ? (far == 0 && !uni(H.special_linked)) : (far == (int)uni(H.sinkp) && !uni(H.special_linked));     // out(source) / in(sink) are only counted
+    const bool consumed = uni(ctx[SW_SERIAL]) != 0;
+    if(lane == 0 && consumed) { if(A) unlink_out(far, c); else unlink_in(far, c); }
+    wsync();
+    PROF_ADD(PF_T_MERGE_MASK);
+    if(ALD_UNLIKELY(!consumed)) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); wsync(); return; }     // c kept a remainder: the reference asserts on the degree of x
+    // ---- phase 6 (lane q): place of merged edge q in far's list = behind the last old entry whose key does not exceed its own
+    // (old entries carry older ids), and among the new ones by (key, creation order).  Read-only walk; the links are written in 6c.
+    int32_t *pred = inv, *succ = (int32_t*)sq, *srt = (int32_t*)sq + STAR_MAX;
+    if(!counted) {
+        for(int q = lane; q < n; q += ALD_WAVE) {
+            const uint32_t key = A ? tkey((uint32_t)oth[q]) : (uint32_t)oth[q];
+            int last = -1, cur = A ? first_out(far) : first_in(far), guard = MAXE;
+            while(cur >= 0 && guard-- > 0) {
+                const uint64_t w = *(const uint64_t*)&H.ed[cur].lk;
+                const uint32_t kc = A ? tkey((uint32_t)((w >> 16) & 0xFFFF)) : (uint32_t)(w & 0xFFFF);
+                if(kc > key) break;
+                last = cur; cur = A ? lk_next((uint32_t)(w >> 48)) : lk_next((uint32_t)((w >> 32) & 0xFFFF));
+            }
+            int r = 0;
+            for(int k = 0; k < n; k++) { const uint32_t kk = A ? tkey((uint32_t)oth[k]) : (uint32_t)oth[k]; r += (kk < key || (kk == key && k < q)) ? 1 : 0; }
+            pred[q] = last; succ[q] = cur; srt[r] = q;
+        }
+        wsync();
+        for(int r = lane; r < n; r += ALD_WAVE) {
+            const int q = srt[r], f = fe[ord[q]];
+            const bool first_of_gap = (r == 0) || pred[srt[r - 1]] != pred[q], last_of_gap = (r + 1 >= n) || pred[srt[r + 1]] != pred[q];
+            const IDX nx = last_of_gap ? (succ[q] < 0 ? NIL : (IDX)succ[q]) : (IDX)fe[ord[srt[r + 1]]];
+            if(A) H.ed[f].lk.onx = nx; else H.ed[f].lk.inx = nx;
+            if(first_of_gap) { if(pred[q] < 0) { if(A) H.out_head[far] = (IDX)f; else H.in_head[far] = (IDX)f; } else { if(A) H.ed[pred[q]].lk.onx = (IDX)f; else H.ed[pred[q]].lk.inx = (IDX)f; } }
+        }
+    }
+    wsync();
+    // ---- phase 7 (lane 0): what is left and inherently ordered -- the support pool, the phasing lists, the counters
+    if(lane == 0) {
+        if(A) H.out_deg[far] = (IDX)((int)uni(H.out_deg[far]) + n); else H.in_deg[far] = (IDX)((int)uni(H.in_deg[far]) + n);
+        if(any_dup || any_multi || uni(H.hl_n) != 0) for(int q = 0; q < n; q++) {
+            const int f = fe[ord[q]];
+            if(any_dup) { if(A) relink_in(oth[q], f, (uint32_t)far); else relink_out(oth[q], f, tkey((uint32_t)far)); }
+            if(any_multi) { const uint32_t nsf = uni(C.ed[f].sp_len); if(!(nsc == 1 && nsf == 1)) { if(!(A ? intersect_samples(c, f, f) : intersect_samples(f, c, f))) break; } }
+            if(A) hs_replace2(c, f, f); else hs_replace2(f, c, f);
+            if(n == 1) hs_replace1(c, f);
+        }
+        H.next_id = (int)uni(H.eid[fe[ord[n - 1]]]) + 1;
+        if(n >= 2) hs_remove(c);
+        // remove_edge(c) (already out of far's list); x is left without edges
+        H.ed[c].lk.es = NIL; H.hflag[c] = 0;
+        { int fh = uni(H.free_head); H.ed[c].lk.onx = fh < 0 ? NIL : (IDX)fh; H.free_head = c; H.free_cnt = uni(H.free_cnt) + 1; }
+        H.in_head[x] = NIL; H.out_head[x] = NIL; H.in_deg[x] = 0; H.out_deg[x] = 0; H.nz[x] = 0;
+    }
+    wsync();
+    PROF_ADD(PF_T_MERGE_ADD);
+    #undef SW_REPLAY
+}
+ALD_FN void star_wave_in(int x) { star_wave_body<true>(uni(x)); }
+ALD_FN void star_wave_out(int x) { star_wave_body<false>(uni(x)); }
+// wave-level entry (ALL lanes): fans of up to STAR_MAX edges go lane-parallel, anything else through the sequential form on lane 0
+ALD_INL void decompose_trivial_vertex_wave(int x)
+{
+    x = uni(x);
+    const int nin = uni(H.in_deg[x]), nout = uni(H.out_deg[x]);
+    if(nin == 1 && nout >= 1 && nout <= STAR_MAX) star_wave_in(x);
+    else if(nout == 1 && nin >= 1 && nin <= STAR_MAX) star_wave_out(x);
+    else { if(lane_id() == 0) decompose_trivial_vertex(x); wsync(); }
+}
+
 // scallop::decompose_vertex_extend (scallop.cc:1675-1986); pe2w = n sorted pairs in the work area
 // SMALL: pe2w and the work arrays are in the LDS scratch (known address space -> ds_* accesses); otherwise wherever the router and
 // the capacity rules put them
@@ -1133,10 +1407,9 @@ ALD_INL bool sweep_trivial(int mode, int type, double jump_ratio)
         }
         if(code == SC_BAD) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); wsync(); return true; }
         if(code != SC_HIT) break;
+        if(lane == 0) trace(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, vlog(H.sw_hit), mode == 1 ? type : 0, H.sw_hit_r);
+        decompose_trivial_vertex_wave(uni(H.sw_hit));
         if(lane == 0) {
-            const int hit = H.sw_hit;
-            trace(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, vlog(hit), mode == 1 ? type : 0, H.sw_hit_r);
-            decompose_trivial_vertex(hit);
             if(uni(H.hs_dirty)) hs_refresh_flags();
             H.sw_dom_base = -1;
         }
@@ -1149,10 +1422,8 @@ ALD_INL bool sweep_trivial(int mode, int type, double jump_ratio)
     if(flag) return true;
     if(mode == 0) return false;
     if(uni(H.sw_best_v) < 0) { if(skippable) { if(lane == 0) H.maybe_triv = 0; wsync(); } return false; }
-    if(lane == 0) {
-        trace(OP_TRIVIAL_BEST, vlog(H.sw_best_v), type, H.sw_best_r);
-        decompose_trivial_vertex(H.sw_best_v);
-    }
+    if(lane == 0) trace(OP_TRIVIAL_BEST, vlog(H.sw_best_v), type, H.sw_best_r);
+    decompose_trivial_vertex_wave(uni(H.sw_best_v));
     wsync();
     PROF_ADD(PF_TRIV_MUT);
     return true;
