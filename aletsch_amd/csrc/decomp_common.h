@@ -41,7 +41,16 @@
   __device__ __forceinline__ int      lane_id() { return (int)threadIdx.x; }
   __device__ __forceinline__ uint64_t wballot(bool p) { return __ballot(p); }
   template<class T> __device__ __forceinline__ T wshfl(T v, int src) { return __shfl(v, src, 64); }
-  __device__ __forceinline__ void     wsync() { __syncthreads(); }   // workgroup == one wave: orders LDS traffic, fences the compiler
+  // workgroup == ONE wavefront: lanes of a wave execute in lock step and the hardware performs a wave's LDS and vector-memory
+  // instructions in issue order, so handing data from one lane to another needs no s_barrier and no drain of the memory counters --
+  // only that the compiler keeps the accesses on their side of the hand-over (LLVM AMDGPU memory model: a fence at "wavefront" scope
+  // emits no instruction).  __syncthreads() here cost an s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier at every one of the few thousand
+  // hand-overs a graph takes, i.e. every global load in flight was waited for right there.
+  #ifdef ALD_WSYNC_BARRIER
+  __device__ __forceinline__ void     wsync() { __syncthreads(); }
+  #else
+  __device__ __forceinline__ void     wsync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+  #endif
   __device__ __forceinline__ unsigned long long atomic_add_u64(ALD_GLOBAL unsigned long long *p, unsigned long long v) { return atomicAdd((unsigned long long*)p, v); }
   __device__ __forceinline__ int      atomic_add_i32(ALD_GLOBAL int *p, int v) { return atomicAdd((int*)p, v); }
   __device__ __forceinline__ int      ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
