@@ -1249,7 +1249,20 @@ ALD_FN int classify_trivial_vertex(int x, bool fast)     // scalar version with 
 }
 ALD_INL double compute_balance_ratio(int v, bool &ok)    // scallop.cc:2578-2602
 {
+#ifndef ALD_HOT_IN_SLAB
     double w1 = in_weights(v), w2 = out_weights(v);
+#else
+    double w1 = 0, w2 = 0;
+    {   // in_weights(v) and out_weights(v), their list steps taken together (see eval_smallest)
+        int a = first_in(v), b = first_out(v);
+        while((a >= 0) | (b >= 0)) {
+            const int ea = a >= 0 ? a : 0, eb = b >= 0 ? b : 0;
+            const double wa = H.ed[ea].w, wb = H.ed[eb].w; const IDX na = H.ed[ea].lk.inx, nb = H.ed[eb].lk.onx;
+            if(a >= 0) { w1 += wa; a = na == NIL ? -1 : (int)na; }
+            if(b >= 0) { w2 += wb; b = nb == NIL ? -1 : (int)nb; }
+        }
+    }
+#endif
     ok = (w1 >= kSMIN) && (w2 >= kSMIN);
     if(w1 >= w2) return w1 / w2; else return w2 / w1;
 }
@@ -1271,19 +1284,33 @@ ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio)
 // scallop::compute_smallest_edge + the guards of resolve_smallest_edges (scallop.cc:858-896, 2967-3030)
 ALD_INL int eval_smallest(int i, double &r)
 {
-    if(!H.nz[i]) return -1;
-    if(H.in_deg[i] <= 1 || H.out_deg[i] <= 1) return -1;
+    {   // the vertex record in one round of loads (the short-circuit form waits for each field before it asks for the next)
+        const int nzv = H.nz[i], d1 = H.in_deg[i], d2 = H.out_deg[i];
+        if((nzv == 0) | (d1 <= 1) | (d2 <= 1)) return -1;
+    }
     int e1 = -1, e2 = -1; double sum1 = 0, sum2 = 0, min1 = DBL_MAX, min2 = DBL_MAX;
+#ifndef ALD_HOT_IN_SLAB
     for(int e = first_in(i); e >= 0; e = next_in(e)) { double w = H.ed[e].w; sum1 += w; if(w > min1) continue; min1 = w; e1 = e; }
     for(int e = first_out(i); e >= 0; e = next_out(e)) { double w = H.ed[e].w; sum2 += w; if(w > min2) continue; min2 = w; e2 = e; }
+#else
+    {   // hot state in the slab (the catch-all class and the twins): every list step is a round trip to L2 -- the two walks advance
+        // together, their steps being independent of each other (in LDS the merged loop costs more than the latency it hides)
+        int a = first_in(i), b = first_out(i);
+        while((a >= 0) | (b >= 0)) {
+            const int ea = a >= 0 ? a : 0, eb = b >= 0 ? b : 0;
+            const double wa = H.ed[ea].w, wb = H.ed[eb].w; const IDX na = H.ed[ea].lk.inx, nb = H.ed[eb].lk.onx;
+            if(a >= 0) { sum1 += wa; if(!(wa > min1)) { min1 = wa; e1 = a; } a = na == NIL ? -1 : (int)na; }
+            if(b >= 0) { sum2 += wb; if(!(wb > min2)) { min2 = wb; e2 = b; } b = nb == NIL ? -1 : (int)nb; }
+        }
+    }
+#endif
     if(e1 < 0 || e2 < 0) return -1;
     if(!(sum1 >= kSMIN) || !(sum2 >= kSMIN)) return -3;          // reference assert(sum1 >= SMIN)
     double r1 = min1 / sum1, r2 = min2 / sum2;
     int e; if(r1 < r2) { r = r1; e = e1; } else { r = r2; e = e2; }
     int s = H.ed[e].lk.es, t = H.ed[e].lk.et;
-    if(H.out_deg[s] <= 1) return -1;
-    if(H.in_deg[t] <= 1) return -1;
     uint8_t f = H.hflag[e];
+    { const int ods = H.out_deg[s], idt = H.in_deg[t]; if((ods <= 1) | (idt <= 1)) return -1; }
     if((f & HF_REXT) && (f & HF_LEXT)) return -1;
     if(t == i && (f & HF_REXT)) return -1;
     if(s == i && (f & HF_LEXT)) return -1;
@@ -1304,7 +1331,9 @@ ALD_INL bool resolve_broken_vertex()
     int vend = H.nv; int x = -1;
     for(int base = 0; base < vend && x < 0; base += ALD_WAVE) {
         int i = base + lane;
-        bool p = (i >= 1 && i < vend && i != H.sinkp) && H.nz[i] && !(H.in_deg[i] >= 1 && H.out_deg[i] >= 1);
+        const bool inr = (i >= 1) & (i < vend) & (i != H.sinkp); const int ii = inr ? i : 0;
+        const int nzv = H.nz[ii], d1 = H.in_deg[ii], d2 = H.out_deg[ii];
+        bool p = inr & (nzv != 0) & !((d1 >= 1) & (d2 >= 1));
         uint64_t m = wballot(p);
         if(m) x = base + ffs64(m);
     }
@@ -1344,8 +1373,24 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
     for(int base = (start / ALD_WAVE) * ALD_WAVE; base < vend; base += ALD_WAVE) {
         int i = base + lane;
         int cls = -9; double r = 0; bool bad = false;
-        if(i >= start && i < vend && H.nz[i] && H.in_deg[i] >= 1 && H.out_deg[i] >= 1 && !(H.in_deg[i] >= 2 && H.out_deg[i] >= 2) && !mixed_strand_vertex(i)) {
-            cls = classify_trivial_fastpath(i, fast);
+        {
+            // classify_trivial_fastpath with every load that does not depend on another issued together: three LDS round trips
+            // (vertex record / first edges / their far ends) instead of one per condition of the short-circuit form
+            const bool inr = (i >= start) & (i < vend); const int ii = inr ? i : 0;
+            const int nzv = H.nz[ii], d1 = H.in_deg[ii], d2 = H.out_deg[ii]; const IDX h1 = H.in_head[ii], h2 = H.out_head[ii];
+            bool elig = inr & (nzv != 0) & (d1 >= 1) & (d2 >= 1) & !((d1 >= 2) & (d2 >= 2));
+            if(H.any_strand) elig = elig && !mixed_strand_vertex(i);
+            const int e1 = (elig & (h1 != NIL)) ? (int)h1 : 0, e2 = (elig & (h2 != NIL)) ? (int)h2 : 0;
+            const IDX sv = H.ed[e1].lk.es, tv = H.ed[e2].lk.et; const uint8_t f1 = H.hflag[e1], f2 = H.hflag[e2];
+            const int s_ = (elig & (sv != NIL)) ? (int)sv : 0, t_ = (elig & (tv != NIL)) ? (int)tv : 0;
+            const int ods = H.out_deg[s_], idt = H.in_deg[t_];
+            if(elig) {
+                if(d1 == 1 && ods == 1) cls = 1;
+                else if(d1 == 1 && fast) cls = (f1 & HF_OCC) ? -2 : 1;
+                else if(d2 == 1 && idt == 1) cls = 1;
+                else if(d2 == 1 && fast) cls = (f2 & HF_OCC) ? -2 : 1;
+                else cls = 2;
+            }
         }
         // lanes that need a dominate query (rare: only edges on phasing paths) are answered by the driver, one at a time on lane 0
         if(cls == -2 && base == dom_base) cls = H.scr_i[lane];
@@ -1795,7 +1840,9 @@ ALD_INL bool sweep_unsplittable(int type, int degree, double max_ratio)
         int i = -1;
         for(int base = (cur / ALD_WAVE) * ALD_WAVE; base < vend && i < 0; base += ALD_WAVE) {
             int i0 = base + lane;
-            uint64_t m = wballot(i0 >= cur && i0 < vend && H.nz[i0] && H.in_deg[i0] >= 2 && H.out_deg[i0] >= 2);
+            const bool inr = (i0 >= cur) & (i0 < vend); const int ii = inr ? i0 : 0;
+            const int nzv = H.nz[ii], d1 = H.in_deg[ii], d2 = H.out_deg[ii];
+            uint64_t m = wballot(inr & (nzv != 0) & (d1 >= 2) & (d2 >= 2));
             if(m) i = base + ffs64(m);
         }
         if(i < 0) break;
