@@ -9,8 +9,10 @@ There is no CPU compute fallback: without a HIP device every compute call raises
 from .packed import PackedGraphs, DecompResult
 from .native import (DecompBatch, DecompError, default_params, load_library, library_path, synth,
                      subsetsum_batch, decompose, SynthSpec, AldParams, TranscriptSink, records_add_graph_offset,
-                     TrstFeatures, GraphExtras, FEATURE_FIELDS, format_transcript, format_features, transcript_id)
+                     TrstFeatures, GraphExtras, FEATURE_FIELDS, format_transcript, format_features, transcript_id,
+                     GraphView, PhaseView, pre_assemble)
 
 __all__ = ["PackedGraphs", "DecompResult", "DecompBatch", "DecompError", "default_params", "load_library",
            "library_path", "synth", "subsetsum_batch", "decompose", "SynthSpec", "AldParams", "TranscriptSink", "records_add_graph_offset",
-           "TrstFeatures", "GraphExtras", "FEATURE_FIELDS", "format_transcript", "format_features", "transcript_id"]
+           "TrstFeatures", "GraphExtras", "FEATURE_FIELDS", "format_transcript", "format_features", "transcript_id",
+           "GraphView", "PhaseView", "pre_assemble"]

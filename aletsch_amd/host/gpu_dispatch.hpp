@@ -104,6 +104,10 @@ public:
     void submit(SpliceGraph &gx, const HyperSet &hx, int sid)
     {
         staged_graph s = stage_graph(gx, hx);                     // the per-graph work stays in the calling thread, outside any shared lock
+        submit_staged(s, sid);
+    }
+    void submit_staged(const staged_graph &s, int sid)
+    {
         lane *L = my_lane();
         std::unique_lock<std::mutex> ll(L->m);
         L->c.append(s, sid);
@@ -114,6 +118,19 @@ public:
         while(ready_graphs_ >= ready_cap_ && !err_) cv_space_.wait(lk);            // the pool is ahead of the GPU: hold the submitter back
         if(err_) throw gpu_error(err_, err_msg_.c_str());
         push_chunk(std::move(full));
+    }
+
+    // The call shape of assembler::assemble(gx, px, sid) itself (meta/assembler.cc:1075): the pre-steps (extend_strands, boundary
+    // grouping, phase projection, hyper_set ctor + filter_nodes) run in the calling thread through the library, then the graph is queued.
+    // Returns false when the reference would have asserted in the pre-steps (the graph is counted as failed, nothing is queued).
+    template<class PhaseSet>
+    bool submit_raw(SpliceGraph &gx, const PhaseSet &px, int sid, int max_group_boundary_distance = 10000)
+    {
+        int st = 0;
+        staged_graph s = stage_raw(gx, px, max_group_boundary_distance, st);
+        if(st > 0) { std::lock_guard<std::mutex> lk(m_); failed_++; return false; }
+        submit_staged(s, sid);
+        return true;
     }
 
     // Hands over every partial chunk and returns when every submitted graph has been merged into the sink.

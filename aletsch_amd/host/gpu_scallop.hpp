@@ -88,6 +88,46 @@ staged_graph stage_graph(SpliceGraph &gr, const HyperSet &hs)
     return s;
 }
 
+class gpu_error : public std::runtime_error {
+public:
+    int code;
+    gpu_error(int c, const char *what) : std::runtime_error(std::string("aletsch_decomp: ") + what + " (" + std::to_string(c) + "): " + ald_last_error()), code(c) {}
+};
+
+// assembler::assemble(gx, px, sid) up to `scallop sx(gx, hx, pa)` (meta/assembler.cc:1075-1086): extend_strands, boundary grouping,
+// phase projection, hyper_set(gx, px), filter_nodes -- done by the library (ald_pre_assemble) on the staged arrays; gx and px are left
+// untouched.  PhaseSet: .pmap (map<vector<int32_t>, int>, rnacore/phase_set.h:24).  `status` receives 0, or the positive status word
+// where the reference would have asserted in those steps (the returned graph is empty then).
+template<class SpliceGraph, class PhaseSet>
+staged_graph stage_raw(SpliceGraph &gx, const PhaseSet &px, int max_group_boundary_distance, int &status)
+{
+    struct no_hyper_set { std::map<std::vector<int>, int> nodes; } none;
+    staged_graph in = stage_graph(gx, none);
+    std::vector<int32_t> off(1, 0), coord, cnt;
+    for(const auto &kv : px.pmap) { coord.insert(coord.end(), kv.first.begin(), kv.first.end()); off.push_back((int32_t)coord.size()); cnt.push_back((int32_t)kv.second); }
+    static const int32_t zero = 0;
+    ald_phase_view pv; pv.num_phases = (int32_t)cnt.size(); pv.phase_offset = off.data(); pv.phase_coord = coord.empty() ? &zero : coord.data(); pv.phase_count = cnt.empty() ? &zero : cnt.data();
+    ald_graph_view gv = in.view();
+    ald_staged *S = nullptr;
+    status = ald_pre_assemble(&gv, &pv, max_group_boundary_distance, &S);
+    if(status < 0) throw gpu_error(status, "ald_pre_assemble");
+    staged_graph out;
+    if(status > 0) return out;
+    ald_graph_view v; ald_staged_view(S, &v);
+    const int V = v.num_vertices, E = v.num_edges, P = v.num_phasing;
+    const int NS = E > 0 ? v.edge_sample_offset[E] : 0, NPV = P > 0 ? v.phasing_offset[P] : 0;
+    out.vertex_offset.assign(v.vertex_offset, v.vertex_offset + V + 1); out.edge_target.assign(v.edge_target, v.edge_target + E); out.edge_weight.assign(v.edge_weight, v.edge_weight + E);
+    out.edge_strand.assign(v.edge_strand, v.edge_strand + E); out.edge_abd.assign(v.edge_abd, v.edge_abd + E); out.edge_sample_offset.assign(v.edge_sample_offset, v.edge_sample_offset + E + 1);
+    out.sample_id.assign(v.sample_id, v.sample_id + NS); out.sample_abd.assign(v.sample_abd, v.sample_abd + NS);
+    out.vertex_weight.assign(v.vertex_weight, v.vertex_weight + V); out.vertex_lpos.assign(v.vertex_lpos, v.vertex_lpos + V); out.vertex_rpos.assign(v.vertex_rpos, v.vertex_rpos + V);
+    out.vertex_type.assign(v.vertex_type, v.vertex_type + V); out.phasing_offset.assign(v.phasing_offset, v.phasing_offset + P + 1); out.phasing_vertex.assign(v.phasing_vertex, v.phasing_vertex + NPV);
+    out.phasing_count.assign(v.phasing_count, v.phasing_count + P); out.edge_count.assign(v.edge_count, v.edge_count + E);
+    if(v.edge_creation_rank) out.edge_rank.assign(v.edge_creation_rank, v.edge_creation_rank + E);
+    out.strand = v.strand;
+    ald_staged_free(S);
+    return out;
+}
+
 template<class Parameters>
 ald_params stage_params(const Parameters &cfg)
 {
@@ -110,12 +150,6 @@ Path make_path(const ald_path_view &pv, const std::vector<int32_t> &lpos, const 
     return p;
 }
 
-class gpu_error : public std::runtime_error {
-public:
-    int code;
-    gpu_error(int c, const char *what) : std::runtime_error(std::string("aletsch_decomp: ") + what + " (" + std::to_string(c) + "): " + ald_last_error()), code(c) {}
-};
-
 // many graphs per launch
 template<class SpliceGraph, class HyperSet, class Parameters, class Path>
 class gpu_scallop_batch {
@@ -132,6 +166,19 @@ public:
     // returns the index under which the graph's result will be available after flush()
     int enqueue(SpliceGraph &gr, const HyperSet &hs) {
         staged_graph s = stage_graph(gr, hs);
+        ald_graph_view g = s.view();
+        int rc = ald_batch_add_graph(b_, &g);
+        if(rc != ALD_OK) throw gpu_error(rc, "ald_batch_add_graph");
+        lpos_.push_back(std::move(s.vertex_lpos)); rpos_.push_back(std::move(s.vertex_rpos));
+        return (int)lpos_.size() - 1;
+    }
+    // the same for a graph as assembler::assemble(gx, px, sid) receives it: its pre-steps (meta/assembler.cc:1075-1086) run first.
+    // Returns the ticket, or -1 - status where the reference would have asserted in them (nothing is enqueued then).
+    template<class PhaseSet>
+    int enqueue_raw(SpliceGraph &gx, const PhaseSet &px, int max_group_boundary_distance = 10000) {
+        int st = 0;
+        staged_graph s = stage_raw(gx, px, max_group_boundary_distance, st);
+        if(st > 0) return -1 - st;
         ald_graph_view g = s.view();
         int rc = ald_batch_add_graph(b_, &g);
         if(rc != ALD_OK) throw gpu_error(rc, "ald_batch_add_graph");

@@ -70,6 +70,97 @@ class GraphExtras(C.Structure):
         return x
 
 
+class GraphView(C.Structure):
+    """ald_graph_view (include/aletsch_decomp.h): one splice graph as caller-owned arrays"""
+    _fields_ = [("num_vertices", _I), ("num_edges", _I), ("vertex_offset", C.POINTER(_I)), ("edge_target", C.POINTER(_I)), ("edge_weight", C.POINTER(_D)),
+                ("edge_strand", C.POINTER(C.c_uint8)), ("edge_abd", C.POINTER(_D)), ("edge_sample_offset", C.POINTER(_I)), ("sample_id", C.POINTER(_I)),
+                ("sample_abd", C.POINTER(_D)), ("vertex_weight", C.POINTER(_D)), ("vertex_lpos", C.POINTER(_I)), ("vertex_rpos", C.POINTER(_I)),
+                ("vertex_type", C.POINTER(_I)), ("num_phasing", _I), ("phasing_offset", C.POINTER(_I)), ("phasing_vertex", C.POINTER(_I)),
+                ("phasing_count", C.POINTER(_I)), ("strand", C.c_char), ("edge_count", C.POINTER(_I)), ("edge_creation_rank", C.POINTER(_I))]
+
+    @classmethod
+    def from_packed(cls, pg: PackedGraphs, g: int = 0):
+        """view of graph g of a packed batch (the arrays stay alive with the returned object)"""
+        sl = pg.graph_slices(); V, E, P = int(pg.g_nv[g]), int(pg.g_ne[g]), int(pg.g_np[g])
+        v = cls(); v._keep = []
+
+        def put(name, arr, dt, t):
+            a = np.ascontiguousarray(arr, dt)
+            if a.size == 0:
+                a = np.zeros(1, dt)
+            v._keep.append(a); setattr(v, name, a.ctypes.data_as(C.POINTER(t)))
+        ov, ovo, oe, oeo, os_, op, opo, opv = (int(sl[k][g]) for k in ("v", "vo", "e", "eo", "s", "p", "po", "pv"))
+        ns = int(sl["s"][g + 1] - sl["s"][g]); npv = int(sl["pv"][g + 1] - sl["pv"][g])
+        v.num_vertices = V; v.num_edges = E; v.num_phasing = P; v.strand = bytes([int(pg.graph_strand[g]) & 0xFF])
+        put("vertex_offset", pg.vertex_offset[ovo:ovo + V + 1], np.int32, _I); put("edge_target", pg.edge_target[oe:oe + E], np.int32, _I)
+        put("edge_weight", pg.edge_weight[oe:oe + E], np.float64, _D); put("edge_strand", pg.edge_strand[oe:oe + E], np.uint8, C.c_uint8)
+        put("edge_abd", pg.edge_abd[oe:oe + E], np.float64, _D); put("edge_sample_offset", pg.edge_sample_offset[oeo:oeo + E + 1], np.int32, _I)
+        put("sample_id", pg.sample_id[os_:os_ + ns], np.int32, _I); put("sample_abd", pg.sample_abd[os_:os_ + ns], np.float64, _D)
+        put("vertex_weight", pg.vertex_weight[ov:ov + V], np.float64, _D); put("vertex_lpos", pg.vertex_lpos[ov:ov + V], np.int32, _I)
+        put("vertex_rpos", pg.vertex_rpos[ov:ov + V], np.int32, _I); put("vertex_type", pg.vertex_type[ov:ov + V], np.int32, _I)
+        put("phasing_offset", pg.phasing_offset[opo:opo + P + 1], np.int32, _I); put("phasing_vertex", pg.phasing_vertex[opv:opv + npv], np.int32, _I)
+        put("phasing_count", pg.phasing_count[op:op + P], np.int32, _I)
+        if pg.edge_count is not None:
+            put("edge_count", pg.edge_count[oe:oe + E], np.int32, _I)
+        if pg.edge_rank is not None:
+            put("edge_creation_rank", pg.edge_rank[oe:oe + E], np.int32, _I)
+        return v
+
+    def to_packed(self) -> PackedGraphs:
+        """copy out as a single-graph batch"""
+        V, E, P = self.num_vertices, self.num_edges, self.num_phasing
+
+        def get(p, n, dt):
+            return np.ctypeslib.as_array(p, shape=(max(n, 1),))[:n].astype(dt).copy() if n > 0 else np.zeros(0, dt)
+        eso = get(self.edge_sample_offset, E + 1, np.int32); po = get(self.phasing_offset, P + 1, np.int32)
+        ns = int(eso[E]) if E > 0 else 0; npv = int(po[P]) if P > 0 else 0
+        return PackedGraphs(
+            g_nv=np.array([V], np.int32), g_ne=np.array([E], np.int32), g_np=np.array([P], np.int32),
+            vertex_offset=get(self.vertex_offset, V + 1, np.int32), edge_target=get(self.edge_target, E, np.int32), edge_weight=get(self.edge_weight, E, np.float64),
+            edge_strand=get(self.edge_strand, E, np.uint8), edge_abd=get(self.edge_abd, E, np.float64), edge_sample_offset=eso,
+            sample_id=get(self.sample_id, ns, np.int32), sample_abd=get(self.sample_abd, ns, np.float64), vertex_weight=get(self.vertex_weight, V, np.float64),
+            vertex_lpos=get(self.vertex_lpos, V, np.int32), vertex_rpos=get(self.vertex_rpos, V, np.int32), vertex_type=get(self.vertex_type, V, np.int32),
+            phasing_offset=po, phasing_vertex=get(self.phasing_vertex, npv, np.int32), phasing_count=get(self.phasing_count, P, np.int32),
+            graph_strand=np.frombuffer(self.strand, np.int8).copy(), edge_count=get(self.edge_count, E, np.int32) if self.edge_count else None,
+            edge_rank=get(self.edge_creation_rank, E, np.int32) if self.edge_creation_rank else None)
+
+
+class PhaseView(C.Structure):
+    """ald_phase_view: phase_set::pmap as flat arrays (exon-coordinate lists with counts)"""
+    _fields_ = [("num_phases", _I), ("phase_offset", C.POINTER(_I)), ("phase_coord", C.POINTER(_I)), ("phase_count", C.POINTER(_I))]
+
+    @classmethod
+    def from_lists(cls, phases):
+        """phases: [([l0, r0, l1, r1, ...], count), ...]"""
+        v = cls(); off = [0]; co = []; cnt = []
+        for coords, c in phases:
+            co += list(coords); off.append(len(co)); cnt.append(c)
+        v._keep = [np.array(off, np.int32), np.array(co if co else [0], np.int32), np.array(cnt if cnt else [0], np.int32)]
+        v.num_phases = len(phases)
+        v.phase_offset, v.phase_coord, v.phase_count = (a.ctypes.data_as(C.POINTER(_I)) for a in v._keep)
+        return v
+
+
+def pre_assemble(pg: PackedGraphs, phases, max_group_boundary_distance: int = 10000, g: int = 0, _lib=None, _prefix="ald"):
+    """The pre-steps of assembler::assemble(gx, px, sid) (meta/assembler.cc:1075-1086) on graph g of `pg` and the phase set `phases`
+    -> (single-graph PackedGraphs as scallop would receive it, smap pairs, tmap pairs, rc); rc > 0: the reference would have asserted."""
+    lib = _lib or load_library()
+    gv = GraphView.from_packed(pg, g); pv = PhaseView.from_lists(phases)
+    h = C.c_void_p()
+    rc = getattr(lib, _prefix + "_pre_assemble")(C.byref(gv), C.byref(pv), C.c_int32(max_group_boundary_distance), C.byref(h))
+    if rc < 0:
+        _check(rc)
+    if rc > 0:
+        return None, None, None, rc
+    out = GraphView(); getattr(lib, _prefix + "_staged_view")(h, C.byref(out))
+    back = out.to_packed()
+    ns, nt = _I(), _I(); sp, tp = C.POINTER(_I)(), C.POINTER(_I)()
+    getattr(lib, _prefix + "_staged_boundary_maps")(h, C.byref(ns), C.byref(sp), C.byref(nt), C.byref(tp))
+    smap = [(sp[2 * i], sp[2 * i + 1]) for i in range(ns.value)]; tmap = [(tp[2 * i], tp[2 * i + 1]) for i in range(nt.value)]
+    getattr(lib, _prefix + "_staged_free")(h)
+    return back, smap, tmap, 0
+
+
 class _ResultView(C.Structure):
     _fields_ = [("status", C.c_int32), ("num_paths", C.c_int32), ("num_iterations", C.c_int32), ("reserved", C.c_int32)]
 
@@ -108,6 +199,11 @@ def load_library():
     lib.ald_tset_add_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64]
     lib.ald_batch_export_iterations.argtypes = [C.c_void_p, C.c_void_p]
     lib.ald_batch_features.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ald_pre_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.ald_staged_view.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ald_staged_boundary_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ald_staged_free.argtypes = [C.c_void_p]
+    lib.ald_batch_add_graph_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     lib.ald_gtf_format_transcript.restype = C.c_int64
     lib.ald_gtf_format_transcript.argtypes = [C.c_char_p, C.c_int64] + [C.c_char_p] * 6 + [C.c_char, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_void_p]
     lib.ald_gtf_format_features.restype = C.c_int64
@@ -188,6 +284,15 @@ class DecompBatch:
 
     def add(self, pg: PackedGraphs):
         _check(self._lib.ald_batch_add_packed(self._h, *pg.c_args()))
+
+    def add_raw(self, pg: PackedGraphs, phases, max_group_boundary_distance: int = 10000, g: int = 0) -> int:
+        """assemble(gx, px, sid) up to the scallop ctor, then staged: ald_batch_add_graph_raw.  Returns 0, or the positive status where
+        the reference would have asserted in the pre-steps (nothing is added then)."""
+        gv = GraphView.from_packed(pg, g); pv = PhaseView.from_lists(phases)
+        rc = self._lib.ald_batch_add_graph_raw(self._h, C.byref(gv), C.byref(pv), C.c_int32(max_group_boundary_distance))
+        if rc < 0:
+            _check(rc)
+        return rc
 
     def upload(self):
         _check(self._lib.ald_batch_upload(self._h))

@@ -143,6 +143,28 @@ int  ald_batch_add_packed(ald_batch *b, int32_t n,
                           const int32_t *edge_creation_rank /* NULL => CSR position; else per graph a permutation of 0..E-1 */);
 int  ald_batch_num_graphs(const ald_batch *b);
 
+/* ---- the pre-steps of assembler::assemble(gx, px, sid) (meta/assembler.cc:1075-1086), so that the boundary can sit at assemble() itself ----
+ * extend_strands (splice_graph.cc:1338-1373), group_start_boundaries / group_end_boundaries (graph_reviser.cc:916-1066: weights and
+ * counts fold along grouped boundaries, the folded boundary edges disappear), phase_set::project_boundaries (phase_set.cc:50-67),
+ * hyper_set(gx, px) (hyper_set.cc:17-29 via build_path_from_exon_coordinates, essential.cc:321-366) and filter_nodes (hyper_set.cc:356-371).
+ * Host code: O(V + E + phase lengths), sequential by nature, and it runs before the graph's wire arrays exist. */
+typedef struct ald_phase_view {            /* phase_set::pmap (rnacore/phase_set.h:21-32) */
+    int32_t        num_phases;
+    const int32_t *phase_offset;           /* [P+1]                                                          */
+    const int32_t *phase_coord;            /* exon coordinates l0 r0 l1 r1 ... per phase (even, non-zero length) */
+    const int32_t *phase_count;            /* [P]                                                            */
+} ald_phase_view;
+typedef struct ald_staged ald_staged;      /* the graph + phasing lists as assemble() hands them to scallop  */
+/* g->num_phasing / phasing_* are ignored: the phasing lists come out of `phases`.  Returns ALD_OK, ALD_ERR_INVALID (malformed input,
+ * incl. parallel source / sink edges, on which the reference's grouping is undefined), or ALD_ST_INVARIANT + ALD_INV_OTHER (> 0) where
+ * the reference would have asserted.  No device is involved. */
+int  ald_pre_assemble(const ald_graph_view *g, const ald_phase_view *phases, int32_t max_group_boundary_distance /* parameters.cc:77: 10000 */, ald_staged **out);
+int  ald_staged_view(const ald_staged *s, ald_graph_view *out);      /* borrowed pointers into s; edge_creation_rank is set */
+int  ald_staged_boundary_maps(const ald_staged *s, int32_t *n_smap, const int32_t **smap_pairs, int32_t *n_tmap, const int32_t **tmap_pairs);   /* (from, to) pairs */
+int  ald_staged_free(ald_staged *s);
+/* ald_pre_assemble + ald_batch_add_graph in one call: the batched form of `assemble(gx, px, sid)` up to `scallop sx(gx, hx, pa)` */
+int  ald_batch_add_graph_raw(ald_batch *b, const ald_graph_view *g, const ald_phase_view *phases, int32_t max_group_boundary_distance);
+
 /* ---- execution (replaces `sx.assemble()`, scallop.cc:38-188) ---- */
 int  ald_batch_upload(ald_batch *b);      /* H2D of the wire buffer (one coalesced copy)      */
 int  ald_batch_run(ald_batch *b);         /* launch decomposition kernels on the batch stream */

@@ -242,6 +242,81 @@ int ora_result_trace(const ora_result *R, int32_t graph, int32_t *n_events, int3
     return 0;
 }
 
+/* the pre-steps of assembler::assemble(gx, px, sid) (meta/assembler.cc:1075-1086) restated on the oracle's containers; the result in the
+ * layout of ald_staged_view (CSR by (source, target, creation), compacted creation ranks) so that it can be compared array by array */
+struct ora_staged {
+    std::vector<int32_t> vertex_offset, edge_target, edge_sample_offset, sample_id, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, edge_count, edge_rank;
+    std::vector<double> edge_weight, edge_abd, sample_abd, vertex_weight; std::vector<uint8_t> edge_strand; char strand = '.';
+    std::vector<int32_t> smap, tmap;
+};
+int ora_pre_assemble(const ald_graph_view *g, const ald_phase_view *ph, int32_t dist, ora_staged **out)
+{
+    const int V = g->num_vertices, NE = g->num_edges;
+    ora::Graph gr; for(int i = 0; i < V; i++) gr.add_vertex();
+    gr.strand = g->strand ? g->strand : '.';
+    for(int i = 0; i < V; i++) { gr.vwrt[i] = g->vertex_weight[i]; gr.vinf[i].lpos = g->vertex_lpos[i]; gr.vinf[i].rpos = g->vertex_rpos[i]; gr.vinf[i].type = g->vertex_type ? g->vertex_type[i] : -1; }
+    std::vector<int> src_of(NE), order(NE);
+    for(int s = 0; s < V; s++) for(int k = g->vertex_offset[s]; k < g->vertex_offset[s + 1]; k++) src_of[k] = s;
+    for(int k = 0; k < NE; k++) order[g->edge_creation_rank ? g->edge_creation_rank[k] : k] = k;
+    for(int q = 0; q < NE; q++) {
+        const int k = order[q]; int e = gr.add_edge(src_of[k], g->edge_target[k]);
+        gr.ewrt[e] = g->edge_weight[k]; ora::EdgeInfo &ei = gr.einf[e]; ei.strand = g->edge_strand ? g->edge_strand[k] : 0;
+        double sum = 0;
+        for(int j = g->edge_sample_offset[k]; j < g->edge_sample_offset[k + 1]; j++) { ei.samples.insert(g->sample_id[j]); ei.spAbd[g->sample_id[j]] = g->sample_abd[j]; sum += g->sample_abd[j]; }
+        ei.count = g->edge_count ? g->edge_count[k] : g->edge_sample_offset[k + 1] - g->edge_sample_offset[k]; ei.abd = g->edge_abd ? g->edge_abd[k] : sum;
+    }
+    ora::PhaseSet px;
+    ora_staged *S = new ora_staged();
+    try {
+        if(ph) for(int p = 0; p < ph->num_phases; p++) px.add(std::vector<int32_t>(ph->phase_coord + ph->phase_offset[p], ph->phase_coord + ph->phase_offset[p + 1]), ph->phase_count[p]);
+        ora::extend_strands(gr);
+        std::map<int32_t, int32_t> smap, tmap;
+        ora::group_start_boundaries(gr, smap, dist);
+        ora::group_end_boundaries(gr, tmap, dist);
+        px.project_boundaries(smap, tmap);
+        ora::HyperSet hx(gr, px);
+        hx.filter_nodes(gr);
+        for(auto &x : smap) { S->smap.push_back(x.first); S->smap.push_back(x.second); }
+        for(auto &x : tmap) { S->tmap.push_back(x.first); S->tmap.push_back(x.second); }
+        S->vertex_offset.assign(V + 1, 0); S->edge_sample_offset.push_back(0); S->phasing_offset.push_back(0);
+        std::map<int, int> newrank; { int r = 0; for(int e : gr.se) newrank[e] = r++; }
+        for(int s = 0; s < V; s++) {
+            for(int e : gr.out_edges(s)) {                                      // (target, creation) order
+                S->edge_target.push_back(gr.et[e]); S->edge_weight.push_back(gr.ewrt[e]); S->edge_strand.push_back((uint8_t)gr.einf[e].strand); S->edge_abd.push_back(gr.einf[e].abd);
+                S->edge_count.push_back(gr.einf[e].count); S->edge_rank.push_back(newrank[e]);
+                for(int sid : gr.einf[e].samples) { S->sample_id.push_back(sid); S->sample_abd.push_back(gr.einf[e].spAbd[sid]); }
+                S->edge_sample_offset.push_back((int32_t)S->sample_id.size());
+            }
+            S->vertex_offset[s + 1] = (int32_t)S->edge_target.size();
+        }
+        for(int i = 0; i < V; i++) { S->vertex_weight.push_back(gr.vwrt[i]); S->vertex_lpos.push_back(gr.vinf[i].lpos); S->vertex_rpos.push_back(gr.vinf[i].rpos); S->vertex_type.push_back(gr.vinf[i].type); }
+        S->strand = gr.strand;
+        for(auto &x : hx.nodes) { for(int q : x.first) S->phasing_vertex.push_back(q); S->phasing_offset.push_back((int32_t)S->phasing_vertex.size()); S->phasing_count.push_back(x.second); }
+    } catch(const ora::AssertFail &a) { delete S; return ALD_ST_INVARIANT + a.cls; }
+    *out = S;
+    return 0;
+}
+int ora_staged_view(const ora_staged *S, ald_graph_view *g)
+{
+    static const int32_t zi = 0; static const double zd = 0; static const uint8_t zb = 0;
+    memset(g, 0, sizeof(*g));
+    g->num_vertices = (int32_t)S->vertex_weight.size(); g->num_edges = (int32_t)S->edge_target.size();
+    g->vertex_offset = S->vertex_offset.data(); g->edge_target = S->edge_target.empty() ? &zi : S->edge_target.data(); g->edge_weight = S->edge_weight.empty() ? &zd : S->edge_weight.data();
+    g->edge_strand = S->edge_strand.empty() ? &zb : S->edge_strand.data(); g->edge_abd = S->edge_abd.empty() ? &zd : S->edge_abd.data();
+    g->edge_sample_offset = S->edge_sample_offset.data(); g->sample_id = S->sample_id.empty() ? &zi : S->sample_id.data(); g->sample_abd = S->sample_abd.empty() ? &zd : S->sample_abd.data();
+    g->vertex_weight = S->vertex_weight.data(); g->vertex_lpos = S->vertex_lpos.data(); g->vertex_rpos = S->vertex_rpos.data(); g->vertex_type = S->vertex_type.data();
+    g->num_phasing = (int32_t)S->phasing_count.size(); g->phasing_offset = S->phasing_offset.data();
+    g->phasing_vertex = S->phasing_vertex.empty() ? &zi : S->phasing_vertex.data(); g->phasing_count = S->phasing_count.empty() ? &zi : S->phasing_count.data();
+    g->strand = S->strand; g->edge_count = S->edge_count.empty() ? &zi : S->edge_count.data(); g->edge_creation_rank = S->edge_rank.empty() ? nullptr : S->edge_rank.data();
+    return 0;
+}
+int ora_staged_boundary_maps(const ora_staged *S, int32_t *n_smap, const int32_t **smap_pairs, int32_t *n_tmap, const int32_t **tmap_pairs)
+{
+    *n_smap = (int32_t)(S->smap.size() / 2); *smap_pairs = S->smap.data(); *n_tmap = (int32_t)(S->tmap.size() / 2); *tmap_pairs = S->tmap.data();
+    return 0;
+}
+void ora_staged_free(ora_staged *S) { delete S; }
+
 /* Graph-layer script runner: the same edit/dump language as oracle/ref_drivers/ref_graph_main.cc, executed on the oracle's
  * creation-ordered containers, so that the dump can be diffed against the reference-built oracle/_ref/ref_graph. */
 int ora_graph_script(const char *script, char *out, int32_t cap)

@@ -178,8 +178,166 @@ struct Graph {
 // ---------------------------------------------------------------------------------------------
 // hyper_set (scallop/hyper_set.cc) -- phasing paths as edge-id lists + the edit API
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// what assembler::assemble(gx, px, sid) does before it builds the scallop object (meta/assembler.cc:1075-1086)
+// PARITY UNPINNED: splice_graph.cc / graph_reviser.cc / essential.cc need config.h, Boost.ICL and htslib to build
+// ---------------------------------------------------------------------------------------------
+inline bool check_continuous_vertices(const Graph &gr, int x, int y) {       // essential.cc:436-446
+    if(x >= y) return true;
+    for(int i = x; i < y; i++) { if(gr.edge(i, i + 1) < 0) return false; if(gr.vinf[i].rpos != gr.vinf[i + 1].lpos) return false; }
+    return true;
+}
+inline void extend_strands(Graph &gr) {                                      // splice_graph.cc:1338-1373
+    for(int e : gr.se) {
+        int sd = gr.einf[e].strand, s = gr.es[e], t = gr.et[e];
+        int32_t p1 = gr.vinf[s].rpos, p2 = gr.vinf[t].lpos;
+        if(p1 >= p2) continue;
+        if(s + 2 != t) continue;
+        double we = gr.ewrt[e], wv = gr.vwrt[s + 1];
+        if(we <= wv) continue;
+        if(gr.vinf[s + 1].lpos != p1) continue;
+        if(gr.vinf[s + 1].rpos != p2) continue;
+        int e1 = gr.edge(s, s + 1), e2 = gr.edge(s + 1, t);
+        if(e1 >= 0) { if(gr.einf[e1].strand == 0) gr.einf[e1].strand = sd; }
+        if(e2 >= 0) { if(gr.einf[e2].strand == 0) gr.einf[e2].strand = sd; }
+    }
+}
+inline void group_start_boundaries(Graph &gr, std::map<int32_t, int32_t> &smap, int32_t max_group_boundary_distance) {     // graph_reviser.cc:916-991
+    smap.clear();
+    std::vector<int> v;
+    for(int e : gr.out_edges(0)) v.push_back(gr.et[e]);
+    if(v.size() <= 1) return;
+    std::sort(v.begin(), v.end());
+    int32_t p1 = gr.vinf[v[0]].lpos, p2 = p1; int k1 = v[0], k2 = k1;
+    int pa = gr.edge(0, v[0]); ORA_ASSERT(INV_OTHER, pa >= 0);
+    double wa = gr.ewrt[pa]; EdgeInfo ea = gr.einf[pa];
+    for(size_t i = 1; i < v.size(); i++) {
+        int32_t p = gr.vinf[v[i]].lpos;
+        int pb = gr.edge(0, v[i]); ORA_ASSERT(INV_OTHER, pb >= 0);
+        double wb = gr.ewrt[pb]; const EdgeInfo eb = gr.einf[pb];
+        bool b = check_continuous_vertices(gr, k2, v[i]);
+        ORA_ASSERT(INV_OTHER, p >= p2);
+        if(p - p2 > max_group_boundary_distance) b = false;
+        if(b == false) { p1 = p; p2 = p; k1 = v[i]; k2 = v[i]; pa = pb; wa = wb; ea = eb; }
+        else {
+            smap.insert(std::make_pair(p, p1));
+            for(int j = k1; j < v[i]; j++) {
+                int pc = gr.edge(j, j + 1); ORA_ASSERT(INV_OTHER, pc >= 0);
+                double vc = gr.vwrt[j], wc = gr.ewrt[pc];
+                gr.vwrt[j] = vc + wb;
+                gr.einf[pc].count += eb.count;
+                gr.ewrt[pc] = wc + wb;
+            }
+            wa += wb; ea.count += eb.count;
+            gr.ewrt[pa] = wa; gr.einf[pa] = ea;
+            gr.remove_edge(pb);
+            k2 = v[i]; p2 = p;
+        }
+    }
+}
+inline void group_end_boundaries(Graph &gr, std::map<int32_t, int32_t> &tmap, int32_t max_group_boundary_distance) {       // graph_reviser.cc:993-1066
+    tmap.clear();
+    const int n = gr.num_vertices() - 1;
+    std::vector<int> v;
+    for(int e : gr.in_edges(n)) v.push_back(gr.es[e]);
+    if(v.size() <= 1) return;
+    std::sort(v.begin(), v.end(), std::greater<int>());
+    int32_t p1 = gr.vinf[v[0]].rpos, p2 = p1; int k1 = v[0], k2 = k1;
+    int pa = gr.edge(v[0], n); ORA_ASSERT(INV_OTHER, pa >= 0);
+    double wa = gr.ewrt[pa];
+    for(size_t i = 1; i < v.size(); i++) {
+        int32_t p = gr.vinf[v[i]].rpos;
+        int pb = gr.edge(v[i], n); ORA_ASSERT(INV_OTHER, pb >= 0);
+        double wb = gr.ewrt[pb];
+        bool b = check_continuous_vertices(gr, v[i], k2);
+        ORA_ASSERT(INV_OTHER, p <= p2);
+        if(p2 - p > max_group_boundary_distance) b = false;
+        if(b == false) { p1 = p; p2 = p; k1 = v[i]; k2 = v[i]; pa = pb; wa = wb; }
+        else {
+            tmap.insert(std::make_pair(p, p1));
+            for(int j = v[i]; j < k1; j++) {
+                int pc = gr.edge(j, j + 1); ORA_ASSERT(INV_OTHER, pc >= 0);
+                double wc = gr.ewrt[pc];
+                gr.ewrt[pc] = wc + wb;
+                gr.vwrt[j + 1] = wc + wb;                 // (yes: the edge's weight, not the vertex's -- graph_reviser.cc:1052)
+            }
+            wa += wb; gr.ewrt[pa] = wa;
+            gr.remove_edge(pb);
+            k2 = v[i]; p2 = p;
+        }
+    }
+}
+struct PhaseSet {                               // rnacore/phase_set.h:21-32
+    std::map<std::vector<int32_t>, int> pmap;
+    void add(const std::vector<int32_t> &v, int c) { ORA_ASSERT(INV_OTHER, !v.empty() && v.size() % 2 == 0); if(pmap.find(v) == pmap.end()) pmap.insert(std::make_pair(v, c)); else pmap[v] += c; }   // phase_set.cc:12-25
+    void project_boundaries(const std::map<int32_t, int32_t> &smap, const std::map<int32_t, int32_t> &tmap) {             // phase_set.cc:50-67
+        PhaseSet ps;
+        for(auto &x : pmap) {
+            std::vector<int32_t> v = x.first; int c = x.second;
+            auto is = smap.find(v.front()); auto it = tmap.find(v.back());
+            if(is != smap.end()) v[0] = is->second;
+            if(it != tmap.end()) v[v.size() - 1] = it->second;
+            ps.add(v, c);
+        }
+        pmap = std::move(ps.pmap);
+    }
+};
+inline bool build_path_from_exon_coordinates(const Graph &gr, const std::map<int32_t, int> &lindex, const std::map<int32_t, int> &rindex,
+                                             const std::vector<int32_t> &v, std::vector<int> &vv) {                     // essential.cc:321-366
+    vv.clear();
+    if(v.size() <= 0) return true;
+    int n = (int)v.size() / 2;
+    std::vector<std::pair<int, int>> pp(n);
+    for(int k = 0; k < n; k++) {
+        int32_t p = v[2 * k + 0], q = v[2 * k + 1];
+        if(p < 0 || q < 0) return false;
+        if(p >= q) return false;
+        if(lindex.find(p) == lindex.end()) return false;
+        if(rindex.find(q) == rindex.end()) return false;
+        pp[k].first = lindex.find(p)->second; pp[k].second = rindex.find(q)->second;
+    }
+    for(int k = 0; k < n; k++) {
+        int a = pp[k].first, b = pp[k].second;
+        if(a > b) return false;
+        if(check_continuous_vertices(gr, a, b) == false) return false;
+        for(int j = a; j <= b; j++) vv.push_back(j);
+    }
+    for(size_t i = 0; i + 1 < vv.size(); i++) ORA_ASSERT(INV_OTHER, vv[i] < vv[i + 1]);
+    return true;
+}
+inline bool check_valid_path(const Graph &gr, const std::vector<int> &vv) {      // essential.cc:448-459
+    int n = gr.num_vertices() - 1;
+    for(size_t k = 0; k + 1 < vv.size(); k++) {
+        if(vv[k] < 0 || vv[k] > n) return false;
+        if(vv[k + 1] < 0 || vv[k + 1] > n) return false;
+        if(gr.edge(vv[k], vv[k + 1]) < 0) return false;
+    }
+    return true;
+}
+
 struct HyperSet {
     std::map<std::vector<int>, int> nodes;      // MVII nodes (after ctor + filter_nodes: boundary input)
+    HyperSet() {}
+    HyperSet(const Graph &gr, const PhaseSet &ps) {       // hyper_set.cc:17-29; lindex / rindex: splice_graph.cc:1087-1099
+        std::map<int32_t, int> lindex, rindex; int n = gr.num_vertices() - 1;
+        for(int i = 0; i <= n; i++) { if(i != 0) lindex.insert(std::make_pair(gr.vinf[i].lpos, i)); if(i != n) rindex.insert(std::make_pair(gr.vinf[i].rpos, i)); }
+        for(auto &x : ps.pmap) {
+            std::vector<int> vv;
+            if(build_path_from_exon_coordinates(gr, lindex, rindex, x.first, vv) == false) continue;
+            for(size_t k = 0; k < vv.size(); k++) vv[k]--;
+            add_node_list(vv, x.second);
+        }
+    }
+    void add_node_list(const std::vector<int> &s, int c, int o = 1) {   // hyper_set.cc:40-48
+        std::vector<int> v = s; std::sort(v.begin(), v.end());
+        for(size_t i = 0; i < v.size(); i++) v[i] += o;
+        if(nodes.find(v) == nodes.end()) nodes.insert(std::make_pair(v, c)); else nodes[v] += c;
+    }
+    void filter_nodes(const Graph &gr) {        // hyper_set.cc:356-371
+        std::map<std::vector<int>, int> mv;
+        for(auto &x : nodes) { if(x.first.size() <= 1) continue; if(check_valid_path(gr, x.first) == false) continue; mv.insert(x); }
+        nodes = mv;
+    }
     std::vector<std::vector<int>> edges;
     std::vector<int> ecnts;
     std::map<int, std::set<int>> e2s;

@@ -141,7 +141,22 @@ PARITY_CONFIGS = {
     "stranded": dict(seed=14, n_graphs=150, v_min=10, v_max=60, edges_per_vertex=3, strand_mode=1, layout_mode=1),
     "phasing": dict(seed=15, n_graphs=150, v_min=10, v_max=60, edges_per_vertex=3, phasing_per_graph=12, weight_mode=2),
     "everything": dict(seed=16, n_graphs=150, v_min=6, v_max=100, edges_per_vertex=3, phasing_per_graph=20, weight_mode=1, n_samples=4, strand_mode=1, layout_mode=1),
+    # the shape of real multi-sample data (tens of samples, phasing paths in the hundreds, edge counts that were ADDED along
+    # grouped boundaries and so differ from the number of supporting samples, graph_reviser.cc:965-975)
+    "real_shaped": dict(seed=17, n_graphs=60, v_min=20, v_max=120, edges_per_vertex=3, n_samples=30, phasing_per_graph=150, weight_mode=2, strand_mode=1, layout_mode=1,
+                        _extra_counts=3),
 }
+
+
+def make_batch(name: str) -> PackedGraphs:
+    """The synthetic batch of a PARITY_CONFIGS entry (keys starting with '_' are post-processing steps, not generator fields)."""
+    import aletsch_amd as A
+    kw = dict(PARITY_CONFIGS[name]); extra = kw.pop("_extra_counts", 0)
+    pg = A.synth(**kw)
+    if extra:
+        rng = np.random.default_rng(kw["seed"])
+        pg.edge_count = (pg.sample_counts() + rng.integers(0, extra + 1, pg.edge_target.size)).astype(np.int32)
+    return pg
 
 
 def transcript_stream_from_result(pg: PackedGraphs, res: DecompResult, sid=None, skip_single_exon: bool = False) -> np.ndarray:
@@ -196,3 +211,79 @@ def oracle_features(pg: PackedGraphs, extras=None):
         out.append(([f[i].as_dict() for i in range(k)], comp[:k].copy(), bool(bad)))
     O.ora_result_free(h)
     return r, out
+
+
+def gene_like_raw(rng, n_runs=6, strand="+"):
+    """A splice graph as assembler::assemble(gx, px, sid) receives it (before its pre-steps), plus a phase set in exon coordinates:
+    exons cut into runs of TOUCHING partial exons (edges j -> j+1 inside a run), junctions between runs, several start / end boundaries
+    close to each other (so that group_start/end_boundaries fold some), junctions that jump exactly over one partial exon (so that
+    extend_strands lends a strand), multi-sample edge_info with counts; phases walk real paths, some start / end on boundaries that
+    get grouped away, some are invalid (unknown coordinate, broken continuity).  -> (graph dict for PackedGraphs.from_graphs, phases)"""
+    runs = []; pos = 1000; v = 1; lpos = [0]; rpos = [0]
+    for r in range(n_runs):
+        k = int(rng.integers(1, 5)); run = []
+        for _ in range(k):
+            ln = int(rng.integers(30, 400)); lpos.append(pos); rpos.append(pos + ln); pos += ln; run.append(v); v += 1
+        runs.append(run); pos += int(rng.integers(50, 3000))
+    V = v + 1; lpos.append(pos); rpos.append(pos); lpos[0] = rpos[0] = 1000
+    ns = int(rng.integers(1, 6))
+
+    def info(w):
+        ids = sorted(set([0] + [int(x) for x in rng.integers(0, 8, ns)]))      # one sample supports every edge: intersections never go empty
+        return {i: float(rng.integers(1, 30)) for i in ids}
+    edges = []
+    have = set()
+
+    def add(s, t, w, st=0):
+        if (s, t) in have or not (0 <= s < t < V):
+            return
+        have.add((s, t)); edges.append((s, t, float(w), st, info(w)))
+    sd = {"+": 1, "-": 2, ".": 0}[strand]
+    for run in runs:
+        for a, b in zip(run, run[1:]):
+            add(a, b, rng.integers(2, 60))
+    for a, b in zip(runs, runs[1:]):                       # junctions between consecutive runs (+ a few skips)
+        add(a[-1], b[0], rng.integers(2, 80), sd)
+        if len(a) > 1 and rng.random() < 0.5:
+            add(a[int(rng.integers(0, len(a)))], b[int(rng.integers(0, len(b)))], rng.integers(1, 30), sd)
+    for i in range(len(runs) - 2):
+        if rng.random() < 0.4:
+            add(runs[i][-1], runs[i + 2][0], rng.integers(1, 25), sd)
+    for run in runs:                                       # a junction over exactly one partial exon: s -> s+2 with s+1 filling the gap
+        if len(run) >= 3 and rng.random() < 0.7:
+            add(run[0], run[2], rng.integers(40, 90), sd)
+    starts = set([runs[0][0]]) | set(int(x) for x in rng.choice(runs[0] + runs[1], size=min(3, len(runs[0] + runs[1])), replace=False))
+    ends = set([runs[-1][-1]]) | set(int(x) for x in rng.choice(runs[-1] + runs[-2], size=min(3, len(runs[-1] + runs[-2])), replace=False))
+    for s in sorted(starts):
+        add(0, s, rng.integers(1, 40))
+    for t in sorted(ends):
+        add(t, V - 1, rng.integers(1, 40))
+    order = rng.permutation(len(edges))                    # creation order of the caller's graph (pointer order in the reference)
+    edges = [edges[i] for i in order]
+    vw = [0.0] + [float(rng.integers(1, 50)) for _ in range(V - 2)] + [0.0]
+    g = dict(V=V, edges=edges, vw=vw, lpos=lpos, rpos=rpos, strand=strand)
+    # phases: exon-coordinate lists along forward walks of the graph
+    adj = {}
+    for s, t, *_ in edges:
+        adj.setdefault(s, []).append(t)
+    phases = []
+    for _ in range(int(rng.integers(3, 14))):
+        x = int(rng.choice(sorted(starts) + [r[0] for r in runs])); walk = [x]
+        while x in adj and len(walk) < 12 and rng.random() < 0.85:
+            nxt = [t for t in adj[x] if t != V - 1]
+            if not nxt:
+                break
+            x = int(rng.choice(nxt)); walk.append(x)
+        co = []
+        for a in walk:                                     # merge touching consecutive vertices into exons
+            if co and co[-1] == lpos[a]:
+                co[-1] = rpos[a]
+            else:
+                co += [lpos[a], rpos[a]]
+        kind = rng.random()
+        if kind < 0.1:
+            co[int(rng.integers(0, len(co)))] += 7          # a coordinate no vertex has
+        elif kind < 0.15 and len(co) >= 4:
+            co[1], co[2] = co[2], co[1]
+        phases.append((co, int(rng.integers(1, 6))))
+    return g, phases

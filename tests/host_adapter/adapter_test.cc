@@ -22,6 +22,7 @@ struct mock_graph {
     const mock_vertex_info &get_vertex_info(int v) const { return vi[v]; }
 };
 struct mock_hyper_set { std::map<std::vector<int>, int> nodes; };
+struct mock_phase_set { std::map<std::vector<int32_t>, int> pmap; };       // rnacore/phase_set.h:24
 struct mock_parameters { double max_decompose_error_ratio[8] = {0.30, 0.00, 1.10, 1.10, 0.75, 0.30, 0.00, 1.00}; double min_guaranteed_edge_weight = 0.01, min_transcript_coverage = 2.0; int max_num_exons = 10000; };
 struct mock_path { std::vector<int> v; std::vector<std::pair<int, int>> junc; int length = 0; double abd = 0, weight = 0, conf = 0, reads = 0; char strand = '.'; int count = 0; };
 
@@ -40,12 +41,29 @@ static void print_paths(int status, const std::vector<mock_path> &paths)
     for(auto &p : paths) { printf("%.17g %.17g %.17g %d %d %c %zu :", p.weight, p.abd, p.reads, p.length, p.count, p.strand, p.junc.size()); for(int x : p.v) printf(" %d", x); printf("\n"); }
 }
 
+// "raw N": N graphs as assembler::assemble(gx, px, sid) receives them (the P lines after the edges are PHASES in exon coordinates:
+//          "len count c0 c1 ..."), through gpu_scallop_batch::enqueue_raw -- the library runs the pre-steps -- then ONE flush
 // no argument: one graph through aletsch::gpu_scallop (ctor + assemble() + .paths);
 // "batch N": N graphs through aletsch::gpu_scallop_batch -- enqueue all, ONE flush, paths(i) per ticket, then clear() and a second round
 int main(int argc, char **argv)
 {
     mock_parameters cfg;
     try {
+        if(argc >= 3 && std::string(argv[1]) == "raw") {
+            const int N = atoi(argv[2]);
+            std::vector<mock_graph> gs((size_t)N); std::vector<mock_phase_set> ps((size_t)N);
+            for(int n = 0; n < N; n++) {
+                mock_hyper_set as_lists;                                   // read_graph parses "len count v..." lines: here they are coordinates
+                if(!read_graph(gs[(size_t)n], as_lists)) return 2;
+                for(auto &kv : as_lists.nodes) ps[(size_t)n].pmap[std::vector<int32_t>(kv.first.begin(), kv.first.end())] += kv.second;
+            }
+            aletsch::gpu_scallop_batch<mock_graph, mock_hyper_set, mock_parameters, mock_path> batch(cfg, 0);
+            std::vector<int> ticket;
+            for(int n = 0; n < N; n++) ticket.push_back(batch.enqueue_raw(gs[(size_t)n], ps[(size_t)n], 10000));
+            batch.flush();
+            for(int n = 0; n < N; n++) { if(ticket[(size_t)n] < 0) printf("status %d paths 0\n", -1 - ticket[(size_t)n]); else print_paths(batch.status(ticket[(size_t)n]), batch.paths(ticket[(size_t)n])); }
+            return 0;
+        }
         if(argc >= 3 && std::string(argv[1]) == "batch") {
             const int N = atoi(argv[2]);
             std::vector<mock_graph> gs((size_t)N); std::vector<mock_hyper_set> hs((size_t)N);

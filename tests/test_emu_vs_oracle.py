@@ -10,8 +10,7 @@ import common
 
 @pytest.mark.parametrize("name", list(common.PARITY_CONFIGS))
 def test_engine_matches_oracle(name):
-    kw = dict(common.PARITY_CONFIGS[name])       # the full configuration, exactly what the GPU tier runs
-    pg = A.synth(**kw)
+    pg = common.make_batch(name)                 # the full configuration, exactly what the GPU tier runs
     want, st, _, _ = common.oracle_run(pg)
     got, it, cl = common.emu_run(pg)
     assert not common.compare_results(want, got, pg.n)

@@ -185,3 +185,45 @@ def test_batched_adapter_enqueue_flush_paths():
             assert int(f[3]) == want.length[i] and int(f[4]) == want.count[i] and f[5] == chr(want.strand[i])
             assert [int(x) for x in vs.split()] == [int(x) for x in want.path_vertices[want.pv_offset[i]:want.pv_offset[i + 1]]]
     assert pos == len(out)
+
+
+@pytest.mark.gpu
+def test_adapter_takes_graphs_as_assemble_receives_them():
+    """aletsch::gpu_scallop_batch::enqueue_raw: the call shape of assembler::assemble(gx, px, sid) (meta/assembler.cc:1075) -- the graph
+    BEFORE extend_strands / boundary grouping and the phase set in exon coordinates; the library runs the pre-steps (ald_pre_assemble).
+    Output per graph == the oracle's pre-steps followed by the oracle's decomposition."""
+    build()
+    from aletsch_amd.packed import PackedGraphs
+    rng = np.random.default_rng(12)
+    texts = []; staged = []
+    for t in range(30):
+        g, phases = common.gene_like_raw(rng, n_runs=int(rng.integers(3, 8)), strand=".")
+        g["edges"] = [(s, tt, w, 0, {0: w}) for s, tt, w, _st, _sp in g["edges"]]          # what the mock edge_info of adapter_test carries
+        pg = PackedGraphs.from_graphs([g])
+        order = sorted(range(len(g["edges"])), key=lambda k: (g["edges"][k][0], g["edges"][k][1]))
+        pg.edge_rank = np.array(order, np.int32)
+        lines = ["%d %d %d" % (g["V"], len(g["edges"]), len(phases))]
+        lines += ["%r %d %d" % (float(g["vw"][i]), g["lpos"][i], g["rpos"][i]) for i in range(g["V"])]
+        lines += ["%d %d %r" % (s, tt, w) for s, tt, w, _a, _b in g["edges"]]                # listing order == creation order == gr.edges()
+        lines += ["%d %d %s" % (len(co), c, " ".join(str(x) for x in co)) for co, c in phases]
+        texts.append("\\n".join(lines) + "\\n")
+        import ctypes as C
+        O = common.oracle_lib()
+        O.ora_pre_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+        O.ora_staged_view.argtypes = [C.c_void_p, C.c_void_p]; O.ora_staged_free.argtypes = [C.c_void_p]; O.ora_staged_boundary_maps.argtypes = [C.c_void_p] * 5
+        want, _, _, rc = A.pre_assemble(pg, phases, 10000, _lib=O, _prefix="ora")
+        staged.append((want, rc))
+    out = subprocess.run([BIN, "raw", str(len(texts))], input="".join(texts), capture_output=True, text=True, check=True).stdout.splitlines()
+    pos = 0; n_paths = 0
+    for want_pg, rc in staged:
+        head = out[pos].split(); pos += 1
+        if rc:
+            assert int(head[1]) == rc and int(head[3]) == 0
+            continue
+        want = common.oracle_run(want_pg)[0]
+        assert head[0] == "status" and int(head[1]) == int(want.status[0]) and int(head[3]) == int(want.path_offset[1]), head
+        for i in range(int(want.path_offset[1])):
+            f, vs = out[pos].split(" :"); f = f.split(); pos += 1; n_paths += 1
+            assert float(f[0]) == want.weight[i] and float(f[1]) == want.abd[i] and float(f[2]) == want.reads[i]
+            assert [int(x) for x in vs.split()] == [int(x) for x in want.path_vertices[want.pv_offset[i]:want.pv_offset[i + 1]]]
+    assert pos == len(out) and n_paths > 50

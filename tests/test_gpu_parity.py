@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("name", list(common.PARITY_CONFIGS))
 def test_hip_matches_oracle(name):
-    pg = A.synth(**common.PARITY_CONFIGS[name])
+    pg = common.make_batch(name)
     want = common.oracle_run(pg)[0]
     got = A.decompose(pg, device=0)
     bad = common.compare_results(want, got, pg.n, conf_tol=1e-9)
@@ -547,3 +547,49 @@ def test_transcript_features_match_oracle():
         f0, _, _ = b.features(0)
         assert all(f.start_loss1 == 0 and f.gr_reads == 0 for f in f0)
     assert n_complete > 500 and n_single > 0 and n_intron > 0, (n_complete, n_single, n_assert, n_intron)
+
+
+def test_replayed_dumps_on_gpu():
+    """graphs that arrive as the reference's text dump (splice_graph::write + hyper_set::write; aletsch_amd/graphio.py): parsed, staged
+    with the creation order of the dump's lines, decomposed by the HIP kernels, compared with the oracle"""
+    from aletsch_amd import graphio
+    src = A.synth(seed=83, n_graphs=400, v_min=6, v_max=90, edges_per_vertex=3, weight_mode=1, phasing_per_graph=10, layout_mode=0)
+    src.edge_strand[:] = 0; src.vertex_weight[:] = np.round(src.vertex_weight)
+    pg, meta = graphio.read_bundle_dump(graphio.write_bundle_dump(src))
+    assert pg.n == src.n and np.array_equal(pg.edge_weight, src.edge_weight)
+    want = common.oracle_run(pg, threads=4)[0]
+    got = A.decompose(pg, 0)
+    assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
+    assert (got.status == 0).all()
+
+
+def test_raw_graphs_through_the_pre_steps_on_gpu():
+    """ald_batch_add_graph_raw: graphs as assembler::assemble(gx, px, sid) receives them + phase sets in exon coordinates; the library
+    runs extend_strands / boundary grouping / phase projection / hyper_set ctor / filter_nodes on the host, the kernels decompose;
+    against the oracle's pre-steps + decomposition"""
+    import ctypes as C
+    from aletsch_amd.packed import PackedGraphs
+    O = common.oracle_lib()
+    O.ora_pre_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    O.ora_staged_view.argtypes = [C.c_void_p, C.c_void_p]; O.ora_staged_free.argtypes = [C.c_void_p]; O.ora_staged_boundary_maps.argtypes = [C.c_void_p] * 5
+    rng = np.random.default_rng(1076)
+    want_parts = []; n_assert = 0
+    with A.DecompBatch(0) as b:
+        for t in range(300):
+            g, phases = common.gene_like_raw(rng, n_runs=int(rng.integers(3, 10)), strand="+-."[t % 3])
+            pg = PackedGraphs.from_graphs([g])
+            pg.edge_rank = np.array(sorted(range(len(g["edges"])), key=lambda k: (g["edges"][k][0], g["edges"][k][1])), np.int32)
+            pg.edge_count = (pg.sample_counts() + rng.integers(0, 3, pg.edge_target.size)).astype(np.int32)
+            want, _, _, rc_o = A.pre_assemble(pg, phases, 10000, _lib=O, _prefix="ora")
+            rc = b.add_raw(pg, phases, 10000)
+            assert rc == rc_o
+            if rc:
+                n_assert += 1; continue
+            want_parts.append(want)
+        assert b.n == len(want_parts) and n_assert < 60
+        b.upload(); b.run(); b.download()
+        got = b.result()
+    batch = PackedGraphs.concat(want_parts)
+    want = common.oracle_run(batch, threads=4)[0]
+    assert not common.compare_results(want, got, batch.n, conf_tol=1e-9)
+    assert (want.status == 0).sum() > 200
