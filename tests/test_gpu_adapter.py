@@ -206,7 +206,7 @@ def test_adapter_takes_graphs_as_assemble_receives_them():
         lines += ["%r %d %d" % (float(g["vw"][i]), g["lpos"][i], g["rpos"][i]) for i in range(g["V"])]
         lines += ["%d %d %r" % (s, tt, w) for s, tt, w, _a, _b in g["edges"]]                # listing order == creation order == gr.edges()
         lines += ["%d %d %s" % (len(co), c, " ".join(str(x) for x in co)) for co, c in phases]
-        texts.append("\\n".join(lines) + "\\n")
+        texts.append("\n".join(lines) + "\n")
         import ctypes as C
         O = common.oracle_lib()
         O.ora_pre_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
