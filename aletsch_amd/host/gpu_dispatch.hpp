@@ -18,6 +18,11 @@
 // the serial loop; with several, chunks interleave as the pool produced them, exactly as the reference's merge order is whatever
 // `mylock` produced.
 //
+// Several MI355X in ONE process (the reference's own shape: one process, one pool -- meta/incubator.cc:609-637): give the queue a device
+// list.  Every device gets its own slots and its own GPU thread; the pack thread deals batches to the least loaded device; the merge
+// thread takes finished batches in the order they were CUT (= ticket order), whichever device finishes first, so the merged set does
+// not depend on the number of devices.  No collective is involved: bundles are independent, the result set lives in host memory.
+//
 // C++11, header only; compiles inside the reference tree with its own types (see gpu_scallop.hpp for the members used).
 #pragma once
 #include "gpu_scallop.hpp"
@@ -73,28 +78,35 @@ public:
     // sink: the shared result set (the reference's `tmerge`); skip_single_exon: cfg.skip_single_exon_transcripts (assembler.cc:1117);
     // chunk_graphs: graphs a submitting thread collects before it hands them over (capped by batch_graphs)
     gpu_assembly_queue(const Parameters &cfg, ald_tset *sink, bool skip_single_exon = false, int device = 0, int batch_graphs = 65536, int slots = 4, int chunk_graphs = 2048)
+        : gpu_assembly_queue(cfg, sink, skip_single_exon, std::vector<int>(1, device), batch_graphs, slots, chunk_graphs) {}
+    // devices: HIP device ordinals (an ordinal may repeat: two GPU threads then share that device); slots: batch objects PER device
+    gpu_assembly_queue(const Parameters &cfg, ald_tset *sink, bool skip_single_exon, const std::vector<int> &devices, int batch_graphs = 65536, int slots = 4, int chunk_graphs = 2048)
         : sink_(sink), skip_(skip_single_exon), batch_graphs_(batch_graphs < 1 ? 1 : batch_graphs)
     {
         if(!sink) throw std::invalid_argument("gpu_assembly_queue: null sink");
+        if(devices.empty()) throw std::invalid_argument("gpu_assembly_queue: empty device list");
         if(slots < 1) slots = 1;
+        const int ndev = (int)devices.size();
         chunk_graphs_ = chunk_graphs < 1 ? 1 : chunk_graphs; if(chunk_graphs_ > batch_graphs_) chunk_graphs_ = batch_graphs_;
-        ready_cap_ = (long)batch_graphs_ * (slots + 1);
+        ready_cap_ = (long)batch_graphs_ * (slots * ndev + 1);
         ald_params p = stage_params(cfg);
-        slots_.resize((size_t)slots);
-        for(auto &s : slots_) {
-            int rc = ald_batch_create(&p, device, &s.b);
+        slots_.resize((size_t)slots * ndev); gpu_q_.resize((size_t)ndev); dev_load_.assign((size_t)ndev, 0);
+        for(size_t i = 0; i < slots_.size(); i++) {
+            slots_[i].dev = (int)(i / (size_t)slots);
+            int rc = ald_batch_create(&p, devices[(size_t)slots_[i].dev], &slots_[i].b);
             if(rc != ALD_OK) { for(auto &q : slots_) if(q.b) ald_batch_destroy(q.b); throw gpu_error(rc, "ald_batch_create"); }
         }
+        cv_gpu_.reset(new std::condition_variable[(size_t)ndev]);
         pack_thread_ = std::thread([this] { pack_loop(); });
-        gpu_thread_ = std::thread([this] { gpu_loop(); });
+        for(int d = 0; d < ndev; d++) gpu_threads_.emplace_back([this, d] { gpu_loop(d); });
         merge_thread_ = std::thread([this] { merge_loop(); });
     }
     ~gpu_assembly_queue()
     {
         try { drain(); } catch(...) {}
         { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
-        cv_pack_.notify_all(); cv_gpu_.notify_all(); cv_merge_.notify_all();
-        pack_thread_.join(); gpu_thread_.join(); merge_thread_.join();
+        cv_pack_.notify_all(); for(size_t d = 0; d < gpu_q_.size(); d++) cv_gpu_[d].notify_all(); cv_merge_.notify_all();
+        pack_thread_.join(); for(auto &t : gpu_threads_) t.join(); merge_thread_.join();
         for(auto &s : slots_) if(s.b) ald_batch_destroy(s.b);
     }
     gpu_assembly_queue(const gpu_assembly_queue &) = delete;
@@ -156,7 +168,7 @@ public:
 
 private:
     enum { FREE, BUSY };
-    struct slot { ald_batch *b = nullptr; std::vector<int32_t> sid; long first = 0; int state = FREE; };
+    struct slot { ald_batch *b = nullptr; std::vector<int32_t> sid; long first = 0; int state = FREE; int dev = 0; bool done = false; };
     struct lane { std::mutex m; packed_chunk c; };
 
     lane *my_lane()
@@ -185,13 +197,17 @@ private:
                 std::unique_lock<std::mutex> lk(m_);
                 for(;;) {
                     const bool work = ready_graphs_ >= batch_graphs_ || (flush_ && !ready_.empty());
-                    if(work) { for(size_t k = 0; k < slots_.size(); k++) if(slots_[k].state == FREE) { i = (int)k; break; } if(i >= 0) break; }
+                    if(work) {                                            // a free slot on the device with the fewest batches in flight
+                        for(size_t k = 0; k < slots_.size(); k++) if(slots_[k].state == FREE && (i < 0 || dev_load_[(size_t)slots_[k].dev] < dev_load_[(size_t)slots_[(size_t)i].dev])) i = (int)k;
+                        if(i >= 0) break;
+                    }
                     else if(stop_) return;
                     cv_pack_.wait(lk);
                 }
                 long got = 0;
                 while(!ready_.empty() && got < batch_graphs_) { got += ready_.front().n(); take.push_back(std::move(ready_.front())); ready_.pop_front(); }
-                ready_graphs_ -= got; gathering_ = true; slots_[(size_t)i].state = BUSY; batches_++;
+                ready_graphs_ -= got; gathering_ = true; slots_[(size_t)i].state = BUSY; slots_[(size_t)i].done = false; batches_++;
+                dev_load_[(size_t)slots_[(size_t)i].dev]++; cut_order_.push_back(i);                      // merged in the order the batches are cut
                 cv_space_.notify_all();
             }
             const auto t0 = std::chrono::steady_clock::now();
@@ -205,14 +221,15 @@ private:
             if(rc != ALD_OK) fail(rc, "ald_batch_add_packed");
             t_pack_ += std::chrono::duration<double>(t1 - t0).count();
             gathering_ = false; in_flight_++;
-            gpu_q_.push_back(i); cv_gpu_.notify_one();
+            gpu_q_[(size_t)S.dev].push_back(i); cv_gpu_[(size_t)S.dev].notify_one();
         }
     }
-    void gpu_loop()                                               // upload, kernel, download of one batch at a time
+    void gpu_loop(int d)                                          // upload, kernel, download of one batch at a time, on device slot d
     {
+        std::deque<int> &mine = gpu_q_[(size_t)d];
         for(;;) {
             int i; bool ok;
-            { std::unique_lock<std::mutex> lk(m_); while(gpu_q_.empty() && !stop_) cv_gpu_.wait(lk); if(gpu_q_.empty()) return; i = gpu_q_.front(); gpu_q_.pop_front(); ok = !err_; }
+            { std::unique_lock<std::mutex> lk(m_); while(mine.empty() && !stop_) cv_gpu_[(size_t)d].wait(lk); if(mine.empty()) return; i = mine.front(); mine.pop_front(); ok = !err_; }
             slot &S = slots_[(size_t)i];
             const auto t1 = std::chrono::steady_clock::now();
             int rc = ALD_OK; const char *what = "ald_batch_upload";
@@ -228,14 +245,19 @@ private:
             if(rc != ALD_OK) fail(rc, what);
             t_gpu_ += std::chrono::duration<double>(t2 - t1).count();
             failed_ += bad;
-            merge_q_.push_back(i); cv_merge_.notify_one();
+            S.done = true; dev_load_[(size_t)d]--; cv_merge_.notify_one(); cv_pack_.notify_all();
         }
     }
     void merge_loop()
     {
         for(;;) {
             int i; bool ok;
-            { std::unique_lock<std::mutex> lk(m_); while(merge_q_.empty() && !stop_) cv_merge_.wait(lk); if(merge_q_.empty()) return; i = merge_q_.front(); merge_q_.pop_front(); ok = !err_; }
+            {   // the oldest cut batch, once its device is done with it: ticket order, whichever device finishes first
+                std::unique_lock<std::mutex> lk(m_);
+                while(!(!cut_order_.empty() && slots_[(size_t)cut_order_.front()].done) && !(stop_ && cut_order_.empty())) cv_merge_.wait(lk);
+                if(cut_order_.empty()) return;
+                i = cut_order_.front(); cut_order_.pop_front(); ok = !err_;
+            }
             slot &S = slots_[(size_t)i];
             int rc = ALD_OK;
             const auto t0 = std::chrono::steady_clock::now();
@@ -245,20 +267,21 @@ private:
             std::lock_guard<std::mutex> lk(m_);
             t_merge_ += std::chrono::duration<double>(t1 - t0).count();
             if(rc != ALD_OK) fail(rc, "ald_tset_add_batch");
-            S.state = FREE; in_flight_--;
+            S.state = FREE; S.done = false; in_flight_--;
             cv_pack_.notify_all(); cv_done_.notify_all();
         }
     }
 
     ald_tset *sink_; bool skip_; int batch_graphs_, chunk_graphs_ = 1; long ready_cap_ = 0;
     mutable std::mutex m_;
-    std::condition_variable cv_pack_, cv_gpu_, cv_merge_, cv_done_, cv_space_;
-    std::vector<slot> slots_; std::deque<int> gpu_q_, merge_q_; std::deque<packed_chunk> ready_;
+    std::condition_variable cv_pack_, cv_merge_, cv_done_, cv_space_;
+    std::unique_ptr<std::condition_variable[]> cv_gpu_;           // one per device slot
+    std::vector<slot> slots_; std::vector<std::deque<int>> gpu_q_; std::vector<int> dev_load_; std::deque<int> cut_order_; std::deque<packed_chunk> ready_;
     std::map<std::thread::id, std::unique_ptr<lane>> lanes_;
     long next_ = 0, failed_ = 0, batches_ = 0, ready_graphs_ = 0; int in_flight_ = 0; bool stop_ = false, flush_ = false, gathering_ = false;
     double t_pack_ = 0, t_gpu_ = 0, t_merge_ = 0;
     int err_ = 0; std::string err_msg_;
-    std::thread pack_thread_, gpu_thread_, merge_thread_;
+    std::thread pack_thread_, merge_thread_; std::vector<std::thread> gpu_threads_;
 };
 
 } // namespace aletsch

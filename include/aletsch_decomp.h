@@ -274,6 +274,18 @@ int  ald_batch_transcript_stream(const ald_batch *b, const int32_t *sid, int32_t
 /* Merge such a stream, graph by graph in stream order (assembler.cc:1105-1133): coverage = log(1 + weight) is taken here, on the host;
  * tid = tid_base + ((graph + graph_offset) << 20 | path index), i.e. what ald_tset_add_batch gives the same graph in an unsharded batch */
 int  ald_tset_add_stream(ald_tset *t, const uint32_t *words, int64_t n_words, int32_t graph_offset, int64_t tid_base);
+/* ---- the exchange step for a multi-PROCESS host (one process per MI355X): transcript streams -> rank 0 over RCCL / xGMI ----
+ * (A host that drives all its devices from one process -- aletsch::gpu_assembly_queue over a device list -- needs none of this.)
+ * RCCL is loaded on first use.  Bootstrap: rank 0 calls ald_comm_unique_id and ships the 128 bytes to the other ranks by its own
+ * means; then every rank calls ald_comm_create.  ald_comm_gather_streams is a collective: every rank passes its stream and the
+ * global id of its first graph; rank 0 receives all streams back to back in rank order (== ascending global graph id), ready for
+ * ald_tset_add_stream(t, all_words + offsets[r], offsets[r + 1] - offsets[r], graph_offsets[r], tid_base). */
+typedef struct ald_comm ald_comm;
+int  ald_comm_unique_id(uint8_t id[128]);
+int  ald_comm_create(const uint8_t id[128], int32_t world, int32_t rank, int32_t device, ald_comm **out);
+int  ald_comm_gather_streams(ald_comm *c, const uint32_t *words, int64_t n_words, int32_t graph_offset,
+                             const uint32_t **all_words /* rank 0 */, const int64_t **offsets /* [world + 1] */, const int32_t **graph_offsets /* [world] */);
+int  ald_comm_destroy(ald_comm *c);
 int  ald_tset_size(const ald_tset *t, int64_t *n_items, int64_t *n_exons, int64_t *n_samples);
 /* items in the reference's iteration order (hash ascending, then bucket order) */
 int  ald_tset_export(const ald_tset *t, uint64_t *hash, int32_t *count, char *strand, double *coverage, double *cov2, double *conf, double *abd,

@@ -1,5 +1,6 @@
 // dispatch_test.cc -- exercises aletsch_amd/host/gpu_dispatch.hpp (queue + flusher over the C ABI) with the mock types of
-// adapter_test.cc.  stdin: "N T B S" (graphs, submitting threads, graphs per batch, slots), then N graphs in adapter_test's format.
+// adapter_test.cc.  stdin: "N T B S D" (graphs, submitting threads, graphs per batch, slots per device, device slots -- all on HIP
+// device 0: D > 1 runs the several-devices-in-one-process form with D GPU threads), then N graphs in adapter_test's format.
 // Thread t submits graphs t, t + T, ...; sample id of graph g = g % 3.  Prints the merged sink.  Driven by tests/test_gpu_adapter.py.
 #include "../../aletsch_amd/host/gpu_dispatch.hpp"
 #include <cstdio>
@@ -23,8 +24,8 @@ struct mock_parameters { double max_decompose_error_ratio[8] = {0.30, 0.00, 1.10
 
 int main()
 {
-    int N, T, B, S;
-    if(scanf("%d %d %d %d", &N, &T, &B, &S) != 4) return 2;
+    int N, T, B, S, D;
+    if(scanf("%d %d %d %d %d", &N, &T, &B, &S, &D) != 5) return 2;
     std::vector<mock_graph> gs((size_t)N); std::vector<mock_hyper_set> hs((size_t)N); mock_parameters cfg;
     for(int n = 0; n < N; n++) {
         int V, E, P; mock_graph &g = gs[(size_t)n];
@@ -36,7 +37,7 @@ int main()
     ald_tset *tm = nullptr;
     if(ald_tset_create(0.8, &tm) != ALD_OK) return 3;
     try {
-        aletsch::gpu_assembly_queue<mock_graph, mock_hyper_set, mock_parameters> q(cfg, tm, false, 0, B, S);
+        aletsch::gpu_assembly_queue<mock_graph, mock_hyper_set, mock_parameters> q(cfg, tm, false, std::vector<int>((size_t)D, 0), B, S);
         std::vector<std::thread> th;
         for(int t = 0; t < T; t++) th.emplace_back([&, t] { for(int n = t; n < N; n += T) q.submit(gs[(size_t)n], hs[(size_t)n], n % 3); });
         for(auto &x : th) x.join();

@@ -142,11 +142,16 @@ def test_dispatch_queue_matches_the_serial_merge():
     assert len(want) > 100
     text = "".join(graph_text(pg.select(np.array([g]))) for g in range(pg.n))
     # one submitter, batches of 64 graphs, 3 slots: five batches, the last one partial
-    out = subprocess.run([DBIN], input="%d 1 64 3\n%s" % (pg.n, text), capture_output=True, text=True, check=True).stdout.splitlines()
+    out = subprocess.run([DBIN], input="%d 1 64 3 1\n%s" % (pg.n, text), capture_output=True, text=True, check=True).stdout.splitlines()
     assert out[0] == "submitted %d failed %d batches 5" % (pg.n, n_failed), out[0]
     assert _parse_sink(out[1:]) == want
+    # several devices in one process (here: three GPU threads with two batch objects each, all on device 0): batches finish in any
+    # order, the merge takes them in the order they were cut -- same set, bit for bit
+    out = subprocess.run([DBIN], input="%d 1 32 2 3\n%s" % (pg.n, text), capture_output=True, text=True, check=True).stdout.splitlines()
+    assert out[0] == "submitted %d failed %d batches 10" % (pg.n, n_failed), out[0]
+    assert _parse_sink(out[1:]) == want
     # four submitters, batches of 32, 2 slots (submitters wait for a free slot): ticket order is up to the scheduler
-    out = subprocess.run([DBIN], input="%d 4 32 2\n%s" % (pg.n, text), capture_output=True, text=True, check=True).stdout.splitlines()
+    out = subprocess.run([DBIN], input="%d 4 32 2 2\n%s" % (pg.n, text), capture_output=True, text=True, check=True).stdout.splitlines()
     assert out[0].startswith("submitted %d failed %d batches" % (pg.n, n_failed)), out[0]
     got = _parse_sink(out[1:])
     key = lambda x: (x["hash"], x["strand"], tuple(tuple(e) for e in x["exons"]))

@@ -593,3 +593,41 @@ def test_raw_graphs_through_the_pre_steps_on_gpu():
     want = common.oracle_run(batch, threads=4)[0]
     assert not common.compare_results(want, got, batch.n, conf_tol=1e-9)
     assert (want.status == 0).sum() > 200
+
+
+def test_rccl_gather_behind_the_c_abi():
+    """ald_comm_*: the exchange step for a multi-process host, in C behind the ABI (RCCL loaded on first use): unique id -> communicator ->
+    gather of the finished-transcript streams to rank 0 -> ald_tset_add_stream.  One rank here (RCCL refuses two ranks on one device,
+    and this box has one); run in a fresh process so that the library's RCCL and torch's bundled copy never share an address space."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import ctypes as C, sys, numpy as np
+        sys.path.insert(0, %r)
+        import aletsch_amd as A
+        lib = A.load_library()
+        lib.ald_comm_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        lib.ald_comm_gather_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(C.c_int32))]
+        lib.ald_comm_destroy.argtypes = [C.c_void_p]
+        uid = (C.c_uint8 * 128)()
+        assert lib.ald_comm_unique_id(uid) == 0, lib.ald_last_error()
+        comm = C.c_void_p()
+        assert lib.ald_comm_create(uid, 1, 0, 0, C.byref(comm)) == 0, lib.ald_last_error()
+        pg = A.synth(seed=47, n_graphs=800, v_min=8, v_max=60, edges_per_vertex=3, layout_mode=1, weight_mode=2)
+        sid = (np.arange(pg.n) %% 3).astype(np.int32)
+        with A.DecompBatch(0) as b:
+            b.add(pg); b.upload(); b.run(); b.download()
+            w = b.transcript_stream(sid)
+            direct = A.TranscriptSink(0.8); direct.add_batch(b, sid)
+        for rep in range(2):                                   # buffers are reused on the second step
+            allw = C.POINTER(C.c_uint32)(); offs = C.POINTER(C.c_int64)(); goffs = C.POINTER(C.c_int32)()
+            assert lib.ald_comm_gather_streams(comm, C.c_void_p(w.ctypes.data), C.c_int64(w.size), C.c_int32(0), C.byref(allw), C.byref(offs), C.byref(goffs)) == 0, lib.ald_last_error()
+            assert offs[0] == 0 and offs[1] == w.size and goffs[0] == 0
+            got = np.ctypeslib.as_array(allw, shape=(w.size,)).copy()
+            assert np.array_equal(got, w)
+        via = A.TranscriptSink(0.8); via.add_stream(got, graph_offset=int(goffs[0]))
+        assert via.items() == direct.items() and len(via.items()) > 500
+        assert lib.ald_comm_destroy(comm) == 0
+        print("COMM_OK", w.size)
+    ''') % common.ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "COMM_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
