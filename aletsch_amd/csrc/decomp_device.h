@@ -903,6 +903,13 @@ template<bool A> ALD_INL void star_wave_body(int x)
     int32_t *fe = (int32_t*)H.scr_i, *ord = fe + STAR_MAX, *inv = fe + 2 * STAR_MAX, *oth = fe + 3 * STAR_MAX, *ctx = (int32_t*)H.scr_i;
     double *fw = (double*)H.scr_d, *sq = fw + STAR_MAX;                  // pair weights (list order) / per merge: (sum, later r1), in merge order
     double *dctx = fw + 2 * STAR_MAX;                                      // [0] = weight c starts with, [1] = vertex weight of x
+    // what the merges need of c's record and of vertex x is asked for NOW, by every lane (one broadcast request each): the round
+    // trip to L2 runs under phases 0..2 instead of in front of phase 3
+    const int c_early = A ? first_in(x) : first_out(x);
+    const double medc = C.ed[c_early].med, cc = C.ed[c_early].econf, abc = C.ed[c_early].s0abd, vw_early = C.vx[x].vw;
+    const int meic_v = C.ed[c_early].mei, cntc_v = C.ed[c_early].ecount, stc_v = C.ed[c_early].estrand, idc_v = C.ed[c_early].s0id;
+    const uint32_t nsc_v = C.ed[c_early].sp_len;
+    const int lt_v = C.vx[x].lpos, rt_v = C.vx[x].rpos, ov_v = C.vx[x].v2v;
     // ---- phase 0 (lane 0): gather the fan, balance_vertex(x) on the gathered weights, pair weights -- as in the sequential form
     if(lane == 0) {
         const int c = A ? u_first_in(x) : u_first_out(x);
@@ -944,7 +951,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
     if(lane == 0) {
         double mdc = 0; int bad = 0;
         for(int q = 0; q < n; q++) { double w = fw[ord[q]]; if(ALD_UNLIKELY(!(w >= mw - kSMIN))) bad = ALD_ST_INVARIANT + ALD_INV_WEIGHT; mdc = (q == 0) ? w : mdc + w; }
-        dctx[0] = mdc; dctx[1] = C.vx[x].vw;
+        dctx[0] = mdc; dctx[1] = vw_early;
         if(bad) ctx[SW_FAIL] = bad;
     }
     for(int j = lane; j < n; j += ALD_WAVE) H.ed[fe[j]].w = fw[j];
@@ -952,10 +959,9 @@ template<bool A> ALD_INL void star_wave_body(int x)
     if(uni(ctx[SW_FAIL])) { if(lane == 0) fail(ctx[SW_FAIL]); wsync(); return; }
     PROF_ADD(PF_T_SETUP);
     const int id0 = uni(H.next_id);
-    const double medc = C.ed[c].med, cc = C.ed[c].econf;
-    const int meic = uni(C.ed[c].mei), cntc = uni(C.ed[c].ecount), stc = uni(C.ed[c].estrand);
-    const uint32_t nsc = uni(C.ed[c].sp_len); const int idc = uni(C.ed[c].s0id); const double abc = C.ed[c].s0abd;
-    const int lt = uni(C.vx[x].lpos), rt = uni(C.vx[x].rpos), ov = uni(C.vx[x].v2v);
+    const int meic = uni(meic_v), cntc = uni(cntc_v), stc = uni(stc_v), idc = uni(idc_v);
+    const uint32_t nsc = uni(nsc_v);
+    const int lt = uni(lt_v), rt = uni(rt_v), ov = uni(ov_v);
     // what is left of c before merge q, whether merge q cuts a piece off, the id of its merged edge: replayed by lane q
     #define SW_REPLAY(q_, wcur_, sc_, rem_, nid_, dead_) \
         double wcur_ = dctx[0], rem_ = 0; bool sc_ = false, dead_ = false; int nid_ = id0; \
@@ -969,11 +975,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
     for(int q = lane; q < n; q += ALD_WAVE) {
         SW_REPLAY(q, wcur, sc, rem, nid, dead);
         const int j = ord[q]; const double ww = fw[j];
-        int bad = 0;
-        if(dead) bad = ALD_ST_INVARIANT + ALD_INV_OTHER;                      // the sequential form would be handed a dead edge here
-        else if(nid - (sc ? 1 : 0) >= 0xFFF0) bad = ALD_ST_CAPACITY;          // the id counter as merge q finds it
-        else if(!(cntc > 0 && C.ed[fe[j]].ecount > 0)) bad = ALD_ST_INVARIANT + ALD_INV_COUNT;
-        if(ALD_UNLIKELY(bad)) { ctx[SW_FAIL] = bad; }                          // (any failing lane: the graph is abandoned with one of the statuses the sequence would raise; see below)
+        (void)nid; (void)dead;
         double sfan = 0;
         for(int k = 0; k < n; k++) if(inv[k] >= q) sfan += fw[k];             // not merged yet, list order
         double sc_side = 0; sc_side += sc ? rem : wcur; if(sc) sc_side += ww;
@@ -981,24 +983,6 @@ template<bool A> ALD_INL void star_wave_body(int x)
         oth[q] = A ? (int)H.ed[fe[j]].lk.et : (int)H.ed[fe[j]].lk.es;
     }
     wsync();
-    // which failure the sequence meets first: the smallest q that has one
-    if(uni(ctx[SW_FAIL])) {
-        int code = 0;
-        if(lane == 0) {
-            double wcur = dctx[0]; int nid = id0; bool dead = false;
-            for(int q = 0; q < n && !code; q++) {
-                const double ww = fw[ord[q]]; const bool sc = !(fabs(wcur - ww) <= kSMIN);
-                if(dead) code = ALD_ST_INVARIANT + ALD_INV_OTHER;
-                else if(nid >= 0xFFF0) code = ALD_ST_CAPACITY;
-                else if(!(cntc > 0 && C.ed[fe[ord[q]]].ecount > 0)) code = ALD_ST_INVARIANT + ALD_INV_COUNT;
-                if(sc) { nid++; double rem = wcur - ww; if(rem <= mw) rem = mw; wcur = rem; } else dead = true;
-                nid++;
-            }
-            fail(code ? code : ctx[SW_FAIL]);
-        }
-        wsync();
-        return;
-    }
     PROF_ADD(PF_T_MERGE_LOAD);
     // ---- phase 4 (lane 0): the weight of x, merge by merge; sq[q] becomes r1 of merge q
     if(lane == 0) {
@@ -1021,17 +1005,24 @@ template<bool A> ALD_INL void star_wave_body(int x)
     bool dup = false;
     for(int q = lane; q < n; q += ALD_WAVE) { const int o = oth[q]; for(int k = 0; k < q; k++) if(oth[k] == o) dup = true; }
     const bool any_dup = wballot(dup) != 0;
-    bool multi = false;
+    bool multi = false, broken = false;
     for(int q = lane; q < n; q += ALD_WAVE) {
         SW_REPLAY(q, wcur, sc, rem, nid, dead);
-        (void)rem; (void)dead;
+        (void)rem;
         const int j = ord[q], f = fe[j]; const double ww = fw[j];
         const double wc0 = sc ? ww : wcur;
         const double medc1 = sc ? medc * ww / wcur : medc;
         const double r1 = sq[q];
         const double medf = C.ed[f].med, cf = C.ed[f].econf;
-        const int meif = C.ed[f].mei, stf = C.ed[f].estrand;
+        const int meif = C.ed[f].mei, stf = C.ed[f].estrand, cntf = C.ed[f].ecount;
         const uint32_t nsf = C.ed[f].sp_len; const int idf = C.ed[f].s0id; const double abf = C.ed[f].s0abd;
+        {   // what the sequential form checks when it reaches merge q, in its order: a consumed c, the id counter, the two counts
+            int code = 0;
+            if(dead) code = ALD_ST_INVARIANT + ALD_INV_OTHER;
+            else if(nid - (sc ? 1 : 0) >= 0xFFF0) code = ALD_ST_CAPACITY;
+            else if(!(cntc > 0 && cntf > 0)) code = ALD_ST_INVARIANT + ALD_INV_COUNT;
+            inv[q] = code; if(ALD_UNLIKELY(code)) broken = true;
+        }
         if(nsc == 1 && nsf == 1) {
             if(idf == idc) { const double xa = A ? abc : abf, ya = A ? abf : abc; const double mn = (ya < xa) ? ya : xa; C.ed[f].sp_off = 0; C.ed[f].ecount = 1; C.ed[f].eabd = 0.0 + mn; C.ed[f].s0abd = mn; }
             else { C.ed[f].sp_off = 0; C.ed[f].sp_len = 0; C.ed[f].ecount = 0; C.ed[f].eabd = 0; C.ed[f].s0id = 0; C.ed[f].s0abd = 0; }
@@ -1046,6 +1037,12 @@ template<bool A> ALD_INL void star_wave_body(int x)
         if(!any_dup) { if(A) relink_in_lane(oth[q], f, (uint32_t)far); else relink_out_lane(oth[q], f, tkey((uint32_t)far)); }
     }
     const bool any_multi = wballot(multi) != 0;
+    if(ALD_UNLIKELY(wballot(broken) != 0)) {                                    // the failure the sequence meets first: the smallest q that has one
+        wsync();
+        if(lane == 0) for(int q = 0; q < n; q++) if(inv[q]) { fail(inv[q]); break; }
+        wsync();
+        return;
+    }
     // far's list: c leaves it now (lane 0, while nothing else touches a list of that kind), the merged edges enter it below
     const bool counted = A ? (far == 0 && !uni(H.special_linked)) : (far == (int)uni(H.sinkp) && !uni(H.special_linked));     // out(source) / in(sink) are only counted
     const bool consumed = uni(ctx[SW_SERIAL]) != 0;
