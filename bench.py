@@ -4,7 +4,7 @@
 One "step" = one pass of the hot path over one batch of synthetic splice graphs, host arrays in -> host results out:
 pack into the pinned wire buffer (ald_batch_add_packed) + ONE H2D copy + the decomposition kernels + D2H of the status words and
 packed path records (+ at N > 1 the RCCL gather of the finished transcripts to rank 0, the path's only exchange step: SURVEY.md 8e).
-Three batch objects rotate so that staging and H2D of batch k+1 run on a host thread / the copy engine while the kernel of
+Four batch objects rotate so that staging and H2D of batches k+1 and k+2 run on two host threads / the copy engine while the kernel of
 batch k runs; kernels never overlap each other, so the per-launch HIP-event time is that of one kernel on an otherwise idle GPU.
 `value` is that H2D-inclusive rate (SURVEY.md 8d's definition of the metric); `value_resident` is the rate of a second timed loop
 over batches that are already resident in HBM (kernel + D2H only), the figure round 1 reported.
@@ -44,7 +44,7 @@ N_CUS = 256
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graphs", type=int, default=100000, help="graphs per GPU (BASELINE configs[1]: 100k)")
     ap.add_argument("--vertices", type=int, default=64)
@@ -200,7 +200,7 @@ def main() -> int:
         dist.barrier(); dist.destroy_process_group()
         return 0
 
-    NB = 3
+    NB = 4                                               # in flight: one kernel, one download, two being staged
     batches = [A.DecompBatch(dev) for _ in range(NB)]
     stream_read = {}                                     # batch -> event reached once the exchange has read what it sent
 
@@ -228,19 +228,51 @@ def main() -> int:
             free.put(b)
         err = []
 
-        def stager():
+        todo = queue.Queue()
+        for _ in range(k):
+            todo.put(1)
+
+        added = queue.Queue()
+        stage_s = [0.0, 0.0, 0.0]                                # busy seconds: host copy / pack + H2D / main thread waiting for a staged batch
+
+        def adder():                                             # stage 1: caller's arrays -> the batch's canonical host arrays (+ in-CSR)
             try:
-                for _ in range(k):
+                while True:
+                    try:
+                        todo.get_nowait()
+                    except queue.Empty:
+                        added.put(None); return
                     b = free.get()
+                    t_ = time.perf_counter()
                     if staged:
-                        b.clear(); b.add(pg); b.upload()         # pack into the pinned wire buffer + ONE H2D copy + first-pass work lists
-                    ready.put(b)
+                        b.clear(); b.add(pg)
+                    stage_s[0] += time.perf_counter() - t_
+                    added.put(b)
             except BaseException as e:                           # surface the failure in the main thread instead of a hang
+                err.append(e); added.put(None); ready.put(None)
+
+        def uploader():                                          # stage 2: pack into the pinned wire buffer + ONE H2D copy + first-pass work lists
+            try:
+                while True:
+                    b = added.get()
+                    if b is None:
+                        return
+                    t_ = time.perf_counter()
+                    if staged:
+                        b.upload()
+                    stage_s[1] += time.perf_counter() - t_
+                    ready.put(b)
+            except BaseException as e:
                 err.append(e); ready.put(None)
-        th = threading.Thread(target=stager, daemon=True); th.start()
+        # two staging threads in a row: the host-side copy of batch k+2 runs while the H2D copy of batch k+1 holds the PCIe link
+        ths = [threading.Thread(target=adder, daemon=True), threading.Thread(target=uploader, daemon=True)]
+        for th in ths:
+            th.start()
         prev = None
         for _ in range(k):
+            t_ = time.perf_counter()
             cur = ready.get()
+            stage_s[2] += time.perf_counter() - t_
             if cur is None:
                 raise err[0]
             if prev is not None:
@@ -253,7 +285,10 @@ def main() -> int:
                 ms.append(finish(prev)); free.put(prev)  # ... while the previous records travel to the host
             prev = cur
         ms.append(finish(prev)); free.put(prev)
-        th.join()
+        for th in ths:
+            th.join()
+        if staged and os.environ.get("ALD_BENCH_STAGES"):
+            sys.stderr.write("[bench] %d steps: add %.1f ms, upload %.1f ms, main waited for a staged batch %.1f ms (per step)\n" % (k, 1e3 * stage_s[0] / k, 1e3 * stage_s[1] / k, 1e3 * stage_s[2] / k))
         return ms
 
     def timed(k, staged):
@@ -294,7 +329,7 @@ def main() -> int:
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "timed_step": "ald_batch_add_packed (pack into the pinned wire buffer) + H2D + decomposition kernels + D2H of status / path records"
-                          + (" + RCCL gather of the finished transcripts to rank 0" if dist_on else "") + "; staging of batch k+1 overlaps the kernel of batch k (3 batch objects)",
+                          + (" + RCCL gather of the finished transcripts to rank 0" if dist_on else "") + "; staging of batches k+1 (pack + H2D) and k+2 (host copy) on two host threads overlaps the kernel of batch k (4 batch objects)",
             "value_resident": args.graphs * world * args.steps / elapsed_res, "ms_per_step_resident": elapsed_res / args.steps * 1e3,
             "config": {"workload": f"{args.graphs} synthetic splice graphs per GPU, {args.vertices} vertices / {args.edges} edges each "
                                    + ("(BASELINE.json configs[1]; U[1,100) FP64 weights, 1 supporting sample per edge, no phasing paths)" if args.weights == "uniform" else
