@@ -1,6 +1,8 @@
+import os
 # randomized parity sweep GPU vs oracle: many configurations x seeds at sizes where rare interleavings occur
 import sys, os, time, numpy as np
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import aletsch_amd as A, common
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
 thr = max(1, min(16, len(os.sched_getaffinity(0))))

@@ -1,7 +1,9 @@
+import os
 # Sustained host-arrays-in -> merged-transcript-set-out rate with the stages overlapped on host threads (ctypes drops the GIL):
 #   stage (add + upload)  |  kernel (run + download)  |  merge (sink.add_batch)      -- three batches in flight
 import sys, time, threading, queue, numpy as np
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import aletsch_amd as A
 n = 100000; rounds = 8
 pgs = [A.synth(seed=1002 + k, n_graphs=n, v_min=64, v_max=64, fixed_edges=256) for k in range(2)]
