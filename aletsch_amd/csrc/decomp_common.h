@@ -76,6 +76,7 @@ enum { K_EMPTY_VERTEX = -9 };                   // util/constants.h:53
 enum { OP_BROKEN = 1, OP_TRIVIAL_FAST = 2, OP_TRIVIAL_NOW = 3, OP_TRIVIAL_BEST = 4, OP_SMALL_NOW = 5, OP_SMALLEST = 6,
        OP_UNSPLIT_NOW = 7, OP_UNSPLIT_BEST = 8, OP_GREEDY = 9, OP_COLLECT = 10 };
 enum { HF_OCC = 1, HF_LEXT = 2, HF_REXT = 4 };
+enum { NZ_MEMBER = 1, NZ_MEMO_VALID = 2, NZ_MEMO_TYPE_SHIFT = 2 /* 3 bits */, NZ_MEMO_DEG_GT1 = 32 };      // bits of Hot::nz
 // path record (4-byte words): [0]=graph [1]=path index [2]=#vertices [3]=length [4]=count [5]=strand char
 //                             [6..13] = weight, abd, conf, reads (f64)   [14..14+nv) vertices, padded to an even word count
 enum { REC_HDR_WORDS = 14 };

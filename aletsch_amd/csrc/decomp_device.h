@@ -57,7 +57,7 @@ struct Hot {
     EdgeHot  ed[MAXE];                          // (sums, balance, smallest-edge evaluation) still makes one LDS access per step
     uint16_t eid[MAXE];                         // creation id == scallop edge index (ids >= 65535 -> the graph moves up a class)
     IDX      in_head[MAXV], out_head[MAXV], in_deg[MAXV], out_deg[MAXV];
-    uint8_t  nz[MAXV];                          // scallop::nonzeroset membership
+    uint8_t  nz[MAXV];                          // bit 0: scallop::nonzeroset membership; bits 1..5: router class of the vertex on the CURRENT graph (NZ_MEMO_*)
     uint8_t  hflag[MAXE];                       // HF_* (phasing occupancy / extend flags / protect)
     // wave-uniform context
     ALD_GLOBAL uint8_t *cold;                   // this wave's HBM slab
@@ -972,10 +972,18 @@ template<bool A> ALD_INL void star_wave_body(int x)
             rem_ = wcur_; if(sc_) { nid_ += 1; rem_ = wcur_ - w2_; if(rem_ <= mw) rem_ = mw; } \
         }
     // ---- phase 3 (lane q): the two weight sums around x at merge q, left in LDS for the vertex-weight chain
+    // The fan edge's own record is asked for here and used in phase 5: a lane keeps ONE merge (n <= STAR_MAX <= the wave), so the
+    // values stay in its registers across phase 4 and the round trip to L2 runs under it.  (The single-lane emulation walks all merges
+    // in every phase and reads the record where it is used.)
+    double pf_med = 0, pf_conf = 0, pf_abd = 0; int pf_mei = 0, pf_st = 0, pf_cnt = 0, pf_id = 0; uint32_t pf_ns = 0; uint64_t pf_mask0 = 0;
     for(int q = lane; q < n; q += ALD_WAVE) {
         SW_REPLAY(q, wcur, sc, rem, nid, dead);
         const int j = ord[q]; const double ww = fw[j];
         (void)nid; (void)dead;
+#ifndef ALD_EMU
+        { const int f = fe[j]; pf_med = C.ed[f].med; pf_conf = C.ed[f].econf; pf_abd = C.ed[f].s0abd; pf_mei = C.ed[f].mei; pf_st = C.ed[f].estrand; pf_cnt = C.ed[f].ecount;
+          pf_id = C.ed[f].s0id; pf_ns = C.ed[f].sp_len; pf_mask0 = C.ed[f].mask[0]; }
+#endif
         double sfan = 0;
         for(int k = 0; k < n; k++) if(inv[k] >= q) sfan += fw[k];             // not merged yet, list order
         double sc_side = 0; sc_side += sc ? rem : wcur; if(sc) sc_side += ww;
@@ -1013,9 +1021,13 @@ template<bool A> ALD_INL void star_wave_body(int x)
         const double wc0 = sc ? ww : wcur;
         const double medc1 = sc ? medc * ww / wcur : medc;
         const double r1 = sq[q];
-        const double medf = C.ed[f].med, cf = C.ed[f].econf;
-        const int meif = C.ed[f].mei, stf = C.ed[f].estrand, cntf = C.ed[f].ecount;
-        const uint32_t nsf = C.ed[f].sp_len; const int idf = C.ed[f].s0id; const double abf = C.ed[f].s0abd;
+#ifdef ALD_EMU
+        pf_med = C.ed[f].med; pf_conf = C.ed[f].econf; pf_abd = C.ed[f].s0abd; pf_mei = C.ed[f].mei; pf_st = C.ed[f].estrand; pf_cnt = C.ed[f].ecount;
+        pf_id = C.ed[f].s0id; pf_ns = C.ed[f].sp_len; pf_mask0 = C.ed[f].mask[0];
+#endif
+        const double medf = pf_med, cf = pf_conf;
+        const int meif = pf_mei, stf = pf_st, cntf = pf_cnt;
+        const uint32_t nsf = pf_ns; const int idf = pf_id; const double abf = pf_abd;
         {   // what the sequential form checks when it reaches merge q, in its order: a consumed c, the id counter, the two counts
             int code = 0;
             if(dead) code = ALD_ST_INVARIANT + ALD_INV_OTHER;
@@ -1029,7 +1041,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
         } else multi = true;                                                  // pool allocation: sequential, below
         C.ed[f].econf = A ? cc + cf : cf + cc;
         { const int sty = A ? stf : stc, stx = A ? stc : stf; C.ed[f].estrand = (uint8_t)(sty != 0 ? sty : stx); }
-        for(int k = 0; k < NW; k++) { uint64_t mk = C.ed[c].mask[k] | C.ed[f].mask[k]; if(ov >= 0 && (ov >> 6) == k) mk |= (1ull << (ov & 63)); C.ed[f].mask[k] = mk; }
+        for(int k = 0; k < NW; k++) { uint64_t mk = C.ed[c].mask[k] | (k == 0 ? pf_mask0 : C.ed[f].mask[k]); if(ov >= 0 && (ov >> 6) == k) mk |= (1ull << (ov & 63)); C.ed[f].mask[k] = mk; }
         const int mi = A ? rt - lt + meic + meif : rt - lt + meif + meic;
         C.ed[f].med = A ? mi * r1 + medc1 + medf : mi * r1 + medf + medc1; C.ed[f].mei = mi;
         H.eid[f] = (uint16_t)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
@@ -1151,7 +1163,7 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
     for(int i = 0; i < n; i++) { int u1 = PLOC(a[i]), u2 = PLOC(b[i]); if(mdeg[u1] == 1 && mdeg[u2] == 1) evx[u1] = nn++; else if(mdeg[u1] >= 2 && mdeg[u2] >= 2) newedges++; }
     if(ALD_UNLIKELY(nn > MAXV || free_slots() < newedges)) { fail(ALD_ST_CAPACITY); return; }
     H.maybe_broken = 1; H.maybe_triv = 1;
-    for(int i = m; i < nn; i++) { H.in_head[i] = NIL; H.out_head[i] = NIL; H.in_deg[i] = 0; H.out_deg[i] = 0; H.nz[i] = 1; C.vx[i].vw = 0; C.vx[i].lpos = 0; C.vx[i].rpos = 0; C.vx[i].vtype = -1; C.vx[i].v2v = -1; C.vx[i].memo = 0; }
+    for(int i = m; i < nn; i++) { H.in_head[i] = NIL; H.out_head[i] = NIL; H.in_deg[i] = 0; H.out_deg[i] = 0; H.nz[i] = 1; C.vx[i].vw = 0; C.vx[i].lpos = 0; C.vx[i].rpos = 0; C.vx[i].vtype = -1; C.vx[i].v2v = -1; }
     H.nv = nn;
     for(int i = 0; i < nin; i++) {               // ev1: detach in-edges onto their new vertex
         int k = evx[i]; if(k < 0) continue; int e = loc_e[i];
@@ -1282,7 +1294,7 @@ ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio)
 ALD_INL int eval_smallest(int i, double &r)
 {
     {   // the vertex record in one round of loads (the short-circuit form waits for each field before it asks for the next)
-        const int nzv = H.nz[i], d1 = H.in_deg[i], d2 = H.out_deg[i];
+        const int nzv = H.nz[i] & NZ_MEMBER, d1 = H.in_deg[i], d2 = H.out_deg[i];
         if((nzv == 0) | (d1 <= 1) | (d2 <= 1)) return -1;
     }
     int e1 = -1, e2 = -1; double sum1 = 0, sum2 = 0, min1 = DBL_MAX, min2 = DBL_MAX;
@@ -1329,7 +1341,7 @@ ALD_INL bool resolve_broken_vertex()
     for(int base = 0; base < vend && x < 0; base += ALD_WAVE) {
         int i = base + lane;
         const bool inr = (i >= 1) & (i < vend) & (i != H.sinkp); const int ii = inr ? i : 0;
-        const int nzv = H.nz[ii], d1 = H.in_deg[ii], d2 = H.out_deg[ii];
+        const int nzv = H.nz[ii] & NZ_MEMBER, d1 = H.in_deg[ii], d2 = H.out_deg[ii];
         bool p = inr & (nzv != 0) & !((d1 >= 1) & (d2 >= 1));
         uint64_t m = wballot(p);
         if(m) x = base + ffs64(m);
@@ -1374,7 +1386,7 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
             // classify_trivial_fastpath with every load that does not depend on another issued together: three LDS round trips
             // (vertex record / first edges / their far ends) instead of one per condition of the short-circuit form
             const bool inr = (i >= start) & (i < vend); const int ii = inr ? i : 0;
-            const int nzv = H.nz[ii], d1 = H.in_deg[ii], d2 = H.out_deg[ii]; const IDX h1 = H.in_head[ii], h2 = H.out_head[ii];
+            const int nzv = H.nz[ii] & NZ_MEMBER, d1 = H.in_deg[ii], d2 = H.out_deg[ii]; const IDX h1 = H.in_head[ii], h2 = H.out_head[ii];
             bool elig = inr & (nzv != 0) & (d1 >= 1) & (d2 >= 1) & !((d1 >= 2) & (d2 >= 2));
             if(H.any_strand) elig = elig && !mixed_strand_vertex(i);
             const int e1 = (elig & (h1 != NIL)) ? (int)h1 : 0, e2 = (elig & (h2 != NIL)) ? (int)h2 : 0;
@@ -1818,6 +1830,13 @@ ALD_FN void restore_pairs(int n)
     const Pairs S = pairs_at(lds, true), D = pairs_at(lds, false);
     for(int i = 0; i < n; i++) { D.a[i] = S.a[i]; D.b[i] = S.b[i]; D.w[i] = S.w[i]; }
 }
+// forget every vertex's remembered router class (the graph changed); called by ALL lanes
+ALD_INL void memo_clear()
+{
+    const int nv = uni(H.nv);
+    for(int i = lane_id(); i < nv; i += ALD_WAVE) H.nz[i] &= NZ_MEMBER;
+    wsync();
+}
 // scallop::resolve_unsplittable_vertex (scallop.cc:1004-1060)
 ALD_INL bool sweep_unsplittable(int type, int degree, double max_ratio)
 {
@@ -1838,7 +1857,7 @@ ALD_INL bool sweep_unsplittable(int type, int degree, double max_ratio)
         for(int base = (cur / ALD_WAVE) * ALD_WAVE; base < vend && i < 0; base += ALD_WAVE) {
             int i0 = base + lane;
             const bool inr = (i0 >= cur) & (i0 < vend); const int ii = inr ? i0 : 0;
-            const int nzv = H.nz[ii], d1 = H.in_deg[ii], d2 = H.out_deg[ii];
+            const int nzv = H.nz[ii] & NZ_MEMBER, d1 = H.in_deg[ii], d2 = H.out_deg[ii];
             uint64_t m = wballot(inr & (nzv != 0) & (d1 >= 2) & (d2 >= 2));
             if(m) i = base + ffs64(m);
         }
@@ -1848,16 +1867,15 @@ ALD_INL bool sweep_unsplittable(int type, int degree, double max_ratio)
             PROF_DECL;
             // classify() comes first in the reference and build() -- with its side effect on the edge confidences -- only runs when
             // type and degree fit (router.cc:61-81, scallop.cc:1004-1030).  The six passes of one iteration classify the same vertices
-            // on the same graph: the class is kept per vertex (stamped with an epoch that moves on every change of the graph), and a
-            // pass that cannot use the vertex does not run the router again.
-            const int ep = uni(H.ro_epoch); const bool memo_on = ep < 0xFFFF;
-            const int mm = uni(C.vx[i].memo);
-            const bool known = memo_on && ((mm >> 16) & 0xFFFF) == ep;
+            // on the same graph: the class is kept per vertex -- in the spare bits of its nonzeroset byte in LDS, wiped whenever the
+            // graph changes (memo_clear) -- and a pass that cannot use the vertex does not run the router again.  (The sweeps only ever
+            // ask for degree <= 1 or any degree: one bit says which side of that line the vertex is on.)
+            const int mm = uni(H.nz[i]);
             bool rok;
-            if(known && (((mm >> 13) & 7) != type || (mm & 0x1FFF) > (degree < 0x1FFF ? degree : 0x1FFF))) rok = false;
+            if((mm & NZ_MEMO_VALID) && (((mm >> NZ_MEMO_TYPE_SHIFT) & 7) != type || ((mm & NZ_MEMO_DEG_GT1) && degree <= 1))) rok = false;
             else {
                 rok = router_run(i, type, degree);
-                if(rok && memo_on) { int dg = uni(H.ro_degree); if(dg > 0x1FFF) dg = 0x1FFF; if(dg < 0) dg = 0; C.vx[i].memo = (ep << 16) | ((uni(H.ro_type) & 7) << 13) | dg; }
+                if(rok) H.nz[i] = (uint8_t)((mm & NZ_MEMBER) | NZ_MEMO_VALID | ((uni(H.ro_type) & 7) << NZ_MEMO_TYPE_SHIFT) | (uni(H.ro_degree) > 1 ? NZ_MEMO_DEG_GT1 : 0));
             }
             PROF_ADD(PF_G_BALANCE);
             if(rok && H.ro_type == type && H.ro_degree <= degree) {
@@ -1876,7 +1894,7 @@ ALD_INL bool sweep_unsplittable(int type, int degree, double max_ratio)
         wsync();
         act = wshfl(act, 0);
         if(H.status) return true;
-        if(act) { flag = true; if(lane == 0) H.ro_epoch = uni(H.ro_epoch) + 1; wsync(); }
+        if(act) { flag = true; memo_clear(); }
         cur = i + 1;
     }
     if(flag) return true;
@@ -2073,7 +2091,7 @@ ALD_INL bool load_graph()
         for(int k = o0; k < o1; k++) { H.ed[k].lk.es = (IDX)i; H.ed[k].lk.onx = (k + 1 < o1) ? (IDX)(k + 1) : NIL; }
         for(int k = i0; k < i1; k++) { H.ed[ie[k]].lk.inx = (k + 1 < i1) ? (IDX)ie[k + 1] : NIL; }
         C.vx[i].vw = A->in.vertex_weight[ov + i]; C.vx[i].lpos = A->in.vertex_lpos[ov + i]; C.vx[i].rpos = A->in.vertex_rpos[ov + i];
-        C.vx[i].vtype = A->in.vertex_type[ov + i]; C.vx[i].v2v = i; C.vx[i].memo = 0;
+        C.vx[i].vtype = A->in.vertex_type[ov + i]; C.vx[i].v2v = i;
     }
     bool strand = false;
     ALD_GLOBAL const int32_t *so = A->in.edge_sample_offset + oeo;
@@ -2156,8 +2174,7 @@ ALD_INL void run_graph()
         if(uni(sweep_trivial(1, 1, r_triv))) continue;
         if(uni(sweep_smallest(r_small))) continue;
         PROF_RESET();
-        if(lane_id() == 0) H.ro_epoch = uni(H.ro_epoch) + 1;      // anything may have changed since the last cascade
-        wsync();
+        memo_clear();                                              // anything may have changed since the last cascade
         bool un = uni(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, 1, 0.01)) || uni(sweep_unsplittable(T_SPLITTABLE_PURE, 1, 0.01))
                || uni(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, r_single)) || uni(sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, r_pure))
                || uni(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, DBL_MAX)) || uni(sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, DBL_MAX));
