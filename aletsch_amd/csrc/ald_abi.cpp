@@ -8,7 +8,6 @@
 #include <thread>
 #include <chrono>
 #include <iterator>
-#include "../host/transcript_sink.hpp"
 #include <mutex>
 #include <string>
 #include <cstdlib>
@@ -222,6 +221,8 @@ int ald_batch_destroy(ald_batch *b)
     DevBuf *bufs[] = {&b->d_in, &b->d_status, &b->d_npaths, &b->d_niters, &b->d_pool, &b->d_poolused, &b->d_trace_n, &b->d_trace_codes, &b->d_trace_vals, &b->d_work, &b->d_counter, &b->d_args};
     for(DevBuf *d : bufs) d->release();
     for(int c = 0; c < ALD_NUM_CLASSES; c++) b->d_slabs[c].release();
+    for(DevBuf &d : b->red) d.release();
+    for(PinBuf &d : b->red_pin) d.release();
     for(int q = 0; q < ALD_SIDE_STREAMS; q++) if(b->cstream[q]) { hipStreamSynchronize(b->cstream[q]); hipStreamDestroy(b->cstream[q]); }
     for(int c = 0; c < ALD_NUM_CLASSES; c++) if(b->cdone[c]) hipEventDestroy(b->cdone[c]);
     if(b->ev0) hipEventDestroy(b->ev0);
@@ -420,7 +421,7 @@ int ald_batch_download(ald_batch *b)
     b->res.clear();
     // the records land in a pinned buffer (kept across runs) through an async copy on the batch stream: the copy engine moves them
     // while another batch's kernel may be running, and the host thread only waits
-    if(b->pin_out.ensure(4 * (size_t)used + 64)) return set_err(ALD_ERR_NOMEM, "pinned result buffer");
+    if(b->pin_out.ensure(4 * (size_t)used + 64, true)) return set_err(ALD_ERR_NOMEM, "pinned result buffer");
     if(n > 0) {
         HIPCHK(hipMemcpy(b->n_paths.data(), b->d_npaths.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(b->n_iters.data(), b->d_niters.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
@@ -543,14 +544,6 @@ int ald_batch_export_transcripts(const ald_batch *b, int64_t *total_exons, doubl
 }
 
 /* ---- result sink: transcript_set restated (aletsch_amd/host/transcript_sink.hpp) ---- */
-// Buckets (intron-chain hashes) never interact: the set is kept as NSHARD independent tables, bucket h in table h % NSHARD, so that a
-// whole batch can be merged by NSHARD host threads without a lock; the export walks all keys in ascending order.
-enum { ALD_TSET_SHARDS = 16 };
-struct ald_tset {
-    std::vector<aletsch::transcript_sink> shard; double overlap;
-    explicit ald_tset(double ov) : shard(ALD_TSET_SHARDS, aletsch::transcript_sink(ov)), overlap(ov) {}
-    void add(aletsch::transcript_sink &ts) { for(auto &x : ts.mt) shard[x.first % ALD_TSET_SHARDS].add_bucket(x.first, x.second); }
-};
 
 int ald_tset_create(double single_exon_overlap, ald_tset **out) { if(!out) return ALD_ERR_INVALID; *out = new ald_tset(single_exon_overlap); return ALD_OK; }
 int ald_tset_destroy(ald_tset *t) { delete t; return ALD_OK; }
@@ -730,6 +723,13 @@ int ald_tset_add_stream(ald_tset *t, const uint32_t *words, int64_t n_words, int
         x.tid = tid_base + ((((int64_t)w[0] + graph_offset) << 20) | (int64_t)w[1]);
         x.xs.assign((const int32_t*)(w + TS_HDR), (const int32_t*)(w + TS_HDR) + 2 * (size_t)w[5]);
     });
+    return ALD_OK;
+}
+
+int ald_tset_merge(ald_tset *dst, ald_tset *src)
+{
+    if(!dst || !src || dst == src) return ALD_ERR_INVALID;
+    for(auto &sh : src->shard) { dst->add(sh); sh.clear(); }
     return ALD_OK;
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "host_pack.h"
+#include "../host/transcript_sink.hpp"
 #include <string>
 #include <vector>
 
@@ -15,7 +16,11 @@ struct DevBuf {
 };
 struct PinBuf {
     void *p = nullptr; size_t cap = 0;
-    int ensure(size_t bytes) { if(bytes <= cap) return 0; if(p) hipHostFree(p); p = nullptr; cap = 0; size_t want = bytes + bytes / 4 + 256; if(hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return -1; cap = want; return 0; }
+    // landing: a buffer the copy engine fills and the CPU then READS a lot (record parsing, exon gathers): non-coherent pinned memory is
+    // cacheable on the CPU side; visibility is given by the stream synchronisation every reader does first
+    int ensure(size_t bytes, bool landing = false) { if(bytes <= cap) return 0; if(p) hipHostFree(p); p = nullptr; cap = 0; size_t want = bytes + bytes / 4 + 256;
+        const unsigned flags = landing && !getenv("ALD_PIN_COHERENT") ? hipHostMallocNonCoherent : hipHostMallocDefault;
+        if(hipHostMalloc(&p, want, flags) != hipSuccess) return -1; cap = want; return 0; }
     void release() { if(p) hipHostFree(p); p = nullptr; cap = 0; }
 };
 
@@ -55,8 +60,18 @@ struct ald_batch {
     bool indexed = false;
     const void *launched_slab[ALD_NUM_CLASSES] = {};      // test hook (ald_batch_debug_slab)
     rvec<uint32_t> tstream;                                // last transcript stream built from this batch (ald_batch_transcript_stream)
+    DevBuf red[20]; PinBuf red_pin[8];                     // scratch of ald_batch_reduce_transcripts, kept across calls (tset_reduce.hip)
 };
 
+
+// The result sink behind ald_tset_*.  Buckets (intron-chain hashes) never interact: the set is kept as NSHARD independent tables, bucket h
+// in table h % NSHARD, so that a whole batch can be merged by NSHARD host threads without a lock; the export walks all keys in ascending order.
+enum { ALD_TSET_SHARDS = 16 };
+struct ald_tset {
+    std::vector<aletsch::transcript_sink> shard; double overlap;
+    explicit ald_tset(double ov) : shard(ALD_TSET_SHARDS, aletsch::transcript_sink(ov)), overlap(ov) {}
+    void add(aletsch::transcript_sink &ts) { for(auto &x : ts.mt) shard[x.first % ALD_TSET_SHARDS].add_bucket(x.first, x.second); }
+};
 
 int ald_ensure_index(const ald_batch *b);                 // per-graph index over the record stream of the last download (built on first use)
 int ald_set_err(int code, const std::string &msg);        // sets the calling thread's ald_last_error() text, returns `code`

@@ -211,6 +211,13 @@ def load_library():
     lib.ald_transcript_id.restype = C.c_int64
     lib.ald_transcript_id.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_int32]
     lib.ald_tset_export.argtypes = [C.c_void_p] * 19
+    lib.ald_batch_reduce_transcripts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.POINTER(C.c_void_p)]
+    lib.ald_tset_flat_size.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 3
+    lib.ald_tset_flat_export.argtypes = [C.c_void_p] * 19
+    lib.ald_tset_flat_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.ald_tset_add_flat.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ald_tset_merge.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ald_tset_flat_free.argtypes = [C.c_void_p]
     _LIB = lib
     return lib
 
@@ -358,6 +365,24 @@ class DecompBatch:
             _check(rc)
         return [f[i] for i in range(rv.num_paths)], comp[:rv.num_paths], rc
 
+    def reduce_transcripts(self, sid=None, tid_base: int = 0, skip_single_exon: bool = False, single_exon_overlap: float = 0.8, into: Optional["TranscriptSink"] = None):
+        """The batch's transcripts merged into an EMPTY set on the GPU (ald_batch_reduce_transcripts) -> (items in TranscriptSink.items()
+        form, stats dict); `into`: also merge the reduced set into that persistent sink (ald_tset_add_flat)."""
+        sp = None
+        if sid is not None:
+            sid = np.ascontiguousarray(sid, np.int32); assert len(sid) == self.n; sp = C.c_void_p(sid.ctypes.data)
+        h = C.c_void_p()
+        _check(self._lib.ald_batch_reduce_transcripts(self._h, sp, C.c_int64(tid_base), C.c_int32(int(skip_single_exon)), C.c_double(single_exon_overlap), C.byref(h)))
+        try:
+            if into is not None:
+                _check(self._lib.ald_tset_add_flat(into._h, h))
+            st = [C.c_double(), C.c_double(), C.c_int64(), C.c_int64()]
+            _check(self._lib.ald_tset_flat_stats(h, *[C.byref(x) for x in st]))
+            items = _export_items(lambda *a: self._lib.ald_tset_flat_size(h, *a), lambda *a: self._lib.ald_tset_flat_export(h, *a))
+        finally:
+            self._lib.ald_tset_flat_free(h)
+        return items, dict(device_ms=st[0].value, total_ms=st[1].value, device_groups=st[2].value, host_items=st[3].value)
+
     def transcript_stream(self, sid=None, skip_single_exon: bool = False) -> np.ndarray:
         """Finished transcripts of the downloaded batch as one self-contained uint32 stream (copy): what ranks exchange in the
         multi-GPU gather and what TranscriptSink.add_stream merges."""
@@ -379,6 +404,24 @@ class DecompBatch:
         v = [C.c_int32() for _ in range(4)]; sb = C.c_int64(); ng = C.c_int32()
         _check(self._lib.ald_batch_class_info(self._h, cls, C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), C.byref(v[3]), C.byref(sb), C.byref(ng)))
         return dict(maxv=v[0].value, maxe=v[1].value, blocks_per_cu=v[2].value, blocks_last_run=v[3].value, slab_bytes=sb.value, n_graphs=ng.value)
+
+
+def _export_items(size_fn, export_fn):
+    """drive an (ald_tset_size, ald_tset_export)-shaped pair -> list of dicts"""
+    n = C.c_int64(); ne = C.c_int64(); ns = C.c_int64()
+    _check(size_fn(C.byref(n), C.byref(ne), C.byref(ns)))
+    n, ne, ns = n.value, ne.value, ns.value
+    z = lambda k, dt: np.zeros(max(k, 1), dt)
+    h = z(n, np.uint64); cnt = z(n, np.int32); st = z(n, np.int8); cov = z(n, np.float64); cov2 = z(n, np.float64); conf = z(n, np.float64); abd = z(n, np.float64)
+    c1 = z(n, np.int32); c2 = z(n, np.int32); tid = z(n, np.int64); eo = z(n + 1, np.int64); lr = z(2 * ne, np.int32)
+    so = z(n + 1, np.int64); ssid = z(ns, np.int32); scov2 = z(ns, np.float64); sconf = z(ns, np.float64); sabd = z(ns, np.float64); sc1 = z(ns, np.int32)
+    _check(export_fn(*[C.c_void_p(x.ctypes.data) for x in (h, cnt, st, cov, cov2, conf, abd, c1, c2, tid, eo, lr, so, ssid, scov2, sconf, sabd, sc1)]))
+    out = []
+    for i in range(n):
+        out.append(dict(hash=int(h[i]), count=int(cnt[i]), strand=chr(st[i]), coverage=float(cov[i]), cov2=float(cov2[i]), conf=float(conf[i]), abd=float(abd[i]),
+                        count1=int(c1[i]), count2=int(c2[i]), tid=int(tid[i]), exons=[(int(lr[2 * k]), int(lr[2 * k + 1])) for k in range(eo[i], eo[i + 1])],
+                        samples=[dict(sid=int(ssid[k]), cov2=float(scov2[k]), conf=float(sconf[k]), abd=float(sabd[k]), count1=int(sc1[k])) for k in range(so[i], so[i + 1])]))
+    return out
 
 
 class TranscriptSink:
@@ -423,6 +466,10 @@ class TranscriptSink:
             sid = np.ascontiguousarray(sid, np.int32); assert len(sid) == batch.n; sp = C.c_void_p(sid.ctypes.data)
         _check(self._lib.ald_tset_add_batch(self._h, batch._h, sp, C.c_int64(tid_base), C.c_int32(int(skip_single_exon))))
 
+    def merge(self, other: "TranscriptSink"):
+        """transcript_set::add(transcript_set&): every bucket of `other` zipped into this set; `other` is left empty."""
+        _check(self._lib.ald_tset_merge(self._h, other._h))
+
     def add_stream(self, words: np.ndarray, graph_offset: int = 0, tid_base: int = 0):
         """Merge a transcript stream (DecompBatch.transcript_stream, possibly gathered from another rank) graph by graph."""
         words = np.ascontiguousarray(words, np.uint32)
@@ -430,20 +477,7 @@ class TranscriptSink:
 
     def items(self):
         """List of dicts in the reference's iteration order (bucket hash ascending, then bucket order)."""
-        n = C.c_int64(); ne = C.c_int64(); ns = C.c_int64()
-        _check(self._lib.ald_tset_size(self._h, C.byref(n), C.byref(ne), C.byref(ns)))
-        n, ne, ns = n.value, ne.value, ns.value
-        z = lambda k, dt: np.zeros(max(k, 1), dt)
-        h = z(n, np.uint64); cnt = z(n, np.int32); st = z(n, np.int8); cov = z(n, np.float64); cov2 = z(n, np.float64); conf = z(n, np.float64); abd = z(n, np.float64)
-        c1 = z(n, np.int32); c2 = z(n, np.int32); tid = z(n, np.int64); eo = z(n + 1, np.int64); lr = z(2 * ne, np.int32)
-        so = z(n + 1, np.int64); ssid = z(ns, np.int32); scov2 = z(ns, np.float64); sconf = z(ns, np.float64); sabd = z(ns, np.float64); sc1 = z(ns, np.int32)
-        _check(self._lib.ald_tset_export(self._h, *[C.c_void_p(x.ctypes.data) for x in (h, cnt, st, cov, cov2, conf, abd, c1, c2, tid, eo, lr, so, ssid, scov2, sconf, sabd, sc1)]))
-        out = []
-        for i in range(n):
-            out.append(dict(hash=int(h[i]), count=int(cnt[i]), strand=chr(st[i]), coverage=float(cov[i]), cov2=float(cov2[i]), conf=float(conf[i]), abd=float(abd[i]),
-                            count1=int(c1[i]), count2=int(c2[i]), tid=int(tid[i]), exons=[(int(lr[2 * k]), int(lr[2 * k + 1])) for k in range(eo[i], eo[i + 1])],
-                            samples=[dict(sid=int(ssid[k]), cov2=float(scov2[k]), conf=float(sconf[k]), abd=float(sabd[k]), count1=int(sc1[k])) for k in range(so[i], so[i + 1])]))
-        return out
+        return _export_items(lambda *a: self._lib.ald_tset_size(self._h, *a), lambda *a: self._lib.ald_tset_export(self._h, *a))
 
 
 def _two_pass(fn, *args) -> str:

@@ -274,6 +274,26 @@ int  ald_batch_transcript_stream(const ald_batch *b, const int32_t *sid, int32_t
 /* Merge such a stream, graph by graph in stream order (assembler.cc:1105-1133): coverage = log(1 + weight) is taken here, on the host;
  * tid = tid_base + ((graph + graph_offset) << 20 | path index), i.e. what ald_tset_add_batch gives the same graph in an unsharded batch */
 int  ald_tset_add_stream(ald_tset *t, const uint32_t *words, int64_t n_words, int32_t graph_offset, int64_t tid_base);
+/* ---- transcript-set reduction of a whole batch on the GPU (replaces the per-graph loop `ts.add(t, 1, sid)` ... `tm.add(ts)` of
+ * meta/assembler.cc:1105-1133 over rnacore/transcript_set.cc:38-175 for one region's graphs) ----
+ * The transcripts of a downloaded batch merged exactly as the reference merges them into an EMPTY transcript_set, graph by graph in
+ * ascending graph id: transcripts with two or more exons on the device (exon join, intron-chain hash, stable radix sort by group,
+ * one lane per group folding its members in the reference's order of floating-point additions), single-exon transcripts -- whose
+ * overlap rule depends on the order of the comparisons -- on the host.  The result is FLAT (arrays in the reference's iteration order:
+ * ascending bucket hash, bucket order inside), item for item and bit for bit what ald_tset_add_batch into an empty set followed by
+ * ald_tset_export gives; ald_tset_add_flat merges it into a persistent set as transcript_set::add(transcript_set&) does. */
+typedef struct ald_tset_flat ald_tset_flat;
+int  ald_batch_reduce_transcripts(const ald_batch *b, const int32_t *sid /* [graphs] or NULL => -1 */, int64_t tid_base, int32_t skip_single_exon,
+                                  double single_exon_overlap, ald_tset_flat **out);
+int  ald_tset_flat_size(const ald_tset_flat *f, int64_t *n_items, int64_t *n_exons, int64_t *n_samples);
+int  ald_tset_flat_export(const ald_tset_flat *f, uint64_t *hash, int32_t *count, char *strand, double *coverage, double *cov2, double *conf, double *abd,
+                          int32_t *count1, int32_t *count2, int64_t *tid, int64_t *exon_offset, int32_t *exon_lr,
+                          int64_t *sample_offset, int32_t *sample_sid, double *sample_cov2, double *sample_conf, double *sample_abd, int32_t *sample_count1);
+/* device milliseconds (HIP events: kernels, sorts and copies of the reduction), wall milliseconds of the whole call, groups folded on the device, items merged on the host */
+int  ald_tset_flat_stats(const ald_tset_flat *f, double *device_ms, double *total_ms, int64_t *device_groups, int64_t *host_items);
+int  ald_tset_add_flat(ald_tset *t, const ald_tset_flat *f);
+int  ald_tset_flat_free(ald_tset_flat *f);
+
 /* ---- the exchange step for a multi-PROCESS host (one process per MI355X): transcript streams -> rank 0 over RCCL / xGMI ----
  * (A host that drives all its devices from one process -- aletsch::gpu_assembly_queue over a device list -- needs none of this.)
  * RCCL is loaded on first use.  Bootstrap: rank 0 calls ald_comm_unique_id and ships the 128 bytes to the other ranks by its own
@@ -286,6 +306,8 @@ int  ald_comm_create(const uint8_t id[128], int32_t world, int32_t rank, int32_t
 int  ald_comm_gather_streams(ald_comm *c, const uint32_t *words, int64_t n_words, int32_t graph_offset,
                              const uint32_t **all_words /* rank 0 */, const int64_t **offsets /* [world + 1] */, const int32_t **graph_offsets /* [world] */);
 int  ald_comm_destroy(ald_comm *c);
+/* transcript_set::add(transcript_set&) (transcript_set.cc:156-175): every bucket of src zipped into dst; src is left empty */
+int  ald_tset_merge(ald_tset *dst, ald_tset *src);
 int  ald_tset_size(const ald_tset *t, int64_t *n_items, int64_t *n_exons, int64_t *n_samples);
 /* items in the reference's iteration order (hash ascending, then bucket order) */
 int  ald_tset_export(const ald_tset *t, uint64_t *hash, int32_t *count, char *strand, double *coverage, double *cov2, double *conf, double *abd,

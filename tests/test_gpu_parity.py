@@ -631,3 +631,39 @@ def test_rccl_gather_behind_the_c_abi():
     ''') % common.ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "COMM_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_transcript_set_reduction_on_the_gpu():
+    """ald_batch_reduce_transcripts: the batch's transcripts merged into an empty transcript_set ON THE DEVICE --
+    item for item, field for field, bit for bit (coverage sums in the reference's nesting) what the host sink gives for the same batch
+    (ald_tset_add_batch, itself pinned to the reference's transcript_set.cc).  The batch repeats graphs under different sample ids, so
+    groups with many members, several samples per item and single-exon clusters all occur; then a second batch goes into the same
+    persistent set through ald_tset_add_flat == transcript_set::add(set)."""
+    from aletsch_amd.packed import PackedGraphs
+    base = A.synth(seed=49, n_graphs=1500, v_min=6, v_max=60, edges_per_vertex=3, layout_mode=1, weight_mode=2, phasing_per_graph=2, strand_mode=1)
+    rng = np.random.default_rng(5)
+    pick = rng.integers(0, base.n, 4000)                                   # every graph ~2.7 times, shuffled: equal transcripts from different "samples"
+    pg = base.select(pick)
+    sid = rng.integers(-1, 6, pg.n).astype(np.int32)
+    for skip in (False, True):
+        with A.DecompBatch(0) as b:
+            b.add(pg); b.upload(); b.run(); b.download()
+            host = A.TranscriptSink(0.8); host.add_batch(b, sid, tid_base=3 << 44, skip_single_exon=skip)
+            items, st = b.reduce_transcripts(sid, tid_base=3 << 44, skip_single_exon=skip)
+        want = host.items()
+        assert len(items) == len(want) and len(want) > 3000
+        for a, w in zip(items, want):
+            assert a == w, (skip, a, w)
+        assert st["device_groups"] > 3000 and (skip or st["host_items"] > 0) and max(x["count"] for x in items) >= 3
+        assert max(len(x["samples"]) for x in items) >= 3
+    # two batches into one persistent set: each reduced on the device and merged set-into-set (ald_tset_add_flat), against the host path
+    # doing the same with host-built sets (ald_tset_merge) -- both are transcript_set::add(transcript_set&), transcript_set.cc:156-175
+    other = base.select(rng.integers(0, base.n, 1000)); sid2 = rng.integers(0, 6, other.n).astype(np.int32)
+    flat = A.TranscriptSink(0.8); ref = A.TranscriptSink(0.8)
+    for part, s_, tb in ((pg, sid, 1 << 44), (other, sid2, 2 << 44)):
+        with A.DecompBatch(0) as b:
+            b.add(part); b.upload(); b.run(); b.download()
+            b.reduce_transcripts(s_, tid_base=tb, into=flat)
+            one = A.TranscriptSink(0.8); one.add_batch(b, s_, tid_base=tb)
+            ref.merge(one)
+    assert flat.items() == ref.items() and len(ref.items()) > 3000
