@@ -1110,8 +1110,8 @@ template<bool A> ALD_INL void star_wave_body(int x)
     PROF_ADD(PF_T_MERGE_ADD);
     #undef SW_REPLAY
 }
-ALD_FN void star_wave_in(int x) { star_wave_body<true>(uni(x)); }
-ALD_FN void star_wave_out(int x) { star_wave_body<false>(uni(x)); }
+ALD_INL void star_wave_in(int x) { star_wave_body<true>(uni(x)); }       // inlined into the kernel entry, once (sweep_trivial has ONE decomposition site,
+ALD_INL void star_wave_out(int x) { star_wave_body<false>(uni(x)); }     // run_graph ONE sweep_trivial): no prologue that parks callee-saved registers in scratch
 // wave-level entry (ALL lanes): fans of up to STAR_MAX edges go lane-parallel, anything else through the sequential form on lane 0
 ALD_INL void decompose_trivial_vertex_wave(int x)
 {
@@ -1447,22 +1447,35 @@ ALD_INL bool sweep_trivial(int mode, int type, double jump_ratio)
     if(skippable && !uni(H.maybe_triv)) return false;
     bool flag = false;
     int start = 1;
-    while(start < uni(H.sw_vend)) {
-        int code = uni(scan_trivial(start, mode, type, jump_ratio));     // chunks before `start` hold no unvisited vertex
-        PROF_ADD(PF_TRIV_EVAL);
-        if(code == SC_NEED) {
-            if(lane == 0) {
-                uint64_t need = (uint64_t)H.sw_need_lo | ((uint64_t)H.sw_need_hi << 32); const int base = H.sw_dom_base;
-                while(need) { int l = ffs64(need); need &= need - 1; H.scr_i[l] = classify_trivial_vertex(base + l, mode == 1); }
+    // ONE place decomposes -- the vertex a scan hits (the sweep then goes on behind it) or, when the sweep ends without a hit, its best
+    // candidate: the wave-wide decomposition is inlined here, so it must not be instantiated twice
+    for(;;) {
+        int target = -1; bool last = false;
+        while(start < uni(H.sw_vend)) {
+            int code = uni(scan_trivial(start, mode, type, jump_ratio));     // chunks before `start` hold no unvisited vertex
+            PROF_ADD(PF_TRIV_EVAL);
+            if(code == SC_NEED) {
+                if(lane == 0) {
+                    uint64_t need = (uint64_t)H.sw_need_lo | ((uint64_t)H.sw_need_hi << 32); const int base = H.sw_dom_base;
+                    while(need) { int l = ffs64(need); need &= need - 1; H.scr_i[l] = classify_trivial_vertex(base + l, mode == 1); }
+                }
+                wsync();
+                if(uni(H.sw_dom_base) > start) start = uni(H.sw_dom_base);       // earlier chunks are done (no hit; their candidates are in sw_best_*)
+                continue;
             }
-            wsync();
-            if(uni(H.sw_dom_base) > start) start = uni(H.sw_dom_base);       // earlier chunks are done (no hit; their candidates are in sw_best_*)
-            continue;
+            if(code == SC_BAD) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); wsync(); return true; }
+            if(code == SC_HIT) target = uni(H.sw_hit);
+            break;
         }
-        if(code == SC_BAD) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); wsync(); return true; }
-        if(code != SC_HIT) break;
-        if(lane == 0) trace(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, vlog(H.sw_hit), mode == 1 ? type : 0, H.sw_hit_r);
-        decompose_trivial_vertex_wave(uni(H.sw_hit));
+        if(target < 0) {                             // the sweep is over
+            if(flag) return true;
+            if(mode == 0) return false;
+            if(uni(H.sw_best_v) < 0) { if(skippable) { if(lane == 0) H.maybe_triv = 0; wsync(); } return false; }
+            target = uni(H.sw_best_v); last = true;
+        }
+        if(lane == 0) { if(last) trace(OP_TRIVIAL_BEST, vlog(target), type, H.sw_best_r); else trace(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, vlog(target), mode == 1 ? type : 0, H.sw_hit_r); }
+        decompose_trivial_vertex_wave(target);
+        if(last) { wsync(); PROF_ADD(PF_TRIV_MUT); return true; }
         if(lane == 0) {
             if(uni(H.hs_dirty)) hs_refresh_flags();
             H.sw_dom_base = -1;
@@ -1471,16 +1484,8 @@ ALD_INL bool sweep_trivial(int mode, int type, double jump_ratio)
         PROF_ADD(PF_TRIV_MUT);
         flag = true;
         if(H.status) return true;
-        start = uni(H.sw_hit) + 1;
+        start = target + 1;
     }
-    if(flag) return true;
-    if(mode == 0) return false;
-    if(uni(H.sw_best_v) < 0) { if(skippable) { if(lane == 0) H.maybe_triv = 0; wsync(); } return false; }
-    if(lane == 0) trace(OP_TRIVIAL_BEST, vlog(H.sw_best_v), type, H.sw_best_r);
-    decompose_trivial_vertex_wave(uni(H.sw_best_v));
-    wsync();
-    PROF_ADD(PF_TRIV_MUT);
-    return true;
 }
 
 // scallop::resolve_smallest_edges (scallop.cc:844-945), with the per-vertex result (ratio, edge) kept per lane: removing
@@ -2093,7 +2098,7 @@ ALD_INL bool load_graph()
         C.vx[i].vw = A->in.vertex_weight[ov + i]; C.vx[i].lpos = A->in.vertex_lpos[ov + i]; C.vx[i].rpos = A->in.vertex_rpos[ov + i];
         C.vx[i].vtype = A->in.vertex_type[ov + i]; C.vx[i].v2v = i;
     }
-    bool strand = false;
+    bool strand = false, listed = false;        // listed: some edge has two or more supporting samples (its list lives in the pool)
     ALD_GLOBAL const int32_t *so = A->in.edge_sample_offset + oeo;
     ALD_GLOBAL const int32_t *rank = A->in.edge_rank;      // scallop::scallop -> get_edge_indices (scallop.cc:24, graph_base.cc:139-153): e2i of the input edges
     for(int k = lane; k < E; k += ALD_WAVE) {
@@ -2101,10 +2106,12 @@ ALD_INL bool load_graph()
         uint8_t st = A->in.edge_strand[oe + k]; C.ed[k].estrand = st; if(st) strand = true;
         C.ed[k].med = 0; C.ed[k].mei = 0; C.ed[k].econf = 0; C.ed[k].eabd = A->in.edge_abd[oe + k];
         C.ed[k].sp_off = (uint32_t)so[k]; C.ed[k].sp_len = (uint32_t)(so[k + 1] - so[k]); C.ed[k].ecount = A->in.edge_count[oe + k];
+        if(so[k + 1] - so[k] >= 2) listed = true;
         if(so[k + 1] > so[k]) { C.ed[k].s0id = A->in.sample_id[os + so[k]]; C.ed[k].s0abd = A->in.sample_abd[os + so[k]]; } else { C.ed[k].s0id = 0; C.ed[k].s0abd = 0; }
         for(int q = 0; q < NW; q++) C.ed[k].mask[q] = 0;
     }
-    for(int64_t k = lane; k < ns; k += ALD_WAVE) { C.sp_id[k] = A->in.sample_id[os + k]; C.sp_abd[k] = A->in.sample_abd[os + k]; }
+    // a list of ONE sample is carried inline (s0id / s0abd) and never read from the pool: a batch of single-sample graphs copies nothing
+    if(wballot(listed)) for(int64_t k = lane; k < ns; k += ALD_WAVE) { C.sp_id[k] = A->in.sample_id[os + k]; C.sp_abd[k] = A->in.sample_abd[os + k]; }
     uint64_t sb = wballot(strand);
     if(sb && lane == 0) H.any_strand = 1;
     wsync();
@@ -2170,25 +2177,22 @@ ALD_INL void run_graph()
         bool brk = uni(H.maybe_broken) != 0 && uni(resolve_broken_vertex());
         PROF_ADD(PF_BROKEN);
         if(brk) continue;
-        if(r_triv > 1.0) { if(uni(sweep_trivial(0, 1, r_triv))) continue; }     // resolve_trivial_vertex_fast: a no-op for jump_ratio <= 1 (r >= 1 always)
-        if(uni(sweep_trivial(1, 1, r_triv))) continue;
-        if(uni(sweep_smallest(r_small))) continue;
-        PROF_RESET();
-        memo_clear();                                              // anything may have changed since the last cascade
-        bool un = uni(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, 1, 0.01)) || uni(sweep_unsplittable(T_SPLITTABLE_PURE, 1, 0.01))
-               || uni(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, r_single)) || uni(sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, r_pure))
-               || uni(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, DBL_MAX)) || uni(sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, DBL_MAX));
-        PROF_ADD(PF_UNSPLIT);
-        if(un) continue;
-#if 0
-        if(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, 1, 0.01)) continue;
-        if(sweep_unsplittable(T_SPLITTABLE_PURE, 1, 0.01)) continue;
-        if(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, r_single)) continue;
-        if(sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, r_pure)) continue;
-        if(sweep_unsplittable(T_UNSPLITTABLE_SINGLE, INT_MAX, DBL_MAX)) continue;
-        if(sweep_unsplittable(T_SPLITTABLE_PURE, INT_MAX, DBL_MAX)) continue;
-#endif
-        if(uni(sweep_trivial(1, 2, r_triv))) continue;
+        // the rest of the cascade as a stage loop, so that every rule is instantiated ONCE (the trivial-vertex sweep serves three stages:
+        // resolve_trivial_vertex_fast -- a no-op for jump_ratio <= 1, r >= 1 always -- then type 1, and type 2 at the very end)
+        bool fired = false;
+        for(int stage = (r_triv > 1.0) ? 0 : 1; stage <= 4 && !fired; stage++) {
+            if(stage == 0 || stage == 1 || stage == 4) fired = uni(sweep_trivial(stage == 0 ? 0 : 1, stage == 4 ? 2 : 1, r_triv));
+            else if(stage == 2) fired = uni(sweep_smallest(r_small));
+            else {
+                PROF_RESET();
+                memo_clear();                                          // anything may have changed since the last cascade
+                for(int pass = 0; pass < 6 && !fired; pass++)
+                    fired = uni(sweep_unsplittable((pass & 1) ? T_SPLITTABLE_PURE : T_UNSPLITTABLE_SINGLE, pass < 2 ? 1 : INT_MAX,
+                                                   pass < 2 ? 0.01 : (pass == 2 ? r_single : (pass == 3 ? r_pure : DBL_MAX))));
+                PROF_ADD(PF_UNSPLIT);
+            }
+        }
+        if(fired) continue;
         break;
     }
     if(lane_id() == 0 && H.status == 0 && guard <= 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);

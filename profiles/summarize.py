@@ -3,6 +3,7 @@
 
   python profiles/summarize.py stats  gpurun_out/prof_r1_d/d_results.db   profiles/r01/d_kernel_stats.csv
   python profiles/summarize.py pmc    gpurun_out/pmc_fetch_r1_d/d_results.db gpurun_out/pmc_write_r1_d/d_results.db profiles/r01/d_pmc_traffic.json
+  python profiles/summarize.py sq     gpurun_out/r02b_pmc3/p_results.db gpurun_out/r02b_pmc4/p_results.db profiles/r02/b_pmc_sq.json
 
 `pmc` writes per-launch HBM traffic of the dominant kernel, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section)
 prescribes: FETCH_SIZE and WRITE_SIZE are in KiB, collected in separate passes; on gfx950 FETCH_SIZE tallies 128-B requests
@@ -42,8 +43,25 @@ def pmc(fetch_db, write_db, out, kernel_prefix="ald_decomp_kernel"):
     json.dump(d, open(out, "w"), indent=1); print(json.dumps(d, indent=1))
 
 
-if __name__ == "__main__":
+def main():
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "sq":
+        sq(sys.argv[2:-1], sys.argv[-1])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+
+
+def sq(dbs, out, kernel_prefix="ald_decomp_kernel_c1", graphs=100000):
+    """SQ instruction / wait counters per launch and per graph from one or more --pmc result databases"""
+    vals = {}
+    for db in dbs:
+        c = sqlite3.connect(db)
+        for n, v, k in c.execute("select counter_name, avg(value), count(*) from counters_collection where kernel_name like ? group by counter_name", (kernel_prefix + "%",)):
+            vals[n] = v
+    d = {"kernel": kernel_prefix, "graphs_per_launch": graphs, "per_launch": vals, "per_graph": {k: v / graphs for k, v in vals.items()}}
+    json.dump(d, open(out, "w"), indent=1); print(json.dumps(d["per_graph"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
