@@ -1973,16 +1973,75 @@ ALD_INL void collect_existing_st_paths()
     COLD;
     const int lane = lane_id();
     const int sink = uni(H.sinkp), hw = uni(H.slot_hw);
-    ALD_GLOBAL int32_t *lst = C.wi; int n = 0;           // lane 0's list (work array of the slab: up to MAXE entries)
+    ALD_GLOBAL int32_t *lst = C.wi; int n = 0;           // the source -> sink edges (work array of the slab: up to MAXE entries), by every lane
     for(int base = 0; base < hw; base += ALD_WAVE) {
         int e = base + lane;
         bool p = e < hw && H.ed[e].lk.es == 0 && (int)H.ed[e].lk.et == sink;
         uint64_t m = wballot(p);
-        if(lane == 0) while(m) { int b = ffs64(m); m &= m - 1; lst[n++] = base + b; }
+#ifdef ALD_EMU
+        if(p) lst[n] = e;
+#else
+        if(p) lst[n + __builtin_popcountll(m & ((1ull << lane) - 1))] = e;
+#endif
+        n += __builtin_popcountll(m);
     }
+    wsync();
+    if(n == 0) return;
+    if(tracing() || 3 * n > Cold::w_cap) {        // the op trace lists the paths in order: one at a time
+        if(lane == 0) {
+            for(int i = 1; i < n; i++) { int x = lst[i]; uint32_t id = uni(H.eid[x]); int j = i - 1; while(j >= 0 && (uint32_t)uni(H.eid[lst[j]]) > id) { lst[j + 1] = lst[j]; j--; } lst[j + 1] = x; }
+            for(int i = 0; i < n && !H.status; i++) collect_path(lst[i]);
+        }
+        wsync();
+        return;
+    }
+    // One finished path per lane (scallop::collect_path, scallop.cc:2766-2834, for all of them at once): the vertex set and its length
+    // check, the EMPTY_VERTEX filter, the place among the kept paths in creation-id order (= the path index), the record.
+    ALD_GLOBAL const KernelArgs *A = H.args;
+    ALD_GLOBAL int32_t *ids = C.wi + n, *keep = C.wi + 2 * n;          // [n] creation id / 1 = becomes a path, 0 = filtered, -1 = inconsistent
+    const int nlast = H.V0 - 1;
+    const bool ends_empty = C.vx[0].vtype == K_EMPTY_VERTEX || C.vx[nlast].vtype == K_EMPTY_VERTEX;
+    for(int j = lane; j < n; j += ALD_WAVE) {
+        const int e = lst[j]; int cnt = 0, mi = 0; bool empty = ends_empty;
+        for(int k = 0; k < NW; k++) { uint64_t mk = C.ed[e].mask[k]; while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; cnt++; mi += C.vx[x].rpos - C.vx[x].lpos; if(C.vx[x].vtype == K_EMPTY_VERTEX) empty = true; } }
+        ids[j] = (int32_t)H.eid[e];
+        keep[j] = (C.ed[e].mei != mi || cnt == 0) ? -1 : (empty ? 0 : 1);
+    }
+    wsync();
+    bool bad = false, full = false; int kept_total = 0;
+    for(int j = lane; j < n; j += ALD_WAVE) {
+        const int e = lst[j]; const int32_t id = ids[j]; int rank = 0; bool later_bad = false;
+        for(int k = 0; k < n; k++) { const int kk = keep[k]; if(kk < 0) later_bad = true; if(kk == 1 && ids[k] < id) rank++; }
+        if(later_bad) bad = true;
+        if(keep[j] != 1 || later_bad) continue;
+        int cnt = 0; for(int k = 0; k < NW; k++) cnt += __builtin_popcountll(C.ed[e].mask[k]);
+        const int nvp = cnt + 2;
+        const unsigned long long words = (unsigned long long)(REC_HDR_WORDS + nvp + ((REC_HDR_WORDS + nvp) & 1));
+        const unsigned long long o = atomic_add_u64(A->out.pool_used, words);
+        if(ALD_UNLIKELY(o + words > A->out.pool_cap)) { full = true; continue; }
+        ALD_GLOBAL uint32_t *r = A->out.pool + o;
+        int st = '.';
+        if(C.ed[e].estrand == 1) st = '+';
+        if(C.ed[e].estrand == 2) st = '-';
+        if(st == '.') st = H.gstrand;
+        r[0] = (uint32_t)H.g; r[1] = (uint32_t)(H.n_paths + rank); r[2] = (uint32_t)nvp; r[3] = (uint32_t)C.ed[e].mei; r[4] = (uint32_t)C.ed[e].ecount; r[5] = (uint32_t)st | ((uint32_t)(A->attempt & 0xFF) << 8);
+        ALD_GLOBAL double *d = (ALD_GLOBAL double*)(r + 6);
+        d[0] = H.ed[e].w; d[1] = C.ed[e].eabd; d[2] = exp(C.ed[e].econf); d[3] = C.ed[e].med;
+        ALD_GLOBAL uint32_t *pv = r + REC_HDR_WORDS; int w = 0;
+        pv[w++] = 0;
+        for(int k = 0; k < NW; k++) { uint64_t mk = C.ed[e].mask[k]; while(mk) { int b = ffs64(mk); mk &= mk - 1; pv[w++] = (uint32_t)(k * 64 + b); } }
+        pv[w++] = (uint32_t)nlast;
+        if((REC_HDR_WORDS + nvp) & 1) pv[w] = 0;
+    }
+    const bool any_bad = wballot(bad) != 0, any_full = wballot(full) != 0;
+    wsync();
     if(lane == 0) {
-        for(int i = 1; i < n; i++) { int x = lst[i]; uint32_t id = uni(H.eid[x]); int j = i - 1; while(j >= 0 && (uint32_t)uni(H.eid[lst[j]]) > id) { lst[j + 1] = lst[j]; j--; } lst[j + 1] = x; }
-        for(int i = 0; i < n && !H.status; i++) collect_path(lst[i]);
+        for(int k = 0; k < n; k++) if(keep[k] == 1) kept_total++;
+        if(any_bad) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);                  // assert(mei[e] == mi) / an empty vertex list (scallop.cc:2783)
+        else if(any_full) fail(ALD_ST_POOL_FULL);
+        else H.n_paths += kept_total;
+        // remove_edge for all of them: out(source) / in(sink) are only counted at this point, the slots go back to the free list
+        for(int k = 0; k < n; k++) { const int e = lst[k]; H.hflag[e] = 0; kill_edge_i(e); }
     }
     wsync();
 }
