@@ -360,6 +360,35 @@ ALD_INL void kill_edge_i(int e)
     H.ed[e].lk.es = NIL;
     { int fh = uni(H.free_head); H.ed[e].lk.onx = fh < 0 ? NIL : (IDX)fh; H.free_head = e; H.free_cnt = uni(H.free_cnt) + 1; }
 }
+// remove_edge by the wave (ALL lanes call, e wave-uniform): the edge leaves its source's out-list and its target's in-list AT THE SAME
+// TIME -- lane 0 walks one list, lane 1 the other, same instruction stream, different links -- where kill_edge_i walks them one after
+// the other.  The two lists share no link field (onx / inx), no head and no degree.
+ALD_INL void kill_edge_wave(int e)
+{
+    e = uni(e);
+    const uint64_t w = *(const uint64_t*)&H.ed[e].lk;            // es | et << 16 | inx << 32 | onx << 48, read before anything moves
+    const bool special = H.special_linked != 0; const int sinkp = H.sinkp;
+    for(int side = lane_id(); side < 2; side += ALD_WAVE) {
+        const bool out = (side == 0);
+        const int v = out ? (int)(w & 0xFFFF) : (int)((w >> 16) & 0xFFFF);
+        const IDX nxe = out ? (IDX)(w >> 48) : (IDX)((w >> 32) & 0xFFFF);
+        const bool counted = !special && (out ? v == 0 : v == sinkp);       // out(source) / in(sink): only counted until the final phase
+        IDX *deg = out ? &H.out_deg[v] : &H.in_deg[v];
+        if(!counted) {
+            IDX *pp = out ? &H.out_head[v] : &H.in_head[v]; IDX cur = *pp; int guard = MAXE;
+            while((int)cur != e && cur != NIL && guard-- > 0) { pp = out ? &H.ed[cur].lk.onx : &H.ed[cur].lk.inx; cur = *pp; }
+            if(ALD_UNLIKELY((int)cur != e)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); continue; }      // cannot happen on a consistent state
+            *pp = nxe;
+        }
+        const int dg = (int)*deg - 1; *deg = (IDX)dg;
+        if(!counted && dg <= 1) { H.maybe_triv = 1; if(dg == 0) H.maybe_broken = 1; }
+    }
+    wsync();
+    if(lane_id() == 0) {
+        H.ed[e].lk.es = NIL;
+        const int fh = uni(H.free_head); H.ed[e].lk.onx = fh < 0 ? NIL : (IDX)fh; H.free_head = e; H.free_cnt = uni(H.free_cnt) + 1;
+    }
+}
 ALD_FN int add_edge(int s, int t) { return add_edge_i(uni(s), uni(t)); }
 ALD_FN void kill_edge(int e) { kill_edge_i(uni(e)); }
 ALD_FN void move_edge(int e, int x, int y)      // directed_graph.cc:180-194
@@ -1581,10 +1610,9 @@ ALD_INL bool sweep_smallest(double max_ratio)
             PROF_ADD(PF_SMALL_EVAL);
             if(hit < 0) break;
             const int ds = H.ed[hit_e].lk.es, dt = H.ed[hit_e].lk.et;         // the two vertices whose lists change
-            if(lane == 0) {
-                trace(OP_SMALL_NOW, (int)H.eid[hit_e], vlog(hit), hit_r);
-                kill_edge_i(hit_e); hs_remove(hit_e);
-            }
+            if(lane == 0) trace(OP_SMALL_NOW, (int)H.eid[hit_e], vlog(hit), hit_r);
+            kill_edge_wave(hit_e);
+            if(lane == 0) hs_remove(hit_e);
             wsync();
             // other vertices only look at ds / dt through the guards out_deg[ds] > 1 and in_deg[dt] > 1 (both held for the edge just
             // removed); if one of them stops holding, or the phasing flags moved, every lane evaluates again
@@ -1604,10 +1632,9 @@ ALD_INL bool sweep_smallest(double max_ratio)
         if(!flag) {
             if(best_e < 0) return any;
             const int ds = H.ed[best_e].lk.es, dt = H.ed[best_e].lk.et;
-            if(lane == 0) {
-                trace(OP_SMALLEST, (int)H.eid[best_e], vlog(best_v), best_r);
-                kill_edge_i(best_e); hs_remove(best_e);
-            }
+            if(lane == 0) trace(OP_SMALLEST, (int)H.eid[best_e], vlog(best_v), best_r);
+            kill_edge_wave(best_e);
+            if(lane == 0) hs_remove(best_e);
             wsync();
             any = true;
             // back to the cascade unless R1..R3 provably have nothing to do
