@@ -18,6 +18,8 @@
   static inline int      lane_id() { return 0; }
   static inline uint64_t wballot(bool p) { return p ? 1ull : 0ull; }
   template<class T> static inline T wshfl(T v, int) { return v; }
+  template<class T> static inline T wread(T v, int) { return v; }
+  static inline void     wave_argmin(double &, int &) {}
   static inline void     wsync() {}
   static inline unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
   static inline int      atomic_add_i32(int *p, int v) { int o = *p; *p += v; return o; }
@@ -41,6 +43,51 @@
   __device__ __forceinline__ int      lane_id() { return (int)threadIdx.x; }
   __device__ __forceinline__ uint64_t wballot(bool p) { return __ballot(p); }
   template<class T> __device__ __forceinline__ T wshfl(T v, int src) { return __shfl(v, src, 64); }
+  // value of lane `src`, src WAVE-UNIFORM: v_readlane_b32 (a few cycles) instead of the ds_bpermute_b32 a general shuffle takes
+  __device__ __forceinline__ int      wread(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+  __device__ __forceinline__ double   wread(double v, int src)
+  {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+      return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  }
+  // wave_argmin: over the lanes with vv >= 0, the smallest rr; among equal ones the LARGEST vv (the sequential sweeps keep the later
+  // vertex on `!(ratio < r)`); every lane receives the winner, vv = -1 when no lane has a candidate.  The ratios are non-negative
+  // doubles, whose order is the order of their bit patterns as unsigned integers: the minimum is a 64-bit unsigned min over the wave in
+  // six DPP steps (register-to-register lane permutes: quad, quad, half row, row, row broadcast x 2 -- the CDNA reduction idiom), the
+  // winner then comes from one ballot.  A butterfly of shuffles costs eighteen ds_bpermute_b32 round trips for the same result.  Any
+  // candidate that is negative or NaN (never produced by the rules; bit pattern above +inf) sends the wave through the butterfly.
+  template<int CTRL, int ROWMASK> __device__ __forceinline__ unsigned long long dpp_umin_step(unsigned long long k)
+  {
+      const int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32);
+      const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xf, false), hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xf, false);
+      const unsigned long long k2 = ((unsigned long long)(unsigned)hi2 << 32) | (unsigned)lo2;
+      return k2 < k ? k2 : k;
+  }
+  __device__ __forceinline__ void     wave_argmin(double &rr, int &vv)
+  {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(rr);
+      if(__builtin_expect(__ballot(vv >= 0 && bits > 0x7FF0000000000000ull) != 0, 0)) {
+          const int lane = (int)threadIdx.x;
+          for(int off = 32; off >= 1; off >>= 1) {
+              const double r2 = __shfl(rr, lane ^ off, 64); const int v2 = __shfl(vv, lane ^ off, 64);
+              if((v2 >= 0) && (vv < 0 || r2 < rr || (r2 == rr && v2 > vv))) { rr = r2; vv = v2; }
+          }
+          rr = __shfl(rr, 0, 64); vv = __shfl(vv, 0, 64);
+          return;
+      }
+      unsigned long long k = vv >= 0 ? bits : ~0ull;
+      const unsigned long long mine = k;
+      k = dpp_umin_step<0xB1, 0xf>(k);  k = dpp_umin_step<0x4E, 0xf>(k);          // quad_perm [1,0,3,2], [2,3,0,1]
+      k = dpp_umin_step<0x141, 0xf>(k); k = dpp_umin_step<0x140, 0xf>(k);         // row_half_mirror, row_mirror
+      k = dpp_umin_step<0x142, 0xa>(k); k = dpp_umin_step<0x143, 0xc>(k);         // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+      const unsigned long long kmin = ((unsigned long long)hi << 32) | lo;
+      unsigned long long tied = __ballot(vv >= 0 && mine == kmin);
+      int best = -1;
+      while(tied) { const int l = __ffsll(tied) - 1; tied &= tied - 1; const int v = __builtin_amdgcn_readlane(vv, l); best = v > best ? v : best; }
+      rr = __longlong_as_double((long long)kmin); vv = best;
+  }
   // workgroup == ONE wavefront: lanes of a wave execute in lock step and the hardware performs a wave's LDS and vector-memory
   // instructions in issue order, so handing data from one lane to another needs no s_barrier and no drain of the memory counters --
   // only that the compiler keeps the accesses on their side of the hand-over (LLVM AMDGPU memory model: a fence at "wavefront" scope

@@ -1441,21 +1441,16 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
         // scallop.cc:1222 `if(ratio < jump_ratio) break;`: the first candidate with 1.02 <= r < jump_ratio becomes the root and ends the sweep
         uint64_t stp = (mode == 1) ? wballot(cand && !(r < now_thr) && r < jump_ratio) : 0ull;
         if(stp && (!now || ffs64(stp) < ffs64(now))) {
-            int l = ffs64(stp); best_v = base + l; best_r = wshfl(r, l); code = SC_STOP; break;
+            int l = ffs64(stp); best_v = base + l; best_r = wread(r, l); code = SC_STOP; break;
         }
         // sequential semantics: candidates before the first "now" vertex update (ratio, root); ties go to the LATER vertex
         int lim = now ? ffs64(now) : ALD_WAVE;
         if(mode == 1 && cand && lane < lim && (fvv < 0 || !(frr < r))) { frr = r; fvv = i; }     // folded per lane; ONE reduction after the loop
-        if(now) { hit = base + ffs64(now); hit_r = wshfl(r, ffs64(now)); code = SC_HIT; break; }
+        if(now) { hit = base + ffs64(now); hit_r = wread(r, ffs64(now)); code = SC_HIT; break; }
     }
     if(mode == 1 && code != SC_STOP && code != SC_BAD) {
         double rr = frr; int vv = fvv;
-        for(int off = ALD_WAVE / 2; off >= 1; off >>= 1) {
-            double r2 = wshfl(rr, lane ^ off); int v2 = wshfl(vv, lane ^ off);
-            bool take = (v2 >= 0) && (vv < 0 || r2 < rr || (r2 == rr && v2 > vv));
-            if(take) { rr = r2; vv = v2; }
-        }
-        rr = wshfl(rr, 0); vv = wshfl(vv, 0);
+        wave_argmin(rr, vv);
         if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; }      // if(ratio < r) continue;
     }
     if(lane == 0) { H.sw_best_r = best_r; H.sw_best_v = best_v; H.sw_hit = hit; H.sw_hit_r = hit_r; }
@@ -1568,14 +1563,9 @@ ALD_INL bool sweep_smallest(double max_ratio)
                 int lim = now ? ffs64(now) : ALD_WAVE;
                 bool mine = cand && lane < lim;
                 double rr = mine ? r : DBL_MAX; int vv = mine ? i : -1;
-                for(int off = ALD_WAVE / 2; off >= 1; off >>= 1) {
-                    double r2 = wshfl(rr, lane ^ off); int v2 = wshfl(vv, lane ^ off);
-                    bool take = (v2 >= 0) && (vv < 0 || r2 < rr || (r2 == rr && v2 > vv));
-                    if(take) { rr = r2; vv = v2; }
-                }
-                rr = wshfl(rr, 0); vv = wshfl(vv, 0);
-                if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = wshfl(e, vv - base); }   // if(ratio < r) continue;  (the edge comes from the winning lane)
-                if(now) { int l = ffs64(now); hit = base + l; hit_e = wshfl(e, l); hit_r = wshfl(r, l); }
+                wave_argmin(rr, vv);
+                if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = wread(e, vv - base); }   // if(ratio < r) continue;  (the edge comes from the winning lane)
+                if(now) { int l = ffs64(now); hit = base + l; hit_e = wread(e, l); hit_r = wread(r, l); }
             }
             } else {
             // (1) chunk by chunk, cheap: an invalid evaluation anywhere in the chunk, else the first "now" vertex (ratio < 0.01)
@@ -1586,7 +1576,7 @@ ALD_INL bool sweep_smallest(double max_ratio)
                 const int e = (i >= start && i < vend) ? ce[c] : -1;
                 if(wballot(e == -3)) { badw = true; continue; }
                 const uint64_t now = wballot(e >= 0 && cr[c] < 0.01);
-                if(now) { const int l = ffs64(now); hit = c * ALD_WAVE + l; hit_e = wshfl(e, l); hit_r = wshfl(cr[c], l); }
+                if(now) { const int l = ffs64(now); hit = c * ALD_WAVE + l; hit_e = wread(e, l); hit_r = wread(cr[c], l); }
             }
             if(badw) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); wsync(); return true; }
             // (2) the candidates before it: each lane folds its own chunks (later vertex wins ties), then ONE reduction across lanes
@@ -1598,13 +1588,8 @@ ALD_INL bool sweep_smallest(double max_ratio)
                     const int i = c * ALD_WAVE + lane;
                     if(i >= start && i < lim && ce[c] >= 0 && (vv < 0 || !(rr < cr[c]))) { rr = cr[c]; vv = i; }
                 }
-                for(int off = ALD_WAVE / 2; off >= 1; off >>= 1) {
-                    double r2 = wshfl(rr, lane ^ off); int v2 = wshfl(vv, lane ^ off);
-                    bool take = (v2 >= 0) && (vv < 0 || r2 < rr || (r2 == rr && v2 > vv));
-                    if(take) { rr = r2; vv = v2; }
-                }
-                rr = wshfl(rr, 0); vv = wshfl(vv, 0);
-                if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = wshfl(cget_e(vv / ALD_WAVE), vv % ALD_WAVE); }   // if(ratio < r) continue;
+                wave_argmin(rr, vv);
+                if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = wread(cget_e(vv / ALD_WAVE), vv % ALD_WAVE); }   // if(ratio < r) continue;
             }
             }
             PROF_ADD(PF_SMALL_EVAL);
@@ -1924,13 +1909,13 @@ ALD_INL bool sweep_unsplittable(int type, int degree, double max_ratio)
             }
         }
         wsync();
-        act = wshfl(act, 0);
+        act = wread(act, 0);
         if(H.status) return true;
         if(act) { flag = true; memo_clear(); }
         cur = i + 1;
     }
     if(flag) return true;
-    root = wshfl(root, 0);
+    root = wread(root, 0);
     if(root < 0) return false;
     if(lane == 0) {
         PROF_DECL;
