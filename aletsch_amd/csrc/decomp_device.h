@@ -939,6 +939,8 @@ template<bool A> ALD_INL void star_wave_body(int x)
     const int meic_v = C.ed[c_early].mei, cntc_v = C.ed[c_early].ecount, stc_v = C.ed[c_early].estrand, idc_v = C.ed[c_early].s0id;
     const uint32_t nsc_v = C.ed[c_early].sp_len;
     const int lt_v = C.vx[x].lpos, rt_v = C.vx[x].rpos, ov_v = C.vx[x].v2v;
+    uint64_t cmask_pf[NW <= 2 ? NW : 1];                                   // c's vertex set too when it is one or two words (larger classes read it in phase 5)
+    if(NW <= 2) for(int k = 0; k < NW; k++) cmask_pf[k] = C.ed[c_early].mask[k];
     // ---- phase 0 (lane 0): gather the fan, balance_vertex(x) on the gathered weights, pair weights -- as in the sequential form
     if(lane == 0) {
         const int c = A ? u_first_in(x) : u_first_out(x);
@@ -1070,7 +1072,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
         } else multi = true;                                                  // pool allocation: sequential, below
         C.ed[f].econf = A ? cc + cf : cf + cc;
         { const int sty = A ? stf : stc, stx = A ? stc : stf; C.ed[f].estrand = (uint8_t)(sty != 0 ? sty : stx); }
-        for(int k = 0; k < NW; k++) { uint64_t mk = C.ed[c].mask[k] | (k == 0 ? pf_mask0 : C.ed[f].mask[k]); if(ov >= 0 && (ov >> 6) == k) mk |= (1ull << (ov & 63)); C.ed[f].mask[k] = mk; }
+        for(int k = 0; k < NW; k++) { uint64_t mk = (NW <= 2 ? cmask_pf[NW <= 2 ? k : 0] : C.ed[c].mask[k]) | (k == 0 ? pf_mask0 : C.ed[f].mask[k]); if(ov >= 0 && (ov >> 6) == k) mk |= (1ull << (ov & 63)); C.ed[f].mask[k] = mk; }
         const int mi = A ? rt - lt + meic + meif : rt - lt + meif + meic;
         C.ed[f].med = A ? mi * r1 + medc1 + medf : mi * r1 + medf + medc1; C.ed[f].mei = mi;
         H.eid[f] = (uint16_t)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
@@ -1528,10 +1530,10 @@ ALD_INL bool sweep_smallest(double max_ratio)
     if(lane == 0 && uni(H.hs_dirty)) hs_refresh_flags();
     wsync();
     double cr[NC]; int ce[NC];
-    // Classes of 3..16 chunks keep the arrays in registers: every loop over the chunks is fully unrolled (constant indices) and the few
+    // Classes of up to 16 chunks keep the arrays in registers: every loop over the chunks is fully unrolled (constant indices) and the few
     // accesses with a run-time chunk number go through a select chain; with a run-time index they would live in scratch memory and
-    // every sweep would wait for it chunk by chunk.  Smaller classes are unrolled anyway, larger ones use private memory.
-    constexpr bool REG = (NC > 2 && NC <= 16);
+    // every sweep would wait for it chunk by chunk.  Larger classes use private memory.
+    constexpr bool REG = (NC <= 16);
     auto cput = [&](int c, double r, int e) { if(!REG) { cr[c] = r; ce[c] = e; } else { ALD_UNROLL for(int k = 0; k < NC; k++) if(k == c) { cr[k] = r; ce[k] = e; } } };
     auto cget_e = [&](int c) -> int { if(!REG) return ce[c]; int v = -1; ALD_UNROLL for(int k = 0; k < NC; k++) if(k == c) v = ce[k]; return v; };
     auto eval_chunk = [&](int c, bool every, int ds, int dt) {        // (re-)evaluate this lane's vertex of chunk c
@@ -1551,23 +1553,7 @@ ALD_INL bool sweep_smallest(double max_ratio)
         int start = 1;
         while(start < vend) {
             int hit = -1, hit_e = -1; double hit_r = 0;
-            if(NC <= 2) {
-            // at most two chunks: one pass, the reduction right in the chunk loop
-            for(int c = start / ALD_WAVE; c < NC && c * ALD_WAVE < vend && hit < 0; c++) {
-                const int base = c * ALD_WAVE, i = base + lane;
-                const bool in = (i >= start && i < vend);
-                const double r = cr[c]; const int e = in ? ce[c] : -1;
-                if(wballot(e == -3)) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); wsync(); return true; }
-                bool cand = e >= 0;
-                uint64_t now = wballot(cand && r < 0.01);
-                int lim = now ? ffs64(now) : ALD_WAVE;
-                bool mine = cand && lane < lim;
-                double rr = mine ? r : DBL_MAX; int vv = mine ? i : -1;
-                wave_argmin(rr, vv);
-                if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = wread(e, vv - base); }   // if(ratio < r) continue;  (the edge comes from the winning lane)
-                if(now) { int l = ffs64(now); hit = base + l; hit_e = wread(e, l); hit_r = wread(r, l); }
-            }
-            } else {
+            {
             // (1) chunk by chunk, cheap: an invalid evaluation anywhere in the chunk, else the first "now" vertex (ratio < 0.01)
             const int c0 = start / ALD_WAVE; bool badw = false;
             ALD_UNROLL for(int c = 0; c < NC; c++) {
