@@ -59,6 +59,12 @@ struct Hot {
     IDX      in_head[MAXV], out_head[MAXV], in_deg[MAXV], out_deg[MAXV];
     uint8_t  nz[MAXV];                          // bit 0: scallop::nonzeroset membership; bits 1..5: router class of the vertex on the CURRENT graph (NZ_MEMO_*)
     uint8_t  hflag[MAXE];                       // HF_* (phasing occupancy / extend flags / protect)
+};
+// Everything else a wave keeps about the graph at hand: scalars, the sweep state, the scratch the lanes exchange values through.
+// ALWAYS in LDS -- also for the classes whose graph arrays live in the wave's HBM slab (the twins, the catch-all class): these ~1.7 KB
+// are what every phase boundary and every branch of the rule cascade reads, and a round trip to L2 / the Infinity Cache for each of
+// them was a large part of what made a graph 3-4 times slower there than in the LDS form.
+struct HotCtx {
     // wave-uniform context
     ALD_GLOBAL uint8_t *cold;                   // this wave's HBM slab
     ALD_GLOBAL const KernelArgs *args;
@@ -90,15 +96,27 @@ struct Hot {
 
 #if defined(ALD_EMU)
 static thread_local Hot g_H;
+static thread_local HotCtx g_HC;
 #define H g_H
+#define HC g_HC
 #elif ALD_CLASS_ID >= ALD_FIRST_GLOBAL_CLASS
-// catch-all class: the working set does not fit LDS; the Hot struct is the first part of the wave's HBM slab
+// catch-all class and the twins: the graph arrays do not fit LDS (or leave it to other classes); Hot is the first part of the wave's HBM slab
 __shared__ ALD_GLOBAL Hot *g_Hp;
+__shared__ HotCtx g_HC;
 #define H (*g_Hp)
+#define HC g_HC
 #define ALD_HOT_IN_SLAB 1
+#elif defined(ALD_DYN_LDS)
+// dynamic shared memory (see decomp_class.hip): the only LDS object of the kernel, so it sits at LDS address 0 like the static form
+extern __shared__ __attribute__((aligned(16))) unsigned char g_dyn_lds[];
+enum { HOT_BYTES_ALIGNED = (sizeof(Hot) + 15) / 16 * 16 };
+#define H (*reinterpret_cast<Hot*>(g_dyn_lds))
+#define HC (*reinterpret_cast<HotCtx*>(g_dyn_lds + HOT_BYTES_ALIGNED))
 #else
 __shared__ Hot g_H;
+__shared__ HotCtx g_HC;
 #define H g_H
+#define HC g_HC
 #endif
 
 // cold state: typed views at compile-time offsets of the slab
@@ -122,7 +140,7 @@ struct Cold {
 };
 ALD_INL Cold cold_view()
 {
-    ALD_GLOBAL uint8_t *b = H.cold; Cold C;
+    ALD_GLOBAL uint8_t *b = HC.cold; Cold C;
     C.vx = (ALD_GLOBAL ColdVertex*)(b + CL::o_vx); C.ed = (ALD_GLOBAL ColdEdge*)(b + CL::o_ed);
     C.sp_id = (ALD_GLOBAL int32_t*)(b + CL::o_spid); C.sp_abd = (ALD_GLOBAL double*)(b + CL::o_spabd);
     C.hl = (ALD_GLOBAL int32_t*)(b + CL::o_hl); C.hl_off = (ALD_GLOBAL int32_t*)(b + CL::o_hloff); C.hl_len = (ALD_GLOBAL int32_t*)(b + CL::o_hllen);
@@ -136,7 +154,7 @@ ALD_INL Cold cold_view()
 // The product build compiles none of this (no stamp executes in the measured kernel).
 #if defined(ALD_PROF) && !defined(ALD_EMU)
   #define PROF_DECL unsigned long long prof_t_ = __builtin_readcyclecounter()
-  #define PROF_ADD(k) do { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) H.prof[k] += t1_ - prof_t_; prof_t_ = t1_; } while(0)
+  #define PROF_ADD(k) do { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[k] += t1_ - prof_t_; prof_t_ = t1_; } while(0)
   #define PROF_RESET() (prof_t_ = __builtin_readcyclecounter())
 #else
   #define PROF_DECL do {} while(0)
@@ -150,21 +168,21 @@ enum { PF_LOAD = 0, PF_BROKEN, PF_TRIV_EVAL, PF_TRIV_MUT, PF_SMALL_EVAL, PF_SMAL
 ALD_INL void fail_(int st, int line)
 {
 #ifdef ALD_EMU
-    if(H.status == 0 && getenv("ALD_EMU_VERBOSE")) fprintf(stderr, "[emu] graph %d: status %d raised at decomp_device.h:%d\n", H.g, st, line);
+    if(HC.status == 0 && getenv("ALD_EMU_VERBOSE")) fprintf(stderr, "[emu] graph %d: status %d raised at decomp_device.h:%d\n", HC.g, st, line);
 #endif
-    if(H.status == 0) H.status = st;
+    if(HC.status == 0) HC.status = st;
 }
 #define fail(st) fail_((st), __LINE__)
 #define ALD_UNLIKELY(x) __builtin_expect(!!(x), 0)     // the checks that mirror the reference's asserts: the common path falls through
 ALD_FN void trace_emit(int code, int a, int b, double v)
 {
-    int cap = H.p_trace_cap;
-    ALD_GLOBAL const KernelArgs *A = H.args;
-    int k = H.n_trace++;
-    if(k < cap) { int64_t o = (int64_t)H.g * cap + k; A->out.trace_codes[3 * o] = code; A->out.trace_codes[3 * o + 1] = a; A->out.trace_codes[3 * o + 2] = b; A->out.trace_vals[o] = v; }
+    int cap = HC.p_trace_cap;
+    ALD_GLOBAL const KernelArgs *A = HC.args;
+    int k = HC.n_trace++;
+    if(k < cap) { int64_t o = (int64_t)HC.g * cap + k; A->out.trace_codes[3 * o] = code; A->out.trace_codes[3 * o + 1] = a; A->out.trace_codes[3 * o + 2] = b; A->out.trace_vals[o] = v; }
 }
-ALD_INL bool tracing() { return H.p_trace_cap > 0; }
-ALD_INL void trace(int code, int a, int b, double v) { H.n_iters++; if(H.p_trace_cap > 0) trace_emit(code, a, b, v); }
+ALD_INL bool tracing() { return HC.p_trace_cap > 0; }
+ALD_INL void trace(int code, int a, int b, double v) { HC.n_iters++; if(HC.p_trace_cap > 0) trace_emit(code, a, b, v); }
 // u_*: the same accessors for the scalar (lane-0) routines, with the result marked wave-uniform (see uni() in decomp_common.h)
 ALD_INL int u_first_in(int v) { IDX h = uni(H.in_head[v]); return h == NIL ? -1 : (int)h; }
 ALD_INL int u_first_out(int v) { IDX h = uni(H.out_head[v]); return h == NIL ? -1 : (int)h; }
@@ -181,14 +199,14 @@ ALD_INL double out_weights(int v) { double w = 0; for(int e = first_out(v); e >=
 // in-list of v ordered by (source, id); out-list ordered by (target, id): graph/edge_base.h:35-45
 // out(source 0) and in(sink) grow to dozens of entries and are never iterated by the rule cascade: until the final collect /
 // greedy phase (materialize_special) edges are only counted there, not linked.
-ALD_INL uint32_t tkey(uint32_t p) { return (int)p == H.sinkp ? 0xFFFFu : p; }      // the sink sorts after every other vertex
-ALD_INL int vlog(int p) { return p < H.V0 - 1 ? p : (p == H.sinkp ? H.nv - 1 : p - 1); }   // physical -> reference index (traces)
+ALD_INL uint32_t tkey(uint32_t p) { return (int)p == HC.sinkp ? 0xFFFFu : p; }      // the sink sorts after every other vertex
+ALD_INL int vlog(int p) { return p < HC.V0 - 1 ? p : (p == HC.sinkp ? HC.nv - 1 : p - 1); }   // physical -> reference index (traces)
 ALD_INL uint64_t lkw(int e) { return uni(*(const uint64_t*)&H.ed[e].lk); }            // es | et << 16 | inx << 32 | onx << 48
 ALD_INL int lk_next(uint32_t f) { return f == 0xFFFFu ? -1 : (int)f; }
 ALD_INL void link_in(int v, int e)
 {
     v = uni(v); e = uni(e);
-    if(v == uni(H.sinkp) && !uni(H.special_linked)) { H.in_deg[v]++; return; }
+    if(v == uni(HC.sinkp) && !uni(HC.special_linked)) { H.in_deg[v]++; return; }
     const uint32_t ks = uni(H.ed[e].lk.es), kid = uni(H.eid[e]);
     IDX *pp = &H.in_head[v]; IDX cur = *pp;
     for(int guard = MAXE; uni(cur != NIL) && guard > 0; guard--) {      // (the guard only matters on a corrupted list: never spin)
@@ -203,8 +221,8 @@ ALD_INL void link_in(int v, int e)
 ALD_INL void link_out(int v, int e)
 {
     v = uni(v); e = uni(e);
-    if(v == 0 && !uni(H.special_linked)) { H.out_deg[v]++; return; }
-    const uint32_t sk = (uint32_t)uni(H.sinkp);
+    if(v == 0 && !uni(HC.special_linked)) { H.out_deg[v]++; return; }
+    const uint32_t sk = (uint32_t)uni(HC.sinkp);
     uint32_t kt = uni(H.ed[e].lk.et); const uint32_t kid = uni(H.eid[e]);
     if(kt == sk) kt = 0xFFFFu;
     IDX *pp = &H.out_head[v]; IDX cur = *pp;
@@ -221,8 +239,8 @@ ALD_INL void link_out(int v, int e)
 ALD_INL void link_out_after(int v, int e, int hint)
 {
     v = uni(v); e = uni(e); hint = uni(hint);
-    if(v == 0 && !uni(H.special_linked)) { H.out_deg[v]++; return; }
-    const uint32_t sk = (uint32_t)uni(H.sinkp);
+    if(v == 0 && !uni(HC.special_linked)) { H.out_deg[v]++; return; }
+    const uint32_t sk = (uint32_t)uni(HC.sinkp);
     uint32_t kt = uni(H.ed[e].lk.et); const uint32_t kid = uni(H.eid[e]);
     if(kt == sk) kt = 0xFFFFu;
     IDX *pp = &H.ed[hint].lk.onx; IDX cur = *pp;
@@ -240,28 +258,28 @@ ALD_INL void link_out_after(int v, int e, int hint)
 ALD_INL void unlink_in(int v, int e)
 {
     v = uni(v); e = uni(e);
-    if(v == uni(H.sinkp) && !uni(H.special_linked)) { H.in_deg[v]--; return; }
+    if(v == uni(HC.sinkp) && !uni(HC.special_linked)) { H.in_deg[v]--; return; }
     IDX *pp = &H.in_head[v]; IDX cur = *pp; int guard = MAXE;
     while(uni((int)cur != e && cur != NIL) && guard-- > 0) { pp = &H.ed[cur].lk.inx; cur = *pp; }
     if(ALD_UNLIKELY(uni((int)cur != e))) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }       // cannot happen on a consistent state; never walk off a list
     *pp = H.ed[e].lk.inx;
-    { int dg = (int)uni(H.in_deg[v]) - 1; H.in_deg[v] = (IDX)dg; if(dg <= 1) { H.maybe_triv = 1; if(dg == 0) H.maybe_broken = 1; } }
+    { int dg = (int)uni(H.in_deg[v]) - 1; H.in_deg[v] = (IDX)dg; if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; } }
 }
 ALD_INL void unlink_out(int v, int e)
 {
     v = uni(v); e = uni(e);
-    if(v == 0 && !uni(H.special_linked)) { H.out_deg[v]--; return; }
+    if(v == 0 && !uni(HC.special_linked)) { H.out_deg[v]--; return; }
     IDX *pp = &H.out_head[v]; IDX cur = *pp; int guard = MAXE;
     while(uni((int)cur != e && cur != NIL) && guard-- > 0) { pp = &H.ed[cur].lk.onx; cur = *pp; }
     if(ALD_UNLIKELY(uni((int)cur != e))) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
     *pp = H.ed[e].lk.onx;
-    { int dg = (int)uni(H.out_deg[v]) - 1; H.out_deg[v] = (IDX)dg; if(dg <= 1) { H.maybe_triv = 1; if(dg == 0) H.maybe_broken = 1; } }
+    { int dg = (int)uni(H.out_deg[v]) - 1; H.out_deg[v] = (IDX)dg; if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; } }
 }
 // e stays in v's in-list but its key becomes (ks, newest id): one walk finds its predecessor and its new place
 ALD_INL void relink_in(int v, int e, uint32_t ks)
 {
     v = uni(v); e = uni(e);
-    if(v == uni(H.sinkp) && !uni(H.special_linked)) return;
+    if(v == uni(HC.sinkp) && !uni(HC.special_linked)) return;
     int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
     int guard = MAXE;
     for(int cur = u_first_in(v); cur >= 0 && guard-- > 0; ) {
@@ -280,8 +298,8 @@ ALD_INL void relink_in(int v, int e, uint32_t ks)
 ALD_INL void relink_out(int v, int e, uint32_t kt)         // kt already mapped by tkey()
 {
     v = uni(v); e = uni(e);
-    if(v == 0 && !uni(H.special_linked)) return;
-    const uint32_t sk = (uint32_t)uni(H.sinkp);
+    if(v == 0 && !uni(HC.special_linked)) return;
+    const uint32_t sk = (uint32_t)uni(HC.sinkp);
     int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
     int guard = MAXE;
     for(int cur = u_first_out(v); cur >= 0 && guard-- > 0; ) {
@@ -301,7 +319,7 @@ ALD_INL void relink_out(int v, int e, uint32_t kt)         // kt already mapped 
 // nothing here may be routed through the scalar unit.
 ALD_INL void relink_in_lane(int v, int e, uint32_t ks)
 {
-    if(v == H.sinkp && !H.special_linked) return;
+    if(v == HC.sinkp && !HC.special_linked) return;
     int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
     int guard = MAXE;
     for(int cur = first_in(v); cur >= 0 && guard-- > 0; ) {
@@ -319,8 +337,8 @@ ALD_INL void relink_in_lane(int v, int e, uint32_t ks)
 }
 ALD_INL void relink_out_lane(int v, int e, uint32_t kt)    // kt already mapped by tkey()
 {
-    if(v == 0 && !H.special_linked) return;
-    const uint32_t sk = (uint32_t)H.sinkp;
+    if(v == 0 && !HC.special_linked) return;
+    const uint32_t sk = (uint32_t)HC.sinkp;
     int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
     int guard = MAXE;
     for(int cur = first_out(v); cur >= 0 && guard-- > 0; ) {
@@ -336,16 +354,16 @@ ALD_INL void relink_out_lane(int v, int e, uint32_t kt)    // kt already mapped 
     if(pe < 0) H.out_head[v] = nxe; else H.ed[pe].lk.onx = nxe;
     if(ip < 0) { H.ed[e].lk.onx = H.out_head[v]; H.out_head[v] = (IDX)e; } else { H.ed[e].lk.onx = H.ed[ip].lk.onx; H.ed[ip].lk.onx = (IDX)e; }
 }
-ALD_INL int free_slots() { return uni(H.free_cnt) + (MAXE - uni(H.slot_hw)); }
+ALD_INL int free_slots() { return uni(HC.free_cnt) + (MAXE - uni(HC.slot_hw)); }
 // directed_graph::add_edge (directed_graph.cc:38-48) + i2e.push_back: the new id is the largest
 ALD_INL int add_edge_i(int s, int t)
 {
     s = uni(s); t = uni(t);
-    int e; int fh = uni(H.free_head), hw = uni(H.slot_hw);
-    if(fh >= 0) { e = fh; IDX nx = uni(H.ed[e].lk.onx); H.free_head = nx == NIL ? -1 : (int)nx; H.free_cnt--; }
-    else if(hw < MAXE) { e = hw; H.slot_hw = hw + 1; }
+    int e; int fh = uni(HC.free_head), hw = uni(HC.slot_hw);
+    if(fh >= 0) { e = fh; IDX nx = uni(H.ed[e].lk.onx); HC.free_head = nx == NIL ? -1 : (int)nx; HC.free_cnt--; }
+    else if(hw < MAXE) { e = hw; HC.slot_hw = hw + 1; }
     else { fail(ALD_ST_CAPACITY); return -1; }
-    int id = uni(H.next_id); H.next_id = id + 1;
+    int id = uni(HC.next_id); HC.next_id = id + 1;
     if(ALD_UNLIKELY(id >= 0xFFFF)) { fail(ALD_ST_CAPACITY); return -1; }
     H.ed[e].lk.es = (IDX)s; H.ed[e].lk.et = (IDX)t; H.eid[e] = (uint16_t)id; H.hflag[e] = 0; H.ed[e].w = 0;
     link_out(s, e); link_in(t, e);
@@ -358,7 +376,7 @@ ALD_INL void kill_edge_i(int e)
     e = uni(e);
     unlink_out(uni(H.ed[e].lk.es), e); unlink_in(uni(H.ed[e].lk.et), e);
     H.ed[e].lk.es = NIL;
-    { int fh = uni(H.free_head); H.ed[e].lk.onx = fh < 0 ? NIL : (IDX)fh; H.free_head = e; H.free_cnt = uni(H.free_cnt) + 1; }
+    { int fh = uni(HC.free_head); H.ed[e].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = e; HC.free_cnt = uni(HC.free_cnt) + 1; }
 }
 // remove_edge by the wave (ALL lanes call, e wave-uniform): the edge leaves its source's out-list and its target's in-list AT THE SAME
 // TIME -- lane 0 walks one list, lane 1 the other, same instruction stream, different links -- where kill_edge_i walks them one after
@@ -367,7 +385,7 @@ ALD_INL void kill_edge_wave(int e)
 {
     e = uni(e);
     const uint64_t w = *(const uint64_t*)&H.ed[e].lk;            // es | et << 16 | inx << 32 | onx << 48, read before anything moves
-    const bool special = H.special_linked != 0; const int sinkp = H.sinkp;
+    const bool special = HC.special_linked != 0; const int sinkp = HC.sinkp;
     for(int side = lane_id(); side < 2; side += ALD_WAVE) {
         const bool out = (side == 0);
         const int v = out ? (int)(w & 0xFFFF) : (int)((w >> 16) & 0xFFFF);
@@ -381,12 +399,12 @@ ALD_INL void kill_edge_wave(int e)
             *pp = nxe;
         }
         const int dg = (int)*deg - 1; *deg = (IDX)dg;
-        if(!counted && dg <= 1) { H.maybe_triv = 1; if(dg == 0) H.maybe_broken = 1; }
+        if(!counted && dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; }
     }
     wsync();
     if(lane_id() == 0) {
         H.ed[e].lk.es = NIL;
-        const int fh = uni(H.free_head); H.ed[e].lk.onx = fh < 0 ? NIL : (IDX)fh; H.free_head = e; H.free_cnt = uni(H.free_cnt) + 1;
+        const int fh = uni(HC.free_head); H.ed[e].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = e; HC.free_cnt = uni(HC.free_cnt) + 1;
     }
 }
 ALD_FN int add_edge(int s, int t) { return add_edge_i(uni(s), uni(t)); }
@@ -409,7 +427,7 @@ ALD_INL void strand_degree(int v, int vs[6])
 }
 ALD_INL bool mixed_strand_vertex(int v)
 {
-    if(!H.any_strand) return false;
+    if(!HC.any_strand) return false;
     int vs[6]; strand_degree(v, vs);
     return (vs[1] + vs[4] >= 1) && (vs[2] + vs[5] >= 1);
 }
@@ -433,7 +451,7 @@ ALD_FN bool intersect_samples(int e1, int e2, int z)
     const uint32_t o1 = uni(C.ed[e1].sp_off), o2 = uni(C.ed[e2].sp_off);
     const int i1 = uni(C.ed[e1].s0id), i2 = uni(C.ed[e2].s0id); const double a1 = uni(C.ed[e1].s0abd), a2 = uni(C.ed[e2].s0abd);
     const uint32_t need = n1 < n2 ? n1 : n2;
-    const uint32_t o = H.sp_used;
+    const uint32_t o = HC.sp_used;
     if(ALD_UNLIKELY(o + need > C.sp_cap)) { fail(ALD_ST_CAPACITY); return false; }
     uint32_t i = 0, j = 0, k = 0; double abd = 0; int first_id = 0; double first_abd = 0;
     while(i < n1 && j < n2) {
@@ -443,7 +461,7 @@ ALD_FN bool intersect_samples(int e1, int e2, int z)
                C.sp_id[o + k] = a; C.sp_abd[o + k] = c; abd += c; if(k == 0) { first_id = a; first_abd = c; } k++; i++; j++; }
     }
     C.ed[z].sp_len = k; C.ed[z].ecount = (int32_t)k; C.ed[z].eabd = abd; C.ed[z].s0id = first_id; C.ed[z].s0abd = first_abd;
-    if(k >= 2) { C.ed[z].sp_off = o; H.sp_used = o + k; } else C.ed[z].sp_off = 0;      // a single survivor stays inline
+    if(k >= 2) { C.ed[z].sp_off = o; HC.sp_used = o + k; } else C.ed[z].sp_off = 0;      // a single survivor stays inline
     return true;
 }
 // router.cc:1035-1038: sum over common samples of 0.99*min + 0.01*max
@@ -467,11 +485,11 @@ ALD_FN double common_abd(int e1, int e2)
 // e2s[e] is always a superset of the lists that contain e (hyper_set.cc:626-675,787-818,865-902).
 ALD_FN void hs_refresh_flags()                  // per-slot OCC / LEXT / REXT: hyper_set.cc:949-983 left/right_extend
 {
-    if(!H.hs_dirty) return;
-    H.maybe_triv = 1;
+    if(!HC.hs_dirty) return;
+    HC.maybe_triv = 1;
     COLD;
-    for(int e = 0; e < H.slot_hw; e++) H.hflag[e] = 0;
-    int nl = H.hl_n;
+    for(int e = 0; e < HC.slot_hw; e++) H.hflag[e] = 0;
+    int nl = HC.hl_n;
     for(int k = 0; k < nl; k++) {
         ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]);
         for(int i = 0; i < n; i++) {
@@ -482,32 +500,32 @@ ALD_FN void hs_refresh_flags()                  // per-slot OCC / LEXT / REXT: h
             H.hflag[e] |= f;
         }
     }
-    H.hs_dirty = 0;
+    HC.hs_dirty = 0;
 }
 ALD_FN void hs_remove_lists(int e)              // hyper_set.cc:787-818
 {
     e = uni(e);
-    int nl = H.hl_n;
+    int nl = HC.hl_n;
     COLD;
-    for(int k = 0; k < nl; k++) { ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]); for(int i = 0; i < n; i++) if(v[i] == e) { v[i] = -1; H.hs_dirty = 1; } }
+    for(int k = 0; k < nl; k++) { ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]); for(int i = 0; i < n; i++) if(v[i] == e) { v[i] = -1; HC.hs_dirty = 1; } }
 }
 ALD_FN void hs_replace1_lists(int x, int e)     // hyper_set.cc:609-615 -> 626-675 with |v| == 1
 {
     x = uni(x); e = uni(e);
-    int nl = H.hl_n;
+    int nl = HC.hl_n;
     COLD;
-    for(int k = 0; k < nl; k++) { ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]); for(int i = 0; i < n; i++) if(v[i] == x) { v[i] = e; H.hs_dirty = 1; } }
+    for(int k = 0; k < nl; k++) { ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]); for(int i = 0; i < n; i++) if(v[i] == x) { v[i] = e; HC.hs_dirty = 1; } }
 }
 ALD_FN void hs_replace2_lists(int x, int y, int e)   // hyper_set.cc:617-624 -> 626-675 with |v| == 2
 {
     x = uni(x); y = uni(y); e = uni(e);
-    int nl = H.hl_n;
+    int nl = HC.hl_n;
     COLD;
     for(int k = 0; k < nl; k++) {
         ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]); int w = 0;
         // matches of a 2-pattern with x != y cannot overlap; replace (x,y) by e left to right
         for(int i = 0; i < n; i++) {
-            if(i + 1 < n && v[i] == x && v[i + 1] == y) { v[w++] = e; i++; H.hs_dirty = 1; }
+            if(i + 1 < n && v[i] == x && v[i + 1] == y) { v[w++] = e; i++; HC.hs_dirty = 1; }
             else v[w++] = v[i];
         }
         C.hl_len[k] = w;
@@ -516,7 +534,7 @@ ALD_FN void hs_replace2_lists(int x, int y, int e)   // hyper_set.cc:617-624 -> 
 ALD_FN void hs_insert_between_lists(int x, int y, int e)   // hyper_set.cc:865-902
 {
     x = uni(x); y = uni(y); e = uni(e);
-    int nl = H.hl_n;
+    int nl = HC.hl_n;
     COLD;
     for(int k = 0; k < nl; k++) {
         int n = uni(C.hl_len[k]); ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]);
@@ -524,10 +542,10 @@ ALD_FN void hs_insert_between_lists(int x, int y, int e)   // hyper_set.cc:865-9
         for(int i = 0; i + 1 < n; i++) if(v[i] == x && v[i + 1] == y) cnt++;
         if(cnt == 0) continue;
         if(n + cnt > uni(C.hl_capk[k])) {             // relocate the list to the end of the pool with slack
-            uint32_t ncap = (uint32_t)(n + cnt) * 2u + 4u, o = H.hl_used;
+            uint32_t ncap = (uint32_t)(n + cnt) * 2u + 4u, o = HC.hl_used;
             if(ALD_UNLIKELY(o + ncap > C.hl_cap)) { fail(ALD_ST_CAPACITY); return; }
             for(int i = 0; i < n; i++) C.hl[o + i] = v[i];
-            H.hl_used = o + ncap; C.hl_off[k] = (int32_t)o; C.hl_capk[k] = (int32_t)ncap; v = C.hl + o;
+            HC.hl_used = o + ncap; C.hl_off[k] = (int32_t)o; C.hl_capk[k] = (int32_t)ncap; v = C.hl + o;
         }
         // the reference scans left to right and inserts e after every x that is followed by y
         int w = n + cnt - 1;
@@ -535,20 +553,20 @@ ALD_FN void hs_insert_between_lists(int x, int y, int e)   // hyper_set.cc:865-9
             v[w--] = v[i];
             if(i >= 1 && v[i - 1] == x && v[i] == y) v[w--] = e;
         }
-        C.hl_len[k] = n + cnt; H.hs_dirty = 1;
+        C.hl_len[k] = n + cnt; HC.hs_dirty = 1;
     }
 }
 // a graph without phasing lists (hl_n == 0) pays one LDS read per edit, not a call
-ALD_INL void hs_remove(int e) { if(uni(H.hl_n) != 0) hs_remove_lists(e); }
-ALD_INL void hs_replace1(int x, int e) { if(uni(H.hl_n) != 0) hs_replace1_lists(x, e); }
-ALD_INL void hs_replace2(int x, int y, int e) { if(uni(H.hl_n) != 0) hs_replace2_lists(x, y, e); }
-ALD_INL void hs_insert_between(int x, int y, int e) { if(uni(H.hl_n) != 0) hs_insert_between_lists(x, y, e); }
+ALD_INL void hs_remove(int e) { if(uni(HC.hl_n) != 0) hs_remove_lists(e); }
+ALD_INL void hs_replace1(int x, int e) { if(uni(HC.hl_n) != 0) hs_replace1_lists(x, e); }
+ALD_INL void hs_replace2(int x, int y, int e) { if(uni(HC.hl_n) != 0) hs_replace2_lists(x, y, e); }
+ALD_INL void hs_insert_between(int x, int y, int e) { if(uni(HC.hl_n) != 0) hs_insert_between_lists(x, y, e); }
 // hyper_set.cc:1003-1042 (side == 2, left_dominate) and 1044-1082 (side == 1, right_dominate)
 ALD_FN bool hs_dominate(int e, int side)
 {
     e = uni(e); side = uni(side);
     COLD;
-    int nl = H.hl_n;
+    int nl = HC.hl_n;
     ALD_GLOBAL int32_t *x1 = C.wi, *x2 = C.wi + C.w_cap / 4; int n1 = 0, n2 = 0; const int cap = C.w_cap / 8;
     for(int k = 0; k < nl; k++) {
         ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]);
@@ -579,7 +597,7 @@ ALD_FN bool hs_dominate(int e, int side)
 ALD_FN int split_edge(int ei, double w)
 {
     ei = uni(ei); w = uni(w);
-    if(ALD_UNLIKELY(!(w >= H.p_min_w - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
+    if(ALD_UNLIKELY(!(w >= HC.p_min_w - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
     double ww = uni(H.ed[ei].w);
     if(fabs(ww - w) <= kSMIN) return ei;
     int s = uni(H.ed[ei].lk.es), t = uni(H.ed[ei].lk.et);
@@ -587,7 +605,7 @@ ALD_FN int split_edge(int ei, double w)
     if(p2 < 0) return -1;
     COLD;
     double www = ww - w;
-    double mw = H.p_min_w;
+    double mw = HC.p_min_w;
     if(www <= mw) www = mw;
     H.ed[ei].w = www; H.ed[p2].w = w;
     C.ed[p2].estrand = uni(C.ed[ei].estrand); C.ed[p2].ecount = uni(C.ed[ei].ecount); C.ed[p2].eabd = uni(C.ed[ei].eabd); C.ed[p2].econf = uni(C.ed[ei].econf);
@@ -602,7 +620,7 @@ ALD_FN int split_edge(int ei, double w)
 // sums at the position their (endpoint, id) keys would have had, and everything else is computed from the originals' state.
 ALD_INL int merge_adjacent_edges_i(int x, int y, double ww)
 {
-    const double mw = H.p_min_w;
+    const double mw = HC.p_min_w;
     if(ALD_UNLIKELY(!(ww >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
     if(x < 0 || y < 0) return -1;
     if(H.ed[x].lk.et != uni(H.ed[y].lk.es)) { int t = x; x = y; y = t; }
@@ -617,9 +635,9 @@ ALD_INL int merge_adjacent_edges_i(int x, int y, double ww)
     const int meix = uni(C.ed[x].mei), meiy = uni(C.ed[y].mei), cntx = uni(C.ed[x].ecount), cnty = uni(C.ed[y].ecount), lt = uni(C.vx[xt].lpos), rt = uni(C.vx[xt].rpos), ov = uni(C.vx[xt].v2v);
     const int stx = uni(C.ed[x].estrand), sty = uni(C.ed[y].estrand);
     // split_edge(x, ww), split_edge(y, ww): a piece of weight ww gets the next id, the original keeps max(w - ww, min_w)
-    if(ALD_UNLIKELY(uni(H.next_id) >= 0xFFF0)) { fail(ALD_ST_CAPACITY); return -1; }
-    if(sx) { H.next_id++; double r = wx - ww; if(r <= mw) r = mw; H.ed[x].w = r; }
-    if(sy) { H.next_id++; double r = wy - ww; if(r <= mw) r = mw; H.ed[y].w = r; }
+    if(ALD_UNLIKELY(uni(HC.next_id) >= 0xFFF0)) { fail(ALD_ST_CAPACITY); return -1; }
+    if(sx) { HC.next_id++; double r = wx - ww; if(r <= mw) r = mw; H.ed[x].w = r; }
+    if(sy) { HC.next_id++; double r = wy - ww; if(r <= mw) r = mw; H.ed[y].w = r; }
     const double wx0 = sx ? ww : wx, wy0 = sy ? ww : wy;                 // weights of the two pieces being merged
     const double medx1 = sx ? medx * ww / wx : medx, medy1 = sy ? medy * ww / wy : medy;
     // merge_adjacent_equal_edges(piece x, piece y)
@@ -660,7 +678,7 @@ ALD_FN int merge_adjacent_edges(int x, int y, double ww) { return merge_adjacent
 ALD_INL void balance_vertex_i(int v)
 {
     if(H.in_deg[v] == 0 || uni(H.out_deg[v]) == 0) return;
-    const double mw = H.p_min_w;
+    const double mw = HC.p_min_w;
     double w1 = 0, w2 = 0;
     for(int e = u_first_in(v); e >= 0; e = u_next_in(e)) { double w = uni(H.ed[e].w); if(ALD_UNLIKELY(!(w >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w1 += w; }
     for(int e = u_first_out(v); e >= 0; e = u_next_out(e)) { double w = uni(H.ed[e].w); if(ALD_UNLIKELY(!(w >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w2 += w; }
@@ -687,17 +705,17 @@ static constexpr int PW_CAP = Cold::w_cap / 8;       // pairs per area in the sl
 ALD_INL Pairs pairs_at(bool lds, bool parked)
 {
     Pairs p;
-    if(lds) { int o = parked ? 2 * LP : 0; p.a = (int32_t*)H.scr_i + o; p.b = p.a + LP; p.w = (double*)H.scr_d + (parked ? LP : 0); p.cap = LP; }
+    if(lds) { int o = parked ? 2 * LP : 0; p.a = (int32_t*)HC.scr_i + o; p.b = p.a + LP; p.w = (double*)HC.scr_d + (parked ? LP : 0); p.cap = LP; }
     else { COLD; int o = parked ? PW_CAP : 0; p.a = (int32_t*)(C.wi + Cold::w_cap / 2) + o; p.b = (int32_t*)(C.wi + Cold::w_cap / 2 + Cold::w_cap / 4) + o; p.w = (double*)(C.wd + Cold::w_cap / 2) + o; p.cap = PW_CAP; }
     return p;
 }
-ALD_INL Pairs pairs_cur() { return pairs_at(H.pw_lds != 0, false); }
+ALD_INL Pairs pairs_cur() { return pairs_at(HC.pw_lds != 0, false); }
 // scalar arenas for the router / the decompositions: LDS when the vertex is small, else the lower half of the slab's work arrays
 struct Arena { int32_t *i; double *d; int cap_i, cap_d; };
 ALD_INL Arena arena_at(bool lds)
 {
     Arena a;
-    if(lds) { a.i = (int32_t*)H.scr_i + 4 * LP; a.d = (double*)H.scr_d + 2 * LP; a.cap_i = ARENA_I; a.cap_d = ARENA_D; }
+    if(lds) { a.i = (int32_t*)HC.scr_i + 4 * LP; a.d = (double*)HC.scr_d + 2 * LP; a.cap_i = ARENA_I; a.cap_d = ARENA_D; }
     else { COLD; a.i = (int32_t*)C.wi; a.d = (double*)C.wd; a.cap_i = Cold::w_cap / 2; a.cap_d = Cold::w_cap / 2; }
     return a;
 }
@@ -729,14 +747,14 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
 {
     COLD;
     PROF_DECL;
-    const double mw = H.p_min_w;
+    const double mw = HC.p_min_w;
     const int c = A ? u_first_in(x) : u_first_out(x);
     // [n] fan edges in adjacency-list order, -1 once merged / [n] positions in fe, ascending creation id / [n] pe2w weight of (c, fan
     // edge): a fan of at most STAR_MAX edges uses the arena part of the LDS scratch (the parked pair area stays intact), a larger
     // one the first quarter of the slab's work arrays (the region [3/8, 1/2) of wi belongs to decompose_vertex_extend)
-    int32_t *fe = SMALL ? (int32_t*)H.scr_i + 4 * LP : (int32_t*)C.wi;
+    int32_t *fe = SMALL ? (int32_t*)HC.scr_i + 4 * LP : (int32_t*)C.wi;
     int32_t *ord = SMALL ? fe + STAR_MAX : (int32_t*)(C.wi + Cold::w_cap / 8);
-    double *fw = SMALL ? (double*)H.scr_d + 2 * LP : (double*)C.wd;
+    double *fw = SMALL ? (double*)HC.scr_d + 2 * LP : (double*)C.wd;
     // balance_vertex(x) (scallop.cc:2486-2576) on the gathered weights: the same sums, ratios, clamps and remainder fix-up in the
     // same order as the list-walking form (balance_vertex_i), but the fan is walked once and nothing is written back until the
     // pe2w sums below are known
@@ -797,11 +815,11 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         const int j = ord[q], f = fe[j]; const double ww = fw[j];
         const double wcur = H.ed[c].w;                                   // what is left of c
         const bool sc = uni(!(fabs(wcur - ww) <= kSMIN));                        // split_edge(c, ww) cuts a piece off (scallop.cc:2433-2484)
-        int nid = uni(H.next_id);
+        int nid = uni(HC.next_id);
         if(nid >= 0xFFF0) { C.vx[x].vw = vwt; fail(ALD_ST_CAPACITY); return; }
         double rem = wcur;
         if(sc) { nid++; rem = wcur - ww; if(rem <= mw) rem = mw; H.ed[c].w = rem; }    // the piece takes an id and disappears in the merge
-        H.next_id = nid + 1;                                                // id of the merged edge
+        HC.next_id = nid + 1;                                                // id of the merged edge
         const double wc0 = sc ? ww : wcur;
         const double medc1 = sc ? medc * ww / wcur : medc;
         // everything the step needs from f's record, in one round of independent loads (one 64-byte line for NW == 1)
@@ -867,7 +885,7 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
             }
             int32_t *t2 = src; src = dst; dst = t2;
         }
-        const bool counted = A ? (far == 0 && !uni(H.special_linked)) : (far == (int)uni(H.sinkp) && !uni(H.special_linked));
+        const bool counted = A ? (far == 0 && !uni(HC.special_linked)) : (far == (int)uni(HC.sinkp) && !uni(HC.special_linked));
         if(!counted) {
             IDX *pp = A ? &H.out_head[far] : &H.in_head[far]; IDX cur = *pp; int guard = MAXE + n;
             for(int q = 0; q < n; q++) {
@@ -888,7 +906,7 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     // remove_edge(c); x is left without edges
     if(A) unlink_out(far, c); else unlink_in(far, c);
     H.ed[c].lk.es = NIL; H.hflag[c] = 0;
-    { int fh = uni(H.free_head); H.ed[c].lk.onx = fh < 0 ? NIL : (IDX)fh; H.free_head = c; H.free_cnt = uni(H.free_cnt) + 1; }
+    { int fh = uni(HC.free_head); H.ed[c].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = c; HC.free_cnt = uni(HC.free_cnt) + 1; }
     H.in_head[x] = NIL; H.out_head[x] = NIL; H.in_deg[x] = 0; H.out_deg[x] = 0; H.nz[x] = 0;
     PROF_ADD(PF_T_TAIL);
 }
@@ -928,9 +946,9 @@ template<bool A> ALD_INL void star_wave_body(int x)
     COLD;
     PROF_DECL;
     const int lane = lane_id();
-    const double mw = H.p_min_w;
-    int32_t *fe = (int32_t*)H.scr_i, *ord = fe + STAR_MAX, *inv = fe + 2 * STAR_MAX, *oth = fe + 3 * STAR_MAX, *ctx = (int32_t*)H.scr_i;
-    double *fw = (double*)H.scr_d, *sq = fw + STAR_MAX;                  // pair weights (list order) / per merge: (sum, later r1), in merge order
+    const double mw = HC.p_min_w;
+    int32_t *fe = (int32_t*)HC.scr_i, *ord = fe + STAR_MAX, *inv = fe + 2 * STAR_MAX, *oth = fe + 3 * STAR_MAX, *ctx = (int32_t*)HC.scr_i;
+    double *fw = (double*)HC.scr_d, *sq = fw + STAR_MAX;                  // pair weights (list order) / per merge: (sum, later r1), in merge order
     double *dctx = fw + 2 * STAR_MAX;                                      // [0] = weight c starts with, [1] = vertex weight of x
     // what the merges need of c's record and of vertex x is asked for NOW, by every lane (one broadcast request each): the round
     // trip to L2 runs under phases 0..2 instead of in front of phase 3
@@ -989,7 +1007,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
     wsync();
     if(uni(ctx[SW_FAIL])) { if(lane == 0) fail(ctx[SW_FAIL]); wsync(); return; }
     PROF_ADD(PF_T_SETUP);
-    const int id0 = uni(H.next_id);
+    const int id0 = uni(HC.next_id);
     const int meic = uni(meic_v), cntc = uni(cntc_v), stc = uni(stc_v), idc = uni(idc_v);
     const uint32_t nsc = uni(nsc_v);
     const int lt = uni(lt_v), rt = uni(rt_v), ov = uni(ov_v);
@@ -1087,7 +1105,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
         return;
     }
     // far's list: c leaves it now (lane 0, while nothing else touches a list of that kind), the merged edges enter it below
-    const bool counted = A ? (far == 0 && !uni(H.special_linked)) : (far == (int)uni(H.sinkp) && !uni(H.special_linked));     // out(source) / in(sink) are only counted
+    const bool counted = A ? (far == 0 && !uni(HC.special_linked)) : (far == (int)uni(HC.sinkp) && !uni(HC.special_linked));     // out(source) / in(sink) are only counted
     const bool consumed = uni(ctx[SW_SERIAL]) != 0;
     if(lane == 0 && consumed) { if(A) unlink_out(far, c); else unlink_in(far, c); }
     wsync();
@@ -1123,18 +1141,18 @@ template<bool A> ALD_INL void star_wave_body(int x)
     // ---- phase 7 (lane 0): what is left and inherently ordered -- the support pool, the phasing lists, the counters
     if(lane == 0) {
         if(A) H.out_deg[far] = (IDX)((int)uni(H.out_deg[far]) + n); else H.in_deg[far] = (IDX)((int)uni(H.in_deg[far]) + n);
-        if(any_dup || any_multi || uni(H.hl_n) != 0) for(int q = 0; q < n; q++) {
+        if(any_dup || any_multi || uni(HC.hl_n) != 0) for(int q = 0; q < n; q++) {
             const int f = fe[ord[q]];
             if(any_dup) { if(A) relink_in(oth[q], f, (uint32_t)far); else relink_out(oth[q], f, tkey((uint32_t)far)); }
             if(any_multi) { const uint32_t nsf = uni(C.ed[f].sp_len); if(!(nsc == 1 && nsf == 1)) { if(!(A ? intersect_samples(c, f, f) : intersect_samples(f, c, f))) break; } }
             if(A) hs_replace2(c, f, f); else hs_replace2(f, c, f);
             if(n == 1) hs_replace1(c, f);
         }
-        H.next_id = (int)uni(H.eid[fe[ord[n - 1]]]) + 1;
+        HC.next_id = (int)uni(H.eid[fe[ord[n - 1]]]) + 1;
         if(n >= 2) hs_remove(c);
         // remove_edge(c) (already out of far's list); x is left without edges
         H.ed[c].lk.es = NIL; H.hflag[c] = 0;
-        { int fh = uni(H.free_head); H.ed[c].lk.onx = fh < 0 ? NIL : (IDX)fh; H.free_head = c; H.free_cnt = uni(H.free_cnt) + 1; }
+        { int fh = uni(HC.free_head); H.ed[c].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = c; HC.free_cnt = uni(HC.free_cnt) + 1; }
         H.in_head[x] = NIL; H.out_head[x] = NIL; H.in_deg[x] = 0; H.out_deg[x] = 0; H.nz[x] = 0;
     }
     wsync();
@@ -1163,7 +1181,7 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
     int32_t *a = P.a, *b = P.b; double *w = P.w;
     const int deg = (int)uni(H.in_deg[root]) + (int)uni(H.out_deg[root]);
     // the visiting order of the nested decompositions (jump_ratio > 1 only) must survive them: it always lives in the slab
-    const Arena AR = SMALL ? arena_at(true) : arena_at(4 * deg <= ARENA_I && deg <= ARENA_D && !(H.p_ratio[7] > 1.0));
+    const Arena AR = SMALL ? arena_at(true) : arena_at(4 * deg <= ARENA_I && deg <= ARENA_D && !(HC.p_ratio[7] > 1.0));
     if(ALD_UNLIKELY(4 * deg > AR.cap_i || deg > AR.cap_d || deg > C.w_cap / 16)) { fail(ALD_ST_CAPACITY); return; }
     int nloc = 0; int32_t *loc_e = AR.i;
     for(int e = u_first_in(root); e >= 0; e = u_next_in(e)) { loc_e[nloc++] = e; }
@@ -1173,7 +1191,7 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
     int32_t *evx = AR.i + 2 * deg;                // [nloc] new vertex of the edge (ev1 / ev2), or -1
     double *mweight = AR.d;                       // [nloc]
     for(int i = 0; i < nloc; i++) { mdeg[i] = 0; evx[i] = -1; mweight[i] = 0; }
-    const double mw = H.p_min_w;
+    const double mw = HC.p_min_w;
     double total_weight = 0;
     for(int i = 0; i < n; i++) {
         if(ALD_UNLIKELY(!(w[i] >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
@@ -1188,14 +1206,14 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
     for(int i = 0; i < nloc; i++) mweight[i] = mweight[i] / total_weight * vertex_weight;
     // new vertices (scallop.cc:1753-1806) are appended at the end of the physical index space; the reference gives them the
     // indices m.. and moves the sink behind them -- same relative order, no edge has to move here
-    int m = H.nv, nn = m;
+    int m = HC.nv, nn = m;
     for(int i = 0; i < nloc; i++) { if(ALD_UNLIKELY(mdeg[i] == 0)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; } if(mdeg[i] >= 2) evx[i] = nn++; }
     int newedges = 0;
     for(int i = 0; i < n; i++) { int u1 = PLOC(a[i]), u2 = PLOC(b[i]); if(mdeg[u1] == 1 && mdeg[u2] == 1) evx[u1] = nn++; else if(mdeg[u1] >= 2 && mdeg[u2] >= 2) newedges++; }
     if(ALD_UNLIKELY(nn > MAXV || free_slots() < newedges)) { fail(ALD_ST_CAPACITY); return; }
-    H.maybe_broken = 1; H.maybe_triv = 1;
+    HC.maybe_broken = 1; HC.maybe_triv = 1;
     for(int i = m; i < nn; i++) { H.in_head[i] = NIL; H.out_head[i] = NIL; H.in_deg[i] = 0; H.out_deg[i] = 0; H.nz[i] = 1; C.vx[i].vw = 0; C.vx[i].lpos = 0; C.vx[i].rpos = 0; C.vx[i].vtype = -1; C.vx[i].v2v = -1; }
-    H.nv = nn;
+    HC.nv = nn;
     for(int i = 0; i < nin; i++) {               // ev1: detach in-edges onto their new vertex
         int k = evx[i]; if(k < 0) continue; int e = loc_e[i];
         int p = uni(C.vx[uni(H.ed[e].lk.es)].rpos);
@@ -1233,13 +1251,13 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
             C.ed[z].med = ww / total_weight * vertex_weight; C.ed[z].mei = rlen;
             borrow_edge_strand(C, z, e1); borrow_edge_strand(C, z, e2);
             hs_insert_between(e1, e2, z);
-            if(H.status) return;
+            if(HC.status) return;
         }
     }
     if(ALD_UNLIKELY(H.in_deg[root] != 0 || uni(H.out_deg[root]) != 0)) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }
     H.nz[root] = 0;
     // scallop.cc:1976-1985 resolve_single_trivial_vertex(k, jump_ratio) on the new vertices: a no-op unless jump_ratio > 1
-    double jump = H.p_ratio[7];
+    double jump = HC.p_ratio[7];
     if(jump > 1.0) {
         // the reference walks ev1 then ev2, each a std::map keyed by edge id.  The nested decompositions reuse the work area, so
         // the visiting order is parked first in [3/8, 1/2) of wi, which no routine touches.
@@ -1252,7 +1270,7 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
                 order[j + 1] = k; mdeg[j + 1] = loc_e[i]; no++;
             }
         }
-        for(int q = 0; q < no; q++) { resolve_single_trivial_vertex(order[q], jump); if(H.status) return; }
+        for(int q = 0; q < no; q++) { resolve_single_trivial_vertex(order[q], jump); if(HC.status) return; }
     }
 }
 
@@ -1262,7 +1280,7 @@ ALD_INL void decompose_vertex_extend(int root, int n)
 {
     root = uni(root); n = uni(n);
     const int deg = (int)uni(H.in_deg[root]) + (int)uni(H.out_deg[root]);
-    if(uni(H.pw_lds) != 0 && 4 * deg <= ARENA_I && deg <= ARENA_D && !(uni(H.p_ratio[7]) > 1.0)) decompose_vertex_extend_small(root, n);
+    if(uni(HC.pw_lds) != 0 && 4 * deg <= ARENA_I && deg <= ARENA_D && !(uni(HC.p_ratio[7]) > 1.0)) decompose_vertex_extend_small(root, n);
     else decompose_vertex_extend_any(root, n);
 }
 
@@ -1354,7 +1372,7 @@ ALD_INL int eval_smallest(int i, double &r)
     if((f & HF_REXT) && (f & HF_LEXT)) return -1;
     if(t == i && (f & HF_REXT)) return -1;
     if(s == i && (f & HF_LEXT)) return -1;
-    if(H.any_strand) {
+    if(HC.any_strand) {
         COLD;
         int z = C.ed[e].estrand;
         if(z >= 1) { int vs[6]; strand_degree(i, vs); if(s == i && vs[0] + vs[z] <= 1) return -1; if(t == i && vs[3] + vs[z + 3] <= 1) return -1; }
@@ -1366,22 +1384,22 @@ ALD_INL int eval_smallest(int i, double &r)
 // scallop::resolve_broken_vertex (scallop.cc:190-236)
 ALD_INL bool resolve_broken_vertex()
 {
-    if(!uni(H.maybe_broken)) return false;
+    if(!uni(HC.maybe_broken)) return false;
     const int lane = lane_id();
-    int vend = H.nv; int x = -1;
+    int vend = HC.nv; int x = -1;
     for(int base = 0; base < vend && x < 0; base += ALD_WAVE) {
         int i = base + lane;
-        const bool inr = (i >= 1) & (i < vend) & (i != H.sinkp); const int ii = inr ? i : 0;
+        const bool inr = (i >= 1) & (i < vend) & (i != HC.sinkp); const int ii = inr ? i : 0;
         const int nzv = H.nz[ii] & NZ_MEMBER, d1 = H.in_deg[ii], d2 = H.out_deg[ii];
         bool p = inr & (nzv != 0) & !((d1 >= 1) & (d2 >= 1));
         uint64_t m = wballot(p);
         if(m) x = base + ffs64(m);
     }
-    if(x < 0) { wsync(); if(lane == 0) H.maybe_broken = 0; wsync(); return false; }
+    if(x < 0) { wsync(); if(lane == 0) HC.maybe_broken = 0; wsync(); return false; }
     if(lane == 0) {
         if(H.in_deg[x] + H.out_deg[x] == 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);      // assert(ve.size() >= 1)
         else {
-            H.maybe_triv = 1;
+            HC.maybe_triv = 1;
             trace(OP_BROKEN, vlog(x), H.in_deg[x] + H.out_deg[x], 0);
             int guard = MAXE;
             while(first_in(x) >= 0 && guard-- > 0) { int e = first_in(x); kill_edge(e); hs_remove(e); }
@@ -1405,9 +1423,9 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
     const int lane = lane_id();
     const bool fast = (mode == 1);
     const double now_thr = (mode == 1) ? 1.02 : jump_ratio;
-    const int vend = H.sw_vend;                // snapshot of nonzeroset: vertices created later are not visited (the sink is never in it: nz == 0)
-    double best_r = H.sw_best_r; int best_v = H.sw_best_v;
-    const int dom_base = H.sw_dom_base;        // chunk whose dominate queries the driver has answered (scr_i[lane]), or -1
+    const int vend = HC.sw_vend;                // snapshot of nonzeroset: vertices created later are not visited (the sink is never in it: nz == 0)
+    double best_r = HC.sw_best_r; int best_v = HC.sw_best_v;
+    const int dom_base = HC.sw_dom_base;        // chunk whose dominate queries the driver has answered (scr_i[lane]), or -1
     int code = SC_NONE, hit = -1; double hit_r = 0;
     double frr = DBL_MAX; int fvv = -1;          // this lane's best candidate over the chunks scanned (later vertex wins ties)
     for(int base = (start / ALD_WAVE) * ALD_WAVE; base < vend; base += ALD_WAVE) {
@@ -1419,7 +1437,7 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
             const bool inr = (i >= start) & (i < vend); const int ii = inr ? i : 0;
             const int nzv = H.nz[ii] & NZ_MEMBER, d1 = H.in_deg[ii], d2 = H.out_deg[ii]; const IDX h1 = H.in_head[ii], h2 = H.out_head[ii];
             bool elig = inr & (nzv != 0) & (d1 >= 1) & (d2 >= 1) & !((d1 >= 2) & (d2 >= 2));
-            if(H.any_strand) elig = elig && !mixed_strand_vertex(i);
+            if(HC.any_strand) elig = elig && !mixed_strand_vertex(i);
             const int e1 = (elig & (h1 != NIL)) ? (int)h1 : 0, e2 = (elig & (h2 != NIL)) ? (int)h2 : 0;
             const IDX sv = H.ed[e1].lk.es, tv = H.ed[e2].lk.et; const uint8_t f1 = H.hflag[e1], f2 = H.hflag[e2];
             const int s_ = (elig & (sv != NIL)) ? (int)sv : 0, t_ = (elig & (tv != NIL)) ? (int)tv : 0;
@@ -1433,9 +1451,9 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
             }
         }
         // lanes that need a dominate query (rare: only edges on phasing paths) are answered by the driver, one at a time on lane 0
-        if(cls == -2 && base == dom_base) cls = H.scr_i[lane];
+        if(cls == -2 && base == dom_base) cls = HC.scr_i[lane];
         uint64_t need = wballot(cls == -2);
-        if(need) { if(lane == 0) { H.sw_dom_base = base; H.sw_need_lo = (uint32_t)need; H.sw_need_hi = (uint32_t)(need >> 32); } code = SC_NEED; break; }
+        if(need) { if(lane == 0) { HC.sw_dom_base = base; HC.sw_need_lo = (uint32_t)need; HC.sw_need_hi = (uint32_t)(need >> 32); } code = SC_NEED; break; }
         bool cand = (cls == type);
         if(cand) { bool ok; r = compute_balance_ratio(i, ok); if(!ok) bad = true; }
         if(wballot(bad)) { code = SC_BAD; break; }
@@ -1455,7 +1473,7 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
         wave_argmin(rr, vv);
         if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; }      // if(ratio < r) continue;
     }
-    if(lane == 0) { H.sw_best_r = best_r; H.sw_best_v = best_v; H.sw_hit = hit; H.sw_hit_r = hit_r; }
+    if(lane == 0) { HC.sw_best_r = best_r; HC.sw_best_v = best_v; HC.sw_hit = hit; HC.sw_hit_r = hit_r; }
     wsync();
     return code;
 }
@@ -1464,52 +1482,52 @@ ALD_INL bool sweep_trivial(int mode, int type, double jump_ratio)
     mode = uni(mode); type = uni(type); jump_ratio = uni(jump_ratio);
     const int lane = lane_id();
     PROF_DECL;
-    if(lane == 0) { if(uni(H.hs_dirty)) hs_refresh_flags(); H.sw_vend = H.nv; H.sw_best_r = DBL_MAX; H.sw_best_v = -1; H.sw_dom_base = -1; }
+    if(lane == 0) { if(uni(HC.hs_dirty)) hs_refresh_flags(); HC.sw_vend = HC.nv; HC.sw_best_r = DBL_MAX; HC.sw_best_v = -1; HC.sw_dom_base = -1; }
     wsync();
     // R3 (mode 1, type 1) acts whenever a type-1 vertex exists.  After a sweep that found none, one can only appear when a degree
     // drops to <= 1, the phasing flags change or vertices are created -- all of which raise maybe_triv; until then the scan is
     // skipped.  (Stranded graphs also gain candidates when a removal un-mixes a vertex: they always scan.)
-    const bool skippable = (mode == 1 && type == 1 && !uni(H.any_strand));
-    if(skippable && !uni(H.maybe_triv)) return false;
+    const bool skippable = (mode == 1 && type == 1 && !uni(HC.any_strand));
+    if(skippable && !uni(HC.maybe_triv)) return false;
     bool flag = false;
     int start = 1;
     // ONE place decomposes -- the vertex a scan hits (the sweep then goes on behind it) or, when the sweep ends without a hit, its best
     // candidate: the wave-wide decomposition is inlined here, so it must not be instantiated twice
     for(;;) {
         int target = -1; bool last = false;
-        while(start < uni(H.sw_vend)) {
+        while(start < uni(HC.sw_vend)) {
             int code = uni(scan_trivial(start, mode, type, jump_ratio));     // chunks before `start` hold no unvisited vertex
             PROF_ADD(PF_TRIV_EVAL);
             if(code == SC_NEED) {
                 if(lane == 0) {
-                    uint64_t need = (uint64_t)H.sw_need_lo | ((uint64_t)H.sw_need_hi << 32); const int base = H.sw_dom_base;
-                    while(need) { int l = ffs64(need); need &= need - 1; H.scr_i[l] = classify_trivial_vertex(base + l, mode == 1); }
+                    uint64_t need = (uint64_t)HC.sw_need_lo | ((uint64_t)HC.sw_need_hi << 32); const int base = HC.sw_dom_base;
+                    while(need) { int l = ffs64(need); need &= need - 1; HC.scr_i[l] = classify_trivial_vertex(base + l, mode == 1); }
                 }
                 wsync();
-                if(uni(H.sw_dom_base) > start) start = uni(H.sw_dom_base);       // earlier chunks are done (no hit; their candidates are in sw_best_*)
+                if(uni(HC.sw_dom_base) > start) start = uni(HC.sw_dom_base);       // earlier chunks are done (no hit; their candidates are in sw_best_*)
                 continue;
             }
             if(code == SC_BAD) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); wsync(); return true; }
-            if(code == SC_HIT) target = uni(H.sw_hit);
+            if(code == SC_HIT) target = uni(HC.sw_hit);
             break;
         }
         if(target < 0) {                             // the sweep is over
             if(flag) return true;
             if(mode == 0) return false;
-            if(uni(H.sw_best_v) < 0) { if(skippable) { if(lane == 0) H.maybe_triv = 0; wsync(); } return false; }
-            target = uni(H.sw_best_v); last = true;
+            if(uni(HC.sw_best_v) < 0) { if(skippable) { if(lane == 0) HC.maybe_triv = 0; wsync(); } return false; }
+            target = uni(HC.sw_best_v); last = true;
         }
-        if(lane == 0) { if(last) trace(OP_TRIVIAL_BEST, vlog(target), type, H.sw_best_r); else trace(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, vlog(target), mode == 1 ? type : 0, H.sw_hit_r); }
+        if(lane == 0) { if(last) trace(OP_TRIVIAL_BEST, vlog(target), type, HC.sw_best_r); else trace(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, vlog(target), mode == 1 ? type : 0, HC.sw_hit_r); }
         decompose_trivial_vertex_wave(target);
         if(last) { wsync(); PROF_ADD(PF_TRIV_MUT); return true; }
         if(lane == 0) {
-            if(uni(H.hs_dirty)) hs_refresh_flags();
-            H.sw_dom_base = -1;
+            if(uni(HC.hs_dirty)) hs_refresh_flags();
+            HC.sw_dom_base = -1;
         }
         wsync();
         PROF_ADD(PF_TRIV_MUT);
         flag = true;
-        if(H.status) return true;
+        if(HC.status) return true;
         start = target + 1;
     }
 }
@@ -1523,11 +1541,11 @@ ALD_INL bool sweep_smallest(double max_ratio)
 {
     max_ratio = uni(max_ratio);
     const int lane = lane_id();
-    const int vend = uni(H.nv);
+    const int vend = uni(HC.nv);
     constexpr int NC = MAXV / ALD_WAVE;           // per-lane results for every chunk of the class (registers for the small classes, private memory beyond)
     if(vend > NC * ALD_WAVE) { if(lane == 0) fail(ALD_ST_CAPACITY); wsync(); return true; }     // cannot happen: nv <= MAXV
     PROF_DECL;
-    if(lane == 0 && uni(H.hs_dirty)) hs_refresh_flags();
+    if(lane == 0 && uni(HC.hs_dirty)) hs_refresh_flags();
     wsync();
     double cr[NC]; int ce[NC];
     // Classes of up to 16 chunks keep the arrays in registers: every loop over the chunks is fully unrolled (constant indices) and the few
@@ -1544,7 +1562,7 @@ ALD_INL bool sweep_smallest(double max_ratio)
     };
     ALD_UNROLL for(int c = 0; c < NC; c++) { cr[c] = 0; ce[c] = -1; }
     { const int nch = (vend + ALD_WAVE - 1) / ALD_WAVE; for(int c = 0; c < nch; c++) eval_chunk(c, true, -1, -1); }
-    const bool may_chain = !(uni(H.p_ratio[7]) > 1.0) && !uni(H.any_strand);
+    const bool may_chain = !(uni(HC.p_ratio[7]) > 1.0) && !uni(HC.any_strand);
     bool any = false;
     int guard = MAXE + 8;
     while(guard-- > 0) {                          // one sweep of the reference per iteration
@@ -1587,8 +1605,8 @@ ALD_INL bool sweep_smallest(double max_ratio)
             wsync();
             // other vertices only look at ds / dt through the guards out_deg[ds] > 1 and in_deg[dt] > 1 (both held for the edge just
             // removed); if one of them stops holding, or the phasing flags moved, every lane evaluates again
-            const bool all = uni(H.hs_dirty) != 0 || (int)uni(H.out_deg[ds]) <= 1 || (int)uni(H.in_deg[dt]) <= 1;
-            if(uni(H.hs_dirty)) { if(lane == 0) hs_refresh_flags(); wsync(); }
+            const bool all = uni(HC.hs_dirty) != 0 || (int)uni(H.out_deg[ds]) <= 1 || (int)uni(H.in_deg[dt]) <= 1;
+            if(uni(HC.hs_dirty)) { if(lane == 0) hs_refresh_flags(); wsync(); }
             if(NC <= 2) { for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (all || i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } } }
             else if(all) { const int nch = (vend + ALD_WAVE - 1) / ALD_WAVE; for(int c = 0; c < nch; c++) eval_chunk(c, true, -1, -1); }
             else {                                                          // many chunks: go straight to the (one or two) chunks of ds and dt
@@ -1609,7 +1627,7 @@ ALD_INL bool sweep_smallest(double max_ratio)
             wsync();
             any = true;
             // back to the cascade unless R1..R3 provably have nothing to do
-            if(!may_chain || uni(H.status) || uni(H.maybe_broken) || uni(H.maybe_triv) || uni(H.hs_dirty)) { PROF_ADD(PF_SMALL_MUT); return true; }
+            if(!may_chain || uni(HC.status) || uni(HC.maybe_broken) || uni(HC.maybe_triv) || uni(HC.hs_dirty)) { PROF_ADD(PF_SMALL_MUT); return true; }
             if(NC <= 2) { for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } } }
             else {
                 const int c1 = uni(ds) / ALD_WAVE, c2 = uni(dt) / ALD_WAVE;
@@ -1619,14 +1637,14 @@ ALD_INL bool sweep_smallest(double max_ratio)
             PROF_ADD(PF_SMALL_MUT);
         } else {
             any = true;
-            if(!may_chain || uni(H.status) || uni(H.maybe_broken) || uni(H.maybe_triv) || uni(H.hs_dirty)) return true;
+            if(!may_chain || uni(HC.status) || uni(HC.maybe_broken) || uni(HC.maybe_triv) || uni(HC.hs_dirty)) return true;
         }
     }
     return true;
 }
 
 // ---------------------------------------------------------------- router (scallop/router.cc), scalar on lane 0
-// Results in H.ro_type / H.ro_degree / H.ro_ratio / H.ro_npairs; pe2w pairs (sorted, clamped) in the pair area.
+// Results in HC.ro_type / HC.ro_degree / HC.ro_ratio / HC.ro_npairs; pe2w pairs (sorted, clamped) in the pair area.
 // SMALL: every router array lives in the LDS scratch (the common case; the compiler then knows the address space and emits ds_*
 // instead of flat_* accesses); otherwise in the slab's work arrays
 template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_degree)
@@ -1634,8 +1652,8 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     COLD;
     // ---- build_indices (router.cc:225-248)
     int nin = uni(H.in_deg[root]), nout = uni(H.out_deg[root]), n = nin + nout;
-    const int route_bound = (H.hl_n == 0) ? 0 : nin * nout;          // routes only come from phasing lists
-    H.pw_lds = SMALL ? 1 : 0;
+    const int route_bound = (HC.hl_n == 0) ? 0 : nin * nout;          // routes only come from phasing lists
+    HC.pw_lds = SMALL ? 1 : 0;
     const Arena AR = arena_at(SMALL);
     const Pairs PW = pairs_at(SMALL, false);
     const int cap = AR.cap_i;
@@ -1649,7 +1667,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     int nr = 0;
     int32_t *ra = PW.a, *rb = PW.b; double *rc = PW.w;
     {
-        int nl = H.hl_n;
+        int nl = HC.hl_n;
         for(int k = 0; k < nl; k++) {
             ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int len = uni(C.hl_len[k]); int c = uni(C.hl_cnt[k]);
             for(int i = 0; i + 1 < len; i++) {
@@ -1714,8 +1732,8 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
         iso[v] = 1; econf[v] = max_abd / sum_abd;        // the log is taken where it is used (end of build())
     }
     // ---- classify_plain_vertex (router.cc:116-171)
-    H.ro_npairs = 0; H.ro_ratio = 0;
-    if(nin == 1 || nout == 1) { H.ro_type = T_TRIVIAL; H.ro_degree = n; return true; }
+    HC.ro_npairs = 0; HC.ro_ratio = 0;
+    if(nin == 1 || nout == 1) { HC.ro_type = T_TRIVIAL; HC.ro_degree = n; return true; }
     for(int i = 0; i < n; i++) if(ALD_UNLIKELY(udeg[i] < 1)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
     int ncomp = 0;
     for(int i = 0; i < n; i++) comp[i] = -1;
@@ -1737,7 +1755,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
         if(ALD_UNLIKELY(b < 1)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
         rtype = T_SPLITTABLE_PURE; rdeg = b - 1 + (a + 1) / 2;
     }
-    H.ro_type = rtype; H.ro_degree = rdeg;
+    HC.ro_type = rtype; HC.ro_degree = rdeg;
     if(rtype != want_type) return true;
     if(rdeg > max_degree) return true;
     // ---- build() -> thread() (router.cc:193-223, 738-857)
@@ -1794,12 +1812,12 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     if(ALD_UNLIKELY(live != 0)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
     double weight_remain = 0;
     for(int i = 0; i < n; i++) { if(vw[i] <= 0) continue; weight_remain += vw[i]; }
-    H.ro_ratio = weight_remain / weight_sum;
+    HC.ro_ratio = weight_remain / weight_sum;
     for(int i = 0; i < n; i++) if(iso[i] == 1) C.ed[u2e[i]].econf += log(econf[i]);     // router.cc:849-855: side effect of every build()
     sort_pairs(PW, np);
-    const double mw = H.p_min_w;
+    const double mw = HC.p_min_w;
     for(int i = 0; i < np; i++) if(pwt[i] < mw) pwt[i] = mw;                // router.cc:217-220
-    H.ro_npairs = np;
+    HC.ro_npairs = np;
     return true;
 }
 ALD_FN bool router_small(int root, int want_type, int max_degree) { return router_body<true>(uni(root), uni(want_type), uni(max_degree)); }
@@ -1811,7 +1829,7 @@ ALD_INL bool router_run(int root, int want_type, int max_degree)
 #endif
     root = uni(root);
     const int nin = uni(H.in_deg[root]), nout = uni(H.out_deg[root]), n = nin + nout;
-    const int route_bound = (uni(H.hl_n) == 0) ? 0 : nin * nout;
+    const int route_bound = (uni(HC.hl_n) == 0) ? 0 : nin * nout;
     const bool small = (route_bound + n <= LP) && (5 * n + 3 * (route_bound + n) <= ARENA_I) && (3 * n + route_bound + n <= ARENA_D);
     return small ? uni(router_small(root, want_type, max_degree)) : uni(router_large(root, want_type, max_degree));
 }
@@ -1819,24 +1837,24 @@ ALD_INL bool router_run(int root, int want_type, int max_degree)
 ALD_FN void save_pairs(int n)
 {
     n = uni(n);
-    const bool lds = H.pw_lds != 0;
+    const bool lds = HC.pw_lds != 0;
     const Pairs S = pairs_at(lds, false), D = pairs_at(lds, true);
     if(ALD_UNLIKELY(n > D.cap)) { fail(ALD_ST_CAPACITY); return; }
     for(int i = 0; i < n; i++) { D.a[i] = S.a[i]; D.b[i] = S.b[i]; D.w[i] = S.w[i]; }
-    H.park_lds = lds ? 1 : 0;
+    HC.park_lds = lds ? 1 : 0;
 }
 ALD_FN void restore_pairs(int n)
 {
     n = uni(n);
-    const bool lds = H.park_lds != 0;
-    H.pw_lds = lds ? 1 : 0;
+    const bool lds = HC.park_lds != 0;
+    HC.pw_lds = lds ? 1 : 0;
     const Pairs S = pairs_at(lds, true), D = pairs_at(lds, false);
     for(int i = 0; i < n; i++) { D.a[i] = S.a[i]; D.b[i] = S.b[i]; D.w[i] = S.w[i]; }
 }
 // forget every vertex's remembered router class (the graph changed); called by ALL lanes
 ALD_INL void memo_clear()
 {
-    const int nv = uni(H.nv);
+    const int nv = uni(HC.nv);
     for(int i = lane_id(); i < nv; i += ALD_WAVE) H.nz[i] &= NZ_MEMBER;
     wsync();
 }
@@ -1849,7 +1867,7 @@ ALD_INL bool sweep_unsplittable(int type, int degree, double max_ratio)
     type = uni(type); degree = uni(degree); max_ratio = uni(max_ratio);
     COLD;
     const int lane = lane_id();
-    int vend = H.nv;
+    int vend = HC.nv;
     bool flag = false;
     int root = -1; double ratio = max_ratio; int best_np = 0;      // meaningful on lane 0 only
     // The sweep is sequential in the reference: a decomposition (and, for jump_ratio > 1, the trivial decompositions nested in
@@ -1878,25 +1896,25 @@ ALD_INL bool sweep_unsplittable(int type, int degree, double max_ratio)
             if((mm & NZ_MEMO_VALID) && (((mm >> NZ_MEMO_TYPE_SHIFT) & 7) != type || ((mm & NZ_MEMO_DEG_GT1) && degree <= 1))) rok = false;
             else {
                 rok = router_run(i, type, degree);
-                if(rok) H.nz[i] = (uint8_t)((mm & NZ_MEMBER) | NZ_MEMO_VALID | ((uni(H.ro_type) & 7) << NZ_MEMO_TYPE_SHIFT) | (uni(H.ro_degree) > 1 ? NZ_MEMO_DEG_GT1 : 0));
+                if(rok) H.nz[i] = (uint8_t)((mm & NZ_MEMBER) | NZ_MEMO_VALID | ((uni(HC.ro_type) & 7) << NZ_MEMO_TYPE_SHIFT) | (uni(HC.ro_degree) > 1 ? NZ_MEMO_DEG_GT1 : 0));
             }
             PROF_ADD(PF_G_BALANCE);
-            if(rok && H.ro_type == type && H.ro_degree <= degree) {
-                double rr = H.ro_ratio;
+            if(rok && HC.ro_type == type && HC.ro_degree <= degree) {
+                double rr = HC.ro_ratio;
                 if(rr < 0.01) {
                     trace(OP_UNSPLIT_NOW, vlog(i), type, rr);
-                    decompose_vertex_extend(i, H.ro_npairs);
+                    decompose_vertex_extend(i, HC.ro_npairs);
                     PROF_ADD(PF_G_DP);
                     act = 1;
                 } else if(!(rr > ratio)) {
-                    root = i; ratio = rr; best_np = H.ro_npairs;
+                    root = i; ratio = rr; best_np = HC.ro_npairs;
                     save_pairs(best_np);
                 }
             }
         }
         wsync();
         act = wread(act, 0);
-        if(H.status) return true;
+        if(HC.status) return true;
         if(act) { flag = true; memo_clear(); }
         cur = i + 1;
     }
@@ -1920,8 +1938,8 @@ ALD_FN void collect_path(int e)
 {
     e = uni(e);
     COLD;
-    ALD_GLOBAL const KernelArgs *A = H.args;
-    int n = H.V0 - 1;                           // v2v[sink]: the sink's original index
+    ALD_GLOBAL const KernelArgs *A = HC.args;
+    int n = HC.V0 - 1;                           // v2v[sink]: the sink's original index
     int cnt = 0, mi = 0; bool empty = false;
     for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.ed[e].mask[k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; cnt++; mi += uni(C.vx[x].rpos) - uni(C.vx[x].lpos); if(C.vx[x].vtype == K_EMPTY_VERTEX) empty = true; } }
     if(ALD_UNLIKELY(C.ed[e].mei != mi || cnt == 0)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
@@ -1935,8 +1953,8 @@ ALD_FN void collect_path(int e)
         int st = '.';
         if(C.ed[e].estrand == 1) st = '+';
         if(C.ed[e].estrand == 2) st = '-';
-        if(st == '.') st = H.gstrand;
-        r[0] = (uint32_t)H.g; r[1] = (uint32_t)H.n_paths; r[2] = (uint32_t)nvp; r[3] = (uint32_t)mi; r[4] = (uint32_t)uni(C.ed[e].ecount); r[5] = (uint32_t)st | ((uint32_t)(A->attempt & 0xFF) << 8);
+        if(st == '.') st = HC.gstrand;
+        r[0] = (uint32_t)HC.g; r[1] = (uint32_t)HC.n_paths; r[2] = (uint32_t)nvp; r[3] = (uint32_t)mi; r[4] = (uint32_t)uni(C.ed[e].ecount); r[5] = (uint32_t)st | ((uint32_t)(A->attempt & 0xFF) << 8);
         ALD_GLOBAL double *d = (ALD_GLOBAL double*)(r + 6);
         d[0] = uni(H.ed[e].w); d[1] = uni(C.ed[e].eabd); d[2] = exp(C.ed[e].econf); d[3] = uni(C.ed[e].med);
         ALD_GLOBAL uint32_t *pv = r + REC_HDR_WORDS; int w = 0;
@@ -1944,8 +1962,8 @@ ALD_FN void collect_path(int e)
         for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.ed[e].mask[k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; pv[w++] = (uint32_t)(k * 64 + b); } }
         pv[w++] = (uint32_t)n;
         if((REC_HDR_WORDS + nvp) & 1) pv[w] = 0;
-        if(tracing()) { int save = H.n_iters; trace(OP_COLLECT, (int)uni(H.eid[e]), nvp, uni(H.ed[e].w)); H.n_iters = save; }
-        H.n_paths++;
+        if(tracing()) { int save = HC.n_iters; trace(OP_COLLECT, (int)uni(H.eid[e]), nvp, uni(H.ed[e].w)); HC.n_iters = save; }
+        HC.n_paths++;
     }
     H.hflag[e] = 0;
     kill_edge(e);
@@ -1953,11 +1971,11 @@ ALD_FN void collect_path(int e)
 // Before the final phase walks out(0) / in(sink): link every live edge of those two lists (sorted insertion).
 ALD_FN void materialize_special()
 {
-    if(H.special_linked) return;
-    H.special_linked = 1;
-    const int sinkp = H.sinkp;
+    if(HC.special_linked) return;
+    HC.special_linked = 1;
+    const int sinkp = HC.sinkp;
     H.out_head[0] = NIL; H.in_head[sinkp] = NIL; H.out_deg[0] = 0; H.in_deg[sinkp] = 0;
-    for(int e = 0; e < H.slot_hw; e++) {
+    for(int e = 0; e < HC.slot_hw; e++) {
         if(H.ed[e].lk.es == NIL) continue;
         if((int)uni(H.ed[e].lk.es) == 0) link_out(0, e);
         if((int)uni(H.ed[e].lk.et) == sinkp) link_in(sinkp, e);
@@ -1970,7 +1988,7 @@ ALD_INL void collect_existing_st_paths()
 {
     COLD;
     const int lane = lane_id();
-    const int sink = uni(H.sinkp), hw = uni(H.slot_hw);
+    const int sink = uni(HC.sinkp), hw = uni(HC.slot_hw);
     ALD_GLOBAL int32_t *lst = C.wi; int n = 0;           // the source -> sink edges (work array of the slab: up to MAXE entries), by every lane
     for(int base = 0; base < hw; base += ALD_WAVE) {
         int e = base + lane;
@@ -1988,16 +2006,16 @@ ALD_INL void collect_existing_st_paths()
     if(tracing() || 3 * n > Cold::w_cap) {        // the op trace lists the paths in order: one at a time
         if(lane == 0) {
             for(int i = 1; i < n; i++) { int x = lst[i]; uint32_t id = uni(H.eid[x]); int j = i - 1; while(j >= 0 && (uint32_t)uni(H.eid[lst[j]]) > id) { lst[j + 1] = lst[j]; j--; } lst[j + 1] = x; }
-            for(int i = 0; i < n && !H.status; i++) collect_path(lst[i]);
+            for(int i = 0; i < n && !HC.status; i++) collect_path(lst[i]);
         }
         wsync();
         return;
     }
     // One finished path per lane (scallop::collect_path, scallop.cc:2766-2834, for all of them at once): the vertex set and its length
     // check, the EMPTY_VERTEX filter, the place among the kept paths in creation-id order (= the path index), the record.
-    ALD_GLOBAL const KernelArgs *A = H.args;
+    ALD_GLOBAL const KernelArgs *A = HC.args;
     ALD_GLOBAL int32_t *ids = C.wi + n, *keep = C.wi + 2 * n;          // [n] creation id / 1 = becomes a path, 0 = filtered, -1 = inconsistent
-    const int nlast = H.V0 - 1;
+    const int nlast = HC.V0 - 1;
     const bool ends_empty = C.vx[0].vtype == K_EMPTY_VERTEX || C.vx[nlast].vtype == K_EMPTY_VERTEX;
     for(int j = lane; j < n; j += ALD_WAVE) {
         const int e = lst[j]; int cnt = 0, mi = 0; bool empty = ends_empty;
@@ -2021,8 +2039,8 @@ ALD_INL void collect_existing_st_paths()
         int st = '.';
         if(C.ed[e].estrand == 1) st = '+';
         if(C.ed[e].estrand == 2) st = '-';
-        if(st == '.') st = H.gstrand;
-        r[0] = (uint32_t)H.g; r[1] = (uint32_t)(H.n_paths + rank); r[2] = (uint32_t)nvp; r[3] = (uint32_t)C.ed[e].mei; r[4] = (uint32_t)C.ed[e].ecount; r[5] = (uint32_t)st | ((uint32_t)(A->attempt & 0xFF) << 8);
+        if(st == '.') st = HC.gstrand;
+        r[0] = (uint32_t)HC.g; r[1] = (uint32_t)(HC.n_paths + rank); r[2] = (uint32_t)nvp; r[3] = (uint32_t)C.ed[e].mei; r[4] = (uint32_t)C.ed[e].ecount; r[5] = (uint32_t)st | ((uint32_t)(A->attempt & 0xFF) << 8);
         ALD_GLOBAL double *d = (ALD_GLOBAL double*)(r + 6);
         d[0] = H.ed[e].w; d[1] = C.ed[e].eabd; d[2] = exp(C.ed[e].econf); d[3] = C.ed[e].med;
         ALD_GLOBAL uint32_t *pv = r + REC_HDR_WORDS; int w = 0;
@@ -2037,28 +2055,28 @@ ALD_INL void collect_existing_st_paths()
         for(int k = 0; k < n; k++) if(keep[k] == 1) kept_total++;
         if(any_bad) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);                  // assert(mei[e] == mi) / an empty vertex list (scallop.cc:2783)
         else if(any_full) fail(ALD_ST_POOL_FULL);
-        else H.n_paths += kept_total;
+        else HC.n_paths += kept_total;
         // remove_edge for all of them: out(source) / in(sink) are only counted at this point, the slots go back to the free list
         for(int k = 0; k < n; k++) { const int e = lst[k]; H.hflag[e] = 0; kill_edge_i(e); }
     }
     wsync();
 }
 // splice_graph::compute_maximum_path_w (splice_graph.cc:819-885) + directed_graph::topological_sort (directed_graph.cc:420-451)
-// path edges -> upper half of wi, length -> H.tmp0
+// path edges -> upper half of wi, length -> HC.tmp0
 ALD_FN double compute_maximum_path()
 {
     COLD;
-    int n = H.nv;
+    int n = HC.nv;
     ALD_GLOBAL int32_t *vd = C.wi, *q = C.wi + n, *back = C.wi + 2 * n; ALD_GLOBAL double *table = C.wd;
     ALD_GLOBAL int32_t *path = C.wi + Cold::w_cap / 2;
     int qt = 0;
-    const int sinkp = H.sinkp;
+    const int sinkp = HC.sinkp;
     // queue seeded in the reference's index order: physical order with the sink last
     for(int i = 0; i < n; i++) { int d = uni(H.in_deg[i]); vd[i] = d; if(d == 0 && i != sinkp) q[qt++] = i; table[i] = -1; back[i] = -1; }
     if(vd[sinkp] == 0) q[qt++] = sinkp;
     int k = 0;
     while(k < qt) { int x = q[k++]; for(int e = u_first_out(x); e >= 0; e = u_next_out(e)) { int t = uni(H.ed[e].lk.et); if(--vd[t] == 0) q[qt++] = t; } }
-    H.tmp0 = 0;
+    HC.tmp0 = 0;
     if(ALD_UNLIKELY(qt != n)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return -1; }
     int ssi = -1, tti = -1;
     for(int i = 0; i < n; i++) { if(q[i] == 0) ssi = i; if(q[i] == sinkp) tti = i; }
@@ -2082,7 +2100,7 @@ ALD_FN double compute_maximum_path()
     int x = sinkp;
     while(plen < n) { int e = back[x]; if(e < 0) break; path[plen++] = e; x = uni(H.ed[e].lk.es); }
     for(int i = 0; i < plen / 2; i++) { int t = path[i]; path[i] = path[plen - 1 - i]; path[plen - 1 - i] = t; }
-    H.tmp0 = plen;
+    HC.tmp0 = plen;
     return table[sinkp];
 }
 // scallop::greedy_decompose (scallop.cc:2874-2897) + split_merge_path (scallop.cc:2230-2240)
@@ -2090,37 +2108,37 @@ ALD_FN void greedy_decompose()
 {
     COLD;
     bool any = false;
-    for(int i = 0; i < H.nv && !any; i++) if(H.out_deg[i]) any = true;
+    for(int i = 0; i < HC.nv && !any; i++) if(H.out_deg[i]) any = true;
     if(!any) return;
     materialize_special();                         // the DP and the path surgery walk out(0) / in(sink)
     PROF_DECL;
-    for(int rep = 0; rep < 2; rep++) for(int i = 1; i < H.nv; i++) { if(i == H.sinkp) continue; balance_vertex(i); if(H.status) return; }
+    for(int rep = 0; rep < 2; rep++) for(int i = 1; i < HC.nv; i++) { if(i == HC.sinkp) continue; balance_vertex(i); if(HC.status) return; }
     PROF_ADD(PF_G_BALANCE);
-    if(ALD_UNLIKELY(3 * H.nv > C.w_cap / 2)) { fail(ALD_ST_CAPACITY); return; }
+    if(ALD_UNLIKELY(3 * HC.nv > C.w_cap / 2)) { fail(ALD_ST_CAPACITY); return; }
     ALD_GLOBAL int32_t *path = C.wi + Cold::w_cap / 2;
-    const double min_cov = H.p_min_cov;
+    const double min_cov = HC.p_min_cov;
     int guard = 4 * MAXE;
     while(guard-- > 0) {
         double w = compute_maximum_path();
-        int plen = H.tmp0;
+        int plen = HC.tmp0;
         PROF_ADD(PF_G_DP);
-        if(H.status) return;
+        if(HC.status) return;
         if(w < 0) break;
         if(w <= min_cov) break;
-        if(tracing()) { int save = H.n_iters; trace(OP_GREEDY, plen, 0, w); H.n_iters = save; }
+        if(tracing()) { int save = HC.n_iters; trace(OP_GREEDY, plen, 0, w); HC.n_iters = save; }
         if(plen == 0) break;
         if(ALD_UNLIKELY(free_slots() < 2)) { fail(ALD_ST_CAPACITY); return; }
         int ee = split_edge(path[0], w);
-        for(int i = 1; i < plen && ee >= 0 && !H.status; i++) {
+        for(int i = 1; i < plen && ee >= 0 && !HC.status; i++) {
             if(ALD_UNLIKELY(free_slots() < 2)) { fail(ALD_ST_CAPACITY); return; }
             ee = merge_adjacent_edges(ee, path[i], w);     // split(path[i]) + merge with the (already equal) running edge
         }
-        if(H.status) return;
+        if(HC.status) return;
         if(ALD_UNLIKELY(ee < 0)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
         PROF_ADD(PF_G_SPLITMERGE);
         collect_path(ee);
         PROF_ADD(PF_G_COLLECT);
-        if(H.status) return;
+        if(HC.status) return;
     }
 }
 
@@ -2129,20 +2147,20 @@ ALD_INL bool load_graph()
 {
     COLD;
     const int lane = lane_id();
-    ALD_GLOBAL const KernelArgs *A = H.args;
-    const int g = H.g;
+    ALD_GLOBAL const KernelArgs *A = HC.args;
+    const int g = HC.g;
     int V = A->in.g_nv[g], E = A->in.g_ne[g], NP = A->in.g_np[g];
     int64_t ov = A->in.off_v[g], ovo = ov + g, oe = A->in.off_e[g], oeo = oe + g, os = A->in.off_s[g], op = A->in.off_p[g], opo = op + g, opv = A->in.off_pv[g];
     if(lane == 0) {
-        H.V0 = V; H.gstrand = (int)(unsigned char)A->in.graph_strand[g];
-        H.sinkp = V - 1; H.special_linked = 0; H.maybe_broken = 1; H.maybe_triv = 1; H.ro_epoch = 1;
-        H.nv = V; H.next_id = E; H.slot_hw = E; H.free_head = -1; H.free_cnt = 0; H.status = 0; H.any_strand = 0; H.hs_dirty = 1;
-        H.n_paths = 0; H.n_iters = 0; H.n_trace = 0; H.sp_used = 0; H.hl_used = 0; H.hl_n = 0;
+        HC.V0 = V; HC.gstrand = (int)(unsigned char)A->in.graph_strand[g];
+        HC.sinkp = V - 1; HC.special_linked = 0; HC.maybe_broken = 1; HC.maybe_triv = 1; HC.ro_epoch = 1;
+        HC.nv = V; HC.next_id = E; HC.slot_hw = E; HC.free_head = -1; HC.free_cnt = 0; HC.status = 0; HC.any_strand = 0; HC.hs_dirty = 1;
+        HC.n_paths = 0; HC.n_iters = 0; HC.n_trace = 0; HC.sp_used = 0; HC.hl_used = 0; HC.hl_n = 0;
     }
     wsync();
-    if(V + 1 > MAXV || E > MAXE || V > NW * 64 || V < 2) { if(lane == 0) H.status = ALD_ST_CAPACITY; wsync(); return false; }
+    if(V + 1 > MAXV || E > MAXE || V > NW * 64 || V < 2) { if(lane == 0) HC.status = ALD_ST_CAPACITY; wsync(); return false; }
     int64_t ns = A->in.edge_sample_offset[oeo + E];
-    if(ns > (int64_t)C.sp_cap) { if(lane == 0) H.status = ALD_ST_CAPACITY; wsync(); return false; }
+    if(ns > (int64_t)C.sp_cap) { if(lane == 0) HC.status = ALD_ST_CAPACITY; wsync(); return false; }
     ALD_GLOBAL const int32_t *vo = A->in.vertex_offset + ovo, *io = A->in.in_offset + ovo, *ie = A->in.in_edge + oe;
     for(int i = lane; i < V; i += ALD_WAVE) {
         int o0 = vo[i], o1 = vo[i + 1], i0 = io[i], i1 = io[i + 1];
@@ -2170,22 +2188,22 @@ ALD_INL bool load_graph()
     // a list of ONE sample is carried inline (s0id / s0abd) and never read from the pool: a batch of single-sample graphs copies nothing
     if(wballot(listed)) for(int64_t k = lane; k < ns; k += ALD_WAVE) { C.sp_id[k] = A->in.sample_id[os + k]; C.sp_abd[k] = A->in.sample_abd[os + k]; }
     uint64_t sb = wballot(strand);
-    if(sb && lane == 0) H.any_strand = 1;
+    if(sb && lane == 0) HC.any_strand = 1;
     wsync();
     if(lane == 0) {
-        H.sp_used = (uint32_t)ns;
+        HC.sp_used = (uint32_t)ns;
         // hyper_set::build_edges (hyper_set.cc:323-354): keep lists with count >= 2, >= 2 edges, every consecutive pair an edge;
         // directed_graph::edge(s,t) returns the NEWEST parallel edge (directed_graph.cc:60-76)
         ALD_GLOBAL const int32_t *po = A->in.phasing_offset + opo; int nl = 0; uint32_t used = 0;
-        for(int p = 0; p < NP && H.status == 0; p++) {
+        for(int p = 0; p < NP && HC.status == 0; p++) {
             int c = A->in.phasing_count[op + p]; int a = po[p], b = po[p + 1]; int len = b - a;
             if(c <= 1 || len <= 1) continue;
             uint32_t capk = (uint32_t)(len - 1) * 2u + 4u;
-            if(nl >= C.hl_maxlists || used + capk > C.hl_cap) { H.status = ALD_ST_CAPACITY; break; }
+            if(nl >= C.hl_maxlists || used + capk > C.hl_cap) { HC.status = ALD_ST_CAPACITY; break; }
             bool ok = true;
             for(int k = 0; k + 1 < len && ok; k++) {
                 int s = A->in.phasing_vertex[opv + a + k], t = A->in.phasing_vertex[opv + a + k + 1];
-                if(!(s < t) || s < 0 || t >= V) { H.status = ALD_ST_INVARIANT + ALD_INV_OTHER; ok = false; break; }
+                if(!(s < t) || s < 0 || t >= V) { HC.status = ALD_ST_INVARIANT + ALD_INV_OTHER; ok = false; break; }
                 int best = -1;
                 if(s == 0) { for(int e = vo[0]; e < vo[1]; e++) { int tt = H.ed[e].lk.et; if(tt == t) best = e; else if(tt > t) break; } }      // row 0 is not linked: scan the CSR row
                 else for(int e = first_out(s); e >= 0; e = next_out(e)) { int tt = H.ed[e].lk.et; if(tt == t) best = e; else if(tt > t) break; }
@@ -2194,21 +2212,21 @@ ALD_INL bool load_graph()
             if(!ok || len - 1 < 2) continue;
             C.hl_off[nl] = (int32_t)used; C.hl_len[nl] = len - 1; C.hl_capk[nl] = (int32_t)capk; C.hl_cnt[nl] = c; used += capk; nl++;
         }
-        H.hl_used = used; H.hl_n = nl;
+        HC.hl_used = used; HC.hl_n = nl;
     }
     wsync();
-    return H.status == 0;
+    return HC.status == 0;
 }
 
 ALD_INL void finish_graph()
 {
     if(lane_id() == 0) {
-        ALD_GLOBAL const KernelArgs *A = H.args; const int g = H.g;
-        A->out.status[g] = H.status; A->out.n_paths[g] = (H.status == 0 || H.status == ALD_ST_SKIPPED_LARGE) ? H.n_paths : 0; A->out.n_iters[g] = H.n_iters;
+        ALD_GLOBAL const KernelArgs *A = HC.args; const int g = HC.g;
+        A->out.status[g] = HC.status; A->out.n_paths[g] = (HC.status == 0 || HC.status == ALD_ST_SKIPPED_LARGE) ? HC.n_paths : 0; A->out.n_iters[g] = HC.n_iters;
 #ifdef ALD_PROF
-        if(H.p_trace_cap > 0) for(int k = 0; k < PF_COUNT; k++) { int q = H.n_trace++; if(q < A->out.trace_cap) { int64_t o = (int64_t)g * A->out.trace_cap + q; A->out.trace_codes[3 * o] = 100 + k; A->out.trace_codes[3 * o + 1] = 0; A->out.trace_codes[3 * o + 2] = 0; A->out.trace_vals[o] = (double)H.prof[k]; } }
+        if(HC.p_trace_cap > 0) for(int k = 0; k < PF_COUNT; k++) { int q = HC.n_trace++; if(q < A->out.trace_cap) { int64_t o = (int64_t)g * A->out.trace_cap + q; A->out.trace_codes[3 * o] = 100 + k; A->out.trace_codes[3 * o + 1] = 0; A->out.trace_codes[3 * o + 2] = 0; A->out.trace_vals[o] = (double)HC.prof[k]; } }
 #endif
-        if(A->out.trace_cap > 0) A->out.trace_n[g] = H.n_trace;
+        if(A->out.trace_cap > 0) A->out.trace_n[g] = HC.n_trace;
     }
     wsync();
 }
@@ -2218,20 +2236,20 @@ ALD_INL void run_graph()
 {
     PROF_DECL;
 #ifdef ALD_PROF
-    if(lane_id() == 0) for(int k = 0; k < 32; k++) H.prof[k] = 0;
+    if(lane_id() == 0) for(int k = 0; k < 32; k++) HC.prof[k] = 0;
     wsync();
 #endif
     if(!uni(load_graph())) { finish_graph(); return; }
     PROF_ADD(PF_LOAD);
     bool skipped = false;
-    const double r_triv = uni(H.p_ratio[7]), r_small = uni(H.p_ratio[0]), r_single = uni(H.p_ratio[5]), r_pure = uni(H.p_ratio[4]);
-    const int max_exons = uni(H.p_max_exons);
+    const double r_triv = uni(HC.p_ratio[7]), r_small = uni(HC.p_ratio[0]), r_single = uni(HC.p_ratio[5]), r_pure = uni(HC.p_ratio[4]);
+    const int max_exons = uni(HC.p_max_exons);
     int guard = 64 * MAXE;                     // every successful rule consumes an edge or a vertex; far above any real count
     while(guard-- > 0) {
-        if(uni(H.nv) > max_exons) { skipped = true; break; }
-        if(uni(H.status)) break;
+        if(uni(HC.nv) > max_exons) { skipped = true; break; }
+        if(uni(HC.status)) break;
         PROF_RESET();
-        bool brk = uni(H.maybe_broken) != 0 && uni(resolve_broken_vertex());
+        bool brk = uni(HC.maybe_broken) != 0 && uni(resolve_broken_vertex());
         PROF_ADD(PF_BROKEN);
         if(brk) continue;
         // the rest of the cascade as a stage loop, so that every rule is instantiated ONCE (the trivial-vertex sweep serves three stages:
@@ -2252,15 +2270,15 @@ ALD_INL void run_graph()
         if(fired) continue;
         break;
     }
-    if(lane_id() == 0 && H.status == 0 && guard <= 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);
+    if(lane_id() == 0 && HC.status == 0 && guard <= 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);
     wsync();
-    if(uni(H.status) == 0) {
+    if(uni(HC.status) == 0) {
         PROF_RESET();
         collect_existing_st_paths();
         PROF_ADD(PF_COLLECT0);
         if(lane_id() == 0) {
-            if(H.status == 0) greedy_decompose();
-            if(H.status == 0 && skipped) H.status = ALD_ST_SKIPPED_LARGE;
+            if(HC.status == 0) greedy_decompose();
+            if(HC.status == 0 && skipped) HC.status = ALD_ST_SKIPPED_LARGE;
         }
     }
     wsync();
@@ -2275,24 +2293,24 @@ ALD_INL void wave_main(ALD_GLOBAL const KernelArgs *A, int block)
     wsync();
 #endif
     if(lane_id() == 0) {
-        H.args = A;
+        HC.args = A;
 #ifdef ALD_HOT_IN_SLAB
-        H.cold = A->slabs + (uint64_t)block * A->slab_stride + ((sizeof(Hot) + 255) / 256 * 256);
+        HC.cold = A->slabs + (uint64_t)block * A->slab_stride + ((sizeof(Hot) + 255) / 256 * 256);
 #else
-        H.cold = A->slabs + (uint64_t)block * A->slab_stride;
+        HC.cold = A->slabs + (uint64_t)block * A->slab_stride;
 #endif
-        for(int k = 0; k < 8; k++) H.p_ratio[k] = A->prm.max_ratio[k];
-        H.p_min_w = A->prm.min_w; H.p_min_cov = A->prm.min_cov; H.p_max_exons = A->prm.max_num_exons; H.p_trace_cap = A->out.trace_cap;
-        H.pw_lds = 0; H.park_lds = 0;
+        for(int k = 0; k < 8; k++) HC.p_ratio[k] = A->prm.max_ratio[k];
+        HC.p_min_w = A->prm.min_w; HC.p_min_cov = A->prm.min_cov; HC.p_max_exons = A->prm.max_num_exons; HC.p_trace_cap = A->out.trace_cap;
+        HC.pw_lds = 0; HC.park_lds = 0;
     }
     wsync();
     while(true) {
-        if(lane_id() == 0) H.s_next = atomic_add_i32(A->counter, 1);
+        if(lane_id() == 0) HC.s_next = atomic_add_i32(A->counter, 1);
         wsync();
-        int k = H.s_next;
+        int k = HC.s_next;
         wsync();
         if(k >= A->n_work) break;
-        if(lane_id() == 0) H.g = A->work[k];
+        if(lane_id() == 0) HC.g = A->work[k];
         wsync();
         run_graph();
     }
