@@ -11,16 +11,6 @@
 #define ALD_WAVES_PER_EU 4      /* register budget: 512 / 4 = 128 VGPRs per lane (MI355X_MICROARCH.md, Register files) */
 #endif
 
-// ALD_DYN_LDS: the hot state as DYNAMIC shared memory.  With a static __shared__ object the compiler knows that LDS alone limits the
-// class to one wave per SIMD and takes registers accordingly (launch bounds are only honoured up to the occupancy LDS allows, and a
-// per-function register attribute does not reach the callees); but a wave of an LDS-bound class has to fit on its SIMD BESIDE the
-// slab-resident waves of the twin classes, which run at the same time.  With the size unknown at compile time ALD_WAVES_PER_EU is the
-// register budget of the kernel and of everything it calls.
-#ifdef ALD_DYN_LDS
-#define ALD_DYN_BYTES (ALD_CLASS_NS::HOT_BYTES_ALIGNED + sizeof(ALD_CLASS_NS::HotCtx))
-#else
-#define ALD_DYN_BYTES 0
-#endif
 extern "C" __global__ void __launch_bounds__(64, ALD_WAVES_PER_EU) ALD_KERNEL_NAME(const ald::KernelArgs *A)
 {
     ALD_CLASS_NS::wave_main((ALD_GLOBAL const ald::KernelArgs*)A, (int)blockIdx.x);
@@ -29,7 +19,7 @@ extern "C" __global__ void __launch_bounds__(64, ALD_WAVES_PER_EU) ALD_KERNEL_NA
 extern "C" int ALD_CAT(ald_launch_c, ALD_CLASS_ID)(const ald::KernelArgs *dA, int blocks, hipStream_t stream)
 {
     (void)hipGetLastError();                       // drop any stale sticky error of this thread before judging the launch
-    hipLaunchKernelGGL(ALD_KERNEL_NAME, dim3(blocks), dim3(64), ALD_DYN_BYTES, stream, dA);
+    hipLaunchKernelGGL(ALD_KERNEL_NAME, dim3(blocks), dim3(64), 0, stream, dA);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -46,6 +36,6 @@ extern "C" unsigned long long ALD_CAT(ald_hot_slab_bytes_c, ALD_CLASS_ID)()
 extern "C" int ALD_CAT(ald_occupancy_c, ALD_CLASS_ID)()
 {
     int nb = 0;
-    if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ALD_KERNEL_NAME, 64, ALD_DYN_BYTES) != hipSuccess) return 0;
+    if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ALD_KERNEL_NAME, 64, 0) != hipSuccess) return 0;
     return nb;
 }

@@ -106,12 +106,6 @@ __shared__ HotCtx g_HC;
 #define H (*g_Hp)
 #define HC g_HC
 #define ALD_HOT_IN_SLAB 1
-#elif defined(ALD_DYN_LDS)
-// dynamic shared memory (see decomp_class.hip): the only LDS object of the kernel, so it sits at LDS address 0 like the static form
-extern __shared__ __attribute__((aligned(16))) unsigned char g_dyn_lds[];
-enum { HOT_BYTES_ALIGNED = (sizeof(Hot) + 15) / 16 * 16 };
-#define H (*reinterpret_cast<Hot*>(g_dyn_lds))
-#define HC (*reinterpret_cast<HotCtx*>(g_dyn_lds + HOT_BYTES_ALIGNED))
 #else
 __shared__ Hot g_H;
 __shared__ HotCtx g_HC;
