@@ -387,18 +387,28 @@ struct HostBatch {
         for(int i = 0; i < S_COUNT; i++) { sec[i].off = o; o = (o + sec[i].bytes + 255) / 256 * 256; }
         return o < 256 ? 256 : o;
     }
-    void pack_into(uint8_t *dst, const Section sec[S_COUNT]) const
+    void pack_into(uint8_t *dst, const Section sec[S_COUNT]) const { pack_range(dst, sec, 0, ~0ull); }
+    // the bytes [lo, hi) of the wire buffer only (sections are laid out back to back): ald_batch_upload packs the buffer chunk by chunk
+    // and sends every chunk on its way as soon as it is complete, so that packing chunk k+1 runs under the H2D copy of chunk k
+    void pack_range(uint8_t *dst, const Section sec[S_COUNT], uint64_t lo, uint64_t hi) const
     {
-        uint64_t tot = 0; for(int i = 0; i < S_COUNT; i++) tot += sec[i].bytes;
+        struct Piece { uint64_t off; const uint8_t *src; uint64_t len; };
+        Piece pc[S_COUNT]; int np = 0; uint64_t tot = 0;
+        for(int i = 0; i < S_COUNT; i++) {
+            const uint64_t a = std::max<uint64_t>(lo, sec[i].off), b = std::min<uint64_t>(hi, sec[i].off + sec[i].bytes);
+            if(!sec[i].bytes || b <= a) continue;
+            pc[np++] = Piece{a, (const uint8_t*)sec[i].src + (a - sec[i].off), b - a}; tot += b - a;
+        }
+        if(!tot) return;
         unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16;
         if(const char *ev = getenv("ALD_STAGE_THREADS")) { int k = atoi(ev); if(k >= 1 && k <= 64) nthr = (unsigned)k; }
         if(tot < (8u << 20)) nthr = 1;
-        // every thread copies its slice of every section (sections differ in size by orders of magnitude)
-        run_threads(nthr, [&](unsigned t) {
-            for(int i = 0; i < S_COUNT; i++) {
-                const uint64_t b = sec[i].bytes; if(!b) continue;
-                const uint64_t lo = b * t / nthr, hi = b * (t + 1) / nthr;
-                if(hi > lo) memcpy(dst + sec[i].off + lo, (const uint8_t*)sec[i].src + lo, hi - lo);
+        run_threads(nthr, [&](unsigned t) {                     // thread t copies bytes [tot * t / nthr, tot * (t + 1) / nthr) of the pieces laid end to end
+            uint64_t a = tot * t / nthr, b = tot * (t + 1) / nthr, base = 0;
+            for(int i = 0; i < np && a < b; i++) {
+                const uint64_t end = base + pc[i].len;
+                if(a < end) { const uint64_t x = a - base, n = std::min(b, end) - a; memcpy(dst + pc[i].off + x, pc[i].src + x, n); a += n; }
+                base = end;
             }
         });
     }
