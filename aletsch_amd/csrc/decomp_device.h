@@ -1641,7 +1641,7 @@ ALD_INL bool sweep_smallest(double max_ratio)
 // Results in HC.ro_type / HC.ro_degree / HC.ro_ratio / HC.ro_npairs; pe2w pairs (sorted, clamped) in the pair area.
 // SMALL: every router array lives in the LDS scratch (the common case; the compiler then knows the address space and emits ds_*
 // instead of flat_* accesses); otherwise in the slab's work arrays
-template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_degree)
+template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_degree, int pre)
 {
     COLD;
     // ---- build_indices (router.cc:225-248)
@@ -1653,7 +1653,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     const int cap = AR.cap_i;
     if(ALD_UNLIKELY(5 * n > cap)) { fail(ALD_ST_CAPACITY); return false; }
     int32_t *u2e = AR.i;
-    { int k = 0; for(int e = u_first_in(root); e >= 0; e = u_next_in(e)) { u2e[k++] = e; }
+    if(!pre) { int k = 0; for(int e = u_first_in(root); e >= 0; e = u_next_in(e)) { u2e[k++] = e; }
       for(int e = u_first_out(root); e >= 0; e = u_next_out(e)) { u2e[k++] = e; } }
     if(ALD_UNLIKELY(mixed_strand_vertex(root))) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }     // router.cc:71-76
     // ---- routes from the phasing lists (hyper_set::get_routes, hyper_set.cc:553-571), gathered in the pair area
@@ -1690,7 +1690,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     double *vw = AR.d, *uw = AR.d + n, *econf = AR.d + n + maxue;
     // ---- build_bipartite_graph (router.cc:250-325)
     int nue = 0;
-    for(int i = 0; i < n; i++) { udeg[i] = 0; iso[i] = 0; }
+    for(int i = 0; i < n; i++) udeg[i] = 0;
     for(int j = 0; j < nr; j++) {
         int y = rb[j];
         if(ALD_UNLIKELY(H.ed[y].lk.es == NIL || (int)uni(H.ed[y].lk.es) != root)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }   // assert(e2u.find(e2) != end)
@@ -1703,10 +1703,24 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     // isolated vertices attach to the best partner by shared sample abundance (router.cc:1010-1129).
     // Per-node support is fetched once (one round of independent loads); single-sample pairs are then pure arithmetic.
     int32_t *ncnt = comp, *nsid = queue;         // comp / queue are not needed before classify: reuse them as (count, first sample id)
-    double *nabd = AR.d + 2 * n + maxue;         // [n] abundance of the first sample
-    for(int v = 0; v < n; v++) { int e = u2e[v]; ncnt[v] = (int32_t)uni(C.ed[e].sp_len); nsid[v] = uni(C.ed[e].s0id); nabd[v] = uni(C.ed[e].s0abd); }
-    for(int v = 0; v < n; v++) iso[v] = (C.ed[u2e[v]].ecount == 0) ? 2 : 0;      // 2 = "Warning!(count = 0)": not in left / right
+    double *nabd = AR.d;                         // [n] abundance of the first sample (the place of vw, which build() fills much later)
+    if(!pre) {
+        for(int v = 0; v < n; v++) { int e = u2e[v]; ncnt[v] = (int32_t)uni(C.ed[e].sp_len); nsid[v] = uni(C.ed[e].s0id); nabd[v] = uni(C.ed[e].s0abd); }
+        for(int v = 0; v < n; v++) iso[v] = (C.ed[u2e[v]].ecount == 0) ? 2 : 0;      // 2 = "Warning!(count = 0)": not in left / right
+    }
 #define ALD_COMMON(l, r) ((ncnt[l] == 1 && ncnt[r] == 1) ? ((nsid[l] == nsid[r]) ? (0.0 + (0.99 * ((nabd[r] < nabd[l]) ? nabd[r] : nabd[l]) + 0.01 * ((nabd[l] < nabd[r]) ? nabd[r] : nabd[l]))) : 0.0) : common_abd(u2e[l], u2e[r]))
+    if(pre == 2) {
+        // the wave left every node's (partner, shared abundance, share of the total) in comp / nabd / econf (router_prepare): what stays
+        // sequential is which nodes are still isolated when their turn comes
+        for(int v = 0; v < n; v++) {
+            if(iso[v] == 2) continue;
+            if(udeg[v] != 0) continue;
+            const int partner = comp[v];
+            if(ALD_UNLIKELY(partner < 0)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
+            us[nue] = v < nin ? v : partner; ut[nue] = v < nin ? partner : v; uw[nue] = nabd[v]; ualive[nue] = 1; udeg[v]++; udeg[partner]++; nue++;
+            iso[v] = 1;
+        }
+    } else {
     for(int v = 0; v < nin; v++) {
         if(iso[v] == 2) continue;
         if(udeg[v] != 0) continue;
@@ -1724,6 +1738,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
         if(ALD_UNLIKELY(partner < 0)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }
         us[nue] = partner; ut[nue] = v; uw[nue] = max_abd; ualive[nue] = 1; udeg[v]++; udeg[partner]++; nue++;
         iso[v] = 1; econf[v] = max_abd / sum_abd;        // the log is taken where it is used (end of build())
+    }
     }
     // ---- classify_plain_vertex (router.cc:116-171)
     HC.ro_npairs = 0; HC.ro_ratio = 0;
@@ -1814,9 +1829,59 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     HC.ro_npairs = np;
     return true;
 }
-ALD_FN bool router_small(int root, int want_type, int max_degree) { return router_body<true>(uni(root), uni(want_type), uni(max_degree)); }
-ALD_FN bool router_large(int root, int want_type, int max_degree) { return router_body<false>(uni(root), uni(want_type), uni(max_degree)); }
-ALD_INL bool router_run(int root, int want_type, int max_degree)
+ALD_FN bool router_small(int root, int want_type, int max_degree, int pre) { return router_body<true>(uni(root), uni(want_type), uni(max_degree), uni(pre)); }
+ALD_FN bool router_large(int root, int want_type, int max_degree) { return router_body<false>(uni(root), uni(want_type), uni(max_degree), 0); }
+// What the router needs of the root's edges, fetched by the WHOLE WAVE before lane 0 runs it (ALL lanes call; returns the `pre` level
+// for router_run).  Lane l walks to the l-th local edge (in-edges, then out-edges) and asks for ITS support record -- one round of
+// global loads for the vertex instead of one round trip per edge on lane 0.  And where the attachment of isolated nodes is a pure
+// table (no phasing routes, every edge supported by ONE sample: router.cc:1010-1129 reduces to arithmetic on (sample id, abundance)
+// pairs) lane l also finds the partner l would attach to -- best shared abundance, first of equals, with the sum over all candidates
+// in their order -- and leaves (partner, that abundance, its share) where the sequential attachment picks them up.
+ALD_INL int router_prepare(int root)
+{
+    COLD;
+    root = uni(root);
+    const int lane = lane_id();
+    const int nin = uni(H.in_deg[root]), nout = uni(H.out_deg[root]), n = nin + nout;
+    const int route_bound = (uni(HC.hl_n) == 0) ? 0 : nin * nout;
+    const bool small = (route_bound + n <= LP) && (5 * n + 3 * (route_bound + n) <= ARENA_I) && (3 * n + route_bound + n <= ARENA_D);
+    if(!small) return 0;                                                     // (n <= LP <= the wave)
+    const Arena AR = arena_at(true);
+    int32_t *u2e = AR.i, *ncnt = AR.i + 2 * n, *nsid = AR.i + 3 * n, *iso = AR.i + 4 * n; double *nabd = AR.d, *econf = AR.d + 2 * n;
+    bool multi = false;
+    for(int l = lane; l < n; l += ALD_WAVE) {
+        int e;
+        if(l < nin) { e = first_in(root); for(int k = 0; k < l && e >= 0; k++) e = next_in(e); }
+        else { e = first_out(root); for(int k = nin; k < l && e >= 0; k++) e = next_out(e); }
+        if(e < 0) e = 0;                                                       // cannot happen: the degrees count the lists
+        const int cnt = (int)C.ed[e].sp_len, ec = C.ed[e].ecount;
+        u2e[l] = e; ncnt[l] = cnt; nsid[l] = C.ed[e].s0id; nabd[l] = C.ed[e].s0abd; iso[l] = (ec == 0) ? 2 : 0;
+        if(ec != 0 && cnt != 1) multi = true;
+    }
+    wsync();
+    if(route_bound != 0 || wballot(multi) != 0) return 1;
+    // attachment table (maxue == n here, so econf sits at AR.d + 2 n)
+    int partner[(LP + ALD_WAVE - 1) / ALD_WAVE]; double mabd[(LP + ALD_WAVE - 1) / ALD_WAVE], share[(LP + ALD_WAVE - 1) / ALD_WAVE];
+    { int q = 0; for(int v = lane; v < n; v += ALD_WAVE, q++) {
+        int pt = -1; double max_abd = 0.0, sum_abd = 0.0;
+        const int lo = v < nin ? nin : 0, hi = v < nin ? n : nin;
+        const int sv = nsid[v]; const double av = nabd[v];
+        if(iso[v] != 2) for(int r = lo; r < hi; r++) {
+            if(iso[r] == 2) continue;
+            const double ar = nabd[r];
+            // common abundance of (left, right) = 0.99 * min + 0.01 * max of the two abundances when the samples agree; the left node is the in-edge
+            const double al = v < nin ? av : ar, arr = v < nin ? ar : av;
+            const double c = (nsid[r] == sv) ? (0.0 + (0.99 * ((arr < al) ? arr : al) + 0.01 * ((al < arr) ? arr : al))) : 0.0;
+            sum_abd += c; if(c > max_abd) { max_abd = c; pt = r; }
+        }
+        partner[q] = pt; mabd[q] = max_abd; share[q] = max_abd / sum_abd;
+    } }
+    wsync();                                                                   // every lane has read ncnt / nsid / nabd: their places take the results
+    { int q = 0; for(int v = lane; v < n; v += ALD_WAVE, q++) { ncnt[v] = partner[q]; nabd[v] = mabd[q]; econf[v] = share[q]; } }
+    wsync();
+    return 2;
+}
+ALD_INL bool router_run(int root, int want_type, int max_degree, int pre = 0)
 {
 #ifdef ALD_EMU_COUNT
     g_cnt_router++;
@@ -1825,7 +1890,7 @@ ALD_INL bool router_run(int root, int want_type, int max_degree)
     const int nin = uni(H.in_deg[root]), nout = uni(H.out_deg[root]), n = nin + nout;
     const int route_bound = (uni(HC.hl_n) == 0) ? 0 : nin * nout;
     const bool small = (route_bound + n <= LP) && (5 * n + 3 * (route_bound + n) <= ARENA_I) && (3 * n + route_bound + n <= ARENA_D);
-    return small ? uni(router_small(root, want_type, max_degree)) : uni(router_large(root, want_type, max_degree));
+    return small ? uni(router_small(root, want_type, max_degree, pre)) : uni(router_large(root, want_type, max_degree));
 }
 // park / un-park the best candidate's pe2w while an unsplittable sweep goes on
 ALD_FN void save_pairs(int n)
@@ -1878,6 +1943,11 @@ ALD_INL bool sweep_unsplittable(int type, int degree, double max_ratio)
         }
         if(i < 0) break;
         int act = 0;
+        // (the memo test below, on every lane: the same LDS byte) -- when the router is going to run, the wave prepares its inputs
+        int pre = 0;
+        { const int mm = uni(H.nz[i]);
+          const bool skip = (mm & NZ_MEMO_VALID) && (((mm >> NZ_MEMO_TYPE_SHIFT) & 7) != type || ((mm & NZ_MEMO_DEG_GT1) && degree <= 1));
+          if(!skip) pre = router_prepare(i); }
         if(lane == 0) {
             PROF_DECL;
             // classify() comes first in the reference and build() -- with its side effect on the edge confidences -- only runs when
@@ -1889,7 +1959,7 @@ ALD_INL bool sweep_unsplittable(int type, int degree, double max_ratio)
             bool rok;
             if((mm & NZ_MEMO_VALID) && (((mm >> NZ_MEMO_TYPE_SHIFT) & 7) != type || ((mm & NZ_MEMO_DEG_GT1) && degree <= 1))) rok = false;
             else {
-                rok = router_run(i, type, degree);
+                rok = router_run(i, type, degree, pre);
                 if(rok) H.nz[i] = (uint8_t)((mm & NZ_MEMBER) | NZ_MEMO_VALID | ((uni(HC.ro_type) & 7) << NZ_MEMO_TYPE_SHIFT) | (uni(HC.ro_degree) > 1 ? NZ_MEMO_DEG_GT1 : 0));
             }
             PROF_ADD(PF_G_BALANCE);

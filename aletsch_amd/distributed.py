@@ -52,13 +52,29 @@ class StreamGatherer:
         self.cap = 0
         self._pad = None; self._out = None; self._host = None; self._done = None
 
-    def renegotiate(self, n_words: int):
-        """Blocking: agree on a capacity that holds every rank's stream of this shape."""
+    def _largest(self, n_words: int) -> int:
         dev = self.device
         mine = torch.tensor([int(n_words)], dtype=torch.int64, device=dev)
         allv = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
         dist.all_gather(allv, mine)
-        mx = max(int(v.item()) for v in allv)
+        return max(int(v.item()) for v in allv)
+
+    def renegotiate(self, n_words: int):
+        """Blocking: agree on a capacity that holds every rank's stream of this shape."""
+        self._set_capacity(self._largest(n_words))
+
+    def gather_any(self, words: torch.Tensor, graph_offset: int = 0):
+        """`gather` for callers whose batch shape varies from step to step: the sizes are exchanged first (one 8-byte all_gather,
+        blocking), and a stream that would not fit grows the capacity ON EVERY RANK in the same step -- all ranks see the same sizes,
+        so all take the same decision and nothing is ever raised or entered alone.  Costs one small collective per step; the
+        fixed-capacity `gather` stays the form for steady shapes."""
+        mx = self._largest(int(words.numel()))
+        if self.cap == 0 or self.HDR + mx > self.cap:
+            self._set_capacity(mx)
+        return self.gather(words, graph_offset)
+
+    def _set_capacity(self, mx: int):
+        dev = self.device
         cap = self.HDR + mx + int(mx * self.headroom) + 1024
         cap += (-cap) % 64
         if self._done is not None:

@@ -70,6 +70,17 @@ WORKER = textwrap.dedent('''
         assert [len(parse_records(wd.copy())) for wd, _ in G.streams()] == [400, 400]
         print("STEPS_OK")
     dist.barrier()
+    # shapes that change from step to step, rank by rank: gather_any agrees on the sizes first and grows the capacity everywhere at once
+    G2 = RecordGatherer(torch.device("cpu"))
+    for step, sizes in enumerate(((5, 9), (300, 2), (0, 0), (2, 2500), (2600, 1))):
+        w = stream(sizes[rank], 50 + step)
+        G2.gather_any(torch.from_numpy(w.view(np.int32).copy()), graph_offset=7 * rank)
+        if rank == 0:
+            assert [len(parse_records(wd.copy())) for wd, _ in G2.streams()] == list(sizes), step
+            assert [off for _, off in G2.streams()] == [0, 7]
+    if rank == 0:
+        print("ANY_OK")
+    dist.barrier()
     dist.destroy_process_group()
 ''') % ROOT
 
@@ -81,7 +92,7 @@ def test_gloo_world2_gather(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29517", str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "GATHER_OK 28" in r.stdout and "STEPS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "GATHER_OK 28" in r.stdout and "STEPS_OK" in r.stdout and "ANY_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_shard_range_partitions():
