@@ -37,8 +37,10 @@
 namespace ALD_CLASS_NS {
 using namespace ald;
 #ifdef ALD_EMU_COUNT
-static long g_cnt_router = 0, g_cnt_unsweep = 0;
-struct CntPrinter { ~CntPrinter() { if(g_cnt_unsweep) fprintf(stderr, "[emu-count] class %d: unsplittable sweeps %ld router runs %ld\n", ALD_CLASS_ID, g_cnt_unsweep, g_cnt_router); } }; static CntPrinter g_cnt_printer;
+static long g_cnt_router = 0, g_cnt_unsweep = 0, g_cnt_star[34] = {0}, g_cnt_rdeg[34] = {0};
+struct CntPrinter { ~CntPrinter() { if(g_cnt_unsweep) { fprintf(stderr, "[emu-count] class %d: unsplittable sweeps %ld router runs %ld\n", ALD_CLASS_ID, g_cnt_unsweep, g_cnt_router);
+    fprintf(stderr, "[emu-count]   stars by fan size:"); for(int i = 0; i < 34; i++) if(g_cnt_star[i]) fprintf(stderr, " %d:%ld", i, g_cnt_star[i]); fprintf(stderr, "\n");
+    fprintf(stderr, "[emu-count]   router runs by degree:"); for(int i = 0; i < 34; i++) if(g_cnt_rdeg[i]) fprintf(stderr, " %d:%ld", i, g_cnt_rdeg[i]); fprintf(stderr, "\n"); } } }; static CntPrinter g_cnt_printer;
 #endif
 
 enum { MAXV = ClassDims<ALD_CLASS_ID>::MAXV, MAXE = ClassDims<ALD_CLASS_ID>::MAXE, NW = ClassDims<ALD_CLASS_ID>::NW };
@@ -981,6 +983,9 @@ template<bool A> ALD_INL void star_wave_body(int x)
     }
     wsync();
     const int n = uni(ctx[SW_N]), c = uni(ctx[SW_C]), far = uni(ctx[SW_FAR]);
+#ifdef ALD_EMU_COUNT
+    g_cnt_star[n < 33 ? n : 33]++;
+#endif
     if(uni(ctx[SW_FAIL])) { if(lane == 0) fail(ctx[SW_FAIL]); wsync(); return; }
     PROF_ADD(PF_T_BALANCE);
     // ---- phase 1 (lane j): rank of fan edge j by creation id -> ord (merge order) and its inverse
@@ -1822,7 +1827,10 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     double weight_remain = 0;
     for(int i = 0; i < n; i++) { if(vw[i] <= 0) continue; weight_remain += vw[i]; }
     HC.ro_ratio = weight_remain / weight_sum;
-    for(int i = 0; i < n; i++) if(iso[i] == 1) C.ed[u2e[i]].econf += log(econf[i]);     // router.cc:849-855: side effect of every build()
+    // router.cc:849-855: side effect of every build().  (pre: the wave fetched the confidences with the rest -- router_prepare --, so
+    // the updates are stores only instead of one global round trip per attached node)
+    if(pre) { const double *ecf = AR.d + ARENA_D - n; for(int i = 0; i < n; i++) if(iso[i] == 1) C.ed[u2e[i]].econf = ecf[i] + log(econf[i]); }
+    else for(int i = 0; i < n; i++) if(iso[i] == 1) C.ed[u2e[i]].econf += log(econf[i]);
     sort_pairs(PW, np);
     const double mw = HC.p_min_w;
     for(int i = 0; i < np; i++) if(pwt[i] < mw) pwt[i] = mw;                // router.cc:217-220
@@ -1848,6 +1856,7 @@ ALD_INL int router_prepare(int root)
     if(!small) return 0;                                                     // (n <= LP <= the wave)
     const Arena AR = arena_at(true);
     int32_t *u2e = AR.i, *ncnt = AR.i + 2 * n, *nsid = AR.i + 3 * n, *iso = AR.i + 4 * n; double *nabd = AR.d, *econf = AR.d + 2 * n;
+    double *ecf = AR.d + ARENA_D - n;             // the edges' confidences, for the end of build(): the last n slots (`small` keeps 4 n + routes <= ARENA_D)
     bool multi = false;
     for(int l = lane; l < n; l += ALD_WAVE) {
         int e;
@@ -1855,7 +1864,7 @@ ALD_INL int router_prepare(int root)
         else { e = first_out(root); for(int k = nin; k < l && e >= 0; k++) e = next_out(e); }
         if(e < 0) e = 0;                                                       // cannot happen: the degrees count the lists
         const int cnt = (int)C.ed[e].sp_len, ec = C.ed[e].ecount;
-        u2e[l] = e; ncnt[l] = cnt; nsid[l] = C.ed[e].s0id; nabd[l] = C.ed[e].s0abd; iso[l] = (ec == 0) ? 2 : 0;
+        u2e[l] = e; ncnt[l] = cnt; nsid[l] = C.ed[e].s0id; nabd[l] = C.ed[e].s0abd; iso[l] = (ec == 0) ? 2 : 0; ecf[l] = C.ed[e].econf;
         if(ec != 0 && cnt != 1) multi = true;
     }
     wsync();
@@ -1884,7 +1893,7 @@ ALD_INL int router_prepare(int root)
 ALD_INL bool router_run(int root, int want_type, int max_degree, int pre = 0)
 {
 #ifdef ALD_EMU_COUNT
-    g_cnt_router++;
+    g_cnt_router++; { int dg_ = (int)H.in_deg[root] + (int)H.out_deg[root]; g_cnt_rdeg[dg_ < 33 ? dg_ : 33]++; }
 #endif
     root = uni(root);
     const int nin = uni(H.in_deg[root]), nout = uni(H.out_deg[root]), n = nin + nout;
