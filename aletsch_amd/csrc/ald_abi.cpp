@@ -222,6 +222,7 @@ int ald_batch_destroy(ald_batch *b)
     for(DevBuf *d : bufs) d->release();
     for(int c = 0; c < ALD_NUM_CLASSES; c++) b->d_slabs[c].release();
     for(DevBuf &d : b->red) d.release();
+    for(DevBuf &d : b->dts) d.release();
     for(PinBuf &d : b->red_pin) d.release();
     for(int q = 0; q < ALD_SIDE_STREAMS; q++) if(b->cstream[q]) { hipStreamSynchronize(b->cstream[q]); hipStreamDestroy(b->cstream[q]); }
     for(int c = 0; c < ALD_NUM_CLASSES; c++) if(b->cdone[c]) hipEventDestroy(b->cdone[c]);
@@ -675,7 +676,7 @@ int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int6
  * 4-byte words, transcripts in ascending (graph, path index) order:
  *   [graph, path, sid, strand, count1, n_exons, weight f64, conf f64, abd f64, (l, r) * n_exons]        TS_HDR + 2 * n_exons words
  * Records of abandoned attempts and of graphs that did not end well are already gone (HostResults::build), exons are joined. */
-enum { TS_HDR = 12 };
+enum { TS_HDR = ALD_TS_HDR };
 int ald_batch_transcript_stream(const ald_batch *cb, const int32_t *sid, int32_t skip_single_exon, const uint32_t **words, int64_t *n_words)
 {
     if(!cb || !words || !n_words) return ALD_ERR_INVALID;

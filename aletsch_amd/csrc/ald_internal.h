@@ -61,11 +61,13 @@ struct ald_batch {
     const void *launched_slab[ALD_NUM_CLASSES] = {};      // test hook (ald_batch_debug_slab)
     rvec<uint32_t> tstream;                                // last transcript stream built from this batch (ald_batch_transcript_stream)
     DevBuf red[20]; PinBuf red_pin[8];                     // scratch of ald_batch_reduce_transcripts, kept across calls (tset_reduce.hip)
+    DevBuf dts[3];                                         // ald_batch_device_transcript_stream: lengths / offsets / the stream itself
 };
 
 
 // The result sink behind ald_tset_*.  Buckets (intron-chain hashes) never interact: the set is kept as NSHARD independent tables, bucket h
 // in table h % NSHARD, so that a whole batch can be merged by NSHARD host threads without a lock; the export walks all keys in ascending order.
+enum { ALD_TS_HDR = 12 };          // words in front of a transcript's exons in a transcript stream (ald_batch_transcript_stream)
 enum { ALD_TSET_SHARDS = 16 };
 struct ald_tset {
     std::vector<aletsch::transcript_sink> shard; double overlap;

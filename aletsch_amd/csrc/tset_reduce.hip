@@ -154,6 +154,32 @@ __global__ void tx_sfold(TxIn in, const uint64_t *skey2, const int64_t *spos, co
 }
 __global__ void tx_iota(int64_t *v, int64_t n) { const int64_t i = (int64_t)blockIdx.x * TX_BLOCK + threadIdx.x; if(i < n) v[i] = i; }
 
+
+// ---- the finished transcripts of a batch as one stream IN DEVICE MEMORY (ald_batch_device_transcript_stream): what ranks exchange
+__global__ void ts_len(const int32_t *nwords, int64_t np, int skip_single, int64_t *len)
+{
+    const int64_t p = (int64_t)blockIdx.x * TX_BLOCK + threadIdx.x;
+    if(p > np) return;
+    if(p == np) { len[p] = 0; return; }                   // (the exclusive scan over np + 1 entries leaves the total in the last one)
+    const int k = nwords[p];
+    len[p] = (k <= 2 && skip_single) ? 0 : (int64_t)ALD_TS_HDR + k;
+}
+__global__ void ts_emit(TxIn in, const int32_t *exw, const int32_t *nwords, const int64_t *at, const int32_t *sid, uint32_t *out)
+{
+    const int64_t p = (int64_t)blockIdx.x * TX_BLOCK + threadIdx.x;
+    if(p >= in.np) return;
+    const int64_t o = at[p];
+    if(at[p + 1] == o) return;
+    const uint32_t *r = in.pool + in.roff[p]; const int g = (int)r[0], k = nwords[p];
+    uint32_t *w = out + o;
+    w[0] = (uint32_t)g; w[1] = r[1]; w[2] = (uint32_t)(sid ? sid[g] : -1); w[3] = r[5] & 0xFF; w[4] = r[4]; w[5] = (uint32_t)(k / 2);
+    w[6] = r[6]; w[7] = r[7];                              // weight
+    w[8] = r[10]; w[9] = r[11];                            // conf
+    w[10] = r[8]; w[11] = r[9];                            // abd
+    const int32_t *x = exw + in.ex_off[p];
+    for(int q = 0; q < k; q++) w[ALD_TS_HDR + q] = (uint32_t)x[q];
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + TX_BLOCK - 1) / TX_BLOCK); }
 
 } // namespace
@@ -339,6 +365,58 @@ int ald_batch_reduce_transcripts(const ald_batch *cb, const int32_t *sid, int64_
     if(getenv("ALD_SINK_PROF")) { auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
         fprintf(stderr, "[reduce] tables %.1f ms, device section %.1f ms (events %.1f), single-exon host %.1f ms, order + offsets %.1f ms, fill %.1f ms\n", ms(T0, T1), ms(T1, T2), F->device_ms, ms(T2, T3), ms(T3, T4), ms(T4, std::chrono::steady_clock::now())); }
     *out = F;
+    return ALD_OK;
+}
+
+// The stream of ald_batch_transcript_stream, word for word, built on the device and left there: a rank hands it to RCCL without the
+// 200 MB making a round trip through host memory (join + fill on the host threads, then a pageable H2D copy: 70 ms per 100 000
+// graphs, more than the decomposition kernel takes).  The host contributes the path table -- record offsets in (graph, path) order,
+// final attempts only: the index it builds of a downloaded batch anyway -- and one number comes back, the length.
+int ald_batch_device_transcript_stream(const ald_batch *cb, const int32_t *sid, int32_t skip_single_exon, void **dev_words, int64_t *n_words)
+{
+    if(!cb || !dev_words || !n_words) return ALD_ERR_INVALID;
+    if(!cb->downloaded) return ald_set_err(ALD_ERR_STATE, "ald_batch_device_transcript_stream before ald_batch_download");
+    { int rc = ald_ensure_index(cb); if(rc != ALD_OK) return rc; }
+    ald_batch *b = const_cast<ald_batch*>(cb);
+    HCHK(hipSetDevice(b->device));
+    const int n = b->hb.n(); const int64_t np = (int64_t)b->res.paths.size();
+    *dev_words = nullptr; *n_words = 0;
+    if(np == 0) return ALD_OK;
+    PinBuf &p_roff = b->red_pin[5], &p_exoff = b->red_pin[6], &p_tot = b->red_pin[7];
+    DevBuf &d_roff = b->red[0], &d_exoff = b->red[1], &d_exw = b->red[3], &d_nw = b->red[4], &d_key = b->red[5], &d_graph = b->red[9], &d_sid = b->red[10], &d_tmp = b->red[14];
+    DevBuf &d_len = b->dts[0], &d_at = b->dts[1], &d_out = b->dts[2];
+    if(p_roff.ensure(8 * (size_t)np) || p_exoff.ensure(8 * (size_t)np + 8) || p_tot.ensure(64)) return ald_set_err(ALD_ERR_NOMEM, "pinned path table");
+    int64_t *roff = (int64_t*)p_roff.p, *ex_off = (int64_t*)p_exoff.p;
+    unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16; if(np < 50000) nthr = 1;
+    // exon slot of path p = 2 * (vertices between source and sink) words; the prefix over 2 M paths in two passes over per-thread blocks
+    std::vector<int64_t> part(nthr + 1, 0);
+    HostBatch::run_threads(nthr, [&](unsigned t) { int64_t s = 0; for(int64_t p = np * t / nthr; p < np * (t + 1) / nthr; p++) { const PathRec &P = b->res.paths[(size_t)p]; s += 2 * (int64_t)(P.nv > 2 ? P.nv - 2 : 0); } part[t + 1] = s; });
+    for(unsigned t = 0; t < nthr; t++) part[t + 1] += part[t];
+    HostBatch::run_threads(nthr, [&](unsigned t) { int64_t s = part[t]; for(int64_t p = np * t / nthr; p < np * (t + 1) / nthr; p++) { const PathRec &P = b->res.paths[(size_t)p]; roff[p] = (int64_t)P.vert_off - REC_HDR_WORDS; ex_off[p] = s; s += 2 * (int64_t)(P.nv > 2 ? P.nv - 2 : 0); } });
+    const int64_t exw_total = part[nthr]; ex_off[np] = exw_total;
+    if(d_roff.ensure(8 * (size_t)np) || d_exoff.ensure(8 * (size_t)np + 8) || d_exw.ensure(4 * (size_t)exw_total + 16) || d_nw.ensure(4 * (size_t)np) || d_key.ensure(8 * (size_t)np) || d_graph.ensure(4 * (size_t)np)
+       || d_len.ensure(8 * (size_t)np + 8) || d_at.ensure(8 * (size_t)np + 8) || (sid && d_sid.ensure(4 * (size_t)n + 4))) return ald_set_err(ALD_ERR_NOMEM, "transcript stream buffers");
+    hipStream_t st = b->stream;
+    HCHK(hipMemcpyAsync(d_roff.p, roff, 8 * (size_t)np, hipMemcpyHostToDevice, st));
+    HCHK(hipMemcpyAsync(d_exoff.p, ex_off, 8 * (size_t)np + 8, hipMemcpyHostToDevice, st));
+    if(sid) HCHK(hipMemcpyAsync(d_sid.p, sid, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    const BatchIn BI = b->hb.make_batch_in((uint8_t*)b->d_in.p, b->sec);
+    TxIn in; in.roff = (const int64_t*)d_roff.p; in.ex_off = (const int64_t*)d_exoff.p; in.pool = (const uint32_t*)b->d_pool.p;
+    in.off_v = (const int64_t*)BI.off_v; in.lpos = (const int32_t*)BI.vertex_lpos; in.rpos = (const int32_t*)BI.vertex_rpos; in.np = np;
+    hipLaunchKernelGGL(tx_build, dim3(grid_for(np)), dim3(TX_BLOCK), 0, st, in, (int32_t*)d_exw.p, (int32_t*)d_nw.p, (uint64_t*)d_key.p, (int32_t*)d_graph.p);
+    hipLaunchKernelGGL(ts_len, dim3(grid_for(np + 1)), dim3(TX_BLOCK), 0, st, (const int32_t*)d_nw.p, np, (int)(skip_single_exon != 0), (int64_t*)d_len.p);
+    size_t scan_bytes = 0;
+    HCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const int64_t*)d_len.p, (int64_t*)d_at.p, (int)(np + 1), st));
+    if(d_tmp.ensure(scan_bytes + 256)) return ald_set_err(ALD_ERR_NOMEM, "scan scratch");
+    HCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, scan_bytes, (const int64_t*)d_len.p, (int64_t*)d_at.p, (int)(np + 1), st));
+    HCHK(hipMemcpyAsync(p_tot.p, (const int64_t*)d_at.p + np, 8, hipMemcpyDeviceToHost, st));
+    HCHK(hipStreamSynchronize(st));
+    const int64_t total = *(const int64_t*)p_tot.p;
+    if(d_out.ensure(4 * (size_t)total + 64)) return ald_set_err(ALD_ERR_NOMEM, "transcript stream");
+    hipLaunchKernelGGL(ts_emit, dim3(grid_for(np)), dim3(TX_BLOCK), 0, st, in, (const int32_t*)d_exw.p, (const int32_t*)d_nw.p, (const int64_t*)d_at.p, sid ? (const int32_t*)d_sid.p : (const int32_t*)nullptr, (uint32_t*)d_out.p);
+    HCHK(hipStreamSynchronize(st));
+    if(hipGetLastError() != hipSuccess) return ald_set_err(ALD_ERR_HIP, "a transcript-stream kernel failed to launch");
+    *dev_words = d_out.p; *n_words = total;
     return ALD_OK;
 }
 

@@ -189,6 +189,7 @@ def load_library():
         getattr(lib, name).argtypes = [C.c_void_p]
     lib.ald_batch_enable_trace.argtypes = [C.c_void_p, C.c_int32]
     lib.ald_batch_device_records.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    lib.ald_batch_device_transcript_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     lib.ald_records_add_graph_offset.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     lib.ald_tset_destroy.argtypes = [C.c_void_p]
     lib.ald_tset_create.argtypes = [C.c_double, C.POINTER(C.c_void_p)]
@@ -333,6 +334,16 @@ class DecompBatch:
         """(device pointer, word count) of the record stream in HBM -- for a zero-copy hand-over to RCCL (distributed.py)."""
         p = C.c_void_p(); n = C.c_int64()
         _check(self._lib.ald_batch_device_records(self._h, C.byref(p), C.byref(n)))
+        return int(p.value or 0), int(n.value)
+
+    def device_transcript_stream(self, sid=None, skip_single_exon: bool = False):
+        """(device pointer, word count) of the finished-transcript stream built ON the device (== transcript_stream(), word for word):
+        for a zero-copy hand-over to the exchange step (distributed.StreamGatherer / ald_comm_gather_streams)."""
+        p = C.c_void_p(); n = C.c_int64()
+        sp = None
+        if sid is not None:
+            sid = np.ascontiguousarray(sid, np.int32); assert len(sid) == self.n; sp = C.c_void_p(sid.ctypes.data)
+        _check(self._lib.ald_batch_device_transcript_stream(self._h, sp, C.c_int32(int(skip_single_exon)), C.byref(p), C.byref(n)))
         return int(p.value or 0), int(n.value)
 
     def result(self) -> DecompResult:

@@ -173,7 +173,7 @@ def main() -> int:
         else:
             dist.init_process_group(backend="gloo")
     import aletsch_amd as A
-    from aletsch_amd.distributed import StreamGatherer
+    from aletsch_amd.distributed import StreamGatherer, _device_words
 
     dev = local if dist_on else 0
     tdev = torch.device("cpu") if args.dry_run else torch.device("cuda", dev)
@@ -200,21 +200,28 @@ def main() -> int:
         dist.barrier(); dist.destroy_process_group()
         return 0
 
-    NB = 4                                               # in flight: one kernel, one download, two being staged
+    NB = 6 if dist_on else 4                             # in flight: one kernel, one download, two being staged (+ two in the exchange: its kernels wait for room beside the decomposition kernel)
     batches = [A.DecompBatch(dev) for _ in range(NB)]
-    stream_read = {}                                     # batch -> event reached once the exchange has read what it sent
+
+    xs = [0.0, 0.0, 0.0, 0]                              # exchange thread: stream built on the device / gather enqueued / stream read by the gather
 
     def exchange(b):
-        """RCCL gather of this batch's finished transcripts (filtered records, joined exons: ald_batch_transcript_stream) to rank 0;
-        only enqueued: the next kernel is launched behind it and the host never waits for a collective"""
-        w = b.transcript_stream()
-        t = torch.from_numpy(w.view(np.int32)).to(tdev, non_blocking=True)
-        stream_read[id(b)] = gatherer.gather(t, graph_offset=rank * args.graphs)
+        """RCCL gather of this batch's finished transcripts to rank 0.  The stream (final records only, exons joined) is built by
+        kernels and stays in HBM (ald_batch_device_transcript_stream); a zero-copy view of it goes into the gather, so the transcripts
+        travel HBM -> xGMI -> HBM of rank 0.  Runs on its own host thread (a fourth pipeline stage): the thread that launches the
+        kernels never waits for a collective, and the batch goes back to the stagers once the gather has read it."""
+        t0_ = time.perf_counter()
+        ptr, n = b.device_transcript_stream()
+        t1_ = time.perf_counter()
+        t = _device_words(ptr, n, tdev) if n else torch.zeros(0, dtype=torch.int32, device=tdev)
+        read = gatherer.gather(t, graph_offset=rank * args.graphs)
+        t2_ = time.perf_counter()
+        if read is not None:
+            read.synchronize()
+        xs[0] += t1_ - t0_; xs[1] += t2_ - t1_; xs[2] += time.perf_counter() - t2_; xs[3] += 1
 
     def finish(b):
         b.download()                                    # stream sync + D2H of status / packed records (+ class retries)
-        if dist_on:
-            exchange(b)
         return b.kernel_ms()
 
     def bracket():
@@ -243,8 +250,36 @@ def main() -> int:
         todo = queue.Queue()
         for _ in range(w + k + ahead):
             todo.put(1)
-        added = queue.Queue()
-        stage_s = [0.0, 0.0, 0.0]                                # busy seconds: host copy / pack + H2D / main thread waiting for a staged batch
+        added = queue.Queue(); xq = queue.Queue()
+        stage_s = [0.0, 0.0, 0.0, 0.0]                           # busy seconds: host copy / pack + H2D / main thread waiting for a staged batch / exchange
+
+        def exchanger():                                         # stage 4 (multi-GPU only): finished transcripts -> rank 0
+            if tdev.type == "cuda":
+                torch.cuda.set_device(tdev)
+            while True:
+                b = xq.get()
+                try:
+                    if b is None:
+                        return
+                    t_ = time.perf_counter()
+                    exchange(b)
+                    stage_s[3] += time.perf_counter() - t_
+                    free.put(b)
+                except BaseException as e:
+                    err.append(e); ready.put(None)
+                finally:
+                    xq.task_done()
+
+        def release(b):                                          # a downloaded batch: through the exchange when there is one, else straight back
+            if dist_on:
+                xq.put(b)
+            else:
+                free.put(b)
+
+        def drained():                                           # every exchange issued so far has been enqueued (and has read its stream)
+            xq.join()
+            if err:
+                raise err[0]
 
         def adder():                                             # stage 1: caller's arrays -> the batch's canonical host arrays (+ in-CSR)
             try:
@@ -275,7 +310,7 @@ def main() -> int:
                     ready.put(b)
             except BaseException as e:
                 err.append(e); ready.put(None)
-        ths = [threading.Thread(target=adder, daemon=True), threading.Thread(target=uploader, daemon=True)]
+        ths = [threading.Thread(target=adder, daemon=True), threading.Thread(target=uploader, daemon=True)] + ([threading.Thread(target=exchanger, daemon=True)] if dist_on else [])
         for th in ths:
             th.start()
         prev = None; ms = []
@@ -290,23 +325,23 @@ def main() -> int:
             t_ = time.perf_counter()
             if prev is not None:
                 prev.sync()                             # the previous kernel is done ...
-            ev = stream_read.pop(id(cur), None)
-            if ev is not None:
-                ev.synchronize()
             t1_ = time.perf_counter(); main_s[0] += t1_ - t_
             cur.run()                                   # ... the next one starts ...
             t2_ = time.perf_counter(); main_s[1] += t2_ - t1_
             if prev is not None:
-                x = finish(prev); free.put(prev)        # ... while the previous records travel to the host
+                x = finish(prev); release(prev)         # ... while the previous records travel to the host
                 if step > w:
                     ms.append(x)
             main_s[2] += time.perf_counter() - t2_
             prev = cur
             if step == w - 1:                           # last warm-up step: drain it, then the opening bracket
-                finish(prev); free.put(prev); prev = None
-                t0 = bracket(); stage_s[2] = 0.0; main_s = [0.0, 0.0, 0.0]
-        ms.append(finish(prev)); free.put(prev)
+                finish(prev); release(prev); prev = None
+                drained()
+                t0 = bracket(); stage_s[2] = 0.0; stage_s[3] = 0.0; main_s = [0.0, 0.0, 0.0]
+        ms.append(finish(prev)); release(prev)
+        drained()
         t1 = bracket()
+        xq.put(None)
         for th in ths:
             th.join()
         el = t1 - t0
@@ -316,8 +351,10 @@ def main() -> int:
             el = float(te.item())
         if os.environ.get("ALD_BENCH_STAGES"):
             n_st = max(1, w + k + ahead)
-            sys.stderr.write("[bench] %d + %d %s steps: add %.1f ms, upload %.1f ms per batch; timed steps: main waited for a staged batch %.1f ms; main thread: sync %.1f ms, launch %.2f ms, download %.1f ms (per step)\n"
-                             % (w, k, "staged" if staged else "resident", 1e3 * stage_s[0] / n_st, 1e3 * stage_s[1] / n_st, 1e3 * stage_s[2] / k, 1e3 * main_s[0] / k, 1e3 * main_s[1] / k, 1e3 * main_s[2] / k))
+            sys.stderr.write("[bench] %d + %d %s steps: add %.1f ms, upload %.1f ms per batch; timed steps: main waited for a staged batch %.1f ms; main thread: sync %.1f ms, launch %.2f ms, download %.1f ms; exchange thread %.1f ms (per step)\n"
+                             % (w, k, "staged" if staged else "resident", 1e3 * stage_s[0] / n_st, 1e3 * stage_s[1] / n_st, 1e3 * stage_s[2] / k, 1e3 * main_s[0] / k, 1e3 * main_s[1] / k, 1e3 * main_s[2] / k, 1e3 * stage_s[3] / k))
+        if os.environ.get("ALD_BENCH_STAGES") and dist_on and xs[3]:
+            sys.stderr.write("[bench]   exchange thread per batch: device stream %.1f ms, gather enqueue %.1f ms, wait until read %.1f ms\n" % (1e3 * xs[0] / xs[3], 1e3 * xs[1] / xs[3], 1e3 * xs[2] / xs[3]))
         return el, ms
 
     elapsed, kms = run_steps(max(args.warmup, NB), args.steps, True)   # THE timed region: K steps, host arrays in -> host results out (warm-up: at least one pass per batch object, so every pinned / device buffer exists)

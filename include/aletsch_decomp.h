@@ -271,6 +271,11 @@ int  ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int
  * Only graphs that ended ALD_ST_OK / ALD_ST_SKIPPED_LARGE contribute, records of abandoned capacity attempts are gone, exons are joined,
  * single-exon transcripts are left out when skip_single_exon (assembler.cc:1117).  Valid until the next call on this batch. */
 int  ald_batch_transcript_stream(const ald_batch *b, const int32_t *sid, int32_t skip_single_exon, const uint32_t **words, int64_t *n_words);
+/* The same stream, word for word, built by kernels and left in DEVICE memory (exon join, lengths, prefix sum, fill): for the RCCL
+ * exchange of a multi-process host (ald_comm_gather_streams takes host or device pointers alike; torch.distributed a zero-copy view),
+ * so that the finished transcripts travel HBM -> xGMI -> HBM of rank 0 without a detour through this rank's host memory.
+ * Valid until the next run / reduction / stream call on this batch. */
+int  ald_batch_device_transcript_stream(const ald_batch *b, const int32_t *sid, int32_t skip_single_exon, void **dev_words, int64_t *n_words);
 /* Merge such a stream, graph by graph in stream order (assembler.cc:1105-1133): coverage = log(1 + weight) is taken here, on the host;
  * tid = tid_base + ((graph + graph_offset) << 20 | path index), i.e. what ald_tset_add_batch gives the same graph in an unsharded batch */
 int  ald_tset_add_stream(ald_tset *t, const uint32_t *words, int64_t n_words, int32_t graph_offset, int64_t tid_base);

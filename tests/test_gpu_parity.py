@@ -667,3 +667,30 @@ def test_transcript_set_reduction_on_the_gpu():
             one = A.TranscriptSink(0.8); one.add_batch(b, s_, tid_base=tb)
             ref.merge(one)
     assert flat.items() == ref.items() and len(ref.items()) > 3000
+
+
+def test_transcript_stream_built_on_the_device():
+    """ald_batch_device_transcript_stream leaves in HBM, word for word, the stream ald_batch_transcript_stream builds on the host
+    (finished graphs only, exons joined, optional single-exon filter, sample ids) -- read back through a zero-copy tensor view"""
+    import os
+    import torch
+    from aletsch_amd.distributed import _device_words
+    pg = A.synth(seed=4242, n_graphs=3000, v_min=6, v_max=90, edges_per_vertex=3, layout_mode=1, weight_mode=2, phasing_per_graph=2, strand_mode=1)
+    sid = (np.arange(pg.n) % 5).astype(np.int32)
+    os.environ["ALD_DEBUG_UNDERCLASS"] = "1"            # abandoned capacity attempts in the raw pool: they must not show up
+    try:
+        with A.DecompBatch(0) as b:
+            b.add(pg); b.upload(); b.run(); b.download()
+            for skip in (False, True):
+                for s in (sid, None):
+                    want = b.transcript_stream(s, skip)
+                    ptr, n = b.device_transcript_stream(s, skip)
+                    assert n == want.size and n > 0
+                    got = _device_words(ptr, n, torch.device("cuda", 0)).cpu().numpy().view(np.uint32)
+                    assert np.array_equal(got, want), (skip, s is None)
+    finally:
+        del os.environ["ALD_DEBUG_UNDERCLASS"]
+    with A.DecompBatch(0) as b:                             # a batch without a single path
+        b.add(A.synth(seed=5, n_graphs=3, v_min=2, v_max=2, edges_per_vertex=1)); b.upload(); b.run(); b.download()
+        ptr, n = b.device_transcript_stream()
+        assert n == b.transcript_stream().size
