@@ -114,12 +114,22 @@ int ald_comm_gather_streams(ald_comm *c, const uint32_t *words, int64_t n_words,
     c->offsets.assign((size_t)W + 1, 0); c->goffs.assign((size_t)W, 0);
     for(int r = 0; r < W; r++) { c->offsets[(size_t)r + 1] = c->offsets[(size_t)r] + all[2 * (size_t)r]; c->goffs[(size_t)r] = (int32_t)all[2 * (size_t)r + 1]; }
     // payloads: every rank sends, rank 0 receives each stream at its offset
-    if(c->d_send.ensure(4 * (size_t)n_words + 64)) return ald_set_err(ALD_ERR_NOMEM, "send buffer");
-    if(n_words) HCHK(hipMemcpyAsync(c->d_send.p, words, 4 * (size_t)n_words, hipMemcpyHostToDevice, c->stream));
+    // a stream that already lives in HBM (ald_batch_device_transcript_stream) is sent from where it is; a host stream is staged first
+    const void *src = words;
+    {
+        hipPointerAttribute_t at; bool on_device = false;
+        if(n_words && hipPointerGetAttributes(&at, words) == hipSuccess) on_device = (at.type == hipMemoryTypeDevice);
+        (void)hipGetLastError();                                   // (a plain host pointer makes the query fail: not an error here)
+        if(!on_device) {
+            if(c->d_send.ensure(4 * (size_t)n_words + 64)) return ald_set_err(ALD_ERR_NOMEM, "send buffer");
+            if(n_words) HCHK(hipMemcpyAsync(c->d_send.p, words, 4 * (size_t)n_words, hipMemcpyHostToDevice, c->stream));
+            src = c->d_send.p;
+        }
+    }
     const int64_t total = c->offsets[(size_t)W];
     if(c->rank == 0) { if(c->d_recv.ensure(4 * (size_t)total + 64) || c->h_recv.ensure(4 * (size_t)total + 64)) return ald_set_err(ALD_ERR_NOMEM, "receive buffers"); }
     NCHK(R.GroupStart());
-    if(n_words) NCHK(R.Send(c->d_send.p, (size_t)n_words, ncclUint32, 0, c->comm, c->stream));
+    if(n_words) NCHK(R.Send(src, (size_t)n_words, ncclUint32, 0, c->comm, c->stream));
     if(c->rank == 0) for(int r = 0; r < W; r++) { const int64_t k = all[2 * (size_t)r]; if(k) NCHK(R.Recv((uint32_t*)c->d_recv.p + c->offsets[(size_t)r], (size_t)k, ncclUint32, r, c->comm, c->stream)); }
     NCHK(R.GroupEnd());
     if(c->rank == 0 && total) HCHK(hipMemcpyAsync(c->h_recv.p, c->d_recv.p, 4 * (size_t)total, hipMemcpyDeviceToHost, c->stream));

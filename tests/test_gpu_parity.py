@@ -618,12 +618,17 @@ def test_rccl_gather_behind_the_c_abi():
             b.add(pg); b.upload(); b.run(); b.download()
             w = b.transcript_stream(sid)
             direct = A.TranscriptSink(0.8); direct.add_batch(b, sid)
-        for rep in range(2):                                   # buffers are reused on the second step
-            allw = C.POINTER(C.c_uint32)(); offs = C.POINTER(C.c_int64)(); goffs = C.POINTER(C.c_int32)()
-            assert lib.ald_comm_gather_streams(comm, C.c_void_p(w.ctypes.data), C.c_int64(w.size), C.c_int32(0), C.byref(allw), C.byref(offs), C.byref(goffs)) == 0, lib.ald_last_error()
-            assert offs[0] == 0 and offs[1] == w.size and goffs[0] == 0
-            got = np.ctypeslib.as_array(allw, shape=(w.size,)).copy()
-            assert np.array_equal(got, w)
+            for rep in range(3):                               # buffers are reused; the last round sends the stream built in HBM, from where it lies
+                allw = C.POINTER(C.c_uint32)(); offs = C.POINTER(C.c_int64)(); goffs = C.POINTER(C.c_int32)()
+                if rep < 2:
+                    src, n = w.ctypes.data, w.size
+                else:
+                    src, n = b.device_transcript_stream(sid)
+                    assert n == w.size
+                assert lib.ald_comm_gather_streams(comm, C.c_void_p(src), C.c_int64(n), C.c_int32(0), C.byref(allw), C.byref(offs), C.byref(goffs)) == 0, lib.ald_last_error()
+                assert offs[0] == 0 and offs[1] == w.size and goffs[0] == 0
+                got = np.ctypeslib.as_array(allw, shape=(w.size,)).copy()
+                assert np.array_equal(got, w), rep
         via = A.TranscriptSink(0.8); via.add_stream(got, graph_offset=int(goffs[0]))
         assert via.items() == direct.items() and len(via.items()) > 500
         assert lib.ald_comm_destroy(comm) == 0
