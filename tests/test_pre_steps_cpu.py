@@ -66,7 +66,8 @@ def test_pre_steps_by_hand():
     e = [(0, 1, 10.0), (0, 2, 4.0), (0, 4, 3.0), (1, 2, 9.0), (2, 3, 12.0), (3, 4, 11.0), (3, 5, 2.0), (4, 5, 13.0), (5, 6, 15.0), (4, 6, 1.0)]
     g = dict(V=7, edges=[(s, t, w, 1, {0: w, 3: 1.0}) for s, t, w in e], vw=[0, 10, 14, 13, 14, 15, 0], lpos=lpos, rpos=rpos, strand="+")
     pg = PackedGraphs.from_graphs([g])
-    phases = [([200, 400, 5000, 5200], 4), ([100, 400], 2), ([200, 300], 5), ([200, 400, 5000, 5200], 1), ([5000, 5200, 9000, 9200], 3), ([300, 401], 9)]
+    phases = [([200, 400, 5000, 5200], 4), ([100, 400], 2), ([200, 300], 5), ([200, 400, 5000, 5200], 1), ([5000, 5200, 9000, 9200], 3), ([300, 401], 9),
+              ([100, 200, 9000, 9200], 7)]          # vertices [1, 5]: no edge 1 -> 5, so filter_nodes / check_valid_path (essential.cc:448-459) drops it
     out, sm, tm, rc = A.pre_assemble(pg, phases, 500)
     assert rc == 0 and sm == [(200, 100)] and tm == []          # 0->2 folds into 0->1 (touching, 100 apart); 0->4 is 4800 away; 4->6 / 5->6: 4,5 do not touch
     W = {}
@@ -77,6 +78,6 @@ def test_pre_steps_by_hand():
     assert (0, 2) not in W and W[(0, 1)] == (14.0, 4) and W[(1, 2)] == (13.0, 4)      # 10 + 4; count 2 + 2; the edge on the way 9 + 4
     assert list(out.vertex_weight) == [0, 14, 14, 13, 14, 15, 0]                       # vertex 1 (on the way) + 4
     # phases: (200,400,..) starts on the folded boundary -> 100; merges with nothing else; ([100,400]) stays; ([200,300]) -> (100,300);
-    # ([300,401]) has an unknown right coordinate -> dropped; vertex lists: [1,2,3,4] x (4+1), [1,2,3] x 2, [1,2] x 5, [4,5] x 3
+    # ([300,401]) has an unknown right coordinate -> dropped; ([100,200,9000,9200]) is not a path of the graph -> dropped; vertex lists: [1,2,3,4] x (4+1), [1,2,3] x 2, [1,2] x 5, [4,5] x 3
     got = {tuple(out.phasing_vertex[out.phasing_offset[p]:out.phasing_offset[p + 1]]): int(out.phasing_count[p]) for p in range(int(out.g_np[0]))}
     assert got == {(1, 2, 3, 4): 5, (1, 2, 3): 2, (1, 2): 5, (4, 5): 3}
