@@ -126,10 +126,10 @@ int stage_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], i
         P.order[P.nord++] = c;
     }
     std::sort(P.order, P.order + P.nord, [&](int x, int y) { return cost[x] > cost[y]; });
-    double load[ALD_SIDE_STREAMS] = {0, 0, 0};
+    double load[ALD_SIDE_STREAMS_MAX] = {0};
     for(int k = 0; k < P.nord; k++) {
         const int c = P.order[k];
-        int st = 0; for(int q = 1; q < ALD_SIDE_STREAMS; q++) if(load[q] < load[st]) st = q;
+        int st = 0; for(int q = 1; q < b->n_cstream; q++) if(load[q] < load[st]) st = q;
         load[st] += cost[c]; P.stream_of[c] = st;
     }
     return push_pass(b, P);
@@ -205,7 +205,8 @@ int ald_batch_create(const ald_params *p, int device, ald_batch **out)
     b->device = device; b->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     params_from_abi(p, b->prm);
     bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev1) == hipSuccess;
-    for(int q = 0; q < ALD_SIDE_STREAMS && ok; q++) ok = hipStreamCreateWithFlags(&b->cstream[q], hipStreamNonBlocking) == hipSuccess;
+    if(const char *ev = getenv("ALD_SIDE_STREAMS")) { const int k = atoi(ev); if(k >= 1 && k <= ALD_SIDE_STREAMS_MAX) b->n_cstream = k; }      // tuning knob
+    for(int q = 0; q < b->n_cstream && ok; q++) ok = hipStreamCreateWithFlags(&b->cstream[q], hipStreamNonBlocking) == hipSuccess;
     for(int c = 0; c < ALD_NUM_CLASSES && ok; c++) ok = hipEventCreateWithFlags(&b->cdone[c], hipEventDisableTiming) == hipSuccess;
     if(!ok) { ald_batch_destroy(b); return set_err(ALD_ERR_HIP, "stream/event creation failed"); }
     *out = b;
@@ -224,7 +225,7 @@ int ald_batch_destroy(ald_batch *b)
     for(DevBuf &d : b->red) d.release();
     for(DevBuf &d : b->dts) d.release();
     for(PinBuf &d : b->red_pin) d.release();
-    for(int q = 0; q < ALD_SIDE_STREAMS; q++) if(b->cstream[q]) { hipStreamSynchronize(b->cstream[q]); hipStreamDestroy(b->cstream[q]); }
+    for(int q = 0; q < ALD_SIDE_STREAMS_MAX; q++) if(b->cstream[q]) { hipStreamSynchronize(b->cstream[q]); hipStreamDestroy(b->cstream[q]); }
     for(int c = 0; c < ALD_NUM_CLASSES; c++) if(b->cdone[c]) hipEventDestroy(b->cdone[c]);
     if(b->ev0) hipEventDestroy(b->ev0);
     if(b->ev1) hipEventDestroy(b->ev1);

@@ -24,7 +24,7 @@ struct PinBuf {
     void release() { if(p) hipHostFree(p); p = nullptr; cap = 0; }
 };
 
-enum { ALD_SIDE_STREAMS = 3 };
+enum { ALD_SIDE_STREAMS = 3, ALD_SIDE_STREAMS_MAX = 8 };     // default / upper bound of the side streams the classes of a pass are dealt to
 // one pass of a batch, staged: work lists, kernel arguments, grid sizes, stream assignment (see stage_pass)
 struct StagedPass {
     std::vector<int32_t> flat; std::vector<KernelArgs> args;
@@ -40,7 +40,7 @@ struct ald_batch {
     hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // the size classes run concurrently on a few side streams.  Not one per class: a process only gets a handful of hardware queues
     // (4 by default) and streams beyond that share them in creation order, which can put the two heaviest classes behind each other
-    hipStream_t cstream[ALD_SIDE_STREAMS] = {};
+    hipStream_t cstream[ALD_SIDE_STREAMS_MAX] = {}; int n_cstream = ALD_SIDE_STREAMS;
     hipEvent_t cdone[ALD_NUM_CLASSES] = {};
     PinBuf pin_in, pin_out;
     DevBuf d_in, d_status, d_npaths, d_niters, d_pool, d_poolused, d_trace_n, d_trace_codes, d_trace_vals, d_work, d_counter, d_args;
