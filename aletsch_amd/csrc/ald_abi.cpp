@@ -218,7 +218,7 @@ int ald_batch_destroy(ald_batch *b)
     if(!b) return ALD_OK;
     hipSetDevice(b->device);
     if(b->stream) hipStreamSynchronize(b->stream);
-    b->pin_in.release(); b->pin_out.release(); delete b->pass0; b->pass0 = nullptr;
+    b->pin_in.release(); b->pin_out.release(); b->pin_small.release(); delete b->pass0; b->pass0 = nullptr;
     DevBuf *bufs[] = {&b->d_in, &b->d_status, &b->d_npaths, &b->d_niters, &b->d_pool, &b->d_poolused, &b->d_trace_n, &b->d_trace_codes, &b->d_trace_vals, &b->d_work, &b->d_counter, &b->d_args};
     for(DevBuf *d : bufs) d->release();
     for(int c = 0; c < ALD_NUM_CLASSES; c++) b->d_slabs[c].release();
@@ -391,16 +391,24 @@ int ald_batch_download(ald_batch *b)
     if(!b->ran) return set_err(ALD_ERR_STATE, "ald_batch_download before ald_batch_run");
     HIPCHK(hipSetDevice(b->device));
     const int n = b->hb.n();
+    const bool prof = getenv("ALD_DOWNLOAD_PROF") != nullptr; const auto P0 = std::chrono::steady_clock::now(); auto P1 = P0, P2 = P0, P3 = P0;
     b->n_paths.assign(n, 0); b->n_iters.assign(n, 0);
-    std::vector<int32_t> st(n);
+    // Everything comes back through async copies on the batch's OWN stream into pinned memory.  (A synchronous hipMemcpy runs on the
+    // null stream, which waits for every blocking stream of the device -- i.e. for the kernel of the NEXT batch, already in flight in a
+    // pipelined caller: the download of batch k took as long as the kernel of batch k+1, and its record copy ran between two kernels.)
+    if(b->pin_small.ensure(64 + 12 * (size_t)n + 64, true)) return set_err(ALD_ERR_NOMEM, "pinned status buffer");
+    unsigned long long *h_used = (unsigned long long*)b->pin_small.p;
+    int32_t *st = (int32_t*)((uint8_t*)b->pin_small.p + 64), *h_np = st + n, *h_ni = h_np + n;
     unsigned long long used = 0;
   for(int regrow = 0; ; regrow++) {
     bool pool_full = false;
     for(int pass = 0; pass <= ALD_NUM_CLASSES; pass++) {
         HIPCHK(hipStreamSynchronize(b->stream));
+        if(pass == 0 && regrow == 0) P1 = std::chrono::steady_clock::now();
         float ms = 0; if(hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->kernel_ms += ms;
         b->passes++;
-        if(n > 0) HIPCHK(hipMemcpy(st.data(), b->d_status.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+        if(n > 0) { HIPCHK(hipMemcpyAsync(st, b->d_status.p, 4 * (size_t)n, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream)); }
+        if(pass == 0 && regrow == 0) P2 = std::chrono::steady_clock::now();
         // graphs whose working set overflowed their class are retried one class up (records carry the pass number)
         std::vector<int32_t> work[ALD_NUM_CLASSES]; bool any = false;
         for(int g = 0; g < n; g++) {
@@ -415,7 +423,7 @@ int ald_batch_download(ald_batch *b)
         int rc = launch_pass(b, work, pass + 1);
         if(rc != ALD_OK) return rc;
     }
-    HIPCHK(hipMemcpy(&used, b->d_poolused.p, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(h_used, b->d_poolused.p, 8, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream)); used = *h_used;
     if(!pool_full) break;
     // Some graph found the record pool full.  Records behind the first refused one may be missing (the bump pointer moved, nothing was
     // written), so the stream of this run is unusable as a whole: the pool grows -- `used` counts every request made, a lower bound
@@ -433,11 +441,16 @@ int ald_batch_download(ald_batch *b)
     // the records land in a pinned buffer (kept across runs) through an async copy on the batch stream: the copy engine moves them
     // while another batch's kernel may be running, and the host thread only waits
     if(b->pin_out.ensure(4 * (size_t)used + 64, true)) return set_err(ALD_ERR_NOMEM, "pinned result buffer");
+    P3 = std::chrono::steady_clock::now();
     if(n > 0) {
-        HIPCHK(hipMemcpy(b->n_paths.data(), b->d_npaths.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(b->n_iters.data(), b->d_niters.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(h_np, b->d_npaths.p, 4 * (size_t)n, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipMemcpyAsync(h_ni, b->d_niters.p, 4 * (size_t)n, hipMemcpyDeviceToHost, b->stream));
     }
-    if(used) { HIPCHK(hipMemcpyAsync(b->pin_out.p, b->d_pool.p, 4 * used, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream)); }
+    if(used) HIPCHK(hipMemcpyAsync(b->pin_out.p, b->d_pool.p, 4 * used, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if(n > 0) { memcpy(b->n_paths.data(), h_np, 4 * (size_t)n); memcpy(b->n_iters.data(), h_ni, 4 * (size_t)n); }
+    if(prof) { auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+        fprintf(stderr, "[download] wait for the kernel %.2f ms, status copy %.2f ms, retries + counters %.2f ms, records (%.0f MB) %.2f ms\n", ms(P0, P1), ms(P1, P2), ms(P2, P3), 4e-6 * (double)used, ms(P3, std::chrono::steady_clock::now())); }
     b->res.ext_pool = (const uint32_t*)b->pin_out.p; b->res.ext_words = used;
     b->res.status = b->status; b->res.n_iters = b->n_iters; b->res.attempt = b->attempt;
     b->indexed = false;

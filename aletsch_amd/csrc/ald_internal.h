@@ -42,7 +42,7 @@ struct ald_batch {
     // (4 by default) and streams beyond that share them in creation order, which can put the two heaviest classes behind each other
     hipStream_t cstream[ALD_SIDE_STREAMS_MAX] = {}; int n_cstream = ALD_SIDE_STREAMS;
     hipEvent_t cdone[ALD_NUM_CLASSES] = {};
-    PinBuf pin_in, pin_out;
+    PinBuf pin_in, pin_out, pin_small;                     // wire buffer / record landing area / status + counters landing area
     DevBuf d_in, d_status, d_npaths, d_niters, d_pool, d_poolused, d_trace_n, d_trace_codes, d_trace_vals, d_work, d_counter, d_args;
     DevBuf d_slabs[ALD_NUM_CLASSES];
     int blocks[ALD_NUM_CLASSES] = {};

@@ -179,6 +179,7 @@ def load_library():
     if not os.path.exists(path):
         raise DecompError(-100, f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(hipcc --offload-arch=gfx950); there is no CPU fallback for the decomposition path")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # only takes effect if the HIP runtime has not initialised yet
     lib = C.CDLL(path)
     lib.ald_last_error.restype = C.c_char_p
     lib.ald_version.restype = C.c_char_p
