@@ -288,19 +288,25 @@ int ald_batch_reduce_transcripts(const ald_batch *cb, const int32_t *sid, int64_
     // ---- host: single-exon transcripts through the sink (their overlap rule depends on the order of the comparisons)
     aletsch::transcript_sink single(single_exon_overlap);
     {
+        aletsch::sink_transcript x;
+        auto fill = [&](int64_t p, int g) {
+            const PathRec &P = b->res.paths[(size_t)p];
+            x.strand = P.strand; x.coverage = cov[(size_t)p]; x.top.cov2 = x.coverage; x.top.conf = P.conf; x.top.abd = P.abd; x.top.count1 = P.count; x.count2 = 1;
+            x.tid = tid_base + (((int64_t)g << 20) | (p - b->res.path_begin[g]));
+            x.xs.assign(&h_exw[(size_t)ex_off[(size_t)p]], &h_exw[(size_t)ex_off[(size_t)p]] + 2);
+        };
         for(size_t a = 0; a < host_paths.size() && !skip_single_exon; ) {          // one per-graph set per graph that has any (assembler.cc:1105-1133)
             const int g = b->res.paths[(size_t)host_paths[a]].graph;
-            aletsch::transcript_sink ts(single_exon_overlap); bool any = false;
-            for(; a < host_paths.size() && b->res.paths[(size_t)host_paths[a]].graph == g; a++) {
-                const int64_t p = host_paths[a];
-                if(h_nwords[(size_t)p] != 2) continue;                            // (no exon at all: nothing to add)
-                const PathRec &P = b->res.paths[(size_t)p];
-                aletsch::sink_transcript x; x.strand = P.strand; x.coverage = cov[(size_t)p]; x.top.cov2 = x.coverage; x.top.conf = P.conf; x.top.abd = P.abd; x.top.count1 = P.count; x.count2 = 1;
-                x.tid = tid_base + (((int64_t)g << 20) | (p - b->res.path_begin[g]));
-                x.xs.assign(&h_exw[(size_t)ex_off[(size_t)p]], &h_exw[(size_t)ex_off[(size_t)p]] + 2);
-                ts.add(x, 1, sid ? sid[g] : -1); any = true;
+            size_t e = a; int cnt = 0; int64_t first = -1;
+            for(; e < host_paths.size() && b->res.paths[(size_t)host_paths[e]].graph == g; e++)
+                if(h_nwords[(size_t)host_paths[e]] == 2) { if(cnt++ == 0) first = host_paths[e]; }      // (no exon at all: nothing to add)
+            if(cnt == 1) { fill(first, g); single.add(x, 1, sid ? sid[g] : -1); }   // merging a one-item set is the same as adding the item (transcript_set.cc:149-175)
+            else if(cnt > 1) {
+                aletsch::transcript_sink ts(single_exon_overlap);
+                for(size_t q = a; q < e; q++) { const int64_t p = host_paths[q]; if(h_nwords[(size_t)p] != 2) continue; fill(p, g); ts.add(x, 1, sid ? sid[g] : -1); }
+                single.add(ts);
             }
-            if(any) single.add(ts);
+            a = e;
         }
     }
     const auto T3 = std::chrono::steady_clock::now();
@@ -453,22 +459,29 @@ int ald_tset_add_flat(ald_tset *t, const ald_tset_flat *f)
 {
     if(!t || !f) return ALD_ERR_INVALID;
     const size_t n = f->hash.size();
-    for(size_t i = 0; i < n; ) {
-        size_t j = i; aletsch::transcript_sink::bucket vec;
-        for(; j < n && f->hash[j] == f->hash[i]; j++) {
-            aletsch::sink_item z; aletsch::sink_transcript &r = z.trst;
-            r.strand = f->strand[j]; r.coverage = f->coverage[j]; r.top.cov2 = f->cov2[j]; r.top.conf = f->conf[j]; r.top.abd = f->abd[j]; r.top.count1 = f->count1[j]; r.count2 = f->count2[j]; r.tid = f->tid[j];
-            r.xs.assign(f->exon_lr.begin() + 2 * f->exon_offset[j], f->exon_lr.begin() + 2 * f->exon_offset[j + 1]);
-            z.count = f->count[j];
-            for(int64_t s = f->sample_offset[j]; s < f->sample_offset[j + 1]; s++) {
-                aletsch::sink_sample x; x.coverage = r.coverage; x.top.cov2 = f->sample_cov2[(size_t)s]; x.top.conf = f->sample_conf[(size_t)s]; x.top.abd = f->sample_abd[(size_t)s]; x.top.count1 = f->sample_count1[(size_t)s]; x.count2 = r.count2;
-                bool fresh; z.samples.slot(f->sample_sid[(size_t)s], x, fresh);
+    // buckets never interact and bucket h lives in table h % ALD_TSET_SHARDS: thread th zips the buckets of ITS tables (every thread
+    // scans the hashes, which are ascending; building the items is the work)
+    unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > ALD_TSET_SHARDS) nthr = ALD_TSET_SHARDS; if(n < 20000) nthr = 1;
+    HostBatch::run_threads(nthr, [&](unsigned th) {
+        for(size_t i = 0; i < n; ) {
+            size_t j = i + 1; while(j < n && f->hash[j] == f->hash[i]) j++;
+            if((f->hash[i] % ALD_TSET_SHARDS) % nthr != th) { i = j; continue; }
+            aletsch::transcript_sink::bucket vec;
+            for(size_t k = i; k < j; k++) {
+                aletsch::sink_item z; aletsch::sink_transcript &r = z.trst;
+                r.strand = f->strand[k]; r.coverage = f->coverage[k]; r.top.cov2 = f->cov2[k]; r.top.conf = f->conf[k]; r.top.abd = f->abd[k]; r.top.count1 = f->count1[k]; r.count2 = f->count2[k]; r.tid = f->tid[k];
+                r.xs.assign(f->exon_lr.begin() + 2 * f->exon_offset[k], f->exon_lr.begin() + 2 * f->exon_offset[k + 1]);
+                z.count = f->count[k];
+                for(int64_t s = f->sample_offset[k]; s < f->sample_offset[k + 1]; s++) {
+                    aletsch::sink_sample x; x.coverage = r.coverage; x.top.cov2 = f->sample_cov2[(size_t)s]; x.top.conf = f->sample_conf[(size_t)s]; x.top.abd = f->sample_abd[(size_t)s]; x.top.count1 = f->sample_count1[(size_t)s]; x.count2 = r.count2;
+                    bool fresh; z.samples.slot(f->sample_sid[(size_t)s], x, fresh);
+                }
+                vec.push_back(std::move(z));
             }
-            vec.push_back(std::move(z));
+            t->shard[f->hash[i] % ALD_TSET_SHARDS].add_bucket((size_t)f->hash[i], vec);
+            i = j;
         }
-        t->shard[f->hash[i] % ALD_TSET_SHARDS].add_bucket((size_t)f->hash[i], vec);
-        i = j;
-    }
+    });
     return ALD_OK;
 }
 

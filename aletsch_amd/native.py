@@ -395,6 +395,21 @@ class DecompBatch:
             self._lib.ald_tset_flat_free(h)
         return items, dict(device_ms=st[0].value, total_ms=st[1].value, device_groups=st[2].value, host_items=st[3].value)
 
+    def reduce_into(self, sink: "TranscriptSink", sid=None, tid_base: int = 0, skip_single_exon: bool = False, single_exon_overlap: float = 0.8):
+        """reduce_transcripts + ald_tset_add_flat without exporting the items to Python: the merge step of a pipelined caller -> stats dict"""
+        sp = None
+        if sid is not None:
+            sid = np.ascontiguousarray(sid, np.int32); assert len(sid) == self.n; sp = C.c_void_p(sid.ctypes.data)
+        h = C.c_void_p()
+        _check(self._lib.ald_batch_reduce_transcripts(self._h, sp, C.c_int64(tid_base), C.c_int32(int(skip_single_exon)), C.c_double(single_exon_overlap), C.byref(h)))
+        try:
+            _check(self._lib.ald_tset_add_flat(sink._h, h))
+            st = [C.c_double(), C.c_double(), C.c_int64(), C.c_int64()]
+            _check(self._lib.ald_tset_flat_stats(h, *[C.byref(x) for x in st]))
+        finally:
+            self._lib.ald_tset_flat_free(h)
+        return dict(device_ms=st[0].value, total_ms=st[1].value, device_groups=st[2].value, host_items=st[3].value)
+
     def transcript_stream(self, sid=None, skip_single_exon: bool = False) -> np.ndarray:
         """Finished transcripts of the downloaded batch as one self-contained uint32 stream (copy): what ranks exchange in the
         multi-GPU gather and what TranscriptSink.add_stream merges."""

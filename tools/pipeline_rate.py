@@ -1,6 +1,8 @@
 import os
 # Sustained host-arrays-in -> merged-transcript-set-out rate with the stages overlapped on host threads (ctypes drops the GIL):
-#   stage (add + upload)  |  kernel (run + download)  |  merge (sink.add_batch)      -- three batches in flight
+#   stage (add + upload)  |  kernel (run + download)  |  merge      -- three batches in flight
+#   PIPE_MERGE=host (default): the 16-thread host sink (ald_tset_add_batch);  PIPE_MERGE=reduce: the batch reduced on the GPU
+#   (ald_batch_reduce_transcripts) and the reduced set zipped into the persistent one (ald_tset_add_flat)
 import sys, time, threading, queue, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -30,9 +32,12 @@ def merge():
     while True:
         b = done.get()
         if b is None: return
-        t = time.time(); sink.add_batch(b, sid, tid_base=r << 44); tsink += time.time() - t; r += 1; free.put(b)
+        t = time.time()
+        if os.environ.get("PIPE_MERGE", "host") == "reduce": b.reduce_into(sink, sid, tid_base=r << 44)
+        else: sink.add_batch(b, sid, tid_base=r << 44)
+        tsink += time.time() - t; r += 1; free.put(b)
 # warm-up round (allocations), then the timed pipeline
 for b in batches: b.add(pgs[0]); b.upload(); b.run(); b.download(); b.clear()
 th = [threading.Thread(target=f) for f in (stage, kern, merge)]
 t0 = time.time(); [t.start() for t in th]; [t.join() for t in th]; el = time.time() - t0
-print("pipeline: %d batches x %d graphs in %.2f s -> %.0f graphs/s end to end (stage %.2f s, kernel+D2H %.2f s, merge %.2f s busy)" % (rounds, n, el, rounds * n / el, tstage, tkern, tsink), flush=True)
+print(os.environ.get("PIPE_MERGE", "host"), "merge; pipeline: %d batches x %d graphs in %.2f s -> %.0f graphs/s end to end (stage %.2f s, kernel+D2H %.2f s, merge %.2f s busy)" % (rounds, n, el, rounds * n / el, tstage, tkern, tsink), flush=True)
