@@ -602,6 +602,7 @@ unsigned sink_threads(int64_t n_transcripts)
     if(nthr > ALD_TSET_SHARDS) nthr = ALD_TSET_SHARDS;
     return nthr;
 }
+} unsigned ald_sink_threads(int64_t n_items) { return sink_threads(n_items); } namespace {
 const uint32_t ALD_NO_BUCKET = 0xFFFFFFFFu;       // hashes are below 2^31 + 1
 
 // The merge of many graphs' transcripts.  Buckets never interact, so they are dealt to the host threads by hash: every thread walks

@@ -75,5 +75,6 @@ struct ald_tset {
     void add(aletsch::transcript_sink &ts) { for(auto &x : ts.mt) shard[x.first % ALD_TSET_SHARDS].add_bucket(x.first, x.second); }
 };
 
+unsigned ald_sink_threads(int64_t n_items);          // host threads for a merge of n items (ALD_SINK_THREADS overrides; at most one per table)
 int ald_ensure_index(const ald_batch *b);                 // per-graph index over the record stream of the last download (built on first use)
 int ald_set_err(int code, const std::string &msg);        // sets the calling thread's ald_last_error() text, returns `code`

@@ -461,7 +461,7 @@ int ald_tset_add_flat(ald_tset *t, const ald_tset_flat *f)
     const size_t n = f->hash.size();
     // buckets never interact and bucket h lives in table h % ALD_TSET_SHARDS: thread th zips the buckets of ITS tables (every thread
     // scans the hashes, which are ascending; building the items is the work)
-    unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > ALD_TSET_SHARDS) nthr = ALD_TSET_SHARDS; if(n < 20000) nthr = 1;
+    const unsigned nthr = ald_sink_threads((int64_t)n);
     HostBatch::run_threads(nthr, [&](unsigned th) {
         for(size_t i = 0; i < n; ) {
             size_t j = i + 1; while(j < n && f->hash[j] == f->hash[i]) j++;

@@ -664,14 +664,24 @@ def test_transcript_set_reduction_on_the_gpu():
     # two batches into one persistent set: each reduced on the device and merged set-into-set (ald_tset_add_flat), against the host path
     # doing the same with host-built sets (ald_tset_merge) -- both are transcript_set::add(transcript_set&), transcript_set.cc:156-175
     other = base.select(rng.integers(0, base.n, 1000)); sid2 = rng.integers(0, 6, other.n).astype(np.int32)
-    flat = A.TranscriptSink(0.8); ref = A.TranscriptSink(0.8)
-    for part, s_, tb in ((pg, sid, 1 << 44), (other, sid2, 2 << 44)):
-        with A.DecompBatch(0) as b:
-            b.add(part); b.upload(); b.run(); b.download()
-            b.reduce_transcripts(s_, tid_base=tb, into=flat)
-            one = A.TranscriptSink(0.8); one.add_batch(b, s_, tid_base=tb)
-            ref.merge(one)
-    assert flat.items() == ref.items() and len(ref.items()) > 3000
+    import os
+    for thr in (None, "7"):                                 # ald_tset_add_flat on one thread / on seven (one set of tables each)
+        if thr:
+            os.environ["ALD_SINK_THREADS"] = thr
+        try:
+            flat = A.TranscriptSink(0.8); ref = A.TranscriptSink(0.8)
+            for part, s_, tb in ((pg, sid, 1 << 44), (other, sid2, 2 << 44)):
+                with A.DecompBatch(0) as b:
+                    b.add(part); b.upload(); b.run(); b.download()
+                    if thr:
+                        b.reduce_into(flat, s_, tid_base=tb)
+                    else:
+                        b.reduce_transcripts(s_, tid_base=tb, into=flat)
+                    one = A.TranscriptSink(0.8); one.add_batch(b, s_, tid_base=tb)
+                    ref.merge(one)
+            assert flat.items() == ref.items() and len(ref.items()) > 3000
+        finally:
+            os.environ.pop("ALD_SINK_THREADS", None)
 
 
 def test_transcript_stream_built_on_the_device():
