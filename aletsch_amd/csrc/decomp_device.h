@@ -1,20 +1,29 @@
 // decomp_device.h -- the per-graph decomposition engine executed by ONE 64-lane wavefront.
 //
-// One wavefront owns one splice graph.  The graph's hot state (sorted adjacency lists, endpoints,
-// creation ids, FP64 weights, degrees) is a file-scope LDS struct (g_H); cold per-edge / per-vertex
-// state (coverage bookkeeping, sample support, phasing lists, path bitmasks) lives in the wave's
-// private HBM slab, laid out at compile time.  Rule sweeps (reference scallop.cc:844-945,
-// 1180-1234) are evaluated one vertex per lane and reduced with ballots / shuffles; graph surgery
-// (scallop.cc:2198-2484, 1675-1986) and the router (router.cc) are scalar routines run by lane 0,
-// compiled as real functions (not inlined) to keep the register footprint small.
+// One wavefront owns one splice graph.  The graph's hot state (sorted adjacency lists, endpoints, creation ids, FP64 weights,
+// degrees: struct Hot) and the wave's context + exchange scratch (struct HotCtx) live in LDS; cold per-edge / per-vertex state
+// (coverage bookkeeping, sample support, phasing lists, path bitmasks) lives in the wave's private HBM slab, laid out at compile
+// time.  The slab-resident classes (the catch-all and the twins) keep Hot in the slab as well, HotCtx stays in LDS.
 //
-// Every function cites the reference file:line whose behaviour it reproduces.  Ordering rules are
-// the canonical ones of SURVEY.md Appendix A: edge "pointer order" == creation id.
+// Who runs what:
+//   * rule sweeps (scallop.cc:844-945, 1180-1234): one vertex per lane, ballots, one DPP arg-min per sweep;
+//   * the trivial decomposition (scallop.cc:2144-2576): the whole wave, one fan edge per lane (star_wave_body);
+//   * edge removal of the smallest-edge rule: two lanes, one per adjacency list (kill_edge_wave);
+//   * collecting finished source->sink paths: one path per lane (collect_existing_st_paths);
+//   * the router's inputs: gathered by the wave (router_prepare), the router itself (router.cc), the extend decomposition
+//     (scallop.cc:1675-1986), phasing-list edits and the greedy tail: scalar on lane 0, values marked wave-uniform (uni()) so that
+//     integer work runs on the SALU.  The wave-level drivers are inlined into the kernel root (one call site each); only cold
+//     paths are real calls.
+// Lanes hand values to each other through LDS (wsync() = wavefront-scope fence, no s_barrier: a workgroup is one wave), so the
+// single-lane emulation below runs every phase as a loop.
+//
+// Every function cites the reference file:line whose behaviour it reproduces.  Ordering rules are the canonical ones of SURVEY.md
+// Appendix A: edge "pointer order" == creation id (the rank handed across the ABI, else CSR position).
 //
 // Build modes (one translation unit per size class, -DALD_CLASS_ID=k):
 //   hipcc --offload-arch=gfx950   : the product (ALD_WAVE == 64).
-//   g++ -DALD_EMU                 : single-lane emulation, compiled ONLY by tests/kernel_emu to debug
-//                                   the algorithm on a CPU-only box.  Never part of the product library.
+//   g++ -DALD_EMU                 : single-lane emulation, compiled ONLY by tests/kernel_emu to check the algorithm against the
+//                                   oracle on a CPU-only box.  Never part of the product library.
 #pragma once
 #include "decomp_common.h"
 #ifdef ALD_EMU
@@ -23,7 +32,7 @@
 #endif
 
 #ifndef ALD_CLASS_ID
-#error "compile with -DALD_CLASS_ID=<0..4> (one translation unit per size class)"
+#error "compile with -DALD_CLASS_ID=<0..12> (one translation unit per size class)"
 #endif
 #if defined(__HIP__) || defined(__clang__)
   #define ALD_UNROLL _Pragma("unroll")
