@@ -46,8 +46,8 @@
 namespace ALD_CLASS_NS {
 using namespace ald;
 #ifdef ALD_EMU_COUNT
-static long g_cnt_router = 0, g_cnt_unsweep = 0, g_cnt_star[34] = {0}, g_cnt_rdeg[34] = {0};
-struct CntPrinter { ~CntPrinter() { if(g_cnt_unsweep) { fprintf(stderr, "[emu-count] class %d: unsplittable sweeps %ld router runs %ld\n", ALD_CLASS_ID, g_cnt_unsweep, g_cnt_router);
+static long g_cnt_router = 0, g_cnt_unsweep = 0, g_cnt_star[34] = {0}, g_cnt_rdeg[34] = {0}, g_cnt_build = 0, g_cnt_pre[3] = {0};
+struct CntPrinter { ~CntPrinter() { if(g_cnt_unsweep) { fprintf(stderr, "[emu-count] class %d: unsplittable sweeps %ld router runs %ld (of which reach build(): %ld; prepared at level 0/1/2: %ld %ld %ld)\n", ALD_CLASS_ID, g_cnt_unsweep, g_cnt_router, g_cnt_build, g_cnt_pre[0], g_cnt_pre[1], g_cnt_pre[2]);
     fprintf(stderr, "[emu-count]   stars by fan size:"); for(int i = 0; i < 34; i++) if(g_cnt_star[i]) fprintf(stderr, " %d:%ld", i, g_cnt_star[i]); fprintf(stderr, "\n");
     fprintf(stderr, "[emu-count]   router runs by degree:"); for(int i = 0; i < 34; i++) if(g_cnt_rdeg[i]) fprintf(stderr, " %d:%ld", i, g_cnt_rdeg[i]); fprintf(stderr, "\n"); } } }; static CntPrinter g_cnt_printer;
 #endif
@@ -1657,6 +1657,9 @@ ALD_INL bool sweep_smallest(double max_ratio)
 // instead of flat_* accesses); otherwise in the slab's work arrays
 template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_degree, int pre)
 {
+#ifdef ALD_EMU_COUNT
+    g_cnt_pre[pre < 0 ? 0 : pre > 2 ? 2 : pre]++;
+#endif
     COLD;
     // ---- build_indices (router.cc:225-248)
     int nin = uni(H.in_deg[root]), nout = uni(H.out_deg[root]), n = nin + nout;
@@ -1724,7 +1727,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     }
 #define ALD_COMMON(l, r) ((ncnt[l] == 1 && ncnt[r] == 1) ? ((nsid[l] == nsid[r]) ? (0.0 + (0.99 * ((nabd[r] < nabd[l]) ? nabd[r] : nabd[l]) + 0.01 * ((nabd[l] < nabd[r]) ? nabd[r] : nabd[l]))) : 0.0) : common_abd(u2e[l], u2e[r]))
     if(pre == 2) {
-        // the wave left every node's (partner, shared abundance, share of the total) in comp / nabd / econf (router_prepare): what stays
+        // the wave left every node's (partner, shared abundance, log of its share of the total) in comp / nabd / econf (router_prepare): what stays
         // sequential is which nodes are still isolated when their turn comes
         for(int v = 0; v < n; v++) {
             if(iso[v] == 2) continue;
@@ -1781,6 +1784,9 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     HC.ro_type = rtype; HC.ro_degree = rdeg;
     if(rtype != want_type) return true;
     if(rdeg > max_degree) return true;
+#ifdef ALD_EMU_COUNT
+    g_cnt_build++;
+#endif
     // ---- build() -> thread() (router.cc:193-223, 738-857)
     // compute_balanced_weights_components (router.cc:1248-1275): components by smallest member, members ascending
     for(int i = 0; i < n; i++) vw[i] = 0;
@@ -1838,7 +1844,8 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     HC.ro_ratio = weight_remain / weight_sum;
     // router.cc:849-855: side effect of every build().  (pre: the wave fetched the confidences with the rest -- router_prepare --, so
     // the updates are stores only instead of one global round trip per attached node)
-    if(pre) { const double *ecf = AR.d + ARENA_D - n; for(int i = 0; i < n; i++) if(iso[i] == 1) C.ed[u2e[i]].econf = ecf[i] + log(econf[i]); }
+    if(pre == 2) { const double *ecf = AR.d + ARENA_D - n; for(int i = 0; i < n; i++) if(iso[i] == 1) C.ed[u2e[i]].econf = ecf[i] + econf[i]; }     // econf[] already holds the logarithms
+    else if(pre) { const double *ecf = AR.d + ARENA_D - n; for(int i = 0; i < n; i++) if(iso[i] == 1) C.ed[u2e[i]].econf = ecf[i] + log(econf[i]); }
     else for(int i = 0; i < n; i++) if(iso[i] == 1) C.ed[u2e[i]].econf += log(econf[i]);
     sort_pairs(PW, np);
     const double mw = HC.p_min_w;
@@ -1853,7 +1860,7 @@ ALD_FN bool router_large(int root, int want_type, int max_degree) { return route
 // global loads for the vertex instead of one round trip per edge on lane 0.  And where the attachment of isolated nodes is a pure
 // table (no phasing routes, every edge supported by ONE sample: router.cc:1010-1129 reduces to arithmetic on (sample id, abundance)
 // pairs) lane l also finds the partner l would attach to -- best shared abundance, first of equals, with the sum over all candidates
-// in their order -- and leaves (partner, that abundance, its share) where the sequential attachment picks them up.
+// in their order -- and leaves (partner, that abundance, the logarithm of its share) where the sequential attachment picks them up.
 ALD_INL int router_prepare(int root)
 {
     COLD;
@@ -1892,7 +1899,7 @@ ALD_INL int router_prepare(int root)
             const double c = (nsid[r] == sv) ? (0.0 + (0.99 * ((arr < al) ? arr : al) + 0.01 * ((al < arr) ? arr : al))) : 0.0;
             sum_abd += c; if(c > max_abd) { max_abd = c; pt = r; }
         }
-        partner[q] = pt; mabd[q] = max_abd; share[q] = max_abd / sum_abd;
+        partner[q] = pt; mabd[q] = max_abd; share[q] = log(max_abd / sum_abd);      // the logarithm build() adds to the edge's confidence (router.cc:849-855): one per lane, at once
     } }
     wsync();                                                                   // every lane has read ncnt / nsid / nabd: their places take the results
     { int q = 0; for(int v = lane; v < n; v += ALD_WAVE, q++) { ncnt[v] = partner[q]; nabd[v] = mabd[q]; econf[v] = share[q]; } }
