@@ -1861,7 +1861,7 @@ ALD_FN bool router_large(int root, int want_type, int max_degree) { return route
 // table (no phasing routes, every edge supported by ONE sample: router.cc:1010-1129 reduces to arithmetic on (sample id, abundance)
 // pairs) lane l also finds the partner l would attach to -- best shared abundance, first of equals, with the sum over all candidates
 // in their order -- and leaves (partner, that abundance, the logarithm of its share) where the sequential attachment picks them up.
-ALD_INL int router_prepare(int root)
+ALD_FN int router_prepare(int root)
 {
     COLD;
     root = uni(root);
