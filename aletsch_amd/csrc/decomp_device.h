@@ -2073,7 +2073,7 @@ ALD_FN void materialize_special()
 // scallop::collect_existing_st_paths (scallop.cc:2742-2752): ascending edge index == ascending creation id.
 // out(0) / in(sink) are not linked at this point (see link_out): the source->sink edges are picked out of the slot array by the
 // whole wave and ordered by id on lane 0; collect_path's remove_edge then only counts.  Called by ALL lanes.
-ALD_INL void collect_existing_st_paths()
+ALD_FN void collect_existing_st_paths()
 {
     COLD;
     const int lane = lane_id();
@@ -2232,7 +2232,7 @@ ALD_FN void greedy_decompose()
 }
 
 // ---------------------------------------------------------------- load: packed wire arrays -> working state (wave-parallel)
-ALD_INL bool load_graph()
+ALD_FN bool load_graph()
 {
     COLD;
     const int lane = lane_id();
@@ -2307,7 +2307,7 @@ ALD_INL bool load_graph()
     return HC.status == 0;
 }
 
-ALD_INL void finish_graph()
+ALD_FN void finish_graph()
 {
     if(lane_id() == 0) {
         ALD_GLOBAL const KernelArgs *A = HC.args; const int g = HC.g;
