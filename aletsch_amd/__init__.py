@@ -10,9 +10,9 @@ from .packed import PackedGraphs, DecompResult
 from .native import (DecompBatch, DecompError, default_params, load_library, library_path, synth,
                      subsetsum_batch, decompose, SynthSpec, AldParams, TranscriptSink, records_add_graph_offset,
                      TrstFeatures, GraphExtras, FEATURE_FIELDS, format_transcript, format_features, transcript_id,
-                     GraphView, PhaseView, pre_assemble)
+                     GraphView, PhaseView, pre_assemble, reduce_stream)
 
 __all__ = ["PackedGraphs", "DecompResult", "DecompBatch", "DecompError", "default_params", "load_library",
            "library_path", "synth", "subsetsum_batch", "decompose", "SynthSpec", "AldParams", "TranscriptSink", "records_add_graph_offset",
            "TrstFeatures", "GraphExtras", "FEATURE_FIELDS", "format_transcript", "format_features", "transcript_id",
-           "GraphView", "PhaseView", "pre_assemble"]
+           "GraphView", "PhaseView", "pre_assemble", "reduce_stream"]

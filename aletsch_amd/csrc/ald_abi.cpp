@@ -43,15 +43,11 @@ const hot_fn k_hot[ALD_NUM_CLASSES] = { ALD_FOR_EACH_CLASS(ALD_H) };
 
 namespace {
 
-// per-graph index over the raw record stream (consumer-side work, done once on first access)
+// the decoded path table of a downloaded batch.  ald_batch_download builds it from the index the kernel wrote (no parse of the record
+// stream), so there is nothing left to do here but to refuse a batch that has not been downloaded.
 int ensure_index(const ald_batch *cb)
 {
-    ald_batch *b = const_cast<ald_batch*>(cb);
-    if(!b->downloaded) return set_err(ALD_ERR_STATE, "results requested before ald_batch_download");
-    if(b->indexed) return ALD_OK;
-    int rc = b->res.build(b->hb.n(), b->n_paths);
-    if(rc != 0) return set_err(ALD_ERR_STATE, "path record stream is inconsistent (rc=" + std::to_string(rc) + ")");
-    b->indexed = true;
+    if(!cb->downloaded) return set_err(ALD_ERR_STATE, "results requested before ald_batch_download");
     return ALD_OK;
 }
 
@@ -108,6 +104,7 @@ int stage_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], i
         A.in = b->hb.make_batch_in((uint8_t*)b->d_in.p, b->sec);
         A.out.status = (int32_t*)b->d_status.p; A.out.n_paths = (int32_t*)b->d_npaths.p; A.out.n_iters = (int32_t*)b->d_niters.p;
         A.out.pool_used = (unsigned long long*)b->d_poolused.p; A.out.pool = (uint32_t*)b->d_pool.p; A.out.pool_cap = b->pool_cap_words;
+        A.out.index_used = (unsigned long long*)b->d_poolused.p + 1; A.out.index = (unsigned long long*)b->d_index.p; A.out.index_cap = b->index_cap; A.out.graph_first = (long long*)b->d_gfirst.p;
         A.out.trace_cap = b->trace_cap; A.out.trace_n = (int32_t*)b->d_trace_n.p; A.out.trace_codes = (int32_t*)b->d_trace_codes.p; A.out.trace_vals = (double*)b->d_trace_vals.p;
         A.prm = b->prm;
         A.work = (const int32_t*)b->d_work.p + woff; A.n_work = (int32_t)work[c].size(); A.attempt = pass;
@@ -145,6 +142,7 @@ bool refresh_pass_args(ald_batch *b, StagedPass &P)
         KernelArgs &A = P.args[c];
         if(A.slabs != (uint8_t*)b->d_slabs[c].p) { A.slabs = (uint8_t*)b->d_slabs[c].p; changed = true; }
         if(A.out.pool != (uint32_t*)b->d_pool.p || A.out.pool_cap != b->pool_cap_words) { A.out.pool = (uint32_t*)b->d_pool.p; A.out.pool_cap = b->pool_cap_words; changed = true; }
+        if(A.out.index != (unsigned long long*)b->d_index.p || A.out.index_cap != b->index_cap) { A.out.index = (unsigned long long*)b->d_index.p; A.out.index_cap = b->index_cap; changed = true; }
     }
     return changed;
 }
@@ -218,8 +216,8 @@ int ald_batch_destroy(ald_batch *b)
     if(!b) return ALD_OK;
     hipSetDevice(b->device);
     if(b->stream) hipStreamSynchronize(b->stream);
-    b->pin_in.release(); b->pin_out.release(); b->pin_small.release(); delete b->pass0; b->pass0 = nullptr;
-    DevBuf *bufs[] = {&b->d_in, &b->d_status, &b->d_npaths, &b->d_niters, &b->d_pool, &b->d_poolused, &b->d_trace_n, &b->d_trace_codes, &b->d_trace_vals, &b->d_work, &b->d_counter, &b->d_args};
+    b->pin_in.release(); b->pin_out.release(); b->pin_small.release(); b->pin_index.release(); delete b->pass0; b->pass0 = nullptr;
+    DevBuf *bufs[] = {&b->d_in, &b->d_status, &b->d_npaths, &b->d_niters, &b->d_pool, &b->d_poolused, &b->d_index, &b->d_gfirst, &b->d_pbegin, &b->d_ordoff, &b->d_trace_n, &b->d_trace_codes, &b->d_trace_vals, &b->d_work, &b->d_counter, &b->d_args};
     for(DevBuf *d : bufs) d->release();
     for(int c = 0; c < ALD_NUM_CLASSES; c++) b->d_slabs[c].release();
     for(DevBuf &d : b->red) d.release();
@@ -299,7 +297,9 @@ int ald_batch_upload(ald_batch *b)
     uint64_t pool = 0; for(int g = 0; g < n; g++) pool += 16ull * b->hb.g_ne[g] + 256;
     if(const char *ev = getenv("ALD_DEBUG_POOL_WORDS")) { const long long k = atoll(ev); if(k > 0 && (uint64_t)k < pool) pool = (uint64_t)k; }
     b->pool_cap_words = pool;
-    if(b->d_status.ensure(4 * (size_t)n + 4) || b->d_npaths.ensure(4 * (size_t)n + 4) || b->d_niters.ensure(4 * (size_t)n + 4) || b->d_pool.ensure(4 * pool + 64) || b->d_poolused.ensure(64))
+    b->index_cap = pool / (REC_HDR_WORDS + 2) + 1;         // a record is at least a header and two vertices long
+    if(b->d_status.ensure(4 * (size_t)n + 4) || b->d_npaths.ensure(4 * (size_t)n + 4) || b->d_niters.ensure(4 * (size_t)n + 4) || b->d_pool.ensure(4 * pool + 64) || b->d_poolused.ensure(64)
+       || b->d_index.ensure(8 * (size_t)b->index_cap + 64) || b->d_gfirst.ensure(8 * (size_t)n + 8))
         return set_err(ALD_ERR_NOMEM, "device output buffers");
     if(b->trace_cap > 0) {
         if(b->d_trace_n.ensure(4 * (size_t)n + 4) || b->d_trace_codes.ensure(12ull * n * b->trace_cap + 4) || b->d_trace_vals.ensure(8ull * n * b->trace_cap + 8)) return set_err(ALD_ERR_NOMEM, "trace buffers");
@@ -396,10 +396,11 @@ int ald_batch_download(ald_batch *b)
     // Everything comes back through async copies on the batch's OWN stream into pinned memory.  (A synchronous hipMemcpy runs on the
     // null stream, which waits for every blocking stream of the device -- i.e. for the kernel of the NEXT batch, already in flight in a
     // pipelined caller: the download of batch k took as long as the kernel of batch k+1, and its record copy ran between two kernels.)
-    if(b->pin_small.ensure(64 + 12 * (size_t)n + 64, true)) return set_err(ALD_ERR_NOMEM, "pinned status buffer");
+    if(b->pin_small.ensure(64 + 20 * (size_t)n + 64, true)) return set_err(ALD_ERR_NOMEM, "pinned status buffer");
     unsigned long long *h_used = (unsigned long long*)b->pin_small.p;
-    int32_t *st = (int32_t*)((uint8_t*)b->pin_small.p + 64), *h_np = st + n, *h_ni = h_np + n;
-    unsigned long long used = 0;
+    long long *h_gf = (long long*)((uint8_t*)b->pin_small.p + 64);
+    int32_t *st = (int32_t*)(h_gf + n), *h_np = st + n, *h_ni = h_np + n;
+    unsigned long long used = 0, iused = 0;
   for(int regrow = 0; ; regrow++) {
     bool pool_full = false;
     for(int pass = 0; pass <= ALD_NUM_CLASSES; pass++) {
@@ -423,7 +424,7 @@ int ald_batch_download(ald_batch *b)
         int rc = launch_pass(b, work, pass + 1);
         if(rc != ALD_OK) return rc;
     }
-    HIPCHK(hipMemcpyAsync(h_used, b->d_poolused.p, 8, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream)); used = *h_used;
+    HIPCHK(hipMemcpyAsync(h_used, b->d_poolused.p, 16, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream)); used = h_used[0]; iused = h_used[1];
     if(!pool_full) break;
     // Some graph found the record pool full.  Records behind the first refused one may be missing (the bump pointer moved, nothing was
     // written), so the stream of this run is unusable as a whole: the pool grows -- `used` counts every request made, a lower bound
@@ -433,27 +434,42 @@ int ald_batch_download(ald_batch *b)
     uint64_t want = std::max<uint64_t>(2 * b->pool_cap_words, used + used / 4 + 4096);
     if(b->d_pool.ensure(4 * want + 64)) return set_err(ALD_ERR_NOMEM, "record pool");
     b->pool_cap_words = want;
+    b->index_cap = std::max<uint64_t>(want / (REC_HDR_WORDS + 2) + 1, iused + iused / 4 + 64);
+    if(b->d_index.ensure(8 * (size_t)b->index_cap + 64)) return set_err(ALD_ERR_NOMEM, "result index");
     int rc = start_run(b);
     if(rc != ALD_OK) return rc;
   }
     if(used > b->pool_cap_words) used = b->pool_cap_words;
+    if(iused > b->index_cap) iused = b->index_cap;
     b->res.clear();
     // the records land in a pinned buffer (kept across runs) through an async copy on the batch stream: the copy engine moves them
     // while another batch's kernel may be running, and the host thread only waits
-    if(b->pin_out.ensure(4 * (size_t)used + 64, true)) return set_err(ALD_ERR_NOMEM, "pinned result buffer");
+    if(b->pin_out.ensure(4 * (size_t)used + 64, true) || b->pin_index.ensure(8 * (size_t)iused + 64, true)) return set_err(ALD_ERR_NOMEM, "pinned result buffer");
     P3 = std::chrono::steady_clock::now();
     if(n > 0) {
         HIPCHK(hipMemcpyAsync(h_np, b->d_npaths.p, 4 * (size_t)n, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipMemcpyAsync(h_ni, b->d_niters.p, 4 * (size_t)n, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipMemcpyAsync(h_gf, b->d_gfirst.p, 8 * (size_t)n, hipMemcpyDeviceToHost, b->stream));
     }
+    if(iused) HIPCHK(hipMemcpyAsync(b->pin_index.p, b->d_index.p, 8 * iused, hipMemcpyDeviceToHost, b->stream));
     if(used) HIPCHK(hipMemcpyAsync(b->pin_out.p, b->d_pool.p, 4 * used, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    const auto P3b = std::chrono::steady_clock::now();
     if(n > 0) { memcpy(b->n_paths.data(), h_np, 4 * (size_t)n); memcpy(b->n_iters.data(), h_ni, 4 * (size_t)n); }
-    if(prof) { auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
-        fprintf(stderr, "[download] wait for the kernel %.2f ms, status copy %.2f ms, retries + counters %.2f ms, records (%.0f MB) %.2f ms\n", ms(P0, P1), ms(P1, P2), ms(P2, P3), 4e-6 * (double)used, ms(P3, std::chrono::steady_clock::now())); }
     b->res.ext_pool = (const uint32_t*)b->pin_out.p; b->res.ext_words = used;
-    b->res.status = b->status; b->res.n_iters = b->n_iters; b->res.attempt = b->attempt;
-    b->indexed = false;
+    b->res.status = b->status; b->res.n_iters = b->n_iters;
+    // paths AND transcripts of the batch, decoded, in host memory: every record is reached through the index the kernel wrote
+    // (index[graph_first[g] + p]); exons are already joined inside the records; coverage = log(1 + weight) with the host's libm
+    b->total_paths = 0; b->paths_on_device = false;
+    {
+        const int rc = b->res.build(n, b->n_paths.data(), (const unsigned long long*)b->pin_index.p, iused, h_gf);
+        if(rc != 0) return set_err(ALD_ERR_STATE, "result index is inconsistent with the record pool (rc=" + std::to_string(rc) + ")");
+        b->total_paths = (int64_t)b->res.paths.size();
+    }
+    { auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+      b->dl_ms[0] = ms(P0, P1); b->dl_ms[1] = ms(P1, P3); b->dl_ms[2] = ms(P3, P3b); b->dl_ms[3] = ms(P3b, std::chrono::steady_clock::now()); b->dl_bytes = 4 * (int64_t)used + 8 * (int64_t)iused + 20 * (int64_t)n; }
+    if(prof) { auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+        fprintf(stderr, "[download] wait for the kernel %.2f ms, status copy %.2f ms, retries + counters %.2f ms, records + index (%.0f MB) + decode of %lld paths %.2f ms\n", ms(P0, P1), ms(P1, P2), ms(P2, P3), 4e-6 * (double)used + 8e-6 * (double)iused, (long long)b->total_paths, ms(P3, std::chrono::steady_clock::now())); }
     if(b->trace_cap > 0 && n > 0) {
         b->trace_n.resize(n); b->trace_codes.resize(3ull * n * b->trace_cap); b->trace_vals.resize((size_t)n * b->trace_cap);
         HIPCHK(hipMemcpy(b->trace_n.data(), b->d_trace_n.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
@@ -465,6 +481,25 @@ int ald_batch_download(ald_batch *b)
 }
 
 double ald_batch_last_kernel_ms(const ald_batch *b) { return b ? b->kernel_ms : -1; }
+
+int ald_batch_last_download_ms(const ald_batch *b, double *wait_kernel_ms, double *status_retries_ms, double *copy_ms, double *decode_ms, int64_t *bytes_to_host)
+{
+    if(!b) return ALD_ERR_INVALID;
+    if(wait_kernel_ms) *wait_kernel_ms = b->dl_ms[0]; if(status_retries_ms) *status_retries_ms = b->dl_ms[1]; if(copy_ms) *copy_ms = b->dl_ms[2]; if(decode_ms) *decode_ms = b->dl_ms[3];
+    if(bytes_to_host) *bytes_to_host = b->dl_bytes;
+    return ALD_OK;
+}
+
+/* the result index as the kernel wrote it (host copies of the last download): index[graph_first[g] + p] = word offset of record (g, p)
+ * in the raw record stream; graph_first[g] = -1 for a graph without paths or one that did not end well */
+int ald_batch_result_index(const ald_batch *b, const uint64_t **index, int64_t *n_entries, const int64_t **graph_first)
+{
+    if(!b || !b->downloaded) return set_err(ALD_ERR_STATE, "ald_batch_result_index before ald_batch_download");
+    if(index) *index = (const uint64_t*)b->pin_index.p;
+    if(n_entries) *n_entries = b->total_paths;
+    if(graph_first) *graph_first = (const int64_t*)((const uint8_t*)b->pin_small.p + 64);
+    return ALD_OK;
+}
 
 int ald_batch_algorithmic_bytes(const ald_batch *b, int64_t *in_bytes, int64_t *out_bytes)
 {
@@ -522,47 +557,29 @@ int ald_batch_get_trace(const ald_batch *b, int32_t graph, int32_t *n_events, co
     return ALD_OK;
 }
 
-/* scallop::build_transcripts / build_transcript (scallop.cc:3250-3266, essential.cc:719-748): exon join + coverage, host side */
-static void join_exons(const ald_batch *b, int32_t graph, const PathRec &p, std::vector<int32_t> &ex)
-{
-    const int64_t ov = b->hb.off_v[graph];
-    const uint32_t *v = b->res.vertices(p);
-    ex.clear();
-    for(int k = 1; k + 1 < p.nv; k++) {
-        int32_t l = b->hb.vertex_lpos[ov + v[k]], r = b->hb.vertex_rpos[ov + v[k]];
-        if(l >= r) continue;                                  // empty interval: vanishes in the interval map
-        if(!ex.empty() && ex.back() == l) ex.back() = r;      // touching intervals with the same value join
-        else { ex.push_back(l); ex.push_back(r); }
-    }
-}
-
+/* scallop::build_transcripts / build_transcript (scallop.cc:3250-3266, essential.cc:719-748): the exon join is done by the kernel
+ * (the record of a path carries the exons of its transcript), coverage = log(1 + weight) by ald_batch_download */
 int ald_batch_get_transcript(const ald_batch *b, int32_t graph, int32_t path, ald_transcript_view *out)
 {
     if(!b || !out || !b->downloaded || graph < 0 || graph >= b->hb.n()) return ALD_ERR_INVALID;
-    { int rc = ensure_index(b); if(rc != ALD_OK) return rc; }
     int64_t i = b->res.path_begin[graph] + path;
     if(path < 0 || i >= b->res.path_begin[graph + 1]) return ALD_ERR_INVALID;
-    static thread_local std::vector<int32_t> ex;
     const PathRec &p = b->res.paths[i];
-    join_exons(b, graph, p, ex);
-    out->num_exons = (int32_t)(ex.size() / 2); out->exons = ex.data();
-    out->coverage = log(1.0 + p.weight); out->conf = p.conf; out->abd = p.abd; out->count1 = p.count; out->strand = p.strand;
+    out->num_exons = p.nexw / 2; out->exons = b->res.exons(p);
+    out->coverage = p.coverage; out->conf = p.conf; out->abd = p.abd; out->count1 = p.count; out->strand = p.strand;
     return ALD_OK;
 }
 
 int ald_batch_export_transcripts(const ald_batch *b, int64_t *total_exons, double *coverage, int64_t *exon_offset, int32_t *exon_lr)
 {
     if(!b || !b->downloaded) return set_err(ALD_ERR_STATE, "ald_batch_export_transcripts before ald_batch_download");
-    { int rc = ensure_index(b); if(rc != ALD_OK) return rc; }
-    std::vector<int32_t> ex; int64_t te = 0, it = 0;
-    const int n = b->hb.n();
-    for(int g = 0; g < n; g++) for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++, it++) {
-        const PathRec &p = b->res.paths[i];
-        join_exons(b, g, p, ex);
-        if(coverage) { coverage[it] = log(1.0 + p.weight); exon_offset[it] = te; for(size_t k = 0; k < ex.size(); k++) exon_lr[2 * te + k] = ex[k]; }
-        te += (int64_t)(ex.size() / 2);
+    int64_t te = 0; const int64_t np = (int64_t)b->res.paths.size();
+    for(int64_t i = 0; i < np; i++) {
+        const PathRec &p = b->res.paths[(size_t)i];
+        if(coverage) { coverage[i] = p.coverage; exon_offset[i] = te; if(p.nexw) memcpy(exon_lr + 2 * te, b->res.exons(p), 4 * (size_t)p.nexw); }
+        te += p.nexw / 2;
     }
-    if(coverage) exon_offset[it] = te;
+    if(coverage) exon_offset[np] = te;
     if(total_exons) *total_exons = te;
     return ALD_OK;
 }
@@ -592,7 +609,6 @@ int ald_tset_add(ald_tset *t, int32_t n_groups, const int64_t *group_offset, con
 }
 
 } // extern "C"  (the helpers below are templates / C++ types)
-static void join_exons(const ald_batch *b, int32_t graph, const PathRec &p, std::vector<int32_t> &ex);
 namespace {
 unsigned sink_threads(int64_t n_transcripts)
 {
@@ -633,24 +649,6 @@ template<class Make> void merge_groups(ald_tset *t, unsigned nthr, int64_t n_gro
     });
 }
 
-// joined exons of every path of a downloaded batch, one slot per path sized by its internal vertices (pass 1 of both consumers below)
-struct JoinedExons { std::vector<int64_t> off; std::vector<int32_t> len; rvec<int32_t> words; };
-void join_all(const ald_batch *b, unsigned nthr, JoinedExons &J)
-{
-    const int n = b->hb.n(); const int64_t np = (int64_t)b->res.paths.size();
-    J.off.assign((size_t)np + 1, 0); J.len.assign((size_t)np, 0);
-    for(int64_t i = 0; i < np; i++) J.off[(size_t)i + 1] = J.off[(size_t)i] + 2 * (int64_t)(b->res.paths[(size_t)i].nv > 2 ? b->res.paths[(size_t)i].nv - 2 : 0);
-    J.words.resize((size_t)J.off[(size_t)np] + 2);
-    HostBatch::run_threads(nthr, [&](unsigned th) {
-        std::vector<int32_t> ex;
-        const int g0 = (int)((int64_t)n * th / nthr), g1 = (int)((int64_t)n * (th + 1) / nthr);
-        for(int g = g0; g < g1; g++) for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++) {
-            join_exons(b, g, b->res.paths[i], ex);
-            J.len[(size_t)i] = (int32_t)ex.size();
-            if(!ex.empty()) memcpy(&J.words[(size_t)J.off[(size_t)i]], ex.data(), 4 * ex.size());
-        }
-    });
-}
 } // namespace
 
 extern "C" {
@@ -658,32 +656,28 @@ int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int6
 {
     if(!t || !b || !b->downloaded) return ALD_ERR_INVALID;
     auto T0 = std::chrono::steady_clock::now();
-    { int rc = ensure_index(b); if(rc != ALD_OK) return rc; }
-    auto T1 = std::chrono::steady_clock::now();
     const int n = b->hb.n();
     const int64_t np = (int64_t)b->res.paths.size();
     const unsigned nthr = sink_threads(np);
-    // pass 1 (graphs split over the threads, everything local to a graph still in cache): joined exons and bucket of every transcript
-    JoinedExons J; join_all(b, nthr, J);
+    // pass 1: bucket of every transcript (the exons are in the records, joined by the kernel)
     std::vector<uint32_t> bucket((size_t)np, ALD_NO_BUCKET);
     HostBatch::run_threads(nthr, [&](unsigned th) {
         for(int64_t i = np * th / nthr; i < np * (th + 1) / nthr; i++) {
-            if(J.len[(size_t)i] <= 2 && skip_single_exon) continue;            // assembler.cc:1117
-            bucket[(size_t)i] = (uint32_t)aletsch::sink_transcript::chain_key(&J.words[(size_t)J.off[(size_t)i]], (size_t)J.len[(size_t)i]);
+            const PathRec &p = b->res.paths[(size_t)i];
+            if(p.nexw <= 2 && skip_single_exon) continue;                      // assembler.cc:1117
+            bucket[(size_t)i] = (uint32_t)aletsch::sink_transcript::chain_key(b->res.exons(p), (size_t)p.nexw);
         }
     });
     auto T2 = std::chrono::steady_clock::now();
     // pass 2: thread th owns the tables th, th + nthr, ...
-    std::vector<int32_t> graph_of((size_t)np);
-    for(int g = 0; g < n; g++) for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++) graph_of[(size_t)i] = g;
     merge_groups(t, nthr, n, b->res.path_begin.data(), sid, bucket.data(), [&](int64_t i, aletsch::sink_transcript &x) {
-        const PathRec &p = b->res.paths[(size_t)i]; const int g = graph_of[(size_t)i];
-        x.strand = p.strand; x.coverage = log(1.0 + p.weight); x.top.cov2 = x.coverage; x.top.conf = p.conf; x.top.abd = p.abd; x.top.count1 = p.count; x.count2 = 1;
-        x.tid = tid_base + (((int64_t)g << 20) | (int64_t)(i - b->res.path_begin[g]));
-        const int32_t *ex = &J.words[(size_t)J.off[(size_t)i]];
-        x.xs.assign(ex, ex + J.len[(size_t)i]);
+        const PathRec &p = b->res.paths[(size_t)i];
+        x.strand = p.strand; x.coverage = p.coverage; x.top.cov2 = x.coverage; x.top.conf = p.conf; x.top.abd = p.abd; x.top.count1 = p.count; x.count2 = 1;
+        x.tid = tid_base + (((int64_t)p.graph << 20) | (int64_t)p.index);
+        const int32_t *ex = b->res.exons(p);
+        x.xs.assign(ex, ex + p.nexw);
     });
-    if(getenv("ALD_SINK_PROF")) { auto T3 = std::chrono::steady_clock::now(); auto ms = [](auto a, auto b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); }; fprintf(stderr, "[sink] index %.1f ms, hash pass %.1f ms, merge pass %.1f ms (%u threads)\n", ms(T0, T1), ms(T1, T2), ms(T2, T3), nthr); }
+    if(getenv("ALD_SINK_PROF")) { auto T3 = std::chrono::steady_clock::now(); auto ms = [](auto a, auto b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); }; fprintf(stderr, "[sink] hash pass %.1f ms, merge pass %.1f ms (%u threads)\n", ms(T0, T2), ms(T2, T3), nthr); }
     return ALD_OK;
 }
 
@@ -696,24 +690,21 @@ int ald_batch_transcript_stream(const ald_batch *cb, const int32_t *sid, int32_t
 {
     if(!cb || !words || !n_words) return ALD_ERR_INVALID;
     if(!cb->downloaded) return set_err(ALD_ERR_STATE, "ald_batch_transcript_stream before ald_batch_download");
-    { int rc = ensure_index(cb); if(rc != ALD_OK) return rc; }
     ald_batch *b = const_cast<ald_batch*>(cb);
-    const int n = b->hb.n(); const int64_t np = (int64_t)b->res.paths.size();
+    const int64_t np = (int64_t)b->res.paths.size();
     const unsigned nthr = sink_threads(np);
-    JoinedExons J; join_all(b, nthr, J);
     std::vector<int64_t> at((size_t)np + 1, 0);
-    for(int64_t i = 0; i < np; i++) at[(size_t)i + 1] = at[(size_t)i] + ((J.len[(size_t)i] <= 2 && skip_single_exon) ? 0 : TS_HDR + J.len[(size_t)i]);
+    for(int64_t i = 0; i < np; i++) { const int k = b->res.paths[(size_t)i].nexw; at[(size_t)i + 1] = at[(size_t)i] + ((k <= 2 && skip_single_exon) ? 0 : TS_HDR + k); }
     b->tstream.resize((size_t)at[(size_t)np] + 2);
     uint32_t *out = b->tstream.data();
     HostBatch::run_threads(nthr, [&](unsigned th) {
-        const int g0 = (int)((int64_t)n * th / nthr), g1 = (int)((int64_t)n * (th + 1) / nthr);
-        for(int g = g0; g < g1; g++) for(int64_t i = b->res.path_begin[g]; i < b->res.path_begin[g + 1]; i++) {
+        for(int64_t i = np * th / nthr; i < np * (th + 1) / nthr; i++) {
             if(at[(size_t)i + 1] == at[(size_t)i]) continue;
             const PathRec &p = b->res.paths[(size_t)i]; uint32_t *w = out + at[(size_t)i];
-            w[0] = (uint32_t)g; w[1] = (uint32_t)(i - b->res.path_begin[g]); w[2] = (uint32_t)(sid ? sid[g] : -1); w[3] = (uint32_t)(unsigned char)p.strand;
-            w[4] = (uint32_t)p.count; w[5] = (uint32_t)(J.len[(size_t)i] / 2);
+            w[0] = (uint32_t)p.graph; w[1] = (uint32_t)p.index; w[2] = (uint32_t)(sid ? sid[p.graph] : -1); w[3] = (uint32_t)(unsigned char)p.strand;
+            w[4] = (uint32_t)p.count; w[5] = (uint32_t)(p.nexw / 2);
             memcpy(w + 6, &p.weight, 8); memcpy(w + 8, &p.conf, 8); memcpy(w + 10, &p.abd, 8);
-            if(J.len[(size_t)i]) memcpy(w + TS_HDR, &J.words[(size_t)J.off[(size_t)i]], 4 * (size_t)J.len[(size_t)i]);
+            if(p.nexw) memcpy(w + TS_HDR, b->res.exons(p), 4 * (size_t)p.nexw);
         }
     });
     *words = out; *n_words = at[(size_t)np];
@@ -801,7 +792,7 @@ int ald_records_add_graph_offset(uint32_t *words, int64_t n_words, int32_t graph
     int64_t o = 0;
     while(o + REC_HDR_WORDS <= n_words) {
         words[o] += (uint32_t)graph_offset;
-        int64_t w = REC_HDR_WORDS + (int64_t)words[o + 2]; w += w & 1;
+        const int64_t w = (int64_t)rec_words(words[o + 2], words[o + REC_NEXW]);
         if(words[o + 2] < 2 || o + w > n_words) return set_err(ALD_ERR_INVALID, "malformed record stream");
         o += w;
     }

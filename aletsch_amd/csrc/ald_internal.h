@@ -42,8 +42,12 @@ struct ald_batch {
     // (4 by default) and streams beyond that share them in creation order, which can put the two heaviest classes behind each other
     hipStream_t cstream[ALD_SIDE_STREAMS_MAX] = {}; int n_cstream = ALD_SIDE_STREAMS;
     hipEvent_t cdone[ALD_NUM_CLASSES] = {};
-    PinBuf pin_in, pin_out, pin_small;                     // wire buffer / record landing area / status + counters landing area
+    PinBuf pin_in, pin_out, pin_small, pin_index;          // wire buffer / record landing area / status + counters landing area / the result index
     DevBuf d_in, d_status, d_npaths, d_niters, d_pool, d_poolused, d_trace_n, d_trace_codes, d_trace_vals, d_work, d_counter, d_args;
+    DevBuf d_index, d_gfirst;                              // result index written by the kernel: index[graph_first[g] + p] = pool offset of record (g, p)
+    DevBuf d_pbegin, d_ordoff;                             // the same in (graph, path) order, built on the device on demand (tset_reduce.hip: device_path_table)
+    uint64_t index_cap = 0; int64_t total_paths = 0; bool paths_on_device = false;
+    double dl_ms[4] = {0, 0, 0, 0}; int64_t dl_bytes = 0;   // last download: waiting for the kernel / status + retries / D2H copies / decode (diagnostics)
     DevBuf d_slabs[ALD_NUM_CLASSES];
     int blocks[ALD_NUM_CLASSES] = {};
     int occ[ALD_NUM_CLASSES]; ald_batch() { for(int c = 0; c < ALD_NUM_CLASSES; c++) occ[c] = -1; }
@@ -57,7 +61,6 @@ struct ald_batch {
     std::vector<int32_t> trace_n, trace_codes; std::vector<double> trace_vals;
     HostResults res;
     int passes = 0;
-    bool indexed = false;
     const void *launched_slab[ALD_NUM_CLASSES] = {};      // test hook (ald_batch_debug_slab)
     rvec<uint32_t> tstream;                                // last transcript stream built from this batch (ald_batch_transcript_stream)
     DevBuf red[20]; PinBuf red_pin[8];                     // scratch of ald_batch_reduce_transcripts, kept across calls (tset_reduce.hip)

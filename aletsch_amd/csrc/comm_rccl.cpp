@@ -128,10 +128,24 @@ int ald_comm_gather_streams(ald_comm *c, const uint32_t *words, int64_t n_words,
     }
     const int64_t total = c->offsets[(size_t)W];
     if(c->rank == 0) { if(c->d_recv.ensure(4 * (size_t)total + 64) || c->h_recv.ensure(4 * (size_t)total + 64)) return ald_set_err(ALD_ERR_NOMEM, "receive buffers"); }
-    NCHK(R.GroupStart());
-    if(n_words) NCHK(R.Send(src, (size_t)n_words, ncclUint32, 0, c->comm, c->stream));
-    if(c->rank == 0) for(int r = 0; r < W; r++) { const int64_t k = all[2 * (size_t)r]; if(k) NCHK(R.Recv((uint32_t*)c->d_recv.p + c->offsets[(size_t)r], (size_t)k, ncclUint32, r, c->comm, c->stream)); }
-    NCHK(R.GroupEnd());
+    // the grouped section never returns between GroupStart and GroupEnd: a failed Send / Recv is remembered, the group is closed (the
+    // calling thread must not stay in group mode: every later RCCL call on it would be deferred) and the stream drained -- it still
+    // holds the staging copy from the caller's buffer -- before the error goes back
+    {
+        NCHK(R.GroupStart());
+        ncclResult_t bad = ncclSuccess; const char *what = "";
+        if(n_words) { const ncclResult_t r_ = R.Send(src, (size_t)n_words, ncclUint32, 0, c->comm, c->stream); if(r_ != ncclSuccess) { bad = r_; what = "ncclSend"; } }
+        if(c->rank == 0) for(int r = 0; r < W && bad == ncclSuccess; r++) {
+            const int64_t k = all[2 * (size_t)r]; if(!k) continue;
+            const ncclResult_t r_ = R.Recv((uint32_t*)c->d_recv.p + c->offsets[(size_t)r], (size_t)k, ncclUint32, r, c->comm, c->stream);
+            if(r_ != ncclSuccess) { bad = r_; what = "ncclRecv"; }
+        }
+        const ncclResult_t ge = R.GroupEnd();
+        if(bad != ncclSuccess || ge != ncclSuccess) {
+            (void)hipStreamSynchronize(c->stream);
+            return ald_set_err(ALD_ERR_HIP, std::string(bad != ncclSuccess ? what : "ncclGroupEnd") + ": " + R.GetErrorString(bad != ncclSuccess ? bad : ge));
+        }
+    }
     if(c->rank == 0 && total) HCHK(hipMemcpyAsync(c->h_recv.p, c->d_recv.p, 4 * (size_t)total, hipMemcpyDeviceToHost, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
     if(all_words) *all_words = c->rank == 0 ? (const uint32_t*)c->h_recv.p : nullptr;

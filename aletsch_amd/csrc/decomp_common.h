@@ -124,9 +124,17 @@ enum { OP_BROKEN = 1, OP_TRIVIAL_FAST = 2, OP_TRIVIAL_NOW = 3, OP_TRIVIAL_BEST =
        OP_UNSPLIT_NOW = 7, OP_UNSPLIT_BEST = 8, OP_GREEDY = 9, OP_COLLECT = 10 };
 enum { HF_OCC = 1, HF_LEXT = 2, HF_REXT = 4 };
 enum { NZ_MEMBER = 1, NZ_MEMO_VALID = 2, NZ_MEMO_TYPE_SHIFT = 2 /* 3 bits */, NZ_MEMO_DEG_GT1 = 32 };      // bits of Hot::nz
-// path record (4-byte words): [0]=graph [1]=path index [2]=#vertices [3]=length [4]=count [5]=strand char
-//                             [6..13] = weight, abd, conf, reads (f64)   [14..14+nv) vertices, padded to an even word count
-enum { REC_HDR_WORDS = 14 };
+// path record (4-byte words): [0]=graph [1]=path index [2]=#vertices [3]=length [4]=count [5]=strand char | attempt << 8
+//                             [6..13] = weight, abd, conf, reads (f64)   [14] = #exon words (2 per exon)   [15] = 0
+//                             [16..16+nv) vertices, then the exon words (l, r)* of the transcript the path becomes -- touching
+//                             vertex intervals joined, empty ones dropped (essential.cc:719-748) --, padded to an even word count
+enum { REC_HDR_WORDS = 16, REC_NEXW = 14 };
+#if defined(__HIP__)
+  #define ALD_HD __host__ __device__
+#else
+  #define ALD_HD
+#endif
+ALD_HD static inline unsigned long long rec_words(unsigned nv, unsigned nexw) { unsigned long long w = (unsigned long long)REC_HDR_WORDS + nv + nexw; return w + (w & 1); }
 
 // ---- wire format as the kernel sees it: device pointers into ONE coalesced HBM buffer ----
 struct BatchIn {
@@ -147,6 +155,11 @@ struct BatchOut {
     ALD_GLOBAL int32_t *status, *n_paths, *n_iters;        // [n]
     ALD_GLOBAL unsigned long long *pool_used;              // words used (atomic bump)
     ALD_GLOBAL uint32_t *pool; unsigned long long pool_cap;// path-record pool (4-byte words)
+    // result index, written by the kernel: a graph that ENDS WELL reserves n_paths consecutive entries (one atomic per graph) and
+    // leaves the pool offsets of its records there in path order -- index[graph_first[g] + p] = word offset of record (g, p).
+    // Records of abandoned attempts are referenced by nothing.
+    ALD_GLOBAL unsigned long long *index_used; ALD_GLOBAL unsigned long long *index; unsigned long long index_cap;
+    ALD_GLOBAL long long *graph_first;                      // [n]
     ALD_GLOBAL int32_t *trace_n, *trace_codes; ALD_GLOBAL double *trace_vals; int32_t trace_cap;   // optional op trace
 };
 struct Params { double max_ratio[8]; double min_w; double min_cov; int32_t max_num_exons; int32_t pad; };
@@ -217,7 +230,9 @@ struct ColdLayoutT {
     static constexpr uint64_t o_hlcnt = al(o_hlcapk + 4ull * HL_MAXLISTS);
     static constexpr uint64_t o_wi = al(o_hlcnt + 4ull * HL_MAXLISTS);
     static constexpr uint64_t o_wd = al(o_wi + 4ull * W_CAP);
-    static constexpr uint64_t total = (o_wd + 8ull * W_CAP + 255) / 256 * 256;
+    static constexpr int32_t  PO_CAP = MAXE;             // record offsets of the graph at hand, in path order (published by finish_graph)
+    static constexpr uint64_t o_po = al(o_wd + 8ull * W_CAP);
+    static constexpr uint64_t total = (o_po + 8ull * PO_CAP + 255) / 256 * 256;
 };
 
 struct ClassInfo { int maxv, maxe, nw; uint32_t sp_cap, hl_cap; uint64_t slab_bytes; };

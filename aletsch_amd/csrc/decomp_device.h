@@ -140,6 +140,8 @@ struct Cold {
     ALD_GLOBAL int32_t *sp_id; ALD_GLOBAL double *sp_abd;
     ALD_GLOBAL int32_t *hl, *hl_off, *hl_len, *hl_capk, *hl_cnt;   // phasing lists (hyper_set::edges / ecnts); elements are edge SLOTS or -1
     ALD_GLOBAL int32_t *wi; ALD_GLOBAL double *wd;                 // scalar work arrays
+    ALD_GLOBAL unsigned long long *po;                             // pool offsets of this graph's records, in path order
+    static constexpr int32_t po_cap = CL::PO_CAP;
     static constexpr uint32_t sp_cap = CL::SP_CAP, hl_cap = CL::HL_CAP;
     static constexpr int32_t hl_maxlists = CL::HL_MAXLISTS, w_cap = CL::W_CAP;
 };
@@ -151,6 +153,7 @@ ALD_INL Cold cold_view()
     C.hl = (ALD_GLOBAL int32_t*)(b + CL::o_hl); C.hl_off = (ALD_GLOBAL int32_t*)(b + CL::o_hloff); C.hl_len = (ALD_GLOBAL int32_t*)(b + CL::o_hllen);
     C.hl_capk = (ALD_GLOBAL int32_t*)(b + CL::o_hlcapk); C.hl_cnt = (ALD_GLOBAL int32_t*)(b + CL::o_hlcnt);
     C.wi = (ALD_GLOBAL int32_t*)(b + CL::o_wi); C.wd = (ALD_GLOBAL double*)(b + CL::o_wd);
+    C.po = (ALD_GLOBAL unsigned long long*)(b + CL::o_po);
     return C;
 }
 #define COLD const Cold C = cold_view()
@@ -2029,15 +2032,18 @@ ALD_FN void collect_path(int e)
     COLD;
     ALD_GLOBAL const KernelArgs *A = HC.args;
     int n = HC.V0 - 1;                           // v2v[sink]: the sink's original index
-    int cnt = 0, mi = 0; bool empty = false;
-    for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.ed[e].mask[k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; cnt++; mi += uni(C.vx[x].rpos) - uni(C.vx[x].lpos); if(C.vx[x].vtype == K_EMPTY_VERTEX) empty = true; } }
+    int cnt = 0, mi = 0, nexw = 0, last_r = INT_MIN; bool empty = false;      // nexw: exon words of the transcript (build_transcript, essential.cc:719-748)
+    for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.ed[e].mask[k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; cnt++; const int l = uni(C.vx[x].lpos), r = uni(C.vx[x].rpos); mi += r - l; if(C.vx[x].vtype == K_EMPTY_VERTEX) empty = true;
+        if(l < r) { if(nexw == 0 || last_r != l) nexw += 2; last_r = r; } } }
     if(ALD_UNLIKELY(C.ed[e].mei != mi || cnt == 0)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
     if(C.vx[0].vtype == K_EMPTY_VERTEX || uni(C.vx[n].vtype) == K_EMPTY_VERTEX) empty = true;
     if(!empty) {
         int nvp = cnt + 2;
-        unsigned long long words = (unsigned long long)(REC_HDR_WORDS + nvp + ((REC_HDR_WORDS + nvp) & 1));
+        if(ALD_UNLIKELY(HC.n_paths >= C.po_cap)) { fail(ALD_ST_CAPACITY); return; }
+        unsigned long long words = rec_words((unsigned)nvp, (unsigned)nexw);
         unsigned long long o = atomic_add_u64(A->out.pool_used, words);
         if(ALD_UNLIKELY(o + words > A->out.pool_cap)) { fail(ALD_ST_POOL_FULL); return; }     // not this graph's class that is too small: the host grows the pool
+        C.po[HC.n_paths] = o;
         ALD_GLOBAL uint32_t *r = A->out.pool + o;
         int st = '.';
         if(C.ed[e].estrand == 1) st = '+';
@@ -2050,7 +2056,10 @@ ALD_FN void collect_path(int e)
         pv[w++] = 0;
         for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.ed[e].mask[k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; pv[w++] = (uint32_t)(k * 64 + b); } }
         pv[w++] = (uint32_t)n;
-        if((REC_HDR_WORDS + nvp) & 1) pv[w] = 0;
+        r[REC_NEXW] = (uint32_t)nexw; r[REC_NEXW + 1] = 0;
+        { int q = 0; for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.ed[e].mask[k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; const int l = uni(C.vx[x].lpos), rr = uni(C.vx[x].rpos);
+            if(l >= rr) continue; if(q > 0 && (int)pv[w + q - 1] == l) pv[w + q - 1] = (uint32_t)rr; else { pv[w + q] = (uint32_t)l; pv[w + q + 1] = (uint32_t)rr; q += 2; } } } w += q; }
+        if((REC_HDR_WORDS + nvp + nexw) & 1) pv[w] = 0;
         if(tracing()) { int save = HC.n_iters; trace(OP_COLLECT, (int)uni(H.eid[e]), nvp, uni(H.ed[e].w)); HC.n_iters = save; }
         HC.n_paths++;
     }
@@ -2092,7 +2101,7 @@ ALD_FN void collect_existing_st_paths()
     }
     wsync();
     if(n == 0) return;
-    if(tracing() || 3 * n > Cold::w_cap) {        // the op trace lists the paths in order: one at a time
+    if(tracing() || 3 * n > Cold::w_cap || uni(HC.n_paths) + n > Cold::po_cap) {        // the op trace lists the paths in order: one at a time (which also reports a full offset table)
         if(lane == 0) {
             for(int i = 1; i < n; i++) { int x = lst[i]; uint32_t id = uni(H.eid[x]); int j = i - 1; while(j >= 0 && (uint32_t)uni(H.eid[lst[j]]) > id) { lst[j + 1] = lst[j]; j--; } lst[j + 1] = x; }
             for(int i = 0; i < n && !HC.status; i++) collect_path(lst[i]);
@@ -2119,11 +2128,13 @@ ALD_FN void collect_existing_st_paths()
         for(int k = 0; k < n; k++) { const int kk = keep[k]; if(kk < 0) later_bad = true; if(kk == 1 && ids[k] < id) rank++; }
         if(later_bad) bad = true;
         if(keep[j] != 1 || later_bad) continue;
-        int cnt = 0; for(int k = 0; k < NW; k++) cnt += __builtin_popcountll(C.ed[e].mask[k]);
+        int cnt = 0, nexw = 0, last_r = INT_MIN;
+        for(int k = 0; k < NW; k++) { uint64_t mk = C.ed[e].mask[k]; while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; cnt++; const int l = C.vx[x].lpos, rr = C.vx[x].rpos; if(l < rr) { if(nexw == 0 || last_r != l) nexw += 2; last_r = rr; } } }
         const int nvp = cnt + 2;
-        const unsigned long long words = (unsigned long long)(REC_HDR_WORDS + nvp + ((REC_HDR_WORDS + nvp) & 1));
+        const unsigned long long words = rec_words((unsigned)nvp, (unsigned)nexw);
         const unsigned long long o = atomic_add_u64(A->out.pool_used, words);
         if(ALD_UNLIKELY(o + words > A->out.pool_cap)) { full = true; continue; }
+        C.po[HC.n_paths + rank] = o;
         ALD_GLOBAL uint32_t *r = A->out.pool + o;
         int st = '.';
         if(C.ed[e].estrand == 1) st = '+';
@@ -2136,7 +2147,10 @@ ALD_FN void collect_existing_st_paths()
         pv[w++] = 0;
         for(int k = 0; k < NW; k++) { uint64_t mk = C.ed[e].mask[k]; while(mk) { int b = ffs64(mk); mk &= mk - 1; pv[w++] = (uint32_t)(k * 64 + b); } }
         pv[w++] = (uint32_t)nlast;
-        if((REC_HDR_WORDS + nvp) & 1) pv[w] = 0;
+        r[REC_NEXW] = (uint32_t)nexw; r[REC_NEXW + 1] = 0;
+        { int q = 0; for(int k = 0; k < NW; k++) { uint64_t mk = C.ed[e].mask[k]; while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; const int l = C.vx[x].lpos, rr = C.vx[x].rpos;
+            if(l >= rr) continue; if(q > 0 && (int)pv[w + q - 1] == l) pv[w + q - 1] = (uint32_t)rr; else { pv[w + q] = (uint32_t)l; pv[w + q + 1] = (uint32_t)rr; q += 2; } } } w += q; }
+        if((REC_HDR_WORDS + nvp + nexw) & 1) pv[w] = 0;
     }
     const bool any_bad = wballot(bad) != 0, any_full = wballot(full) != 0;
     wsync();
@@ -2309,6 +2323,23 @@ ALD_FN bool load_graph()
 
 ALD_FN void finish_graph()
 {
+    // the graph's part of the result index: a graph that ended well reserves n_paths entries (one atomic) and the wave copies the pool
+    // offsets of its records there, in path order; a graph that did not end well publishes nothing, so its records are unreachable
+    {
+        COLD;
+        ALD_GLOBAL const KernelArgs *A = HC.args; const int g = uni(HC.g);
+        const int st = uni(HC.status), np = (st == 0 || st == ALD_ST_SKIPPED_LARGE) ? uni(HC.n_paths) : 0;
+        if(lane_id() == 0) {
+            long long base = -1;
+            if(np > 0) { const unsigned long long b0 = atomic_add_u64(A->out.index_used, (unsigned long long)np); if(ALD_UNLIKELY(b0 + (unsigned long long)np > A->out.index_cap)) HC.status = ALD_ST_POOL_FULL; else base = (long long)b0; }     // (the host grows pool and index together)
+            A->out.graph_first[g] = base;
+            HC.scr_i[0] = (int32_t)(uint32_t)((unsigned long long)base & 0xFFFFFFFFull); HC.scr_i[1] = (int32_t)(uint32_t)((unsigned long long)base >> 32);
+        }
+        wsync();
+        const long long base = (long long)(((unsigned long long)(uint32_t)uni(HC.scr_i[1]) << 32) | (unsigned long long)(uint32_t)uni(HC.scr_i[0]));
+        if(base >= 0) for(int i = lane_id(); i < np; i += ALD_WAVE) A->out.index[base + i] = C.po[i];
+        wsync();
+    }
     if(lane_id() == 0) {
         ALD_GLOBAL const KernelArgs *A = HC.args; const int g = HC.g;
         A->out.status[g] = HC.status; A->out.n_paths[g] = (HC.status == 0 || HC.status == ALD_ST_SKIPPED_LARGE) ? HC.n_paths : 0; A->out.n_iters[g] = HC.n_iters;

@@ -18,6 +18,7 @@
 #include <map>
 #include <thread>
 #include <cstdlib>
+#include <cmath>
 
 namespace ald {
 
@@ -438,77 +439,65 @@ struct HostBatch {
 };
 
 // ---- results ----
-struct PathRec { int32_t graph, index, nv, length, count; char strand; int attempt; double weight, abd, conf, reads; uint64_t vert_off; };
+// One decoded path record.  vert_off: word offset of its vertex list in the record pool; the exon words of the transcript it becomes
+// follow the vertices (decomp_common.h: record layout); coverage = log(1 + weight) (essential.cc:725), taken with the host's libm.
+struct PathRec { int32_t graph, index, nv, length, count, nexw; char strand; int attempt; double weight, abd, conf, reads, coverage; uint64_t vert_off; };
 struct HostResults {
     std::vector<int32_t> status, n_iters, attempt;       // per graph (attempt = pass that produced the final answer)
     std::vector<int64_t> path_begin;                     // [n+1] into paths (sorted by graph, index)
-    std::vector<PathRec> paths;
-    std::vector<uint32_t> pool;                          // raw record words (vertex lists are read in place) ...
+    rvec<PathRec> paths;
+    std::vector<uint32_t> pool;                          // raw record words (vertex and exon lists are read in place) ...
     const uint32_t *ext_pool = nullptr; uint64_t ext_words = 0;   // ... or a borrowed buffer (the batch's pinned D2H landing area)
     int64_t out_bytes = 0;                               // algorithmic output bytes: sum(4*len + 40)
     void clear() { status.clear(); n_iters.clear(); attempt.clear(); path_begin.clear(); paths.clear(); pool.clear(); ext_pool = nullptr; ext_words = 0; out_bytes = 0; }
     const uint32_t *pool_data() const { return ext_pool ? ext_pool : pool.data(); }
     uint64_t pool_size() const { return ext_pool ? ext_words : (uint64_t)pool.size(); }
     const uint32_t *vertices(const PathRec &p) const { return pool_data() + p.vert_off; }
+    const int32_t *exons(const PathRec &p) const { return (const int32_t*)(pool_data() + p.vert_off + p.nv); }
 
-    // parse the record words; keep only records whose attempt tag matches the graph's final attempt.  Record boundaries need one
-    // serial walk (lengths are in the records); decoding and placing them is split over the host threads.
-    int build(int n, const std::vector<int32_t> &n_paths_dev)
+    // Decode the records through the index the KERNEL wrote: index[graph_first[g] + p] = pool offset of record (g, p), published only
+    // by graphs that ended well (so records of abandoned attempts are never looked at).  No walk over the pool, no counting pass:
+    // every (graph, path) slot is known up front and the graphs are split over the host threads.
+    int build(int n, const int32_t *n_paths_dev, const unsigned long long *index, uint64_t index_n, const long long *graph_first)
     {
         paths.clear(); out_bytes = 0;
         const uint64_t W = pool_size(); const uint32_t *pw = pool_data();
-        std::vector<uint64_t> offs; offs.reserve((size_t)(W / 24) + 16);
-        for(uint64_t o = 0; o + REC_HDR_WORDS <= W; ) {
-            const uint32_t nv = pw[o + 2];
-            uint64_t words = REC_HDR_WORDS + (uint64_t)nv; words += words & 1;
-            if(nv < 2 || o + words > W) return -1;
-            offs.push_back(o); o += words;
+        path_begin.assign((size_t)n + 1, 0); attempt.assign((size_t)n, 0);
+        for(int g = 0; g < n; g++) {
+            const bool ok = status[g] == ALD_ST_OK || status[g] == ALD_ST_SKIPPED_LARGE;
+            const int64_t c = ok ? n_paths_dev[g] : 0;
+            if(c < 0) return -1;
+            if(c > 0 && (graph_first[g] < 0 || (uint64_t)graph_first[g] + (uint64_t)c > index_n)) return -3;
+            path_begin[(size_t)g + 1] = path_begin[(size_t)g] + c;
         }
-        const size_t R = offs.size();
+        const int64_t total = path_begin[(size_t)n];
+        paths.resize((size_t)total);
         unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16;
-        if(R < 50000) nthr = 1;
-        std::vector<uint8_t> keep(R, 0); std::vector<int> bad(nthr, 0);
-        auto run = [&](unsigned nt, auto &&f) {
-            if(nt <= 1) { f(0u); return; }
-            std::vector<std::thread> th; for(unsigned t = 1; t < nt; t++) th.emplace_back([&f, t]() { f(t); });
-            f(0u); for(auto &x : th) x.join();
-        };
-        // which records count (final attempt of a graph that ended well), and how many per graph
-        std::vector<int64_t> cnt(n + 1, 0);
-        std::vector<std::vector<int32_t>> tcnt(nthr);
-        run(nthr, [&](unsigned t) {
-            std::vector<int32_t> &c = tcnt[t]; c.assign(n, 0);
-            for(size_t i = R * t / nthr; i < R * (t + 1) / nthr; i++) {
-                const uint32_t *r = pw + offs[i];
-                const int32_t g = (int32_t)r[0]; const int att = (int)((r[5] >> 8) & 0xFF);
-                if(g < 0 || g >= n) { bad[t] = 1; return; }
-                if((status[g] == ALD_ST_OK || status[g] == ALD_ST_SKIPPED_LARGE) && att == attempt[g]) { keep[i] = 1; c[g]++; }
-            }
-        });
-        for(unsigned t = 0; t < nthr; t++) if(bad[t]) return -1;
-        for(unsigned t = 0; t < nthr; t++) for(int g = 0; g < n; g++) cnt[g + 1] += tcnt[t][g];
-        path_begin.assign(n + 1, 0);
-        int64_t kept = 0;
-        for(int g = 0; g < n; g++) { path_begin[g + 1] = path_begin[g] + cnt[g + 1]; kept += cnt[g + 1]; }
-        paths.resize((size_t)kept);
-        // decode every kept record straight into its slot: (graph, index) is unique per kept record, so the writes are disjoint
-        std::vector<int64_t> ob(nthr, 0);
-        run(nthr, [&](unsigned t) {
-            for(size_t i = R * t / nthr; i < R * (t + 1) / nthr; i++) {
-                if(!keep[i]) continue;
-                const uint32_t *r = pw + offs[i];
-                const int32_t g = (int32_t)r[0], idx = (int32_t)r[1];
-                if(idx < 0 || idx >= cnt[g + 1]) { bad[t] = 2; return; }
-                PathRec &p = paths[(size_t)(path_begin[g] + idx)];
-                p.graph = g; p.index = idx; p.nv = (int32_t)r[2]; p.length = (int32_t)r[3]; p.count = (int32_t)r[4];
+        if(total < 50000) nthr = 1;
+        std::vector<int> bad(nthr, 0); std::vector<int64_t> ob(nthr, 0);
+        HostBatch::run_threads(nthr, [&](unsigned t) {
+            // slices of about equal path counts
+            const int64_t lo = total * t / nthr, hi = total * (t + 1) / nthr;
+            int g = (int)(std::upper_bound(path_begin.begin(), path_begin.end(), lo) - path_begin.begin()) - 1; if(g < 0) g = 0;
+            for(int64_t i = lo; i < hi; i++) {
+                while(g + 1 <= n && path_begin[(size_t)g + 1] <= i) g++;
+                const int32_t idx = (int32_t)(i - path_begin[(size_t)g]);
+                const uint64_t o = index[(uint64_t)graph_first[g] + (uint64_t)idx];
+                if(o + REC_HDR_WORDS > W) { bad[t] = 1; return; }
+                const uint32_t *r = pw + o;
+                const uint32_t nv = r[2], nexw = r[REC_NEXW];
+                if(nv < 2 || (nexw & 1) || nexw > 2 * nv || o + rec_words(nv, nexw) > W || (int32_t)r[0] != g || (int32_t)r[1] != idx) { bad[t] = 2; return; }
+                PathRec &p = paths[(size_t)i];
+                p.graph = g; p.index = idx; p.nv = (int32_t)nv; p.length = (int32_t)r[3]; p.count = (int32_t)r[4]; p.nexw = (int32_t)nexw;
                 p.strand = (char)(r[5] & 0xFF); p.attempt = (int)((r[5] >> 8) & 0xFF);
                 memcpy(&p.weight, r + 6, 8); memcpy(&p.abd, r + 8, 8); memcpy(&p.conf, r + 10, 8); memcpy(&p.reads, r + 12, 8);
-                p.vert_off = offs[i] + REC_HDR_WORDS;
+                p.coverage = log(1.0 + p.weight);
+                p.vert_off = o + REC_HDR_WORDS;
+                if(idx == 0) attempt[(size_t)g] = p.attempt;
                 ob[t] += 4ll * p.nv + 40;
             }
         });
         for(unsigned t = 0; t < nthr; t++) { if(bad[t]) return -2; out_bytes += ob[t]; }
-        for(int g = 0; g < n; g++) if((status[g] == ALD_ST_OK || status[g] == ALD_ST_SKIPPED_LARGE) && cnt[g + 1] != n_paths_dev[g]) return -3;
         return 0;
     }
 };

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-REC_HDR_WORDS = 14
+REC_HDR_WORDS = 16          # decomp_common.h: record header words ([14] = number of exon words behind the vertices)
 
 
 def shard_range(n_graphs: int, rank: int, world: int):
@@ -162,12 +162,13 @@ def parse_records(words: np.ndarray):
     """Decode a record stream into a list of dicts sorted by (graph, path index)."""
     out = []; o = 0
     while o + REC_HDR_WORDS <= words.size:
-        nv = int(words[o + 2])
+        nv = int(words[o + 2]); nx = int(words[o + 14])
         f = words[o + 6:o + 14].view(np.float64)
         out.append(dict(graph=int(words[o]), index=int(words[o + 1]), length=int(words[o + 3]), count=int(words[o + 4]),
                         strand=chr(int(words[o + 5]) & 0xFF), attempt=(int(words[o + 5]) >> 8) & 0xFF,
                         weight=float(f[0]), abd=float(f[1]), conf=float(f[2]), reads=float(f[3]),
-                        v=words[o + REC_HDR_WORDS:o + REC_HDR_WORDS + nv].astype(np.int32).tolist()))
-        w = REC_HDR_WORDS + nv; o += w + (w & 1)
+                        v=words[o + REC_HDR_WORDS:o + REC_HDR_WORDS + nv].astype(np.int32).tolist(),
+                        exons=words[o + REC_HDR_WORDS + nv:o + REC_HDR_WORDS + nv + nx].astype(np.int32).reshape(-1, 2).tolist()))
+        w = REC_HDR_WORDS + nv + nx; o += w + (w & 1)
     out.sort(key=lambda r: (r["graph"], r["index"]))
     return out

@@ -188,6 +188,8 @@ def load_library():
     for name in ("ald_batch_destroy", "ald_batch_clear", "ald_batch_upload", "ald_batch_run", "ald_batch_sync",
                  "ald_batch_download", "ald_batch_num_graphs"):
         getattr(lib, name).argtypes = [C.c_void_p]
+    lib.ald_batch_result_index.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_int64))]
+    lib.ald_batch_last_download_ms.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_int64)]
     lib.ald_batch_enable_trace.argtypes = [C.c_void_p, C.c_int32]
     lib.ald_batch_device_records.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     lib.ald_batch_device_transcript_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
@@ -214,6 +216,7 @@ def load_library():
     lib.ald_transcript_id.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_int32]
     lib.ald_tset_export.argtypes = [C.c_void_p] * 19
     lib.ald_batch_reduce_transcripts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.POINTER(C.c_void_p)]
+    lib.ald_tset_reduce_stream.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.POINTER(C.c_void_p)]
     lib.ald_tset_flat_size.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 3
     lib.ald_tset_flat_export.argtypes = [C.c_void_p] * 19
     lib.ald_tset_flat_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -330,6 +333,20 @@ class DecompBatch:
         if n.value == 0:
             return np.zeros(0, np.uint32)
         return np.ctypeslib.as_array(w, shape=(n.value,)).copy()
+
+    def result_index(self):
+        """(index[n_paths_total] uint64, graph_first[n] int64): the kernel-written index into raw_records() (copies)"""
+        ip = C.POINTER(C.c_uint64)(); n = C.c_int64(); gp = C.POINTER(C.c_int64)()
+        _check(self._lib.ald_batch_result_index(self._h, C.byref(ip), C.byref(n), C.byref(gp)))
+        idx = np.ctypeslib.as_array(ip, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
+        gf = np.ctypeslib.as_array(gp, shape=(self.n,)).copy() if self.n else np.zeros(0, np.int64)
+        return idx, gf
+
+    def download_ms(self):
+        """stages of the last download in host milliseconds + bytes moved to the host (diagnostic)"""
+        v = [C.c_double() for _ in range(4)]; nb = C.c_int64()
+        _check(self._lib.ald_batch_last_download_ms(self._h, *[C.byref(x) for x in v], C.byref(nb)))
+        return dict(wait_kernel=v[0].value, status_retries=v[1].value, copy=v[2].value, decode=v[3].value, bytes_to_host=nb.value)
 
     def device_records(self):
         """(device pointer, word count) of the record stream in HBM -- for a zero-copy hand-over to RCCL (distributed.py)."""
@@ -505,6 +522,27 @@ class TranscriptSink:
     def items(self):
         """List of dicts in the reference's iteration order (bucket hash ascending, then bucket order)."""
         return _export_items(lambda *a: self._lib.ald_tset_size(self._h, *a), lambda *a: self._lib.ald_tset_export(self._h, *a))
+
+
+def reduce_stream(words: np.ndarray, coverage=None, tid=None, tid_base: int = 0, skip_single_exon: bool = False, single_exon_overlap: float = 0.8, device: int = 0):
+    """A transcript stream merged into an EMPTY set by the GPU reduction (ald_tset_reduce_stream) -> (items, stats)"""
+    lib = load_library()
+    words = np.ascontiguousarray(words, np.uint32)
+    cp = tp = None
+    if coverage is not None:
+        coverage = np.ascontiguousarray(coverage, np.float64); cp = C.c_void_p(coverage.ctypes.data)
+    if tid is not None:
+        tid = np.ascontiguousarray(tid, np.int64); tp = C.c_void_p(tid.ctypes.data)
+    h = C.c_void_p()
+    _check(lib.ald_tset_reduce_stream(C.c_int32(device), C.c_void_p(words.ctypes.data), C.c_int64(words.size), cp, tp, C.c_int64(tid_base), C.c_int32(int(skip_single_exon)),
+                                      C.c_double(single_exon_overlap), C.byref(h)))
+    try:
+        st = [C.c_double(), C.c_double(), C.c_int64(), C.c_int64()]
+        _check(lib.ald_tset_flat_stats(h, *[C.byref(x) for x in st]))
+        items = _export_items(lambda *a: lib.ald_tset_flat_size(h, *a), lambda *a: lib.ald_tset_flat_export(h, *a))
+    finally:
+        lib.ald_tset_flat_free(h)
+    return items, dict(device_ms=st[0].value, total_ms=st[1].value, device_groups=st[2].value, host_items=st[3].value)
 
 
 def _two_pass(fn, *args) -> str:

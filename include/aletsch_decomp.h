@@ -29,6 +29,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the entry points declared between this push and the pop at the end of the
+ * file are exported (tests/test_abi_cpu.py checks both directions against `nm -D`). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ---- library-level status codes ---- */
 #define ALD_OK                 0
@@ -169,9 +174,12 @@ int  ald_batch_add_graph_raw(ald_batch *b, const ald_graph_view *g, const ald_ph
 int  ald_batch_upload(ald_batch *b);      /* H2D of the wire buffer (one coalesced copy)      */
 int  ald_batch_run(ald_batch *b);         /* launch decomposition kernels on the batch stream */
 int  ald_batch_sync(ald_batch *b);        /* wait for the stream                              */
-int  ald_batch_download(ald_batch *b);    /* D2H of status + packed path records, index build */
+int  ald_batch_download(ald_batch *b);    /* D2H of status, path records (vertices + joined exons) and the kernel-written index; decode */
 /* device milliseconds of the last ald_batch_run (hipEvents on the batch stream); <0 if n/a */
 double ald_batch_last_kernel_ms(const ald_batch *b);
+/* host milliseconds of the stages of the last ald_batch_download (diagnostic; nothing in the reference corresponds): waiting for the
+ * kernels, status words + class retries, the D2H copies, decoding the records through the index; bytes moved to the host */
+int  ald_batch_last_download_ms(const ald_batch *b, double *wait_kernel_ms, double *status_retries_ms, double *copy_ms, double *decode_ms, int64_t *bytes_to_host);
 /* algorithmic bytes: packed input bytes + packed path-record bytes of the last run */
 int  ald_batch_algorithmic_bytes(const ald_batch *b, int64_t *in_bytes, int64_t *out_bytes);
 
@@ -290,6 +298,13 @@ int  ald_tset_add_stream(ald_tset *t, const uint32_t *words, int64_t n_words, in
 typedef struct ald_tset_flat ald_tset_flat;
 int  ald_batch_reduce_transcripts(const ald_batch *b, const int32_t *sid /* [graphs] or NULL => -1 */, int64_t tid_base, int32_t skip_single_exon,
                                   double single_exon_overlap, ald_tset_flat **out);
+/* The same reduction for transcripts that arrive as a TRANSCRIPT STREAM (format of ald_batch_transcript_stream: groups = runs of
+ * equal graph id, ascending) instead of a decomposed batch -- a stream gathered from another rank, or transcripts produced elsewhere:
+ * they go to `device` and through the very kernels a batch's records go through.  coverage[i] / tid[i] (optional, one per transcript
+ * of the stream in stream order): coverage to merge (NULL: log(1 + weight), essential.cc:725) and transcript id (NULL: tid_base +
+ * (graph << 20 | path)).  Replaces the same loop, meta/assembler.cc:1105-1133 over rnacore/transcript_set.cc:38-175. */
+int  ald_tset_reduce_stream(int32_t device, const uint32_t *words, int64_t n_words, const double *coverage, const int64_t *tid, int64_t tid_base,
+                            int32_t skip_single_exon, double single_exon_overlap, ald_tset_flat **out);
 int  ald_tset_flat_size(const ald_tset_flat *f, int64_t *n_items, int64_t *n_exons, int64_t *n_samples);
 int  ald_tset_flat_export(const ald_tset_flat *f, uint64_t *hash, int32_t *count, char *strand, double *coverage, double *cov2, double *conf, double *abd,
                           int32_t *count1, int32_t *count2, int64_t *tid, int64_t *exon_offset, int32_t *exon_lr,
@@ -325,10 +340,16 @@ int  ald_batch_device_records(const ald_batch *b, const void **device_words, int
 /* host helper for the rank that receives several record streams: adds `graph_offset` to the graph word of every record */
 int  ald_records_add_graph_offset(uint32_t *words, int64_t n_words, int32_t graph_offset);
 
-/* raw packed path-record stream of the last download: 4-byte words, record = [graph, path index, #vertices, length, count,
- * strand | attempt<<8, weight f64, abd f64, conf f64, reads f64, vertices..., pad to even].  This is what ranks exchange
- * over RCCL for the final transcript gather (bench.py --gpus N). */
+/* raw packed path-record pool of the last download: 4-byte words, record = [graph, path index, #vertices, length, count,
+ * strand | attempt<<8, weight f64, abd f64, conf f64, reads f64, #exon words, 0, vertices..., exon words (l, r)*..., pad to even]:
+ * scallop::paths (scallop.h:50) AND what scallop::build_transcripts makes of them (scallop.cc:3250-3266; exon join of
+ * rnacore/essential.cc:735-746 done by the kernel).  The pool also holds the records of abandoned capacity attempts; the records that
+ * count are the ones the index names. */
 int  ald_batch_raw_records(const ald_batch *b, const uint32_t **words, int64_t *n_words);
+/* the result index the decomposition kernel wrote (replaces walking sx.paths / sx.trsts, scallop.h:50-51): index[graph_first[g] + p] =
+ * word offset of record (g, p) in the pool above, p < num_paths of g; graph_first[g] = -1 for a graph without paths or one that did
+ * not end well.  Host copies of the last download, valid until the next one. */
+int  ald_batch_result_index(const ald_batch *b, const uint64_t **index, int64_t *n_entries, const int64_t **graph_first);
 /* diagnostics: size class `cls` (0..4): capacities, resident workgroups per CU, grid of the last run, graphs assigned */
 int  ald_batch_class_info(ald_batch *b, int32_t cls, int32_t *maxv, int32_t *maxe, int32_t *blocks_per_cu, int32_t *blocks_last_run,
                           int64_t *slab_bytes, int32_t *n_graphs);
@@ -376,6 +397,9 @@ int  ald_synth_fill(const ald_synth_spec *s,
 const char *ald_last_error(void);
 const char *ald_version(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

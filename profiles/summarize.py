@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 result databases (gpurun_out/<dir>/*_results.db) into the small summaries committed under profiles/.
 
-  python profiles/summarize.py stats  gpurun_out/prof_r1_d/d_results.db   profiles/r01/d_kernel_stats.csv
+  python profiles/summarize.py stats  gpurun_out/r03a_stats/s_results.db  profiles/r03/a_kernel_stats.csv --skip-first 4 --bench-log gpurun_out/r03a_stats.log
   python profiles/summarize.py pmc    gpurun_out/pmc_fetch_r1_d/d_results.db gpurun_out/pmc_write_r1_d/d_results.db profiles/r01/d_pmc_traffic.json
   python profiles/summarize.py sq     gpurun_out/r02b_pmc3/p_results.db gpurun_out/r02b_pmc4/p_results.db profiles/r02/b_pmc_sq.json
 
@@ -15,15 +15,29 @@ import sqlite3
 import sys
 
 
-def stats(db, out):
+def stats(db, out, skip_first=0, bench_log=None):
+    """per-kernel table (all launches) + for the dominant kernel the launches after the first `skip_first` (cold allocations):
+    avg / median / min / max.  With a bench log (the JSON line of the same command) the steady-state average must not exceed the
+    line's ms_per_step -- a kernel that takes longer than the step it is part of is not evidence of anything."""
     c = sqlite3.connect(db)
     q = ("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(grid_x), max(workgroup_x), max(lds_size), "
          "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(scratch_size) from kernels group by name order by sum(duration) desc")
     rows = list(c.execute(q)); tot = sum(r[2] for r in rows)
+    dom = rows[0][0]
+    d = [r[0] for r in c.execute("select duration from kernels where name=? order by start", (dom,))][skip_first:]
+    d.sort(); n = len(d)
+    avg = sum(d) / n; med = d[n // 2] if n % 2 else 0.5 * (d[n // 2 - 1] + d[n // 2])
     with open(out, "w") as f:
         f.write("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs,Percentage,Grid,Workgroup,LDS,VGPR,AGPR,SGPR,Scratch\n")
         for r in rows:
             f.write('"%s",%d,%d,%.1f,%d,%d,%.4f,%d,%d,%d,%d,%d,%d,%d\n' % (r[0], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot, *r[6:]))
+        f.write('# steady state of "%s": launches after the first %d -> calls=%d avg_ns=%.1f median_ns=%.1f min_ns=%d max_ns=%d\n' % (dom, skip_first, n, avg, med, d[0], d[-1]))
+        if bench_log:
+            line = [ln for ln in open(bench_log) if ln.startswith('{"metric"')][-1]
+            j = json.loads(line)
+            f.write('# bench line of the same run: ms_per_step=%.3f roofline.kernel_ms=%.3f (HIP events) roofline.frac=%.5f\n' % (j["ms_per_step"], j["roofline"]["kernel_ms"], j["roofline"]["frac"]))
+            if avg * 1e-6 > j["ms_per_step"]:
+                print(open(out).read()); sys.exit("steady-state kernel average %.3f ms exceeds ms_per_step %.3f ms" % (avg * 1e-6, j["ms_per_step"]))
     print(open(out).read())
 
 
@@ -45,7 +59,10 @@ def pmc(fetch_db, write_db, out, kernel_prefix="ald_decomp_kernel"):
 
 def main():
     if sys.argv[1] == "stats":
-        stats(sys.argv[2], sys.argv[3])
+        # stats <db> <out.csv> [--skip-first N] [--bench-log <log with the JSON line>]
+        a = sys.argv[4:]; skip = int(a[a.index("--skip-first") + 1]) if "--skip-first" in a else 0
+        log = a[a.index("--bench-log") + 1] if "--bench-log" in a else None
+        stats(sys.argv[2], sys.argv[3], skip, log)
     elif sys.argv[1] == "sq":
         sq(sys.argv[2:-1], sys.argv[-1])
     else:

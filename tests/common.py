@@ -90,6 +90,21 @@ def emu_run(pg: PackedGraphs, trace_cap: int = 0, force_class: int = 0, params=N
     return r, it, cl
 
 
+def emu_transcripts(pg: PackedGraphs):
+    """coverage + exon lists per path as the engine's records carry them (single-lane emulation) -> (DecompResult, cov, exon_offset, exons[.,2])"""
+    E = emu_lib()
+    h = C.c_void_p()
+    assert E.emu_run_packed(*pg.c_args(), None, C.c_int32(0), C.c_int32(0), C.byref(h)) == 0
+    r = export_via(E.emu_result_export, h, pg.n)
+    te = C.c_int64()
+    E.emu_result_export_transcripts(h, C.byref(te), None, None, None)
+    P = len(r.weight)
+    cov = np.zeros(P); eo = np.zeros(P + 1, np.int64); lr = np.zeros(2 * max(te.value, 1), np.int32)
+    E.emu_result_export_transcripts(h, C.byref(te), cov.ctypes.data_as(C.POINTER(C.c_double)), eo.ctypes.data_as(C.POINTER(C.c_int64)), lr.ctypes.data_as(C.POINTER(C.c_int32)))
+    E.emu_result_free(h)
+    return r, cov, eo, lr[:2 * te.value].reshape(-1, 2)
+
+
 def compare_results(want: DecompResult, got: DecompResult, n: int, tol: float = 0.0, conf_tol: float = 0.0):
     """Per graph: same status, same number of paths, identical vertex lists in identical order, exact length /
     count / strand; weight / abd / conf / reads bit-identical when tol == 0, else |d| <= tol * max(1, |x|)

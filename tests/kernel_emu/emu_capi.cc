@@ -38,16 +38,20 @@ int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_
     std::vector<int32_t> status(n, 0), n_paths(n, 0), n_iters(n, 0);
     uint64_t pool_cap = 0; for(int g = 0; g < n; g++) pool_cap += 16ull * B.g_ne[g] + 256;
     if(const char *ev = getenv("ALD_DEBUG_POOL_WORDS")) { const long long k = atoll(ev); if(k > 0 && (uint64_t)k < pool_cap) pool_cap = (uint64_t)k; }     // same knob as ald_batch_upload
-    std::vector<uint32_t> pool(pool_cap); unsigned long long pool_used = 0;
+    std::vector<uint32_t> pool(pool_cap); unsigned long long counters[2] = {0, 0};      // [0] pool words used, [1] index entries used (as in the batch's counter buffer)
+    unsigned long long &pool_used = counters[0], &index_used = counters[1];
+    uint64_t index_cap = pool_cap / (REC_HDR_WORDS + 2) + 1;
+    std::vector<unsigned long long> index(index_cap); std::vector<long long> graph_first(n, -1);
     emu_result *E = new emu_result(); E->n = n; E->trace_cap = trace_cap;
     if(trace_cap > 0) { E->trace_n.assign(n, 0); E->trace_codes.assign(3ull * n * trace_cap, 0); E->trace_vals.assign((size_t)n * trace_cap, 0); }
     A.out.status = status.data(); A.out.n_paths = n_paths.data(); A.out.n_iters = n_iters.data();
     A.out.pool_used = &pool_used; A.out.pool = pool.data(); A.out.pool_cap = pool_cap;
+    A.out.index_used = &index_used; A.out.index = index.data(); A.out.index_cap = index_cap; A.out.graph_first = graph_first.data();
     A.out.trace_cap = trace_cap; A.out.trace_n = E->trace_n.data(); A.out.trace_codes = E->trace_codes.data(); A.out.trace_vals = E->trace_vals.data();
     std::vector<int32_t> cls(n), attempt(n, 0);
   for(int regrow = 0; ; regrow++) {          // the host policy of ald_batch_download: a full record pool grows and the batch runs again
     std::vector<int32_t> work[ALD_NUM_PICK_CLASSES];
-    std::fill(status.begin(), status.end(), 0); std::fill(n_paths.begin(), n_paths.end(), 0); std::fill(attempt.begin(), attempt.end(), 0); pool_used = 0;
+    std::fill(status.begin(), status.end(), 0); std::fill(n_paths.begin(), n_paths.end(), 0); std::fill(attempt.begin(), attempt.end(), 0); pool_used = 0; index_used = 0; std::fill(graph_first.begin(), graph_first.end(), -1);
     if(trace_cap > 0) std::fill(E->trace_n.begin(), E->trace_n.end(), 0);
     for(int g = 0; g < n; g++) {
         int64_t ns = B.off_s[g + 1] - B.off_s[g], npv = B.off_pv[g + 1] - B.off_pv[g];
@@ -81,11 +85,12 @@ int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_
     if(!pool_full || regrow >= 8) break;
     pool_cap = std::max<uint64_t>(2 * pool_cap, pool_used + pool_used / 4 + 4096); pool.assign(pool_cap, 0);
     A.out.pool = pool.data(); A.out.pool_cap = pool_cap;
+    index_cap = pool_cap / (REC_HDR_WORDS + 2) + 1; index.assign(index_cap, 0); A.out.index = index.data(); A.out.index_cap = index_cap;
   }
-    E->R.status = status; E->R.n_iters = n_iters; E->R.attempt = attempt;
+    E->R.status = status; E->R.n_iters = n_iters;
     E->R.pool.assign(pool.begin(), pool.begin() + std::min<uint64_t>(pool_used, pool_cap));
     E->cls = cls;
-    rc = E->R.build(n, n_paths);
+    rc = E->R.build(n, n_paths.data(), index.data(), std::min<uint64_t>(index_used, index_cap), graph_first.data());
     if(rc != 0) { fprintf(stderr, "emu: record parse failed rc=%d\n", rc); delete E; return ALD_ERR_STATE; }
     *out = E;
     return ALD_OK;
@@ -96,6 +101,19 @@ int emu_result_export(const emu_result *E, int64_t *total_paths, int64_t *total_
                       int64_t *pv_offset, int32_t *path_vertices)
 {
     return export_results(E->R, E->n, total_paths, total_path_vertices, status, path_offset, weight, abd, conf, reads, length, count, strand, pv_offset, path_vertices);
+}
+/* the transcripts the records carry (exons joined by the engine, coverage by HostResults::build): same signature as ald_batch_export_transcripts */
+int emu_result_export_transcripts(const emu_result *E, int64_t *total_exons, double *coverage, int64_t *exon_offset, int32_t *exon_lr)
+{
+    int64_t te = 0; const int64_t np = (int64_t)E->R.paths.size();
+    for(int64_t i = 0; i < np; i++) {
+        const PathRec &p = E->R.paths[(size_t)i];
+        if(coverage) { coverage[i] = p.coverage; exon_offset[i] = te; if(p.nexw) memcpy(exon_lr + 2 * te, E->R.exons(p), 4 * (size_t)p.nexw); }
+        te += p.nexw / 2;
+    }
+    if(coverage) exon_offset[np] = te;
+    if(total_exons) *total_exons = te;
+    return 0;
 }
 int emu_result_iters(const emu_result *E, int32_t *iters, int32_t *cls) { for(int g = 0; g < E->n; g++) { iters[g] = E->R.n_iters[g]; cls[g] = E->cls[g]; } return 0; }
 int emu_result_trace(const emu_result *E, int32_t graph, int32_t *n_events, int32_t *codes3, double *values, int32_t cap)

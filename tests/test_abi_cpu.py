@@ -24,6 +24,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/aletsch_decomp.h but not exported"
 
 
+def test_library_exports_nothing_else():
+    """the converse: built with -fvisibility=hidden, the library's dynamic symbol table holds no `ald_*` function the header does not
+    declare (round 2 leaked the per-class launchers and occupancy helpers) and no C++ internals of the host code"""
+    out = os.popen(f"nm -D --defined-only {A.library_path()}").read()
+    exported = sorted(set(ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-2] in ("T", "W", "V", "B", "D")))
+    declared = set(_declared_symbols())
+    extra = [n for n in exported if n.startswith("ald_") and n not in declared]
+    assert not extra, extra
+    host_internals = [n for n in exported if n.startswith("_Z") and ("HostBatch" in n or "ald_batch" in n or "transcript_sink" in n)]
+    assert not host_internals, host_internals[:5]
+
+
 def test_version_and_defaults():
     lib = A.load_library()
     assert b"gfx950" in lib.ald_version()

@@ -177,6 +177,57 @@ def test_sharded_batch_merges_to_the_single_rank_result(tmp_path):
     assert got == want
 
 
+CFG4_WORKER = textwrap.dedent('''
+    import os, sys, json, numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+    import aletsch_amd as A, common
+    from aletsch_amd.distributed import StreamGatherer, merge_streams
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = int(os.environ["ALD_TEST_N"])
+    pg = A.synth(seed=1004 + rank, n_graphs=n, v_min=64, v_max=64, fixed_edges=256)      # SURVEY 8d: cfg4 = seed 1004 + rank, 64v/256e
+    res, _, _ = common.emu_run(pg)
+    words = common.transcript_stream_from_result(pg, res, None, skip_single_exon=True)
+    G = StreamGatherer(torch.device("cpu"))
+    G.gather(torch.from_numpy(words.view(np.int32).copy()), graph_offset=rank * n)           # bench.py's offsets: rank * graphs per rank
+    if rank == 0:
+        sink = merge_streams(A.TranscriptSink(0.8), G.streams())
+        json.dump(sink.items(), open(os.environ["ALD_TEST_OUT"], "w"))
+        print("MERGED", len(sink.items()))
+    dist.barrier()
+    dist.destroy_process_group()
+''') % (ROOT, ROOT)
+
+
+def test_cfg4_shards_merge_in_rank_order(tmp_path):
+    """BASELINE configs[3] with two of its eight ranks: every rank synthesises ITS shard (64v/256e, seed 1004 + rank), decomposes it
+    with the engine (emulated), the finished transcripts are gathered and merged on rank 0 in rank order = ascending global graph id.
+    The merged set equals what one process gets from the two shards' streams merged in that order."""
+    import json
+    import numpy as np
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import aletsch_amd as A
+    import common
+    n = 300
+    single = A.TranscriptSink(0.8)
+    for rank in range(2):
+        pg = A.synth(seed=1004 + rank, n_graphs=n, v_min=64, v_max=64, fixed_edges=256)
+        res, _, _ = common.emu_run(pg)
+        single.add_stream(common.transcript_stream_from_result(pg, res, None, skip_single_exon=True), graph_offset=rank * n)
+    want = single.items()
+    assert len(want) > 1000
+    out = tmp_path / "merged.json"
+    script = tmp_path / "cfg4_worker.py"; script.write_text(CFG4_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", ALD_TEST_N=str(n), ALD_TEST_OUT=str(out))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29521", str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = json.load(open(out))
+    for x in got:
+        x["exons"] = [tuple(e) for e in x["exons"]]
+    assert got == want
+
+
 def test_bench_gpus_flag_starts_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher starts two ranks itself (fresh child processes, before any GPU call), relays rank
     0's JSON line and reports the world the collective actually saw; here as a CPU / gloo dry run of that plumbing"""

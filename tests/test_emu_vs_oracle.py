@@ -17,6 +17,30 @@ def test_engine_matches_oracle(name):
     assert np.array_equal(it, st[:, 3])
 
 
+@pytest.mark.parametrize("name", ["cfg2_64v256e", "stranded", "everything", "real_shaped", "minimal_3v"])
+def test_engine_records_carry_the_transcripts(name):
+    """The engine joins the exons of every path into its record (build_transcript, essential.cc:719-748: touching intervals of
+    consecutive vertices fuse, empty ones vanish); coverage = log(1 + weight) is taken by the host decode.  Both must equal the oracle's
+    transcripts exactly -- no host-side join exists any more."""
+    pg = common.make_batch(name)
+    _, wcov, weo, wlr = common.oracle_transcripts(pg)
+    _, gcov, geo, glr = common.emu_transcripts(pg)
+    assert np.array_equal(weo, geo) and np.array_equal(wlr, glr)
+    assert np.array_equal(wcov, gcov)
+
+
+def test_engine_joins_touching_and_drops_empty_intervals():
+    """hand-made: vertices 1|2 touch (one exon), 3 is an empty interval (vanishes), 4 stands alone"""
+    from aletsch_amd.packed import PackedGraphs
+    g = dict(V=6, edges=[(0, 1, 9.0), (1, 2, 9.0), (2, 3, 9.0), (3, 4, 9.0), (4, 5, 9.0)], vw=[0, 10, 10, 0, 10, 0],
+             lpos=[0, 100, 200, 400, 500, 600], rpos=[0, 200, 300, 400, 600, 600])
+    pg = PackedGraphs.from_graphs([g])
+    r, cov, eo, lr = common.emu_transcripts(pg)
+    assert len(cov) == 1 and lr.tolist() == [[100, 300], [500, 600]]
+    _, wcov, weo, wlr = common.oracle_transcripts(pg)
+    assert np.array_equal(wlr, lr) and np.array_equal(wcov, cov)
+
+
 def test_engine_matches_oracle_at_scale():
     """10 000 graphs of the bench shape (64v / 256e): rare interleavings of the cascade (a removal that flips a degree guard of a
     vertex evaluated earlier, a fan above the fast-path limit, ...) need thousands of graphs to occur at all"""

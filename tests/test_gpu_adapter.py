@@ -232,3 +232,24 @@ def test_adapter_takes_graphs_as_assemble_receives_them():
             assert float(f[0]) == want.weight[i] and float(f[1]) == want.abd[i] and float(f[2]) == want.reads[i]
             assert [int(x) for x in vs.split()] == [int(x) for x in want.path_vertices[want.pv_offset[i]:want.pv_offset[i + 1]]]
     assert pos == len(out) and n_paths > 50
+
+
+@pytest.mark.gpu
+def test_comm_gather_with_several_ranks_on_one_gpu():
+    """ald_comm_gather_streams with W = 2 and 3 ranks (the multi-rank offsets / receive sizing had never executed).  RCCL
+    refuses two ranks on one device, so the ranks are threads of one process and librccl.so is replaced, through ALD_RCCL_LIB, by
+    tests/host_adapter/mock_rccl.cc (device-to-device copies behind the nine nccl* entry points the library binds); then a refused
+    ncclSend: the failing rank must report the error with its thread out of group mode, and nobody may hang."""
+    bld = os.path.join(ROOT, "tests", "_build"); os.makedirs(bld, exist_ok=True)
+    lib = os.path.join(ROOT, "aletsch_amd", "lib"); mock = os.path.join(bld, "libmock_rccl.so"); exe = os.path.join(bld, "comm_ranks_test")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-o", mock, os.path.join(ROOT, "tests", "host_adapter", "mock_rccl.cc")], check=True)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "host_adapter", "comm_ranks_test.cc"), "-o", exe, "-L" + lib, "-laletsch_decomp", "-Wl,-rpath," + lib,
+                    "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-pthread"], check=True)
+    env = dict(os.environ, ALD_RCCL_LIB=mock)
+    for world in ("2", "3"):
+        r = subprocess.run([exe, world], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and "COMM_RANKS_OK world=" + world in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+    for fail in ("1", "0"):
+        r = subprocess.run([exe, "2", fail], capture_output=True, text=True, timeout=300, env=dict(env, ALD_MOCK_RCCL_FAIL_SEND=fail))
+        assert r.returncode == 0 and "injected send failure handled" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]

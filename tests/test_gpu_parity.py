@@ -709,3 +709,84 @@ def test_transcript_stream_built_on_the_device():
         b.add(A.synth(seed=5, n_graphs=3, v_min=2, v_max=2, edges_per_vertex=1)); b.upload(); b.run(); b.download()
         ptr, n = b.device_transcript_stream()
         assert n == b.transcript_stream().size
+
+
+def test_result_index_written_by_the_kernel():
+    """The kernel publishes, per graph that ended well, the pool offsets of its records in path order (one atomic per graph); the
+    host never walks the record stream.  With every graph started one class too low the pool also holds the records of the abandoned
+    attempts -- the index must not name them -- and every named record must be THE record of (graph, path): same vertices, same
+    values as the exported result, exons = the oracle's transcripts."""
+    import os
+    from aletsch_amd.distributed import parse_records, REC_HDR_WORDS
+    pg = A.synth(seed=4243, n_graphs=2500, v_min=6, v_max=90, edges_per_vertex=3, layout_mode=1, weight_mode=2, phasing_per_graph=2, strand_mode=1)
+    os.environ["ALD_DEBUG_UNDERCLASS"] = "1"
+    try:
+        with A.DecompBatch(0) as b:
+            b.add(pg); b.upload(); b.run(); b.download()
+            r = b.result(); raw = b.raw_records(); idx, gf = b.result_index()
+            cov, eo, lr = b.transcripts()
+    finally:
+        del os.environ["ALD_DEBUG_UNDERCLASS"]
+    npaths = np.diff(r.path_offset)
+    assert idx.size == int(npaths.sum()) and ((gf >= 0) == (npaths > 0)).all()
+    allrec = parse_records(raw)
+    assert len(allrec) > idx.size                       # abandoned attempts are in the pool ...
+    seen = set()
+    for g in range(pg.n):
+        for p in range(int(npaths[g])):
+            o = int(idx[int(gf[g]) + p]); assert o not in seen; seen.add(o)
+            assert int(raw[o]) == g and int(raw[o + 1]) == p
+            i = int(r.path_offset[g]) + p
+            nv = int(raw[o + 2]); nx = int(raw[o + 14])
+            assert raw[o + REC_HDR_WORDS:o + REC_HDR_WORDS + nv].astype(np.int32).tolist() == r.path_vertices[int(r.pv_offset[i]):int(r.pv_offset[i + 1])].tolist()
+            assert raw[o + 6:o + 8].view(np.float64)[0] == r.weight[i]
+            assert raw[o + REC_HDR_WORDS + nv:o + REC_HDR_WORDS + nv + nx].astype(np.int32).reshape(-1, 2).tolist() == lr[int(eo[i]):int(eo[i + 1])].tolist()
+    assert len(seen) == idx.size                        # ... and nothing names them
+    _, cov_o, eo_o, lr_o = common.oracle_transcripts(pg)
+    assert np.array_equal(eo, eo_o) and np.array_equal(lr, lr_o) and np.array_equal(cov, cov_o)
+
+
+def test_cfg4_rank0_shard_at_spec():
+    """BASELINE configs[3] as one rank sees it: rank 0's shard of the 1 M-graph job, 125 000 x 64v/256e, seed 1004 + rank,
+    against the oracle on all host cores.  (The other seven ranks run the same code on seeds 1005..1011; the merge of two such shards
+    in rank order is tests/test_distributed_cpu.py::test_cfg4_shards_merge_in_rank_order.)"""
+    import os
+    pg = A.synth(seed=1004, n_graphs=125000, v_min=64, v_max=64, fixed_edges=256)
+    got = A.decompose(pg, device=0)
+    assert int((got.status != 0).sum()) == 0
+    want = common.oracle_run(pg, threads=max(1, len(os.sched_getaffinity(0))))[0]
+    assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
+
+
+def _stream_of_groups(groups):
+    """golden transcript groups (tests/golden/ref_tset.json) -> (transcript stream, coverage[], tid[])"""
+    out = []; cov = []; tid = []
+    for g, (sid, ts) in enumerate(groups):
+        for k, (st, c, conf, abd, c1, t, ex) in enumerate(ts):
+            hdr = np.zeros(12, np.uint32)
+            hdr[0] = g; hdr[1] = k; hdr[2] = np.array([sid], np.int32).view(np.uint32)[0]; hdr[3] = ord(st); hdr[4] = c1; hdr[5] = len(ex)
+            hdr[6:12] = np.array([0.0, conf, abd], np.float64).view(np.uint32)
+            out.append(hdr); out.append(np.array([x for e in ex for x in e], np.int32).view(np.uint32)); cov.append(c); tid.append(t)
+    return (np.concatenate(out) if out else np.zeros(0, np.uint32)), np.array(cov, np.float64), np.array(tid, np.int64)
+
+
+def test_reference_tset_golden_through_the_device_reduction():
+    """The six reference-generated cases of tests/golden/ref_tset.json (oracle/_ref/ref_tset = the reference's transcript_set.cc built
+    from source) through the DEVICE stage of the reduction (ald_tset_reduce_stream: the same tx_* kernels a batch's records go through)
+    -- every field of every merged item, bit for bit.  Before this the device reduction was only compared with the host sink."""
+    import json
+    import os
+    import test_tset_cpu as T
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_tset.json")))
+    n_dev = 0
+    for c in cases:
+        groups = T.as_groups(c)
+        words, cov, tid = _stream_of_groups(groups)
+        items, st = A.reduce_stream(words, coverage=cov, tid=tid)
+        T.check(items, c["items"])
+        n_dev += st["device_groups"]
+        # and with the single-exon filter: the reference's own answer for the filtered input == filtering first
+        items2, _ = A.reduce_stream(words, coverage=cov, tid=tid, skip_single_exon=True)
+        s = A.TranscriptSink(0.8); s.add_groups(groups, skip_single_exon=True)
+        assert items2 == s.items()
+    assert n_dev > 100
