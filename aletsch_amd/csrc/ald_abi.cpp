@@ -464,7 +464,7 @@ int ald_batch_download(ald_batch *b)
     {
         const int rc = b->res.build(n, b->n_paths.data(), (const unsigned long long*)b->pin_index.p, iused, h_gf);
         if(rc != 0) return set_err(ALD_ERR_STATE, "result index is inconsistent with the record pool (rc=" + std::to_string(rc) + ")");
-        b->total_paths = (int64_t)b->res.paths.size();
+        b->total_paths = b->res.n_paths();
     }
     { auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
       b->dl_ms[0] = ms(P0, P1); b->dl_ms[1] = ms(P1, P3); b->dl_ms[2] = ms(P3, P3b); b->dl_ms[3] = ms(P3b, std::chrono::steady_clock::now()); b->dl_bytes = 4 * (int64_t)used + 8 * (int64_t)iused + 20 * (int64_t)n; }
@@ -532,7 +532,7 @@ int ald_batch_get_path(const ald_batch *b, int32_t graph, int32_t path, ald_path
     { int rc = ensure_index(b); if(rc != ALD_OK) return rc; }
     int64_t i = b->res.path_begin[graph] + path;
     if(path < 0 || i >= b->res.path_begin[graph + 1]) return ALD_ERR_INVALID;
-    const PathRec &p = b->res.paths[i];
+    const PathRec p = b->res.path((int64_t)(i));
     out->num_vertices = p.nv; out->vertices = (const int32_t*)b->res.vertices(p);
     out->weight = p.weight; out->abd = p.abd; out->conf = p.conf; out->reads = p.reads; out->length = p.length; out->count = p.count; out->strand = p.strand;
     return ALD_OK;
@@ -564,7 +564,7 @@ int ald_batch_get_transcript(const ald_batch *b, int32_t graph, int32_t path, al
     if(!b || !out || !b->downloaded || graph < 0 || graph >= b->hb.n()) return ALD_ERR_INVALID;
     int64_t i = b->res.path_begin[graph] + path;
     if(path < 0 || i >= b->res.path_begin[graph + 1]) return ALD_ERR_INVALID;
-    const PathRec &p = b->res.paths[i];
+    const PathRec p = b->res.path((int64_t)(i));
     out->num_exons = p.nexw / 2; out->exons = b->res.exons(p);
     out->coverage = p.coverage; out->conf = p.conf; out->abd = p.abd; out->count1 = p.count; out->strand = p.strand;
     return ALD_OK;
@@ -573,9 +573,9 @@ int ald_batch_get_transcript(const ald_batch *b, int32_t graph, int32_t path, al
 int ald_batch_export_transcripts(const ald_batch *b, int64_t *total_exons, double *coverage, int64_t *exon_offset, int32_t *exon_lr)
 {
     if(!b || !b->downloaded) return set_err(ALD_ERR_STATE, "ald_batch_export_transcripts before ald_batch_download");
-    int64_t te = 0; const int64_t np = (int64_t)b->res.paths.size();
+    int64_t te = 0; const int64_t np = b->res.n_paths();
     for(int64_t i = 0; i < np; i++) {
-        const PathRec &p = b->res.paths[(size_t)i];
+        const PathRec p = b->res.path((int64_t)((size_t)i));
         if(coverage) { coverage[i] = p.coverage; exon_offset[i] = te; if(p.nexw) memcpy(exon_lr + 2 * te, b->res.exons(p), 4 * (size_t)p.nexw); }
         te += p.nexw / 2;
     }
@@ -657,13 +657,13 @@ int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int6
     if(!t || !b || !b->downloaded) return ALD_ERR_INVALID;
     auto T0 = std::chrono::steady_clock::now();
     const int n = b->hb.n();
-    const int64_t np = (int64_t)b->res.paths.size();
+    const int64_t np = b->res.n_paths();
     const unsigned nthr = sink_threads(np);
     // pass 1: bucket of every transcript (the exons are in the records, joined by the kernel)
     std::vector<uint32_t> bucket((size_t)np, ALD_NO_BUCKET);
     HostBatch::run_threads(nthr, [&](unsigned th) {
         for(int64_t i = np * th / nthr; i < np * (th + 1) / nthr; i++) {
-            const PathRec &p = b->res.paths[(size_t)i];
+            const PathRec p = b->res.path((int64_t)((size_t)i));
             if(p.nexw <= 2 && skip_single_exon) continue;                      // assembler.cc:1117
             bucket[(size_t)i] = (uint32_t)aletsch::sink_transcript::chain_key(b->res.exons(p), (size_t)p.nexw);
         }
@@ -671,7 +671,7 @@ int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int6
     auto T2 = std::chrono::steady_clock::now();
     // pass 2: thread th owns the tables th, th + nthr, ...
     merge_groups(t, nthr, n, b->res.path_begin.data(), sid, bucket.data(), [&](int64_t i, aletsch::sink_transcript &x) {
-        const PathRec &p = b->res.paths[(size_t)i];
+        const PathRec p = b->res.path((int64_t)((size_t)i));
         x.strand = p.strand; x.coverage = p.coverage; x.top.cov2 = x.coverage; x.top.conf = p.conf; x.top.abd = p.abd; x.top.count1 = p.count; x.count2 = 1;
         x.tid = tid_base + (((int64_t)p.graph << 20) | (int64_t)p.index);
         const int32_t *ex = b->res.exons(p);
@@ -691,16 +691,16 @@ int ald_batch_transcript_stream(const ald_batch *cb, const int32_t *sid, int32_t
     if(!cb || !words || !n_words) return ALD_ERR_INVALID;
     if(!cb->downloaded) return set_err(ALD_ERR_STATE, "ald_batch_transcript_stream before ald_batch_download");
     ald_batch *b = const_cast<ald_batch*>(cb);
-    const int64_t np = (int64_t)b->res.paths.size();
+    const int64_t np = b->res.n_paths();
     const unsigned nthr = sink_threads(np);
     std::vector<int64_t> at((size_t)np + 1, 0);
-    for(int64_t i = 0; i < np; i++) { const int k = b->res.paths[(size_t)i].nexw; at[(size_t)i + 1] = at[(size_t)i] + ((k <= 2 && skip_single_exon) ? 0 : TS_HDR + k); }
+    for(int64_t i = 0; i < np; i++) { const int k = (int)b->res.rec(i)[REC_NEXW]; at[(size_t)i + 1] = at[(size_t)i] + ((k <= 2 && skip_single_exon) ? 0 : TS_HDR + k); }
     b->tstream.resize((size_t)at[(size_t)np] + 2);
     uint32_t *out = b->tstream.data();
     HostBatch::run_threads(nthr, [&](unsigned th) {
         for(int64_t i = np * th / nthr; i < np * (th + 1) / nthr; i++) {
             if(at[(size_t)i + 1] == at[(size_t)i]) continue;
-            const PathRec &p = b->res.paths[(size_t)i]; uint32_t *w = out + at[(size_t)i];
+            const PathRec p = b->res.path((int64_t)((size_t)i)); uint32_t *w = out + at[(size_t)i];
             w[0] = (uint32_t)p.graph; w[1] = (uint32_t)p.index; w[2] = (uint32_t)(sid ? sid[p.graph] : -1); w[3] = (uint32_t)(unsigned char)p.strand;
             w[4] = (uint32_t)p.count; w[5] = (uint32_t)(p.nexw / 2);
             memcpy(w + 6, &p.weight, 8); memcpy(w + 8, &p.conf, 8); memcpy(w + 10, &p.abd, 8);

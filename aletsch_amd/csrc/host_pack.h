@@ -439,28 +439,41 @@ struct HostBatch {
 };
 
 // ---- results ----
-// One decoded path record.  vert_off: word offset of its vertex list in the record pool; the exon words of the transcript it becomes
-// follow the vertices (decomp_common.h: record layout); coverage = log(1 + weight) (essential.cc:725), taken with the host's libm.
+// One decoded path record (a VIEW, made on demand from the record words: HostResults::path).  vert_off: word offset of its vertex list
+// in the record pool; the exon words of the transcript it becomes follow the vertices (decomp_common.h: record layout);
+// coverage = log(1 + weight) (essential.cc:725), taken with the host's libm.
 struct PathRec { int32_t graph, index, nv, length, count, nexw; char strand; int attempt; double weight, abd, conf, reads, coverage; uint64_t vert_off; };
 struct HostResults {
     std::vector<int32_t> status, n_iters, attempt;       // per graph (attempt = pass that produced the final answer)
-    std::vector<int64_t> path_begin;                     // [n+1] into paths (sorted by graph, index)
-    rvec<PathRec> paths;
+    std::vector<int64_t> path_begin;                     // [n+1] into rec_off / coverage (paths sorted by graph, index)
+    rvec<uint64_t> rec_off;                              // [paths] pool offset of the record of every path
+    rvec<double> coverage;                               // [paths] log(1 + weight)
     std::vector<uint32_t> pool;                          // raw record words (vertex and exon lists are read in place) ...
     const uint32_t *ext_pool = nullptr; uint64_t ext_words = 0;   // ... or a borrowed buffer (the batch's pinned D2H landing area)
     int64_t out_bytes = 0;                               // algorithmic output bytes: sum(4*len + 40)
-    void clear() { status.clear(); n_iters.clear(); attempt.clear(); path_begin.clear(); paths.clear(); pool.clear(); ext_pool = nullptr; ext_words = 0; out_bytes = 0; }
+    void clear() { status.clear(); n_iters.clear(); attempt.clear(); path_begin.clear(); rec_off.clear(); coverage.clear(); pool.clear(); ext_pool = nullptr; ext_words = 0; out_bytes = 0; }
     const uint32_t *pool_data() const { return ext_pool ? ext_pool : pool.data(); }
     uint64_t pool_size() const { return ext_pool ? ext_words : (uint64_t)pool.size(); }
+    int64_t n_paths() const { return (int64_t)rec_off.size(); }
+    const uint32_t *rec(int64_t i) const { return pool_data() + rec_off[(size_t)i]; }
     const uint32_t *vertices(const PathRec &p) const { return pool_data() + p.vert_off; }
     const int32_t *exons(const PathRec &p) const { return (const int32_t*)(pool_data() + p.vert_off + p.nv); }
+    PathRec path(int64_t i) const
+    {
+        const uint32_t *r = rec(i); PathRec p;
+        p.graph = (int32_t)r[0]; p.index = (int32_t)r[1]; p.nv = (int32_t)r[2]; p.length = (int32_t)r[3]; p.count = (int32_t)r[4]; p.nexw = (int32_t)r[REC_NEXW];
+        p.strand = (char)(r[5] & 0xFF); p.attempt = (int)((r[5] >> 8) & 0xFF);
+        memcpy(&p.weight, r + 6, 8); memcpy(&p.abd, r + 8, 8); memcpy(&p.conf, r + 10, 8); memcpy(&p.reads, r + 12, 8);
+        p.coverage = coverage[(size_t)i]; p.vert_off = rec_off[(size_t)i] + REC_HDR_WORDS;
+        return p;
+    }
 
-    // Decode the records through the index the KERNEL wrote: index[graph_first[g] + p] = pool offset of record (g, p), published only
-    // by graphs that ended well (so records of abandoned attempts are never looked at).  No walk over the pool, no counting pass:
-    // every (graph, path) slot is known up front and the graphs are split over the host threads.
+    // The path table of a batch from the index the KERNEL wrote: index[graph_first[g] + p] = pool offset of record (g, p), published
+    // only by graphs that ended well (records of abandoned attempts are never looked at).  No walk over the pool, no counting pass,
+    // no copy of the records' fields: per path one offset (checked against the record it names) and the coverage.
     int build(int n, const int32_t *n_paths_dev, const unsigned long long *index, uint64_t index_n, const long long *graph_first)
     {
-        paths.clear(); out_bytes = 0;
+        rec_off.clear(); coverage.clear(); out_bytes = 0;
         const uint64_t W = pool_size(); const uint32_t *pw = pool_data();
         path_begin.assign((size_t)n + 1, 0); attempt.assign((size_t)n, 0);
         for(int g = 0; g < n; g++) {
@@ -471,31 +484,29 @@ struct HostResults {
             path_begin[(size_t)g + 1] = path_begin[(size_t)g] + c;
         }
         const int64_t total = path_begin[(size_t)n];
-        paths.resize((size_t)total);
+        rec_off.resize((size_t)total); coverage.resize((size_t)total);
         unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16;
+        if(const char *ev = getenv("ALD_STAGE_THREADS")) { int k = atoi(ev); if(k >= 1 && k <= 64) nthr = (unsigned)k; }
         if(total < 50000) nthr = 1;
         std::vector<int> bad(nthr, 0); std::vector<int64_t> ob(nthr, 0);
         HostBatch::run_threads(nthr, [&](unsigned t) {
-            // slices of about equal path counts
-            const int64_t lo = total * t / nthr, hi = total * (t + 1) / nthr;
+            const int64_t lo = total * t / nthr, hi = total * (t + 1) / nthr;            // slices of equal path counts
             int g = (int)(std::upper_bound(path_begin.begin(), path_begin.end(), lo) - path_begin.begin()) - 1; if(g < 0) g = 0;
+            int64_t obt = 0;
             for(int64_t i = lo; i < hi; i++) {
-                while(g + 1 <= n && path_begin[(size_t)g + 1] <= i) g++;
+                while(path_begin[(size_t)g + 1] <= i) g++;
                 const int32_t idx = (int32_t)(i - path_begin[(size_t)g]);
                 const uint64_t o = index[(uint64_t)graph_first[g] + (uint64_t)idx];
                 if(o + REC_HDR_WORDS > W) { bad[t] = 1; return; }
                 const uint32_t *r = pw + o;
                 const uint32_t nv = r[2], nexw = r[REC_NEXW];
                 if(nv < 2 || (nexw & 1) || nexw > 2 * nv || o + rec_words(nv, nexw) > W || (int32_t)r[0] != g || (int32_t)r[1] != idx) { bad[t] = 2; return; }
-                PathRec &p = paths[(size_t)i];
-                p.graph = g; p.index = idx; p.nv = (int32_t)nv; p.length = (int32_t)r[3]; p.count = (int32_t)r[4]; p.nexw = (int32_t)nexw;
-                p.strand = (char)(r[5] & 0xFF); p.attempt = (int)((r[5] >> 8) & 0xFF);
-                memcpy(&p.weight, r + 6, 8); memcpy(&p.abd, r + 8, 8); memcpy(&p.conf, r + 10, 8); memcpy(&p.reads, r + 12, 8);
-                p.coverage = log(1.0 + p.weight);
-                p.vert_off = o + REC_HDR_WORDS;
-                if(idx == 0) attempt[(size_t)g] = p.attempt;
-                ob[t] += 4ll * p.nv + 40;
+                double w; memcpy(&w, r + 6, 8);
+                rec_off[(size_t)i] = o; coverage[(size_t)i] = log(1.0 + w);
+                if(idx == 0) attempt[(size_t)g] = (int)((r[5] >> 8) & 0xFF);
+                obt += 4ll * nv + 40;
             }
+            ob[t] = obt;
         });
         for(unsigned t = 0; t < nthr; t++) { if(bad[t]) return -2; out_bytes += ob[t]; }
         return 0;
@@ -506,8 +517,8 @@ static inline int export_results(const HostResults &R, int n, int64_t *total_pat
                                  int32_t *status, int32_t *path_offset, double *weight, double *abd, double *conf, double *reads,
                                  int32_t *length, int32_t *count, char *strand, int64_t *pv_offset, int32_t *path_vertices)
 {
-    int64_t tp = (int64_t)R.paths.size(), tv = 0;
-    for(auto &p : R.paths) tv += p.nv;
+    int64_t tp = R.n_paths(), tv = 0;
+    for(int64_t i = 0; i < tp; i++) tv += (int64_t)R.rec(i)[2];
     if(total_paths) *total_paths = tp;
     if(total_path_vertices) *total_path_vertices = tv;
     if(!status) return ALD_OK;
@@ -515,7 +526,7 @@ static inline int export_results(const HostResults &R, int n, int64_t *total_pat
     for(int g = 0; g < n; g++) { status[g] = R.status[g]; path_offset[g] = (int32_t)R.path_begin[g]; }
     path_offset[n] = (int32_t)R.path_begin[n];
     for(int64_t i = 0; i < tp; i++) {
-        const PathRec &p = R.paths[i];
+        const PathRec p = R.path(i);
         weight[i] = p.weight; abd[i] = p.abd; conf[i] = p.conf; reads[i] = p.reads; length[i] = p.length; count[i] = p.count; strand[i] = p.strand;
         pv_offset[i] = iv;
         const uint32_t *v = R.vertices(p);

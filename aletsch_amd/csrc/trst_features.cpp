@@ -56,7 +56,7 @@ int ald_batch_features(const ald_batch *b, int32_t graph, const ald_graph_extras
     const GraphRO G(b->hb, graph);
     const int64_t p0 = b->res.path_begin[graph]; const int np = (int)(b->res.path_begin[graph + 1] - p0);
     std::vector<std::vector<Junc>> junc((size_t)np);
-    for(int k = 0; k < np; k++) { const PathRec &p = b->res.paths[(size_t)(p0 + k)]; junctions(G, b->res.vertices(p), p.nv, junc[(size_t)k]); }
+    for(int k = 0; k < np; k++) { const PathRec p = b->res.path((int64_t)((size_t)(p0 + k))); junctions(G, b->res.vertices(p), p.nv, junc[(size_t)k]); }
     // unique_junc (scallop.cc:3472-3497): owner of every junction over the whole path set, -1 once two paths share it
     std::map<Junc, int> owner;
     for(int k = 0; k < np; k++) for(const Junc &j : junc[(size_t)k]) { auto it = owner.find(j); if(it == owner.end()) owner[j] = k; else if(it->second != k && it->second != -1) it->second = -1; }
@@ -67,7 +67,7 @@ int ald_batch_features(const ald_batch *b, int32_t graph, const ald_graph_extras
     static const ald_graph_extras none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     if(!X) X = &none;
     for(int pid = 0; pid < np; pid++) {
-        const PathRec &P = b->res.paths[(size_t)(p0 + pid)]; const uint32_t *pv = b->res.vertices(P); const int n = P.nv;
+        const PathRec P = b->res.path((int64_t)((size_t)(p0 + pid))); const uint32_t *pv = b->res.vertices(P); const int n = P.nv;
         ald_trst_features &F = features[pid]; memset(&F, 0, sizeof(F));
         if(complete) complete[pid] = 0;
         if(n < 3) { status = ALD_ST_INVARIANT + ALD_INV_OTHER; continue; }                                     // assert(n >= 3)

@@ -407,16 +407,9 @@ int ald_batch_reduce_transcripts(const ald_batch *cb, const int32_t *sid, int64_
     HCHK(hipSetDevice(b->device));
     { int rc = device_path_table(b); if(rc != ALD_OK) return rc; }
     const int64_t np = b->total_paths;
-    // the host's copies: the record pool and the index are in the batch's pinned landing areas already; the ordered offsets and the
-    // coverages (log(1 + weight), host libm) are flat maps over the decoded path table
-    PinBuf &p_roff = b->red_pin[5], &p_cov = b->red_pin[3];
-    if(p_roff.ensure(8 * (size_t)np + 8, true) || p_cov.ensure(8 * (size_t)np + 8)) return ald_set_err(ALD_ERR_NOMEM, "pinned path table");
-    unsigned long long *h_roff = (unsigned long long*)p_roff.p; double *h_cov = (double*)p_cov.p;
-    if(np > 0) HCHK(hipMemcpyAsync(h_roff, b->d_ordoff.p, 8 * (size_t)np, hipMemcpyDeviceToHost, b->stream));
-    { unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16; if(np < 50000) nthr = 1;
-      const uint32_t *hp = b->res.pool_data();
-      HCHK(hipStreamSynchronize(b->stream));
-      HostBatch::run_threads(nthr, [&](unsigned t) { for(int64_t p = np * t / nthr; p < np * (t + 1) / nthr; p++) { double w; memcpy(&w, hp + h_roff[p] + 6, 8); h_cov[p] = log(1.0 + w); } }); }
+    // the host's side: the record pool is in the batch's pinned landing area, the offsets in (graph, path) order and the coverages
+    // (log(1 + weight), host libm) are the path table ald_batch_download built from the kernel's index
+    const unsigned long long *h_roff = (const unsigned long long*)b->res.rec_off.data(); const double *h_cov = b->res.coverage.data();
     RedScratch S; S.red = b->red; S.pin = b->red_pin; S.st = b->stream;
     return reduce_core(S, (const uint32_t*)b->d_pool.p, (const unsigned long long*)b->d_ordoff.p, b->res.pool_data(), h_roff, h_cov, nullptr, np, b->hb.n(), sid, nullptr, tid_base, skip_single_exon, single_exon_overlap, out);
 }

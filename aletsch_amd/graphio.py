@@ -127,11 +127,14 @@ def write_bundle_dump(pg: PackedGraphs, gids: Optional[List[str]] = None, chrm: 
             out.append("junction %d %d %.2f 1" % (p1, p2, w[k]))
         opo, opv, op = int(sl["po"][g]), int(sl["pv"][g]), int(sl["p"][g])
         po = pg.phasing_offset[opo:opo + P + 1]
-        for p in range(P):                                                         # hyper_set::nodes is a std::map: lexicographic
-            v = pg.phasing_vertex[opv + po[p]:opv + po[p + 1]]
+        nodes = {}                                                                 # hyper_set::nodes is a std::map<vector<int>, int>: add_node_list
+        for p in range(P):                                                         # sorts every list and adds the counts of equal ones (hyper_set.cc:40-48)
+            v = tuple(sorted(int(x) for x in pg.phasing_vertex[opv + po[p]:opv + po[p + 1]]))
+            nodes[v] = nodes.get(v, 0) + int(pg.phasing_count[op + p])
+        for v in sorted(nodes):                                                    # ... and hyper_set::write walks it in key order: lexicographic
             if len(v) <= 2:
                 continue
-            out.append("path %d %s %d 1" % (len(v), " ".join(str(int(x)) for x in v), int(pg.phasing_count[op + p])))
+            out.append("path %d %s %d 1" % (len(v), " ".join(str(x) for x in v), nodes[v]))
     return "\n".join(out) + "\n"
 
 

@@ -229,7 +229,13 @@ private:
         std::deque<int> &mine = gpu_q_[(size_t)d];
         for(;;) {
             int i; bool ok;
-            { std::unique_lock<std::mutex> lk(m_); while(mine.empty() && !stop_) cv_gpu_[(size_t)d].wait(lk); if(mine.empty()) return; i = mine.front(); mine.pop_front(); ok = !err_; }
+            {   // leaves only when the queue is stopping AND no batch cut for this device is still on its way here: the pack thread counts a
+                // batch into dev_load_ when it cuts it (and puts it into the merge order) but queues it only after packing
+                std::unique_lock<std::mutex> lk(m_);
+                while(mine.empty() && !(stop_ && dev_load_[(size_t)d] == 0)) cv_gpu_[(size_t)d].wait(lk);
+                if(mine.empty()) return;
+                i = mine.front(); mine.pop_front(); ok = !err_;
+            }
             slot &S = slots_[(size_t)i];
             const auto t1 = std::chrono::steady_clock::now();
             int rc = ALD_OK; const char *what = "ald_batch_upload";

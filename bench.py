@@ -106,10 +106,23 @@ def cpu_baseline_legs(pg, n_all: int):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import common
     try:
-        cores = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, cores)                                # every core this process may run on (the count is in the line)
+        affinity = os.cpu_count() or 1
+    # every core this process may USE: the affinity mask, cut down to the cgroup's CPU quota where there is one (the GPU box shows all
+    # 256 hardware threads in the mask but gives a one-GPU job a 16-core share; 256 threads on 16 cores' worth of time ran the same
+    # sample at 5.9 k bundles/s against 10.4 k with 16)
+    quota = None
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1]))),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (None if int(t) <= 0 else int(t) / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))):
+        try:
+            quota = parse(open(path).read().strip())
+            break
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+    cores = max(1, min(affinity, int(quota + 0.5)) if quota else affinity)
+    if os.environ.get("ALD_BENCH_CPU_THREADS"):
+        cores = max(1, int(os.environ["ALD_BENCH_CPU_THREADS"]))
     n_all = min(n_all, pg.n); n_one = max(256, min(pg.n, n_all // 12))
     s_all = pg.select(np.arange(n_all)); s_one = pg.select(np.arange(n_one))
     _, _, sec_all, _ = common.oracle_run(s_all, threads=cores)
@@ -118,7 +131,8 @@ def cpu_baseline_legs(pg, n_all: int):
     note = ("oracle/ = CPU restatement of the reference scallop core (container-based port; the survey's probe of the reference itself "
             "measured 157-206 graphs/s per thread on these graphs, BASELINE.md section 2)")
     allc = {"value": s_all.n / sec_all, "unit": "bundles/s", "cores": cores, "kind": "port", "cpu_model": model,
-            "sample": f"first {s_all.n} graphs of the same workload, {cores} threads over independent graphs, {sec_all:.2f} s; {note}"}
+            "affinity_cores": affinity, "cgroup_cpu_quota": quota,
+            "sample": f"first {s_all.n} graphs of the same workload, {cores} threads over independent graphs (affinity mask {affinity} hardware threads, cgroup CPU quota {quota}), {sec_all:.2f} s; {note}"}
     one = {"value": s_one.n / sec_one, "unit": "bundles/s", "cores": 1, "kind": "port", "cpu_model": model,
            "sample": f"first {s_one.n} graphs of the same workload, 1 thread, {sec_one:.2f} s"}
     return allc, one

@@ -44,10 +44,10 @@ int main(int argc, char **argv)
                 void *h = dlopen(getenv("ALD_RCCL_LIB"), RTLD_NOW | RTLD_NOLOAD);
                 int (*in_group)() = h ? (int (*)())dlsym(h, "mock_rccl_thread_in_group") : nullptr;
                 if(r == fail_rank && (e == ALD_OK || !in_group || in_group() != 0)) { fprintf(stderr, "rank %d: failed send not handled (rc=%d, in_group=%d)\n", r, e, in_group ? in_group() : -1); rc[r] = 5; }
-                if(dsrc) hipFree(dsrc);
+                if(dsrc) (void)hipFree(dsrc);
                 break;
             }
-            if(e != ALD_OK) { fprintf(stderr, "rank %d step %d gather: %s\n", r, step, ald_last_error()); rc[r] = 6; if(dsrc) hipFree(dsrc); break; }
+            if(e != ALD_OK) { fprintf(stderr, "rank %d step %d gather: %s\n", r, step, ald_last_error()); rc[r] = 6; if(dsrc) (void)hipFree(dsrc); break; }
             int64_t at = 0;
             for(int q = 0; q < W && rc[r] == 0; q++) {
                 std::vector<uint32_t> want = stream_of(q, step);
@@ -57,7 +57,7 @@ int main(int argc, char **argv)
             }
             if(rc[r] == 0 && offs[W] != at) rc[r] = 9;
             if(r != 0 && all != nullptr) rc[r] = 10;
-            if(dsrc) hipFree(dsrc);
+            if(dsrc) (void)hipFree(dsrc);
         }
         ald_comm_destroy(c);
     });

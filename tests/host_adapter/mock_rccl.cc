@@ -27,6 +27,7 @@ struct World {
 struct Comm { World *w; int rank; };
 std::mutex g_m; std::map<unsigned long long, World*> g_worlds; unsigned long long g_next = 1;
 thread_local int t_group = 0; thread_local std::vector<std::pair<Comm*, Op>> t_pending; thread_local Comm *t_failed = nullptr;      // t_failed: a Send of this group was refused
+thread_local Comm *t_comm = nullptr;        // the communicator this thread (= this rank) works with: a rank with nothing to send still joins the rendezvous
 size_t elt(ncclDataType_t t) { return (t == ncclInt64 || t == ncclUint64 || t == ncclFloat64) ? 8 : (t == ncclInt8 || t == ncclUint8) ? 1 : 4; }
 }
 
@@ -38,7 +39,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int n, ncclUniqueId id, int rank
     World *w;
     { std::lock_guard<std::mutex> l(g_m); World *&slot = g_worlds[k]; if(!slot) { slot = new World(); slot->n = n; slot->ag_src.resize(n); slot->ag_st.resize(n); slot->ops.resize(n); } w = slot; }
     if(w->n != n || rank < 0 || rank >= n) return ncclInvalidArgument;
-    *comm = (ncclComm_t)new Comm{w, rank};
+    *comm = (ncclComm_t)new Comm{w, rank}; t_comm = (Comm*)*comm;
     return ncclSuccess;
 }
 ncclResult_t ncclCommDestroy(ncclComm_t c) { delete (Comm*)c; return ncclSuccess; }
@@ -73,10 +74,11 @@ ncclResult_t ncclGroupEnd()
 {
     if(t_group <= 0) return ncclInvalidUsage;
     if(--t_group > 0) return ncclSuccess;
-    if(t_pending.empty() && !t_failed) return ncclSuccess;
-    // a rank whose Send was refused still takes part in the rendezvous with nothing to offer: its peers then find no matching send
-    // and fail as well instead of waiting for ever
-    Comm *c = t_failed ? t_failed : t_pending.front().first; World *w = c->w;
+    // every rank closes one group per gather, so every rank meets the others here -- also one with nothing to send (an empty stream)
+    // and one whose Send was refused (nothing to offer: its peers then find no matching send and fail as well instead of waiting for ever)
+    Comm *c = t_failed ? t_failed : (t_pending.empty() ? t_comm : t_pending.front().first);
+    if(!c) return ncclSuccess;
+    World *w = c->w;
     if(t_failed) { t_pending.clear(); t_failed = nullptr; }
     for(auto &p : t_pending) if(p.second.send && hipStreamSynchronize(p.second.st) != hipSuccess) return ncclUnhandledCudaError;    // staged payload is complete
     { std::lock_guard<std::mutex> l(w->m); w->ops[c->rank].clear(); for(auto &p : t_pending) w->ops[c->rank].push_back(p.second); }

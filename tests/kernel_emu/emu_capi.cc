@@ -105,9 +105,9 @@ int emu_result_export(const emu_result *E, int64_t *total_paths, int64_t *total_
 /* the transcripts the records carry (exons joined by the engine, coverage by HostResults::build): same signature as ald_batch_export_transcripts */
 int emu_result_export_transcripts(const emu_result *E, int64_t *total_exons, double *coverage, int64_t *exon_offset, int32_t *exon_lr)
 {
-    int64_t te = 0; const int64_t np = (int64_t)E->R.paths.size();
+    int64_t te = 0; const int64_t np = E->R.n_paths();
     for(int64_t i = 0; i < np; i++) {
-        const PathRec &p = E->R.paths[(size_t)i];
+        const PathRec p = E->R.path((int64_t)((size_t)i));
         if(coverage) { coverage[i] = p.coverage; exon_offset[i] = te; if(p.nexw) memcpy(exon_lr + 2 * te, E->R.exons(p), 4 * (size_t)p.nexw); }
         te += p.nexw / 2;
     }

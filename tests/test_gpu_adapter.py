@@ -248,8 +248,8 @@ def test_comm_gather_with_several_ranks_on_one_gpu():
                     "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-pthread"], check=True)
     env = dict(os.environ, ALD_RCCL_LIB=mock)
     for world in ("2", "3"):
-        r = subprocess.run([exe, world], capture_output=True, text=True, timeout=300, env=env)
+        r = subprocess.run([exe, world], capture_output=True, text=True, timeout=90, env=env)
         assert r.returncode == 0 and "COMM_RANKS_OK world=" + world in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
     for fail in ("1", "0"):
-        r = subprocess.run([exe, "2", fail], capture_output=True, text=True, timeout=300, env=dict(env, ALD_MOCK_RCCL_FAIL_SEND=fail))
+        r = subprocess.run([exe, "2", fail], capture_output=True, text=True, timeout=90, env=dict(env, ALD_MOCK_RCCL_FAIL_SEND=fail))
         assert r.returncode == 0 and "injected send failure handled" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]

@@ -1,6 +1,8 @@
 """GPU parity tests proper: the HIP path (through the C ABI) against the oracle on the same seeded inputs.
 Bit-exact: identical path sets in identical order, exact integer fields, bit-identical FP64 weight / abd / reads;
 conf (exp of summed libm logs, reported only) within 1e-9 relative."""
+import os
+
 import numpy as np
 import pytest
 
@@ -790,3 +792,18 @@ def test_reference_tset_golden_through_the_device_reduction():
         s = A.TranscriptSink(0.8); s.add_groups(groups, skip_single_exon=True)
         assert items2 == s.items()
     assert n_dev > 100
+
+
+def test_barrier_variant_of_the_hand_overs():
+    """wsync() is a wavefront-scope fence (no instruction), so every lane-to-lane hand-over through LDS / the slabs relies on
+    same-wave in-order memory.  libaletsch_decomp_wsync.so is the same source with __syncthreads() at every hand-over (make WSYNC=1:
+    a full s_waitcnt drain each time).  A fixed-seed fuzz slice through it against the oracle must be as clean as through the product
+    build -- a divergence between the two forms would show here and not only in the ad-hoc fuzz tool."""
+    import subprocess, sys
+    lib = os.path.join(common.ROOT, "aletsch_amd", "lib", "libaletsch_decomp_wsync.so")
+    assert os.path.exists(lib), "build it with make -C aletsch_amd/csrc WSYNC=1 (python __graft_entry__.py does)"
+    env = dict(os.environ, ALETSCH_DECOMP_LIB=lib, FUZZ_SECONDS="25", FUZZ_SEED="31337")
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "tools", "fuzz_parity.py")], capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("TOTAL graphs") and last.endswith("mismatches 0") and int(last.split()[2]) >= 1000, r.stdout[-1500:]
