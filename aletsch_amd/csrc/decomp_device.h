@@ -1856,6 +1856,152 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     HC.ro_npairs = np;
     return true;
 }
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The router for the vertex it nearly always sees (93 % of its runs on the bench workload): 2 in-edges + 2 out-edges, no phasing
+// routes, one supporting sample per edge -- i.e. router_prepare returned level 2 and left, for the four nodes (0, 1 = the in-edges,
+// 2, 3 = the out-edges, adjacency order), the partner each would attach to, the shared abundance and the logarithm of its share.
+// Same statements as router_body (router.cc:250-325 with every node isolated, 116-171, 738-936, 1010-1129, 1248-1275), but on
+// NAMED scalars instead of arrays in LDS: four node weights, four degrees, at most three edges of the bipartite graph
+//   in-nodes attach first, in index order:   k0 = (0, p0), k1 = (1, p1)
+//   an out-node nobody attached to then attaches itself:   k2 = (partner, that out-node)     (only when p0 == p1)
+// so the graph is either two components of one edge each (SPLITTABLE_PURE, degree 1) or one path of three edges
+// (UNSPLITTABLE_SINGLE, degree 1).  thread() runs as in the general form -- leaf edges in creation order, else one turn at the
+// lightest node of degree >= 2, ties to the later node -- with run-time node indices resolved by select chains over the four
+// scalars (a handful of v_cndmask each) instead of dependent LDS round trips.  Every floating-point operation is the one the general
+// form performs, on the same operands in the same order.  Returns -1 when the vertex is not of this shape (the general form runs),
+// else what router_body returns.
+#define R4_GET(a0, a1, a2, a3, i) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : ((i) == 2 ? (a2) : (a3))))
+#define R4_SET(a0, a1, a2, a3, i, val) do { if((i) == 0) a0 = (val); else if((i) == 1) a1 = (val); else if((i) == 2) a2 = (val); else a3 = (val); } while(0)
+ALD_FN int router_22(int root, int want_type, int max_degree)
+{
+    root = uni(root); want_type = uni(want_type); max_degree = uni(max_degree);
+    COLD;
+    const Arena AR = arena_at(true);
+    const Pairs PW = pairs_at(true, false);
+    const int n = 4;
+    const int32_t *u2e = AR.i, *part = AR.i + 2 * n, *iso = AR.i + 4 * n;
+    const double *nabd = AR.d, *share = AR.d + 2 * n, *ecf = AR.d + ARENA_D - n;
+    const int i0 = uni(iso[0]), i1 = uni(iso[1]), i2 = uni(iso[2]), i3 = uni(iso[3]);
+    if((i0 | i1 | i2 | i3) != 0) return -1;                                   // an edge with count == 0 ("Warning!"): general form
+    const int p0 = uni(part[0]), p1 = uni(part[1]);
+    if(p0 < 2 || p1 < 2) return -1;                                           // no partner (the general form reports it)
+    HC.pw_lds = 1;
+    if(ALD_UNLIKELY(mixed_strand_vertex(root))) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return 0; }     // router.cc:71-76
+    const int e0 = uni(u2e[0]), e1 = uni(u2e[1]), e2 = uni(u2e[2]), e3 = uni(u2e[3]);
+    // ---- build_bipartite_graph + the attachments (router.cc:250-325, 1010-1129)
+    int nue = 2; int ks0 = 0, kt0 = p0, ks1 = 1, kt1 = p1, ks2 = 0, kt2 = 0;                   // edge k: (in-node, out-node)
+    double uw0 = uni(nabd[0]), uw1 = uni(nabd[1]), uw2 = 0;
+    int d0 = 1, d1 = 1, d2 = (p0 == 2) + (p1 == 2), d3 = (p0 == 3) + (p1 == 3);
+    int q = -1;                                                                // the out-node that attaches itself (iso[q] becomes 1)
+    if(p0 == p1) {
+        q = 5 - p0;
+        const int r = uni(part[q]);
+        if(r < 0 || r > 1) return -1;
+        ks2 = r; kt2 = q; uw2 = uni(nabd[q]); nue = 3;
+        if(r == 0) d0++; else d1++;
+        if(q == 2) d2++; else d3++;
+    }
+    // ---- classify_plain_vertex (router.cc:116-171): one path of three edges, or two components of one edge each
+    HC.ro_npairs = 0; HC.ro_ratio = 0;
+    const int rtype = (nue == 3) ? T_UNSPLITTABLE_SINGLE : T_SPLITTABLE_PURE, rdeg = 1;    // nue - n + 2 = 1 / b - 1 + (a + 1) / 2 = 1 with a = 0, b = 2
+    HC.ro_type = rtype; HC.ro_degree = rdeg;
+    if(rtype != want_type) return 1;
+    if(rdeg > max_degree) return 1;
+#ifdef ALD_EMU_COUNT
+    g_cnt_build++;
+#endif
+    // ---- compute_balanced_weights_components (router.cc:1248-1275)
+    const double w0 = uni(H.ed[e0].w), w1 = uni(H.ed[e1].w), w2 = uni(H.ed[e2].w), w3 = uni(H.ed[e3].w);
+    double v0, v1, v2, v3;
+    if(nue == 3) {
+        double sum1 = 0, sum2 = 0; sum1 += w0; sum1 += w1; sum2 += w2; sum2 += w3;
+        const double r1 = sqrt(sum2 / sum1), r2 = sqrt(sum1 / sum2);
+        v0 = w0 * r1; v1 = w1 * r1; v2 = w2 * r2; v3 = w3 * r2;
+    } else {
+        // component 0 = {0, p0}, component 1 = {1, p1}
+        const double wp0 = p0 == 2 ? w2 : w3, wp1 = p1 == 2 ? w2 : w3;
+        double s1 = 0, s2 = 0; s1 += w0; s2 += wp0;
+        const double a1 = sqrt(s2 / s1), a2 = sqrt(s1 / s2);
+        double t1 = 0, t2 = 0; t1 += w1; t2 += wp1;
+        const double b1 = sqrt(t2 / t1), b2 = sqrt(t1 / t2);
+        v0 = w0 * a1; v1 = w1 * b1;
+        v2 = (p0 == 2) ? w2 * a2 : w2 * b2; v3 = (p0 == 3) ? w3 * a2 : w3 * b2;
+    }
+    double weight_sum = 0; weight_sum += v0; weight_sum += v1; weight_sum += v2; weight_sum += v3;
+    // ---- thread() (router.cc:738-936)
+    int32_t *pa = PW.a, *pb = PW.b; double *pwt = PW.w; int np = 0;
+    bool al0 = true, al1 = true, al2 = (nue == 3); int live = nue;
+    #define R4_VW(i) R4_GET(v0, v1, v2, v3, i)
+    #define R4_DEG(i) R4_GET(d0, d1, d2, d3, i)
+    #define R4_U2E(i) R4_GET(e0, e1, e2, e3, i)
+    #define R4_CLEAR(x_) do { \
+        if(al0 && (ks0 == (x_) || kt0 == (x_))) { al0 = false; live--; R4_SET(d0, d1, d2, d3, ks0, R4_DEG(ks0) - 1); R4_SET(d0, d1, d2, d3, kt0, R4_DEG(kt0) - 1); } \
+        if(al1 && (ks1 == (x_) || kt1 == (x_))) { al1 = false; live--; R4_SET(d0, d1, d2, d3, ks1, R4_DEG(ks1) - 1); R4_SET(d0, d1, d2, d3, kt1, R4_DEG(kt1) - 1); } \
+        if(al2 && (ks2 == (x_) || kt2 == (x_))) { al2 = false; live--; R4_SET(d0, d1, d2, d3, ks2, R4_DEG(ks2) - 1); R4_SET(d0, d1, d2, d3, kt2, R4_DEG(kt2) - 1); } } while(0)
+    for(int guard = 0; guard < 8; guard++) {
+        // thread_leaf (router.cc:859-897): edges in creation order
+        int fx = -1, fy = -1, fs = 0, ft = 0;
+        #define R4_LEAF(al, ks, kt) if(fx < 0 && (al)) { const int s_ = (ks), t_ = (kt); const double vs_ = R4_VW(s_), vt_ = R4_VW(t_); \
+            if(!(vs_ < -0.5) && !(vt_ < -0.5)) { if(R4_DEG(s_) == 1 && vs_ <= vt_) { fx = s_; fy = t_; fs = s_; ft = t_; } else if(R4_DEG(t_) == 1 && vt_ <= vs_) { fx = t_; fy = s_; fs = s_; ft = t_; } } }
+        R4_LEAF(al0, ks0, kt0) R4_LEAF(al1, ks1, kt1) R4_LEAF(al2, ks2, kt2)
+        #undef R4_LEAF
+        if(fx >= 0) {
+            const double vx = R4_VW(fx);
+            pa[np] = PMAKE(R4_U2E(fs), fs); pb[np] = PMAKE(R4_U2E(ft), ft); pwt[np] = vx; np++;
+            R4_CLEAR(fx);
+            const double vy = R4_VW(fy) - vx;
+            R4_SET(v0, v1, v2, v3, fy, vy); R4_SET(v0, v1, v2, v3, fx, -1.0);
+            continue;
+        }
+        // thread_turn (router.cc:899-936): the lightest node of degree >= 2, ties to the later one
+        int x = -1; double vx = 0;
+        #define R4_TURN(k_, vk_, dk_) if(!((vk_) < -0.5) && (dk_) > 1 && !(x != -1 && (vk_) > vx)) { x = (k_); vx = (vk_); }
+        R4_TURN(0, v0, d0) R4_TURN(1, v1, d1) R4_TURN(2, v2, d2) R4_TURN(3, v3, d3)
+        #undef R4_TURN
+        if(x == -1) break;
+        // out_edges(x): by the other endpoint (ascending node index), then creation; sum first, then the shares
+        double sum = 0; bool bad = false;
+        for(int t = 0; t < 4; t++) {
+            #define R4_SUM(al, ks, kt, uw) if(al) { const int y_ = ((ks) == x) ? (kt) : (((kt) == x) ? (ks) : -1); if(y_ == t) { sum += (uw); if(!(R4_VW(t) >= vx)) bad = true; } }
+            R4_SUM(al0, ks0, kt0, uw0) R4_SUM(al1, ks1, kt1, uw1) R4_SUM(al2, ks2, kt2, uw2)
+            #undef R4_SUM
+        }
+        if(ALD_UNLIKELY(bad)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return 0; }
+        for(int t = 0; t < 4; t++) {
+            #define R4_SHARE(al, ks, kt, uw) if(al) { const int y_ = ((ks) == x) ? (kt) : (((kt) == x) ? (ks) : -1); if(y_ == t) { \
+                const double wgt = vx * (uw) / sum; const int a_ = x < t ? x : t, b_ = x < t ? t : x; \
+                pa[np] = PMAKE(R4_U2E(a_), a_); pb[np] = PMAKE(R4_U2E(b_), b_); pwt[np] = wgt; np++; \
+                const double vt_ = R4_VW(t) - wgt; R4_SET(v0, v1, v2, v3, t, vt_); } }
+            R4_SHARE(al0, ks0, kt0, uw0) R4_SHARE(al1, ks1, kt1, uw1) R4_SHARE(al2, ks2, kt2, uw2)
+            #undef R4_SHARE
+        }
+        R4_SET(v0, v1, v2, v3, x, -1.0);
+        R4_CLEAR(x);
+    }
+    #undef R4_VW
+    #undef R4_DEG
+    #undef R4_U2E
+    #undef R4_CLEAR
+    if(ALD_UNLIKELY(live != 0)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return 0; }
+    double weight_remain = 0;
+    if(!(v0 <= 0)) weight_remain += v0;
+    if(!(v1 <= 0)) weight_remain += v1;
+    if(!(v2 <= 0)) weight_remain += v2;
+    if(!(v3 <= 0)) weight_remain += v3;
+    HC.ro_ratio = weight_remain / weight_sum;
+    // router.cc:849-855, the side effect of every build(): the attached nodes' confidences (logarithms taken by router_prepare)
+    C.ed[e0].econf = uni(ecf[0]) + uni(share[0]);
+    C.ed[e1].econf = uni(ecf[1]) + uni(share[1]);
+    if(q == 2) C.ed[e2].econf = uni(ecf[2]) + uni(share[2]);
+    if(q == 3) C.ed[e3].econf = uni(ecf[3]) + uni(share[3]);
+    sort_pairs(PW, np);
+    const double mw = HC.p_min_w;
+    for(int i = 0; i < np; i++) if(pwt[i] < mw) pwt[i] = mw;                // router.cc:217-220
+    HC.ro_npairs = np;
+    return 1;
+}
+#undef R4_GET
+#undef R4_SET
 ALD_FN bool router_small(int root, int want_type, int max_degree, int pre) { return router_body<true>(uni(root), uni(want_type), uni(max_degree), uni(pre)); }
 ALD_FN bool router_large(int root, int want_type, int max_degree) { return router_body<false>(uni(root), uni(want_type), uni(max_degree), 0); }
 // What the router needs of the root's edges, fetched by the WHOLE WAVE before lane 0 runs it (ALL lanes call; returns the `pre` level
@@ -1918,6 +2064,9 @@ ALD_INL bool router_run(int root, int want_type, int max_degree, int pre = 0)
     const int nin = uni(H.in_deg[root]), nout = uni(H.out_deg[root]), n = nin + nout;
     const int route_bound = (uni(HC.hl_n) == 0) ? 0 : nin * nout;
     const bool small = (route_bound + n <= LP) && (5 * n + 3 * (route_bound + n) <= ARENA_I) && (3 * n + route_bound + n <= ARENA_D);
+#ifndef ALD_NO_ROUTER22
+    if(pre == 2 && nin == 2 && nout == 2) { const int r22 = uni(router_22(root, want_type, max_degree)); if(r22 >= 0) return r22 != 0; }
+#endif
     return small ? uni(router_small(root, want_type, max_degree, pre)) : uni(router_large(root, want_type, max_degree));
 }
 // park / un-park the best candidate's pe2w while an unsplittable sweep goes on
@@ -1946,7 +2095,11 @@ ALD_INL void memo_clear()
     wsync();
 }
 // scallop::resolve_unsplittable_vertex (scallop.cc:1004-1060)
+#ifdef ALD_UNSPLIT_CALL
+ALD_FN bool sweep_unsplittable(int type, int degree, double max_ratio)
+#else
 ALD_INL bool sweep_unsplittable(int type, int degree, double max_ratio)
+#endif
 {
 #ifdef ALD_EMU_COUNT
     g_cnt_unsweep++;

@@ -52,6 +52,54 @@ struct packed_chunk {
         cat(vertex_weight, s.vertex_weight); cat(vertex_lpos, s.vertex_lpos); cat(vertex_rpos, s.vertex_rpos); cat(vertex_type, s.vertex_type);
         cat(phasing_offset, s.phasing_offset); cat(phasing_vertex, s.phasing_vertex); cat(phasing_count, s.phasing_count); cat(edge_count, s.edge_count); cat(edge_rank, s.edge_rank);
     }
+    // The same as stage_graph() + append(), without the staged_graph in between: ONE walk over gr.edges(), a counting sort into CSR
+    // rows (rows keep the walk's order, i.e. creation order; inside a row a stable insertion by target: rows hold a handful of edges),
+    // every field written straight behind the chunk's last graph.  `tmp` is the calling thread's scratch, kept across graphs.
+    struct scratch { std::vector<int32_t> row, at, ord, dst; std::vector<const void*> eh; };
+    template<class SpliceGraph, class HyperSet>
+    void append_graph(SpliceGraph &gr, const HyperSet &hs, int sample, scratch &tmp)
+    {
+        typedef typename std::decay<decltype(*gr.edges().first)>::type edge_t;       // edge_descriptor (a pointer in the reference)
+        const int V = (int)gr.num_vertices();
+        static_assert(std::is_pointer<edge_t>::value, "edge_descriptor is expected to be a pointer (graph/edge_base.h)");
+        std::vector<const void*> &eh = tmp.eh;
+        eh.clear(); tmp.dst.clear(); tmp.row.assign((size_t)V + 1, 0);
+        std::vector<int32_t> &src = tmp.ord;                                         // source of edge k (walk order), then reused as the CSR permutation
+        src.clear();
+        { auto pe = gr.edges(); for(auto it = pe.first; it != pe.second; ++it) { const int a = (*it)->source(), b = (*it)->target(); eh.push_back((const void*)*it); src.push_back(a); tmp.dst.push_back(b); tmp.row[(size_t)a + 1]++; } }
+        const int E = (int)eh.size();
+        for(int i = 0; i < V; i++) tmp.row[(size_t)i + 1] += tmp.row[(size_t)i];
+        tmp.at.assign(tmp.row.begin(), tmp.row.end() - 1);
+        std::vector<int32_t> perm((size_t)E);                                        // CSR position -> walk position (= scallop's edge index, graph_base.cc:139-153)
+        for(int k = 0; k < E; k++) {
+            const int a = src[(size_t)k]; int pos = tmp.at[(size_t)a]++;
+            const int lo = tmp.row[(size_t)a];
+            while(pos > lo && tmp.dst[(size_t)perm[(size_t)pos - 1]] > tmp.dst[(size_t)k]) { perm[(size_t)pos] = perm[(size_t)pos - 1]; pos--; }      // stable: equal targets keep walk order
+            perm[(size_t)pos] = k;
+        }
+        g_nv.push_back(V); g_ne.push_back(E); graph_strand.push_back(gr.strand); sid.push_back((int32_t)sample);
+        vertex_offset.insert(vertex_offset.end(), tmp.row.begin(), tmp.row.end());
+        const size_t e0 = edge_target.size(), s0 = edge_sample_offset.size();
+        edge_target.resize(e0 + (size_t)E); edge_weight.resize(e0 + (size_t)E); edge_strand.resize(e0 + (size_t)E); edge_abd.resize(e0 + (size_t)E); edge_count.resize(e0 + (size_t)E); edge_rank.resize(e0 + (size_t)E);
+        edge_sample_offset.resize(s0 + (size_t)E + 1); edge_sample_offset[s0] = 0;
+        const size_t smp0 = sample_id.size();
+        for(int q = 0; q < E; q++) {
+            const int k = perm[(size_t)q]; const edge_t e = (edge_t)const_cast<void*>(eh[(size_t)k]);
+            const auto &ei = gr.get_edge_info(e);
+            edge_target[e0 + (size_t)q] = tmp.dst[(size_t)k]; edge_weight[e0 + (size_t)q] = gr.get_edge_weight(e); edge_strand[e0 + (size_t)q] = (uint8_t)ei.strand; edge_abd[e0 + (size_t)q] = ei.abd;
+            edge_count[e0 + (size_t)q] = (int32_t)ei.count; edge_rank[e0 + (size_t)q] = k;
+            if(ei.samples.size() == 1 && ei.spAbd.size() == 1 && ei.spAbd.begin()->first == *ei.samples.begin()) { sample_id.push_back(*ei.samples.begin()); sample_abd.push_back(ei.spAbd.begin()->second); }     // the common case without a hash lookup
+            else for(int sp : ei.samples) { sample_id.push_back(sp); auto f = ei.spAbd.find(sp); sample_abd.push_back(f == ei.spAbd.end() ? 0.0 : f->second); }
+            edge_sample_offset[s0 + (size_t)q + 1] = (int32_t)(sample_id.size() - smp0);
+        }
+        const size_t v0 = vertex_weight.size();
+        vertex_weight.resize(v0 + (size_t)V); vertex_lpos.resize(v0 + (size_t)V); vertex_rpos.resize(v0 + (size_t)V); vertex_type.resize(v0 + (size_t)V);
+        for(int i = 0; i < V; i++) { const auto &vi = gr.get_vertex_info(i); vertex_weight[v0 + (size_t)i] = gr.get_vertex_weight(i); vertex_lpos[v0 + (size_t)i] = vi.lpos; vertex_rpos[v0 + (size_t)i] = vi.rpos; vertex_type[v0 + (size_t)i] = vi.type; }
+        const size_t pv0 = phasing_vertex.size(); int np = 0;
+        phasing_offset.push_back(0);
+        for(const auto &kv : hs.nodes) { for(int x : kv.first) phasing_vertex.push_back(x); phasing_offset.push_back((int32_t)(phasing_vertex.size() - pv0)); phasing_count.push_back(kv.second); np++; }
+        g_np.push_back(np);
+    }
     void reserve_like(const packed_chunk &o)                      // the next chunk of a thread is about as large as its last one
     {
         g_nv.reserve(o.g_nv.size()); g_ne.reserve(o.g_ne.size()); g_np.reserve(o.g_np.size()); graph_strand.reserve(o.graph_strand.size()); sid.reserve(o.sid.size());
@@ -115,14 +163,24 @@ public:
     // Thread-safe.  The graph's transcripts will carry tid = (ticket << 20) | path index, tickets being handed out chunk by chunk.
     void submit(SpliceGraph &gx, const HyperSet &hx, int sid)
     {
-        staged_graph s = stage_graph(gx, hx);                     // the per-graph work stays in the calling thread, outside any shared lock
-        submit_staged(s, sid);
+        // the per-graph work stays in the calling thread: the graph is converted straight into the thread's own chunk (its lock is only
+        // ever contended by drain())
+        lane *L = my_lane();
+        std::unique_lock<std::mutex> ll(L->m);
+        L->c.append_graph(gx, hx, sid, L->tmp);
+        hand_over_if_full(L, ll);
     }
     void submit_staged(const staged_graph &s, int sid)
     {
         lane *L = my_lane();
         std::unique_lock<std::mutex> ll(L->m);
         L->c.append(s, sid);
+        hand_over_if_full(L, ll);
+    }
+private:
+    struct lane;
+    void hand_over_if_full(lane *L, std::unique_lock<std::mutex> &ll)
+    {
         if(L->c.n() < chunk_graphs_) return;
         packed_chunk full; std::swap(full, L->c); L->c.reserve_like(full);
         ll.unlock();
@@ -131,6 +189,7 @@ public:
         if(err_) throw gpu_error(err_, err_msg_.c_str());
         push_chunk(std::move(full));
     }
+public:
 
     // The call shape of assembler::assemble(gx, px, sid) itself (meta/assembler.cc:1075): the pre-steps (extend_strands, boundary
     // grouping, phase projection, hyper_set ctor + filter_nodes) run in the calling thread through the library, then the graph is queued.
@@ -169,7 +228,7 @@ public:
 private:
     enum { FREE, BUSY };
     struct slot { ald_batch *b = nullptr; std::vector<int32_t> sid; long first = 0; int state = FREE; int dev = 0; bool done = false; };
-    struct lane { std::mutex m; packed_chunk c; };
+    struct lane { std::mutex m; packed_chunk c; packed_chunk::scratch tmp; };
 
     lane *my_lane()
     {

@@ -253,3 +253,31 @@ def test_comm_gather_with_several_ranks_on_one_gpu():
     for fail in ("1", "0"):
         r = subprocess.run([exe, "2", fail], capture_output=True, text=True, timeout=90, env=dict(env, ALD_MOCK_RCCL_FAIL_SEND=fail))
         assert r.returncode == 0 and "injected send failure handled" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_replay_dump_program_on_gpu():
+    """tools/replay_dump.cc (in C++ as the host side is): a bundle dump in the reference's own text form
+    (splice_graph::write + hyper_set::write) -> aletsch::read_bundle_dump -> gpu_assembly_queue -> merged transcript set -> GTF through
+    ald_gtf_format_transcript.  The GTF must equal, byte for byte, what the Python path makes of the same dump (graphio reader ->
+    DecompBatch -> TranscriptSink -> format_transcript), whose pieces are each checked against the oracle / the reference's writers."""
+    from aletsch_amd import graphio
+    bld = os.path.join(ROOT, "tests", "_build"); os.makedirs(bld, exist_ok=True)
+    lib = os.path.join(ROOT, "aletsch_amd", "lib"); exe = os.path.join(bld, "replay_dump")
+    subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "replay_dump.cc"),
+                    "-o", exe, "-L" + lib, "-laletsch_decomp", "-Wl,-rpath," + lib, "-pthread"], check=True)
+    src = A.synth(seed=8086, n_graphs=700, v_min=6, v_max=90, edges_per_vertex=3, layout_mode=1, weight_mode=1, phasing_per_graph=5, strand_mode=1)
+    text = graphio.write_bundle_dump(src, chrm="17")
+    r = subprocess.run([exe, "-b", "256"], input=text, capture_output=True, text=True, timeout=300)      # three batches through two slots
+    assert r.returncode == 0, r.stderr[-2000:]
+    pg, meta = graphio.read_bundle_dump(text)
+    with A.DecompBatch(0) as b:
+        b.add(pg); b.upload(); b.run(); b.download()
+        assert (b.result().status == 0).all()
+        sink = A.TranscriptSink(0.8); sink.add_batch(b, np.zeros(pg.n, np.int32), tid_base=0, skip_single_exon=True)
+    want = []
+    for it in sink.items():
+        g, p = it["tid"] >> 20, it["tid"] & ((1 << 20) - 1)
+        want.append(A.format_transcript("17", "aletsch", meta[g]["gid"], A.transcript_id("17", meta[g]["gid"], p), it["strand"], it["coverage"], it["exons"], cov2=-1.0, count=it["count2"]))
+    assert len(want) > 300 and r.stdout == "".join(want)
+    assert ("%d bundles, 0 not decomposed, %d transcripts" % (pg.n, len(want))) in r.stderr

@@ -732,7 +732,7 @@ def test_result_index_written_by_the_kernel():
     npaths = np.diff(r.path_offset)
     assert idx.size == int(npaths.sum()) and ((gf >= 0) == (npaths > 0)).all()
     allrec = parse_records(raw)
-    assert len(allrec) > idx.size                       # abandoned attempts are in the pool ...
+    assert len(allrec) >= idx.size                      # (records of abandoned attempts, if any were written before the overflow, are in the pool ...
     seen = set()
     for g in range(pg.n):
         for p in range(int(npaths[g])):
@@ -743,7 +743,7 @@ def test_result_index_written_by_the_kernel():
             assert raw[o + REC_HDR_WORDS:o + REC_HDR_WORDS + nv].astype(np.int32).tolist() == r.path_vertices[int(r.pv_offset[i]):int(r.pv_offset[i + 1])].tolist()
             assert raw[o + 6:o + 8].view(np.float64)[0] == r.weight[i]
             assert raw[o + REC_HDR_WORDS + nv:o + REC_HDR_WORDS + nv + nx].astype(np.int32).reshape(-1, 2).tolist() == lr[int(eo[i]):int(eo[i + 1])].tolist()
-    assert len(seen) == idx.size                        # ... and nothing names them
+    assert len(seen) == idx.size                        # ... and nothing names them)
     _, cov_o, eo_o, lr_o = common.oracle_transcripts(pg)
     assert np.array_equal(eo, eo_o) and np.array_equal(lr, lr_o) and np.array_equal(cov, cov_o)
 

@@ -2,6 +2,8 @@
 file of splice_graph::build(file) (splice_graph.cc:329-376) and the bundle dump of splice_graph::write + hyper_set::write
 (splice_graph.cc:422-477, hyper_set.cc:1109-1128).  Replayed graphs go through the engine (emulated here, the HIP kernels in the GPU
 tier) and the oracle like any other batch."""
+import os
+
 import numpy as np
 
 import aletsch_amd as A
@@ -91,3 +93,89 @@ def test_a_dump_as_an_aletsch_build_prints_it():
     want, st, _, _ = common.oracle_run(pg); got, it, _ = common.emu_run(pg)
     assert not common.compare_results(want, got, pg.n) and np.array_equal(it, st[:, 3])
     assert (want.status == 0).all() and want.path_offset[1] >= 2 and want.path_offset[2] - want.path_offset[1] == 1
+
+
+# ------------------------------------------------------------------------------------------------ the C++ reader / writer (aletsch_amd/host/graph_io.hpp)
+def _replay_tool():
+    import subprocess
+    exe = os.path.join(common.ROOT, "tests", "_build", "replay_dump"); os.makedirs(os.path.dirname(exe), exist_ok=True)
+    lib = os.path.join(common.ROOT, "aletsch_amd", "lib")
+    subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(common.ROOT, "include"), os.path.join(common.ROOT, "tools", "replay_dump.cc"),
+                    "-o", exe, "-L" + lib, "-laletsch_decomp", "-Wl,-rpath," + lib, "-pthread"], check=True)
+    return exe
+
+
+def test_cxx_reader_and_writer_round_trip_a_dump():
+    """aletsch::read_bundle_dump + write_bundle_dump (C++11, beside gpu_scallop.hpp): the hand-typed dump and a large synthetic one come
+    back byte for byte, and equal what the Python twin writes"""
+    import subprocess
+    exe = _replay_tool()
+    for text in (HAND_DUMP, graphio.write_bundle_dump(A.synth(seed=5150, n_graphs=60, v_min=6, v_max=70, edges_per_vertex=3, layout_mode=1, weight_mode=1, phasing_per_graph=6, strand_mode=1), chrm="3")):
+        back = subprocess.run([exe, "--echo"], input=text, capture_output=True, text=True, check=True).stdout
+        pg, meta = graphio.read_bundle_dump(text)
+        assert back == graphio.write_bundle_dump(pg, gids=[m["gid"] for m in meta], chrm=meta[0]["chrm"])
+        if text is HAND_DUMP:
+            assert back == text
+
+
+def _listing(gid, chrm, strand, V, lpos, rpos, vw, edges, paths=()):
+    out = ["%s %s %s %d %d %d" % (gid, chrm, strand, V, len(edges), len(paths))]
+    out += ["%r %d %d" % (float(vw[i]), lpos[i], rpos[i]) for i in range(V)]
+    out += ["%d %d %r" % (s, t, float(w)) for s, t, w in edges]
+    out += ["%d %d %s" % (len(v), c, " ".join(map(str, v))) for v, c in paths]
+    return "\n".join(out) + "\n"
+
+
+def test_dump_line_order_against_the_reference_containers():
+    """The ORDER of a dump's lines is the iteration order of the reference's containers: sbound = out_edges(0), tbound = in_edges(n),
+    junction = edges() (rnacore/splice_graph.cc:440-476).  tests/golden/ref_graph.json holds those orders as printed by the reference's own
+    graph/*.cc (oracle/_ref/ref_graph) for graphs built by scripts of add / remove / move in a known creation order -- parallel edges
+    included.  Both writers (C++ and Python) must list the edges in exactly those orders; every edge carries its handle as its weight."""
+    import json
+    import subprocess
+    exe = _replay_tool()
+    cases = json.load(open(os.path.join(common.ROOT, "tests", "golden", "ref_graph.json")))
+    checked = 0
+    for c in cases:
+        lines = c["script"].split("\n")
+        if not lines[0].startswith("D"):
+            continue
+        n_v = int(lines[0].split()[1]); edges = {}; h = 0
+        for ln in lines[1:]:                                     # replay the script: final (source, target) of every live handle
+            f = ln.split()
+            if not f:
+                continue
+            if f[0] == "a":
+                edges[h] = (int(f[1]), int(f[2])); h += 1
+            elif f[0] == "r":
+                edges.pop(int(f[1]), None)
+            elif f[0] == "m":
+                edges[int(f[1])] = (int(f[2]), int(f[3]))
+            elif f[0] == "c":
+                for k in [k for k, (s, t) in edges.items() if int(f[1]) in (s, t)]:
+                    edges.pop(k)
+        last = c["dump"].strip().split("end\n")[-1] if c["dump"].strip().endswith("end") else c["dump"]
+        blocks = [b for b in c["dump"].split("end\n") if b.strip()]
+        d = {ln.split(":")[0]: [int(x) for x in ln.split(":")[1].split()] for ln in blocks[-1].splitlines() if ":" in ln and not ln.startswith("edge ")}
+        if any(not (s < t) for s, t in edges.values()) or not edges:
+            continue
+        n = n_v - 1
+        live = d["edges"]                                         # creation order of the live handles, as the reference iterates them
+        assert sorted(live) == sorted(edges)
+        lpos = [0] + [1000 * i for i in range(1, n)] + [1000 * n]; rpos = [0] + [1000 * i + 200 for i in range(1, n)] + [1000 * n]
+        listing = "1\n" + _listing("g", "1", "+", n_v, lpos, rpos, [0] + [5] * (n - 1) + [0], [(edges[k][0], edges[k][1], k + 0.25) for k in live])
+        text = subprocess.run([exe, "--from-listing"], input=listing, capture_output=True, text=True, check=True).stdout
+        hid = lambda ln: int(float(ln.split()[-2]) - 0.25 + 0.5)
+        sb = [hid(ln) for ln in text.splitlines() if ln.startswith("sbound")]
+        tb = [hid(ln) for ln in text.splitlines() if ln.startswith("tbound")]
+        jn = [hid(ln) for ln in text.splitlines() if ln.startswith("junction")]
+        assert sb == [k for k in d["out 0"] if edges[k][1] != n], (c["script"], sb, d["out 0"])
+        assert tb == [k for k in d["in %d" % n] if edges[k][0] != 0]
+        assert jn == [k for k in d["edges"] if edges[k][0] != 0 and edges[k][1] != n]
+        # the Python twin prints the same text for the same graph
+        g = dict(V=n_v, edges=[(edges[k][0], edges[k][1], k + 0.25, 0, {0: 1.0}) for k in live], vw=[0] + [5] * (n - 1) + [0], lpos=lpos, rpos=rpos, strand="+")
+        from aletsch_amd.packed import PackedGraphs
+        pg = PackedGraphs.from_graphs([g]); graphio._set_rank_from_listing(pg, [g["edges"]])
+        assert graphio.write_bundle_dump(pg, gids=["g"], chrm="1") == text
+        checked += 1
+    assert checked >= 8
