@@ -170,7 +170,8 @@ ALD_INL Cold cold_view()
   #define PROF_RESET() do {} while(0)
 #endif
 enum { PF_LOAD = 0, PF_BROKEN, PF_TRIV_EVAL, PF_TRIV_MUT, PF_SMALL_EVAL, PF_SMALL_MUT, PF_UNSPLIT, PF_COLLECT0, PF_G_BALANCE, PF_G_DP, PF_G_SPLITMERGE, PF_G_COLLECT, PF_FINISH,
-       PF_T_BALANCE, PF_T_PAIRS, PF_T_SETUP, PF_T_MERGE_LOAD, PF_T_MERGE_ADD, PF_T_MERGE_ISECT, PF_T_MERGE_MASK, PF_T_MERGE_SUMS, PF_T_MERGE_KILL, PF_T_HS, PF_T_TAIL, PF_COUNT };
+       PF_T_BALANCE, PF_T_PAIRS, PF_T_SETUP, PF_T_MERGE_LOAD, PF_T_MERGE_ADD, PF_T_MERGE_ISECT, PF_T_MERGE_MASK, PF_T_MERGE_SUMS, PF_T_MERGE_KILL, PF_T_HS, PF_T_TAIL,
+       PF_S5_DUP, PF_S5_BODY, PF_S5_RELINK, PF_S6_WALK, PF_S6_LINK, PF_S7, PF_SM_KILL, PF_SM_REEVAL, PF_COUNT };      // finer stamps inside the wave star (parts of M_mask / M_add) and the smallest-edge removal (parts of small_mut)
 
 // ---------------------------------------------------------------- small helpers
 ALD_INL void fail_(int st, int line)
@@ -948,7 +949,8 @@ ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio);
 // support intersections (pool allocation) stay sequential, in creation order.  Every floating-point operation is the one the
 // sequential form performs, on the same operands in the same order.  Called by ALL lanes; cross-lane values travel through the LDS
 // scratch (so the single-lane emulation runs the phases as loops).
-enum { SW_N = 128, SW_C, SW_FAR, SW_FAIL, SW_FAILQ, SW_SERIAL };          // context words in scr_i behind fe / ord / inv / oth (32 each)
+enum { SW_N = 128, SW_C, SW_FAR, SW_FAIL, SW_FAILQ, SW_SERIAL, SW_SMALL };          // context words in scr_i behind fe / ord / inv / oth (32 each)
+enum { STAR_SMALL = 4 };                  // fans up to this size (79 % of them on the bench workload): lane 0 also ranks and sums in phase 0 -- two hand-overs fewer
 template<bool A> ALD_INL void star_wave_body(int x)
 {
     COLD;
@@ -957,7 +959,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
     const double mw = HC.p_min_w;
     int32_t *fe = (int32_t*)HC.scr_i, *ord = fe + STAR_MAX, *inv = fe + 2 * STAR_MAX, *oth = fe + 3 * STAR_MAX, *ctx = (int32_t*)HC.scr_i;
     double *fw = (double*)HC.scr_d, *sq = fw + STAR_MAX;                  // pair weights (list order) / per merge: (sum, later r1), in merge order
-    double *dctx = fw + 2 * STAR_MAX;                                      // [0] = weight c starts with, [1] = vertex weight of x
+    double *dctx = fw + 2 * STAR_MAX;                                      // [0] = weight c starts with
     // what the merges need of c's record and of vertex x is asked for NOW, by every lane (one broadcast request each): the round
     // trip to L2 runs under phases 0..2 instead of in front of phase 3
     const int c_early = A ? first_in(x) : first_out(x);
@@ -991,7 +993,18 @@ template<bool A> ALD_INL void star_wave_body(int x)
             const double wc = wcen;
             for(int j = 0; j < n; j++) { double w2 = fw[j]; fw[j] = A ? (wc <= w2 ? wc : w2) : (w2 <= wc ? w2 : wc); }
         }
-        ctx[SW_N] = n; ctx[SW_C] = c; ctx[SW_FAR] = A ? (int)uni(H.ed[c].lk.es) : (int)uni(H.ed[c].lk.et); ctx[SW_FAIL] = bad; ctx[SW_FAILQ] = -1; ctx[SW_SERIAL] = 0;
+        int small = 0;
+#ifndef ALD_STAR_NO_SMALL
+        if(!bad && n <= STAR_SMALL) {           // phases 1 and 2 right here: merge order by creation id (insertion sort), centre weight, the fan edges' new weights
+            small = 1;
+            for(int i = 0; i < n; i++) { int k = i; const uint32_t id = uni(H.eid[fe[i]]); while(k > 0 && (uint32_t)uni(H.eid[fe[ord[k - 1]]]) > id) { ord[k] = ord[k - 1]; k--; } ord[k] = i; }
+            double mdc = 0;
+            for(int q = 0; q < n; q++) { inv[ord[q]] = q; const double w = fw[ord[q]]; if(ALD_UNLIKELY(!(w >= mw - kSMIN))) bad = ALD_ST_INVARIANT + ALD_INV_WEIGHT; mdc = (q == 0) ? w : mdc + w; }
+            dctx[0] = mdc;
+            for(int j = 0; j < n; j++) H.ed[fe[j]].w = fw[j];
+        }
+#endif
+        ctx[SW_N] = n; ctx[SW_C] = c; ctx[SW_FAR] = A ? (int)uni(H.ed[c].lk.es) : (int)uni(H.ed[c].lk.et); ctx[SW_FAIL] = bad; ctx[SW_FAILQ] = -1; ctx[SW_SERIAL] = 0; ctx[SW_SMALL] = small;
     }
     wsync();
     const int n = uni(ctx[SW_N]), c = uni(ctx[SW_C]), far = uni(ctx[SW_FAR]);
@@ -1000,6 +1013,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
 #endif
     if(uni(ctx[SW_FAIL])) { if(lane == 0) fail(ctx[SW_FAIL]); wsync(); return; }
     PROF_ADD(PF_T_BALANCE);
+    if(!uni(ctx[SW_SMALL])) {
     // ---- phase 1 (lane j): rank of fan edge j by creation id -> ord (merge order) and its inverse
     for(int j = lane; j < n; j += ALD_WAVE) {
         const uint32_t id = H.eid[fe[j]]; int r = 0;
@@ -1011,12 +1025,13 @@ template<bool A> ALD_INL void star_wave_body(int x)
     if(lane == 0) {
         double mdc = 0; int bad = 0;
         for(int q = 0; q < n; q++) { double w = fw[ord[q]]; if(ALD_UNLIKELY(!(w >= mw - kSMIN))) bad = ALD_ST_INVARIANT + ALD_INV_WEIGHT; mdc = (q == 0) ? w : mdc + w; }
-        dctx[0] = mdc; dctx[1] = vw_early;
+        dctx[0] = mdc;
         if(bad) ctx[SW_FAIL] = bad;
     }
     for(int j = lane; j < n; j += ALD_WAVE) H.ed[fe[j]].w = fw[j];
     wsync();
     if(uni(ctx[SW_FAIL])) { if(lane == 0) fail(ctx[SW_FAIL]); wsync(); return; }
+    }
     PROF_ADD(PF_T_SETUP);
     const int id0 = uni(HC.next_id);
     const int meic = uni(meic_v), cntc = uni(cntc_v), stc = uni(stc_v), idc = uni(idc_v);
@@ -1036,10 +1051,11 @@ template<bool A> ALD_INL void star_wave_body(int x)
     // values stay in its registers across phase 4 and the round trip to L2 runs under it.  (The single-lane emulation walks all merges
     // in every phase and reads the record where it is used.)
     double pf_med = 0, pf_conf = 0, pf_abd = 0; int pf_mei = 0, pf_st = 0, pf_cnt = 0, pf_id = 0; uint32_t pf_ns = 0; uint64_t pf_mask0 = 0;
+    double rp_wcur = 0; bool rp_sc = false, rp_dead = false; int rp_nid = 0;      // the lane's replay, kept for phase 5 as well (one merge per lane)
     for(int q = lane; q < n; q += ALD_WAVE) {
         SW_REPLAY(q, wcur, sc, rem, nid, dead);
         const int j = ord[q]; const double ww = fw[j];
-        (void)nid; (void)dead;
+        rp_wcur = wcur; rp_sc = sc; rp_dead = dead; rp_nid = nid;
 #ifndef ALD_EMU
         { const int f = fe[j]; pf_med = C.ed[f].med; pf_conf = C.ed[f].econf; pf_abd = C.ed[f].s0abd; pf_mei = C.ed[f].mei; pf_st = C.ed[f].estrand; pf_cnt = C.ed[f].ecount;
           pf_id = C.ed[f].s0id; pf_ns = C.ed[f].sp_len; pf_mask0 = C.ed[f].mask[0]; }
@@ -1054,7 +1070,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
     PROF_ADD(PF_T_MERGE_LOAD);
     // ---- phase 4 (lane 0): the weight of x, merge by merge; sq[q] becomes r1 of merge q
     if(lane == 0) {
-        double vwt = dctx[1], wcur = dctx[0]; bool sc = false;
+        double vwt = vw_early, wcur = dctx[0]; bool sc = false;          // (lane 0 asked for the vertex weight itself, at the top)
         for(int q = 0; q < n; q++) {
             const double ww = fw[ord[q]];
             sc = !(fabs(wcur - ww) <= kSMIN);                                     // split_edge(c, ww) cuts a piece off (scallop.cc:2433-2484)
@@ -1074,9 +1090,17 @@ template<bool A> ALD_INL void star_wave_body(int x)
     for(int q = lane; q < n; q += ALD_WAVE) { const int o = oth[q]; for(int k = 0; k < q; k++) if(oth[k] == o) dup = true; }
     const bool any_dup = wballot(dup) != 0;
     bool multi = false, broken = false;
+#ifdef ALD_PROF
+    { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[PF_S5_DUP] += t1_ - prof_t_; }
+    unsigned long long prof_s5_ = __builtin_readcyclecounter();
+#endif
     for(int q = lane; q < n; q += ALD_WAVE) {
+#ifdef ALD_EMU
         SW_REPLAY(q, wcur, sc, rem, nid, dead);
         (void)rem;
+#else
+        const double wcur = rp_wcur; const bool sc = rp_sc, dead = rp_dead; const int nid = rp_nid;
+#endif
         const int j = ord[q], f = fe[j]; const double ww = fw[j];
         const double wc0 = sc ? ww : wcur;
         const double medc1 = sc ? medc * ww / wcur : medc;
@@ -1106,7 +1130,13 @@ template<bool A> ALD_INL void star_wave_body(int x)
         C.ed[f].med = A ? mi * r1 + medc1 + medf : mi * r1 + medf + medc1; C.ed[f].mei = mi;
         H.eid[f] = (uint16_t)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
         if(A) H.ed[f].lk.es = (IDX)far; else H.ed[f].lk.et = (IDX)far;
+#ifdef ALD_PROF
+        { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[PF_S5_BODY] += t1_ - prof_s5_; prof_s5_ = t1_; }
+#endif
         if(!any_dup) { if(A) relink_in_lane(oth[q], f, (uint32_t)far); else relink_out_lane(oth[q], f, tkey((uint32_t)far)); }
+#ifdef ALD_PROF
+        { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[PF_S5_RELINK] += t1_ - prof_s5_; prof_s5_ = t1_; }
+#endif
     }
     const bool any_multi = wballot(multi) != 0;
     if(ALD_UNLIKELY(wballot(broken) != 0)) {                                    // the failure the sequence meets first: the smallest q that has one
@@ -1140,6 +1170,9 @@ template<bool A> ALD_INL void star_wave_body(int x)
             pred[q] = last; succ[q] = cur; srt[r] = q;
         }
         wsync();
+#ifdef ALD_PROF
+        { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[PF_S6_WALK] += t1_ - prof_t_; }
+#endif
         for(int r = lane; r < n; r += ALD_WAVE) {
             const int q = srt[r], f = fe[ord[q]];
             const bool first_of_gap = (r == 0) || pred[srt[r - 1]] != pred[q], last_of_gap = (r + 1 >= n) || pred[srt[r + 1]] != pred[q];
@@ -1149,6 +1182,9 @@ template<bool A> ALD_INL void star_wave_body(int x)
         }
     }
     wsync();
+#ifdef ALD_PROF
+    unsigned long long prof_s7_ = __builtin_readcyclecounter();
+#endif
     // ---- phase 7 (lane 0): what is left and inherently ordered -- the support pool, the phasing lists, the counters
     if(lane == 0) {
         if(A) H.out_deg[far] = (IDX)((int)uni(H.out_deg[far]) + n); else H.in_deg[far] = (IDX)((int)uni(H.in_deg[far]) + n);
@@ -1167,6 +1203,9 @@ template<bool A> ALD_INL void star_wave_body(int x)
         H.in_head[x] = NIL; H.out_head[x] = NIL; H.in_deg[x] = 0; H.out_deg[x] = 0; H.nz[x] = 0;
     }
     wsync();
+#ifdef ALD_PROF
+    { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[PF_S7] += t1_ - prof_s7_; }
+#endif
     PROF_ADD(PF_T_MERGE_ADD);
     #undef SW_REPLAY
 }
@@ -1636,6 +1675,10 @@ ALD_INL bool sweep_smallest(double max_ratio)
             kill_edge_wave(best_e);
             if(lane == 0) hs_remove(best_e);
             wsync();
+#ifdef ALD_PROF
+            { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[PF_SM_KILL] += t1_ - prof_t_; }
+            const unsigned long long prof_re_ = __builtin_readcyclecounter();
+#endif
             any = true;
             // back to the cascade unless R1..R3 provably have nothing to do
             if(!may_chain || uni(HC.status) || uni(HC.maybe_broken) || uni(HC.maybe_triv) || uni(HC.hs_dirty)) { PROF_ADD(PF_SMALL_MUT); return true; }
@@ -1645,6 +1688,9 @@ ALD_INL bool sweep_smallest(double max_ratio)
                 eval_chunk(c1, false, ds, dt);
                 if(c2 != c1) eval_chunk(c2, false, ds, dt);
             }
+#ifdef ALD_PROF
+            { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[PF_SM_REEVAL] += t1_ - prof_re_; }
+#endif
             PROF_ADD(PF_SMALL_MUT);
         } else {
             any = true;
@@ -2254,7 +2300,7 @@ ALD_FN void collect_existing_st_paths()
     }
     wsync();
     if(n == 0) return;
-    if(tracing() || 3 * n > Cold::w_cap || uni(HC.n_paths) + n > Cold::po_cap) {        // the op trace lists the paths in order: one at a time (which also reports a full offset table)
+    if(tracing() || 5 * n > Cold::w_cap || uni(HC.n_paths) + n > Cold::po_cap) {        // the op trace lists the paths in order: one at a time (which also reports a full offset table)
         if(lane == 0) {
             for(int i = 1; i < n; i++) { int x = lst[i]; uint32_t id = uni(H.eid[x]); int j = i - 1; while(j >= 0 && (uint32_t)uni(H.eid[lst[j]]) > id) { lst[j + 1] = lst[j]; j--; } lst[j + 1] = x; }
             for(int i = 0; i < n && !HC.status; i++) collect_path(lst[i]);
@@ -2266,12 +2312,14 @@ ALD_FN void collect_existing_st_paths()
     // check, the EMPTY_VERTEX filter, the place among the kept paths in creation-id order (= the path index), the record.
     ALD_GLOBAL const KernelArgs *A = HC.args;
     ALD_GLOBAL int32_t *ids = C.wi + n, *keep = C.wi + 2 * n;          // [n] creation id / 1 = becomes a path, 0 = filtered, -1 = inconsistent
+    ALD_GLOBAL int32_t *nvs = C.wi + 3 * n, *nxs = C.wi + 4 * n;       // [n] vertices on the path / exon words of its transcript (build_transcript, essential.cc:719-748)
     const int nlast = HC.V0 - 1;
     const bool ends_empty = C.vx[0].vtype == K_EMPTY_VERTEX || C.vx[nlast].vtype == K_EMPTY_VERTEX;
     for(int j = lane; j < n; j += ALD_WAVE) {
-        const int e = lst[j]; int cnt = 0, mi = 0; bool empty = ends_empty;
-        for(int k = 0; k < NW; k++) { uint64_t mk = C.ed[e].mask[k]; while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; cnt++; mi += C.vx[x].rpos - C.vx[x].lpos; if(C.vx[x].vtype == K_EMPTY_VERTEX) empty = true; } }
-        ids[j] = (int32_t)H.eid[e];
+        const int e = lst[j]; int cnt = 0, mi = 0, nexw = 0, last_r = INT_MIN; bool empty = ends_empty;
+        for(int k = 0; k < NW; k++) { uint64_t mk = C.ed[e].mask[k]; while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; cnt++; const int l = C.vx[x].lpos, rr = C.vx[x].rpos; mi += rr - l; if(C.vx[x].vtype == K_EMPTY_VERTEX) empty = true;
+            if(l < rr) { if(nexw == 0 || last_r != l) nexw += 2; last_r = rr; } } }
+        ids[j] = (int32_t)H.eid[e]; nvs[j] = cnt; nxs[j] = nexw;
         keep[j] = (C.ed[e].mei != mi || cnt == 0) ? -1 : (empty ? 0 : 1);
     }
     wsync();
@@ -2281,8 +2329,7 @@ ALD_FN void collect_existing_st_paths()
         for(int k = 0; k < n; k++) { const int kk = keep[k]; if(kk < 0) later_bad = true; if(kk == 1 && ids[k] < id) rank++; }
         if(later_bad) bad = true;
         if(keep[j] != 1 || later_bad) continue;
-        int cnt = 0, nexw = 0, last_r = INT_MIN;
-        for(int k = 0; k < NW; k++) { uint64_t mk = C.ed[e].mask[k]; while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; cnt++; const int l = C.vx[x].lpos, rr = C.vx[x].rpos; if(l < rr) { if(nexw == 0 || last_r != l) nexw += 2; last_r = rr; } } }
+        const int cnt = nvs[j], nexw = nxs[j];
         const int nvp = cnt + 2;
         const unsigned long long words = rec_words((unsigned)nvp, (unsigned)nexw);
         const unsigned long long o = atomic_add_u64(A->out.pool_used, words);
@@ -2368,7 +2415,8 @@ ALD_FN void greedy_decompose()
     if(!any) return;
     materialize_special();                         // the DP and the path surgery walk out(0) / in(sink)
     PROF_DECL;
-    for(int rep = 0; rep < 2; rep++) for(int i = 1; i < HC.nv; i++) { if(i == HC.sinkp) continue; balance_vertex(i); if(HC.status) return; }
+    // (a vertex without in- or out-edges is left alone by balance_vertex, scallop.cc:2488-2489: most of them by now -- no call for those)
+    for(int rep = 0; rep < 2; rep++) for(int i = 1; i < HC.nv; i++) { if(i == HC.sinkp) continue; if(H.in_deg[i] == 0 || uni(H.out_deg[i]) == 0) continue; balance_vertex(i); if(HC.status) return; }
     PROF_ADD(PF_G_BALANCE);
     if(ALD_UNLIKELY(3 * HC.nv > C.w_cap / 2)) { fail(ALD_ST_CAPACITY); return; }
     ALD_GLOBAL int32_t *path = C.wi + Cold::w_cap / 2;

@@ -3,7 +3,7 @@ os.environ["ALETSCH_DECOMP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import aletsch_amd as A
-names = ["load","broken","triv_eval","triv_mut","small_eval","small_mut","unsplit","collect0","g_balance","g_dp","g_splitmerge","g_collect","finish","T_balance","T_pairs","T_setup","M_load","M_add","M_isect","M_mask","M_sums","M_kill","T_hs","T_tail"]
+names = ["load","broken","triv_eval","triv_mut","small_eval","small_mut","unsplit","collect0","g_balance","g_dp","g_splitmerge","g_collect","finish","T_balance","T_pairs","T_setup","M_load","M_add","M_isect","M_mask","M_sums","M_kill","T_hs","T_tail","S5_dup","S5_body","S5_relink","S6_walk","S6_link","S7_tail","SM_kill","SM_reeval"]
 import os
 CFG = os.environ.get("PROF_CFG", "cfg2")
 for n in (20000 if CFG.startswith("cfg2") else 600,):
@@ -19,4 +19,4 @@ for n in (20000 if CFG.startswith("cfg2") else 600,):
         tot /= cnt
         top = tot[:8].sum()                      # load .. collect0 partition a graph's life; g_* are parts of `unsplit`, T_* / M_* parts of `triv_mut`
         print(f"n={n} kernel_ms={b.kernel_ms():.2f}  mean cycles/graph (top-level phases) = {top:.0f}")
-        for k, nm in enumerate(names): print(f"   {nm:14s} {tot[k]:12.0f}  {100*tot[k]/top:5.1f}%" + ("" if k < 8 else "   (part of " + ("unsplit: router / extend" if k < 13 else "triv_mut") + ")"))
+        for k, nm in enumerate(names): print(f"   {nm:14s} {tot[k]:12.0f}  {100*tot[k]/top:5.1f}%" + ("" if k < 8 else "   (part of " + ("unsplit: router / extend" if k < 13 else ("triv_mut" if k < 30 else "small_mut")) + ")"))
