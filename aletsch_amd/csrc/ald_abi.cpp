@@ -263,6 +263,23 @@ int ald_batch_add_packed(ald_batch *b, int32_t n, const int32_t *g_nv, const int
     return ALD_OK;
 }
 
+int ald_batch_add_packed_raw(ald_batch *b, int32_t n, const int32_t *g_nv, const int32_t *g_ne, const int32_t *g_np,
+                             const int32_t *vertex_offset, const int32_t *edge_target, const double *edge_weight, const uint8_t *edge_strand, const double *edge_abd,
+                             const int32_t *edge_sample_offset, const int32_t *sample_id, const double *sample_abd,
+                             const double *vertex_weight, const int32_t *vertex_lpos, const int32_t *vertex_rpos, const int32_t *vertex_type,
+                             const int32_t *phasing_offset, const int32_t *phasing_vertex, const int32_t *phasing_count, const char *graph_strand, const int32_t *edge_count,
+                             const int32_t *edge_creation_rank,
+                             const int32_t *raw_max_group_boundary_distance, const int32_t *g_nphase, const int32_t *phase_offset, const int32_t *phase_coord, const int32_t *phase_count)
+{
+    if(!b || n < 0 || !g_nv || !g_ne) return ALD_ERR_INVALID;
+    b->uploaded = b->ran = b->downloaded = false;
+    int rc = b->hb.add_packed_raw(n, g_nv, g_ne, g_np, vertex_offset, edge_target, edge_weight, edge_strand, edge_abd, edge_sample_offset, sample_id, sample_abd,
+                                  vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand, edge_count, edge_creation_rank,
+                                  raw_max_group_boundary_distance, g_nphase, phase_offset, phase_coord, phase_count);
+    if(rc != ALD_OK) return set_err(rc, b->hb.err);
+    return ALD_OK;
+}
+
 int ald_batch_num_graphs(const ald_batch *b) { return b ? b->hb.n() : 0; }
 
 int ald_batch_enable_trace(ald_batch *b, int32_t max_events_per_graph)
@@ -314,6 +331,7 @@ int ald_batch_upload(ald_batch *b)
         std::vector<int32_t> work[ALD_NUM_CLASSES];
         for(int g = 0; g < n; g++) {
             int64_t ns = b->hb.off_s[g + 1] - b->hb.off_s[g], npv = b->hb.off_pv[g + 1] - b->hb.off_pv[g];
+            if(b->hb.g_rawdist[g] >= 0) npv += 2 * (b->hb.off_rc[g + 1] - b->hb.off_rc[g]);      // a raw graph's lists do not exist yet: an estimate (too small a class is retried one up)
             int c = debug_underclass(pick_class(b->hb.g_nv[g], b->hb.g_ne[g], ns, npv));
             b->cls0[g] = c;
             if(c >= 0) work[c].push_back(g);

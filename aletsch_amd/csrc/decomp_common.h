@@ -150,6 +150,10 @@ struct BatchIn {
     ALD_GLOBAL const char    *graph_strand;
     ALD_GLOBAL const int32_t *edge_count;                               // edge_info.count at hand-over (not always |samples|)
     ALD_GLOBAL const int32_t *edge_rank;                                // creation rank (scallop edge index) of every input edge, or null: CSR position
+    // raw graphs (the pre-steps of assembler::assemble run in the kernel's load phase): null when the batch holds none
+    ALD_GLOBAL const int32_t *g_rawdist;                                // [n] -1: staged graph, else max_group_boundary_distance of a raw one
+    ALD_GLOBAL const int64_t *off_rp, *off_rc;                          // [n+1] prefix of raw phases / of their coordinates
+    ALD_GLOBAL const int32_t *rphase_offset, *rphase_coord, *rphase_count;   // local CSR (np + 1 entries at off_rp[g] + g), exon coordinates, counts
 };
 struct BatchOut {
     ALD_GLOBAL int32_t *status, *n_paths, *n_iters;        // [n]

@@ -2446,6 +2446,268 @@ ALD_FN void greedy_decompose()
     }
 }
 
+
+// hyper_set::build_edges (hyper_set.cc:323-354) on lane 0: keep lists with count >= 2, >= 2 edges, every consecutive pair an edge;
+// directed_graph::edge(s,t) returns the NEWEST parallel edge (directed_graph.cc:60-76).  po / pv / pc: NP vertex lists (offsets,
+// vertices, counts) -- the staged phasing lists of the wire buffer, or the lists a raw graph's phases were turned into.
+ALD_FN void build_phasing_lists(ALD_GLOBAL const int32_t *vo, int V, int NP, ALD_GLOBAL const int32_t *po, ALD_GLOBAL const int32_t *pvx, ALD_GLOBAL const int32_t *pcn)
+{
+    COLD;
+    int nl = 0; uint32_t used = 0;
+    for(int p = 0; p < NP && HC.status == 0; p++) {
+        int c = pcn[p]; int a = po[p], b = po[p + 1]; int len = b - a;
+        if(c <= 1 || len <= 1) continue;
+        uint32_t capk = (uint32_t)(len - 1) * 2u + 4u;
+        if(nl >= C.hl_maxlists || used + capk > C.hl_cap) { HC.status = ALD_ST_CAPACITY; break; }
+        bool ok = true;
+        for(int k = 0; k + 1 < len && ok; k++) {
+            int s = pvx[a + k], t = pvx[a + k + 1];
+            if(!(s < t) || s < 0 || t >= V) { HC.status = ALD_ST_INVARIANT + ALD_INV_OTHER; ok = false; break; }
+            int best = -1;
+            if(s == 0) { for(int e = vo[0]; e < vo[1]; e++) { if(H.ed[e].lk.es == NIL) continue; int tt = H.ed[e].lk.et; if(tt == t) best = e; else if(tt > t) break; } }      // row 0 is not linked: scan the CSR row
+            else for(int e = first_out(s); e >= 0; e = next_out(e)) { int tt = H.ed[e].lk.et; if(tt == t) best = e; else if(tt > t) break; }
+            if(best < 0) ok = false; else C.hl[used + k] = best;
+        }
+        if(!ok || len - 1 < 2) continue;
+        C.hl_off[nl] = (int32_t)used; C.hl_len[nl] = len - 1; C.hl_capk[nl] = (int32_t)capk; C.hl_cnt[nl] = c; used += capk; nl++;
+    }
+    HC.hl_used = used; HC.hl_n = nl;
+}
+
+// ---------------------------------------------------------------- raw graphs: what assembler::assemble(gx, px, sid)
+// does to a graph and its phase set BEFORE it builds the scallop object (meta/assembler.cc:1075-1086), in the wave that just loaded it:
+//   gx.extend_strands()                            rnacore/splice_graph.cc:1338-1373      one candidate edge per lane
+//   group_start_boundaries / group_end_boundaries  rnacore/graph_reviser.cc:916-1066      a left-to-right fold over the source's /
+//                                                                                          sink's few edges: lane 0
+//   px.project_boundaries(smap, tmap)              rnacore/phase_set.cc:50-67             one phase per lane
+//   hyper_set hx(gx, px) + hx.filter_nodes(gx)     scallop/hyper_set.cc:17-29, 356-371    one phase per lane (coordinate -> vertex by
+//        (build_path_from_exon_coordinates, check_valid_path: essential.cc:321-366, 448-459)      binary search), equal lists fold
+// The graph is still exactly the input at this point, so adjacency is read from the wire's CSR rows (sorted by (target, creation))
+// and in-CSR; an edge the grouping removes is flagged first and leaves the lists at the end, the creation ids are then compacted as
+// the host path's re-staging does.  Work arrays of the slab: [0, 2E) of wi for the compaction, smap / tmap and the phase table behind
+// them, the phases' vertex lists in wd.  Called by ALL lanes; false (status set) where the reference would have asserted.
+enum { RAW_DEAD = 0x80, RAW_SMAP = 2 * MAXE, RAW_TMAP = 2 * MAXE + 2 * MAXV, RAW_TV = 6 * MAXE, RAW_TV_CAP = (2 * MAXE - 4) / 3, RAW_VTX_CAP = 2 * Cold::w_cap };
+static_assert(4 * MAXV <= 4 * MAXE, "boundary maps do not fit their slab region");
+ALD_INL int raw_edge(ALD_GLOBAL const int32_t *vo, int s, int t)      // directed_graph::edge(s, t) on the input rows: the newest live parallel edge, or -1
+{
+    int best = -1;
+    for(int k = vo[s]; k < vo[s + 1]; k++) { if(H.hflag[k] & RAW_DEAD) continue; const int tt = H.ed[k].lk.et; if(tt == t) best = k; else if(tt > t) break; }
+    return best;
+}
+ALD_INL bool raw_continuous(const Cold &C, ALD_GLOBAL const int32_t *vo, int x, int y)      // check_continuous_vertices (essential.cc:436-446)
+{
+    if(x >= y) return true;
+    for(int i = x; i < y; i++) { if(raw_edge(vo, i, i + 1) < 0) return false; if(C.vx[i].rpos != C.vx[i + 1].lpos) return false; }
+    return true;
+}
+ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t *vo, ALD_GLOBAL const int32_t *io, ALD_GLOBAL const int32_t *ie,
+                                int NPH, ALD_GLOBAL const int32_t *pho, ALD_GLOBAL const int32_t *phc, ALD_GLOBAL const int32_t *phn)
+{
+    COLD;
+    const int lane = lane_id();
+    const int n = V - 1;
+    // ---- splice_graph::extend_strands: a junction s -> s+2 that jumps exactly over vertex s+1 and outweighs it lends its strand to the
+    // edges s -> s+1 and s+1 -> s+2 (the newest parallel ones) if they have none; junctions are visited in creation order, so an edge
+    // takes the strand of the OLDEST qualifying junction that has one.  Here every edge a -> a+1 looks for its junctions itself (they
+    // are never targets themselves, nothing a lane reads is written by another).
+    if(uni(HC.any_strand)) {
+        for(int k = lane; k < E; k += ALD_WAVE) {
+            const int a = H.ed[k].lk.es, t = H.ed[k].lk.et;
+            if(t != a + 1 || C.ed[k].estrand != 0) continue;
+            if(k + 1 < vo[a + 1] && (int)H.ed[k + 1].lk.et == t) continue;               // not the newest a -> a+1
+            uint32_t best_id = 0xFFFFFFFFu; int best_st = 0;
+            for(int leg = 0; leg < 2; leg++) {
+                const int s = leg == 0 ? a : a - 1;                                       // the junction s -> s+2; this edge is its first / second leg
+                if(s < 0 || s + 2 >= V) continue;
+                const int32_t p1 = C.vx[s].rpos, p2 = C.vx[s + 2].lpos;
+                if(p1 >= p2 || C.vx[s + 1].lpos != p1 || C.vx[s + 1].rpos != p2) continue;
+                const double vmid = C.vx[s + 1].vw;
+                for(int j = vo[s]; j < vo[s + 1]; j++) {
+                    if((int)H.ed[j].lk.et != s + 2) continue;
+                    if(H.ed[j].w <= vmid) continue;
+                    const int st = C.ed[j].estrand; const uint32_t id = H.eid[j];
+                    if(st != 0 && id < best_id) { best_id = id; best_st = st; }
+                }
+            }
+            if(best_st) C.ed[k].estrand = (uint8_t)best_st;
+        }
+        wsync();
+    }
+    // ---- group_start_boundaries / group_end_boundaries (lane 0)
+    if(lane == 0) {
+        int ns = 0, nt = 0, bad = 0, removed = 0;
+        ALD_GLOBAL int32_t *smap = C.wi + RAW_SMAP, *tmap = C.wi + RAW_TMAP;
+        {   // start boundaries that reach the same run of touching vertices within `dist` fold into the leftmost one
+            const int r0 = vo[0], r1 = vo[1];                                           // the source's row: targets ascending (parallel ones were refused at staging)
+            if(r1 - r0 > 1) {
+                int v0 = H.ed[r0].lk.et; int32_t p1 = C.vx[v0].lpos, p2 = p1; int k1 = v0, k2 = v0, pa = r0;
+                for(int q = r0 + 1; q < r1 && !bad; q++) {
+                    const int vi = H.ed[q].lk.et, pb = q; const int32_t p = C.vx[vi].lpos;
+                    const double wb = H.ed[pb].w; const int cb = C.ed[pb].ecount;
+                    bool b = raw_continuous(C, vo, k2, vi);
+                    if(p < p2) { bad = 1; break; }                                        // assert(p >= p2)
+                    if(p - p2 > dist) b = false;
+                    if(!b) { p1 = p; p2 = p; k1 = vi; k2 = vi; pa = pb; continue; }
+                    smap[2 * ns] = p; smap[2 * ns + 1] = p1; ns++;
+                    for(int j = k1; j < vi; j++) {
+                        const int pc = raw_edge(vo, j, j + 1);
+                        if(pc < 0) { bad = 1; break; }                                    // assert(pc.second == true)
+                        C.vx[j].vw = C.vx[j].vw + wb; C.ed[pc].ecount += cb; H.ed[pc].w = H.ed[pc].w + wb;
+                    }
+                    if(bad) break;
+                    H.ed[pa].w += wb; C.ed[pa].ecount += cb;
+                    H.hflag[pb] |= RAW_DEAD; removed++;
+                    k2 = vi; p2 = p;
+                }
+            }
+        }
+        if(!bad) {   // the mirror image from the right -- with the reference's own asymmetries (vertex takes edge weight + wb; no count moves)
+            const int i0 = io[n], i1 = io[n + 1];                                       // in-edges of the sink: sources ascending
+            int q = i1 - 1; while(q >= i0 && (H.hflag[ie[q]] & RAW_DEAD)) q--;
+            if(q >= i0) {
+                int pa = ie[q]; const int v0 = H.ed[pa].lk.es; int32_t p1 = C.vx[v0].rpos, p2 = p1; int k1 = v0, k2 = v0; int live = 0;
+                for(int z = i0; z < i1; z++) if(!(H.hflag[ie[z]] & RAW_DEAD)) live++;
+                if(live > 1) for(q--; q >= i0 && !bad; q--) {
+                    const int pb = ie[q]; if(H.hflag[pb] & RAW_DEAD) continue;
+                    const int vi = H.ed[pb].lk.es; const int32_t p = C.vx[vi].rpos; const double wb = H.ed[pb].w;
+                    bool b = raw_continuous(C, vo, vi, k2);
+                    if(p > p2) { bad = 1; break; }                                        // assert(p <= p2)
+                    if(p2 - p > dist) b = false;
+                    if(!b) { p1 = p; p2 = p; k1 = vi; k2 = vi; pa = pb; continue; }
+                    tmap[2 * nt] = p; tmap[2 * nt + 1] = p1; nt++;
+                    for(int j = vi; j < k1; j++) {
+                        const int pc = raw_edge(vo, j, j + 1);
+                        if(pc < 0) { bad = 1; break; }
+                        const double wc = H.ed[pc].w; H.ed[pc].w = wc + wb; C.vx[j + 1].vw = wc + wb;
+                    }
+                    if(bad) break;
+                    H.ed[pa].w += wb;
+                    H.hflag[pb] |= RAW_DEAD; removed++;
+                    k2 = vi; p2 = p;
+                }
+            }
+        }
+        if(bad) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);
+        HC.scr_i[0] = ns; HC.scr_i[1] = nt; HC.scr_i[2] = removed;
+    }
+    wsync();
+    if(uni(HC.status)) return false;
+    const int ns = uni(HC.scr_i[0]), nt = uni(HC.scr_i[1]), removed = uni(HC.scr_i[2]);
+    // ---- the folded boundary edges leave the graph; the creation ids of the others close ranks (the order is what matters: every id
+    // handed out later is larger)
+    if(removed) {
+        ALD_GLOBAL int32_t *flag = C.wi, *nrank = C.wi + E;
+        for(int k = lane; k < E; k += ALD_WAVE) flag[H.eid[k]] = (H.hflag[k] & RAW_DEAD) ? 0 : 1;
+        wsync();
+        int base = 0;
+        for(int r0 = 0; r0 < E; r0 += ALD_WAVE) {
+            const int r = r0 + lane; const bool f = r < E && flag[r] != 0;
+            const uint64_t m = wballot(f);
+#ifdef ALD_EMU
+            if(r < E) nrank[r] = base;
+#else
+            if(r < E) nrank[r] = base + __builtin_popcountll(m & ((1ull << lane) - 1));
+#endif
+            base += __builtin_popcountll(m);
+        }
+        wsync();
+        for(int k = lane; k < E; k += ALD_WAVE) if(!(H.hflag[k] & RAW_DEAD)) H.eid[k] = (uint16_t)nrank[H.eid[k]];
+        wsync();
+        if(lane == 0) {
+            for(int k = 0; k < E; k++) if(H.hflag[k] & RAW_DEAD) { H.hflag[k] = 0; kill_edge_i(k); }
+            HC.next_id = base;
+            for(int i = 1; i < n; i++) if(H.in_deg[i] == 0 && H.out_deg[i] == 0) H.nz[i] = 0;      // (nonzeroset is taken after the pre-steps: scallop.cc:1664-1673)
+        }
+        wsync();
+    }
+    // ---- phases: exon coordinates -> vertex lists (one phase per lane), equal lists fold their counts
+    ALD_GLOBAL int32_t *tv = C.wi + RAW_TV;                                   // [0] = number of lists, [1 ..] offsets (NPH + 1), then counts (NPH)
+    ALD_GLOBAL int32_t *tv_off = tv + 1, *tv_cnt = tv + 1 + RAW_TV_CAP + 1;
+    ALD_GLOBAL int32_t *vtx = (ALD_GLOBAL int32_t*)C.wd;
+    if(NPH > RAW_TV_CAP) { if(lane == 0) fail(ALD_ST_CAPACITY); wsync(); return false; }
+    if(NPH == 0) { if(lane == 0) { tv[0] = 0; tv_off[0] = 0; } wsync(); return true; }
+    // are the vertices' left / right ends in ascending order (they are, for a splice graph)?  Then a coordinate is found by bisection
+    bool unsorted = false;
+    for(int i = 1 + lane; i < n; i += ALD_WAVE) { if(C.vx[i].lpos > C.vx[i + 1].lpos) unsorted = true; if(i + 1 < n && C.vx[i].rpos > C.vx[i + 1].rpos) unsorted = true; }
+    if(lane == 0 && n >= 2 && C.vx[0].rpos > C.vx[1].rpos) unsorted = true;
+    const bool sorted = wballot(unsorted) == 0;
+    ALD_GLOBAL const int32_t *smap = C.wi + RAW_SMAP, *tmap = C.wi + RAW_TMAP;
+    // build_vertex_index (splice_graph.cc:1087-1099): lindex over vertices 1..n, rindex over 0..n-1, the FIRST vertex with a coordinate wins
+    auto lfind = [&](int32_t p) -> int {
+        if(sorted) { int lo = 1, hi = n + 1; while(lo < hi) { const int mid = (lo + hi) >> 1; if(C.vx[mid].lpos < p) lo = mid + 1; else hi = mid; } return (lo <= n && C.vx[lo].lpos == p) ? lo : -1; }
+        for(int i = 1; i <= n; i++) if(C.vx[i].lpos == p) return i;
+        return -1; };
+    auto rfind = [&](int32_t q) -> int {
+        if(sorted) { int lo = 0, hi = n; while(lo < hi) { const int mid = (lo + hi) >> 1; if(C.vx[mid].rpos < q) lo = mid + 1; else hi = mid; } return (lo < n && C.vx[lo].rpos == q) ? lo : -1; }
+        for(int i = 0; i < n; i++) if(C.vx[i].rpos == q) return i;
+        return -1; };
+    // pass 1: is the phase a path of the graph, and how long is its vertex list?  (-1: dropped)
+    int total = 0; bool assert_hit = false;
+    for(int p0 = 0; p0 < NPH; p0 += ALD_WAVE) {
+        const int p = p0 + lane; int len = -1;
+        if(p < NPH) {
+            const int a0 = pho[p], m = pho[p + 1] - a0, ne = m / 2; len = 0; int prev = -1; bool backwards = false;
+            for(int k = 0; k < ne && len >= 0; k++) {
+                int32_t x = phc[a0 + 2 * k], y = phc[a0 + 2 * k + 1];
+                if(k == 0) for(int z = 0; z < ns; z++) if(smap[2 * z] == x) { x = smap[2 * z + 1]; break; }            // project_boundaries: first / last coordinate
+                if(k == ne - 1) for(int z = 0; z < nt; z++) if(tmap[2 * z] == y) { y = tmap[2 * z + 1]; break; }
+                if(x < 0 || y < 0 || x >= y) { len = -1; break; }
+                const int a = lfind(x), b = rfind(y);
+                if(a < 0 || b < 0 || a > b || !raw_continuous(C, vo, a, b)) { len = -1; break; }
+                if(a <= prev) backwards = true;
+                prev = b; len += b - a + 1;
+            }
+            if(len >= 0 && backwards) assert_hit = true;                                      // a valid list that does not ascend: assert(vv[i] < vv[i + 1]) (essential.cc:364)
+        }
+        // offsets of the chunk's lists: a serial prefix over the wave's lengths through the LDS scratch
+        if(p < NPH) HC.scr_i[8 + lane] = len;
+        wsync();
+        if(lane == 0) { const int cnt = (NPH - p0) < ALD_WAVE ? (NPH - p0) : ALD_WAVE; int run = total; for(int l = 0; l < cnt; l++) { tv_off[p0 + l] = run; const int x = HC.scr_i[8 + l]; tv_cnt[p0 + l] = x < 0 ? -1 : 0; if(x > 0) run += x; } HC.scr_i[7] = run; }
+        wsync();
+        total = uni(HC.scr_i[7]);
+    }
+    if(wballot(assert_hit)) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER); wsync(); return false; }
+    if(total > RAW_VTX_CAP) { if(lane == 0) fail(ALD_ST_CAPACITY); wsync(); return false; }
+    if(lane == 0) tv_off[NPH] = total;
+    wsync();
+    // pass 2: the vertex lists themselves
+    for(int p = lane; p < NPH; p += ALD_WAVE) {
+        if(tv_cnt[p] < 0) continue;
+        const int a0 = pho[p], m = pho[p + 1] - a0, ne = m / 2; int w = tv_off[p];
+        for(int k = 0; k < ne; k++) {
+            int32_t x = phc[a0 + 2 * k], y = phc[a0 + 2 * k + 1];
+            if(k == 0) for(int z = 0; z < ns; z++) if(smap[2 * z] == x) { x = smap[2 * z + 1]; break; }
+            if(k == ne - 1) for(int z = 0; z < nt; z++) if(tmap[2 * z] == y) { y = tmap[2 * z + 1]; break; }
+            const int a = lfind(x), b = rfind(y);
+            for(int j = a; j <= b; j++) vtx[w++] = j;
+        }
+    }
+    wsync();
+    // equal lists are ONE node of hyper_set::nodes (a std::map keyed by the list): the first of them takes the counts of all
+    for(int p = lane; p < NPH; p += ALD_WAVE) {
+        if(tv_cnt[p] < 0) continue;
+        const int o = tv_off[p], len = tv_off[p + 1] - o; int rep = p;
+        for(int q = 0; q < p && rep == p; q++) {
+            if(tv_cnt[q] < 0 || tv_off[q + 1] - tv_off[q] != len) continue;
+            bool eq = true; for(int k = 0; k < len && eq; k++) eq = vtx[tv_off[q] + k] == vtx[o + k];
+            if(eq) rep = q;
+        }
+        if(rep != p) tv_cnt[p] = -2 - rep;                                                    // folded into list `rep`
+    }
+    wsync();
+    for(int p = lane; p < NPH; p += ALD_WAVE) {
+        if(tv_cnt[p] != 0) continue;                                                          // a representative: its own count + the counts of its copies
+        int c = phn[p];
+        for(int q = p + 1; q < NPH; q++) if(tv_cnt[q] == -2 - p) c += phn[q];
+        tv_cnt[p] = c;
+    }
+    wsync();
+    for(int p = lane; p < NPH; p += ALD_WAVE) if(tv_cnt[p] < 0) tv_cnt[p] = 0;                // dropped or folded: build_edges skips a count <= 1
+    if(lane == 0) tv[0] = NPH;
+    wsync();
+    return true;
+}
+
 // ---------------------------------------------------------------- load: packed wire arrays -> working state (wave-parallel)
 ALD_FN bool load_graph()
 {
@@ -2493,30 +2755,17 @@ ALD_FN bool load_graph()
     if(wballot(listed)) for(int64_t k = lane; k < ns; k += ALD_WAVE) { C.sp_id[k] = A->in.sample_id[os + k]; C.sp_abd[k] = A->in.sample_abd[os + k]; }
     uint64_t sb = wballot(strand);
     if(sb && lane == 0) HC.any_strand = 1;
+    if(lane == 0) HC.sp_used = (uint32_t)ns;
     wsync();
+    // a raw graph: the pre-steps of assembler::assemble(gx, px, sid) first
+    const int rawdist = A->in.g_rawdist ? uni(A->in.g_rawdist[g]) : -1;
+    if(rawdist >= 0) {
+        const int64_t orp = A->in.off_rp[g], orc = A->in.off_rc[g];
+        if(!uni(pre_assemble_device(rawdist, V, E, vo, io, ie, (int)(A->in.off_rp[g + 1] - orp), A->in.rphase_offset + orp + g, A->in.rphase_coord + orc, A->in.rphase_count + orp))) { wsync(); return false; }
+    }
     if(lane == 0) {
-        HC.sp_used = (uint32_t)ns;
-        // hyper_set::build_edges (hyper_set.cc:323-354): keep lists with count >= 2, >= 2 edges, every consecutive pair an edge;
-        // directed_graph::edge(s,t) returns the NEWEST parallel edge (directed_graph.cc:60-76)
-        ALD_GLOBAL const int32_t *po = A->in.phasing_offset + opo; int nl = 0; uint32_t used = 0;
-        for(int p = 0; p < NP && HC.status == 0; p++) {
-            int c = A->in.phasing_count[op + p]; int a = po[p], b = po[p + 1]; int len = b - a;
-            if(c <= 1 || len <= 1) continue;
-            uint32_t capk = (uint32_t)(len - 1) * 2u + 4u;
-            if(nl >= C.hl_maxlists || used + capk > C.hl_cap) { HC.status = ALD_ST_CAPACITY; break; }
-            bool ok = true;
-            for(int k = 0; k + 1 < len && ok; k++) {
-                int s = A->in.phasing_vertex[opv + a + k], t = A->in.phasing_vertex[opv + a + k + 1];
-                if(!(s < t) || s < 0 || t >= V) { HC.status = ALD_ST_INVARIANT + ALD_INV_OTHER; ok = false; break; }
-                int best = -1;
-                if(s == 0) { for(int e = vo[0]; e < vo[1]; e++) { int tt = H.ed[e].lk.et; if(tt == t) best = e; else if(tt > t) break; } }      // row 0 is not linked: scan the CSR row
-                else for(int e = first_out(s); e >= 0; e = next_out(e)) { int tt = H.ed[e].lk.et; if(tt == t) best = e; else if(tt > t) break; }
-                if(best < 0) ok = false; else C.hl[used + k] = best;
-            }
-            if(!ok || len - 1 < 2) continue;
-            C.hl_off[nl] = (int32_t)used; C.hl_len[nl] = len - 1; C.hl_capk[nl] = (int32_t)capk; C.hl_cnt[nl] = c; used += capk; nl++;
-        }
-        HC.hl_used = used; HC.hl_n = nl;
+        if(rawdist < 0) build_phasing_lists(vo, V, NP, A->in.phasing_offset + opo, A->in.phasing_vertex + opv, A->in.phasing_count + op);
+        else build_phasing_lists(vo, V, uni(C.wi[RAW_TV + 0]), C.wi + RAW_TV + 1, (ALD_GLOBAL const int32_t*)C.wd, C.wi + RAW_TV + 1 + RAW_TV_CAP + 1);
     }
     wsync();
     return HC.status == 0;

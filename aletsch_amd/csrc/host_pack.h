@@ -42,6 +42,13 @@ struct HostBatch {
     rvec<int32_t> phasing_offset, phasing_vertex, phasing_count; rvec<char> graph_strand;
     rvec<int32_t> edge_count;
     rvec<int32_t> edge_rank; bool has_rank = false;   // creation rank of every input edge (optional: empty until a caller supplies one, then identity-filled for the rest)
+    // RAW graphs (row f1): a graph as assembler::assemble(gx, px, sid) receives it + its phase set in exon coordinates; the pre-steps
+    // (extend_strands, boundary grouping, phase projection, hyper_set ctor, filter_nodes) run in the kernel's load phase.
+    // g_rawdist[g] = -1: an ordinary (staged) graph, else max_group_boundary_distance of a raw one.  Kept for every graph (a few bytes);
+    // the sections only travel when the batch holds a raw graph.
+    rvec<int32_t> g_rawdist; rvec<int64_t> off_rp{0}, off_rc{0};      // [n] / [n+1] prefix of raw phases / of their coordinates
+    rvec<int32_t> rphase_offset, rphase_coord, rphase_count;          // per graph a local CSR of np + 1 entries (at off_rp[g] + g), coordinates, counts
+    bool has_raw = false;
     std::vector<int32_t> cur_, perm_; std::vector<uint8_t> seen_;          // scratch of add_graph, kept across calls
     std::string err;
 
@@ -54,17 +61,19 @@ struct HostBatch {
         edge_sample_offset.clear(); sample_id.clear(); sample_abd.clear();
         vertex_weight.clear(); vertex_lpos.clear(); vertex_rpos.clear(); vertex_type.clear();
         in_offset.clear(); in_edge.clear(); phasing_offset.clear(); phasing_vertex.clear(); phasing_count.clear(); graph_strand.clear(); edge_count.clear(); edge_rank.clear(); has_rank = false;
+        g_rawdist.clear(); off_rp.assign(1, 0); off_rc.assign(1, 0); rphase_offset.clear(); rphase_coord.clear(); rphase_count.clear(); has_raw = false;
         err.clear();
     }
 
     // sizes of every array: a rejected graph must leave the batch exactly as it found it (the element-wise path appends while it checks)
-    struct Mark { size_t a[28]; bool has_rank; };
+    struct Mark { size_t a[34]; bool has_rank, has_raw; };
     Mark mark() const
     {
         Mark m = {{ g_nv.size(), g_ne.size(), g_np.size(), off_v.size(), off_e.size(), off_s.size(), off_p.size(), off_pv.size(),
                     vertex_offset.size(), edge_target.size(), edge_weight.size(), edge_strand.size(), edge_abd.size(), edge_sample_offset.size(), sample_id.size(), sample_abd.size(),
                     vertex_weight.size(), vertex_lpos.size(), vertex_rpos.size(), vertex_type.size(), in_offset.size(), in_edge.size(),
-                    phasing_offset.size(), phasing_vertex.size(), phasing_count.size(), graph_strand.size(), edge_count.size(), edge_rank.size() }, has_rank};
+                    phasing_offset.size(), phasing_vertex.size(), phasing_count.size(), graph_strand.size(), edge_count.size(), edge_rank.size(),
+                    g_rawdist.size(), off_rp.size(), off_rc.size(), rphase_offset.size(), rphase_coord.size(), rphase_count.size() }, has_rank, has_raw};
         return m;
     }
     void rollback(const Mark &m)
@@ -74,6 +83,7 @@ struct HostBatch {
         sample_id.resize(m.a[14]); sample_abd.resize(m.a[15]); vertex_weight.resize(m.a[16]); vertex_lpos.resize(m.a[17]); vertex_rpos.resize(m.a[18]); vertex_type.resize(m.a[19]);
         in_offset.resize(m.a[20]); in_edge.resize(m.a[21]); phasing_offset.resize(m.a[22]); phasing_vertex.resize(m.a[23]); phasing_count.resize(m.a[24]); graph_strand.resize(m.a[25]);
         edge_count.resize(m.a[26]); edge_rank.resize(m.a[27]); has_rank = m.has_rank;
+        g_rawdist.resize(m.a[28]); off_rp.resize(m.a[29]); off_rc.resize(m.a[30]); rphase_offset.resize(m.a[31]); rphase_coord.resize(m.a[32]); rphase_count.resize(m.a[33]); has_raw = m.has_raw;
     }
     // the first graph that brings a creation rank turns the column on: every edge staged before it gets its CSR position
     void enable_rank()
@@ -208,6 +218,31 @@ struct HostBatch {
         g_nv.push_back(V); g_ne.push_back(E); g_np.push_back(np_kept); graph_strand.push_back(g.strand ? g.strand : '.');
         off_v.push_back(off_v.back() + V); off_e.push_back(off_e.back() + E); off_s.push_back(off_s.back() + (int64_t)(sample_id.size() - s0));
         off_p.push_back(off_p.back() + np_kept); off_pv.push_back(off_pv.back() + (int64_t)(phasing_vertex.size() - pv0));
+        g_rawdist.push_back(-1); off_rp.push_back(off_rp.back()); off_rc.push_back(off_rc.back()); rphase_offset.push_back(0);
+        return ALD_OK;
+    }
+    // A graph BEFORE the pre-steps of assemble(gx, px, sid) + its phase set (meta/assembler.cc:1075-1086).  The graph is staged like any
+    // other (CSR rows sorted, creation ranks carried); its own phasing arrays are ignored, the phases travel as exon coordinates and the
+    // kernel derives the phasing lists from them.  What the reference's grouping is undefined on is refused here, as ald_pre_assemble does.
+    int add_graph_raw(const ald_graph_view &g0, const ald_phase_view *ph, int32_t max_group_boundary_distance)
+    {
+        if(max_group_boundary_distance < 0) { err = "negative max_group_boundary_distance"; return ALD_ERR_INVALID; }
+        const int P = ph ? ph->num_phases : 0;
+        if(P < 0 || (P > 0 && (!ph->phase_offset || !ph->phase_count || (ph->phase_offset[P] > 0 && !ph->phase_coord)))) { err = "null phase arrays"; return ALD_ERR_INVALID; }
+        for(int p = 0; p < P; p++) { const int a = ph->phase_offset[p], b = ph->phase_offset[p + 1]; if(b <= a || ((b - a) & 1)) { err = "a phase is a non-empty list of exon coordinate PAIRS"; return ALD_ERR_INVALID; } }   // phase_set::add asserts
+        const Mark m = mark();
+        ald_graph_view g = g0; g.num_phasing = 0; g.phasing_offset = nullptr; g.phasing_vertex = nullptr; g.phasing_count = nullptr;
+        int rc = add_graph_body(g);
+        if(rc != ALD_OK) { rollback(m); return rc; }
+        const int gi = n() - 1, V = g_nv[gi], E = g_ne[gi]; const int64_t oe = off_e[gi], ovo = off_v[gi] + gi;
+        // parallel edges out of the source / into the sink: the rows are sorted by target, the in-CSR by source
+        for(int k = vertex_offset[ovo] + 1; k < vertex_offset[ovo + 1]; k++) if(edge_target[oe + k] == edge_target[oe + k - 1]) { rollback(m); err = "parallel edges out of the source: the reference's boundary grouping is undefined on them"; return ALD_ERR_INVALID; }
+        { int last = -1; for(int k = in_offset[ovo + V - 1]; k < in_offset[ovo + V]; k++) { const int e = in_edge[oe + k]; int s = 0; while(vertex_offset[ovo + s + 1] <= e) s++; if(s == last) { rollback(m); err = "parallel edges into the sink: the reference's boundary grouping is undefined on them"; return ALD_ERR_INVALID; } last = s; } }
+        (void)E;
+        g_rawdist[(size_t)gi] = max_group_boundary_distance; has_raw = true;
+        const size_t c0 = rphase_coord.size();
+        for(int p = 0; p < P; p++) { for(int k = ph->phase_offset[p]; k < ph->phase_offset[p + 1]; k++) rphase_coord.push_back(ph->phase_coord[k]); rphase_offset.push_back((int32_t)(rphase_coord.size() - c0)); rphase_count.push_back(ph->phase_count[p]); }
+        off_rp.back() += P; off_rc.back() += (int64_t)(rphase_coord.size() - c0);
         return ALD_OK;
     }
 
@@ -312,6 +347,8 @@ struct HostBatch {
         if(np) g_np.insert(g_np.end(), np, np + n); else g_np.resize(n0 + n, 0);
         graph_strand.resize(n0 + n); for(int i = 0; i < n; i++) graph_strand[n0 + i] = (gstrand && gstrand[i]) ? gstrand[i] : '.';
         off_v.resize(n0 + n + 1); off_e.resize(n0 + n + 1); off_s.resize(n0 + n + 1); off_p.resize(n0 + n + 1); off_pv.resize(n0 + n + 1);
+        { const int64_t rp = off_rp.back(), rc = off_rc.back(); g_rawdist.resize(n0 + n); off_rp.resize(n0 + n + 1); off_rc.resize(n0 + n + 1); const size_t r0 = rphase_offset.size(); rphase_offset.resize(r0 + n);
+          for(int i = 0; i < n; i++) { g_rawdist[n0 + i] = -1; off_rp[n0 + i + 1] = rp; off_rc[n0 + i + 1] = rc; rphase_offset[r0 + i] = 0; } }
         for(int i = 0; i < n; i++) { off_v[n0 + i + 1] = off_v[n0] + iv[i + 1]; off_e[n0 + i + 1] = off_e[n0] + ie[i + 1]; off_s[n0 + i + 1] = off_s[n0] + is[i + 1]; off_p[n0 + i + 1] = off_p[n0] + ip[i + 1]; off_pv[n0 + i + 1] = off_pv[n0] + ipv[i + 1]; }
         vertex_offset.resize(vo0 + TV + n); in_offset.resize(vo0 + TV + n);
         edge_target.resize(e0 + TE); edge_weight.resize(e0 + TE); edge_strand.resize(e0 + TE); edge_abd.resize(e0 + TE); edge_count.resize(e0 + TE); in_edge.resize(e0 + TE); if(has_rank) edge_rank.resize(e0 + TE);
@@ -357,6 +394,70 @@ struct HostBatch {
         run_threads(nthr, fill);
         return ALD_OK;
     }
+    // add_packed for a run of graphs some (or all) of which are RAW: raw_dist[i] >= 0 marks graph i as one (its max_group_boundary_distance),
+    // such a graph brings phases (nph[i] of them: local CSR rpoff with nph[i] + 1 entries per graph, coordinates, counts) and no phasing lists
+    int add_packed_raw(int32_t n, const int32_t *nv, const int32_t *ne, const int32_t *np,
+                       const int32_t *voff, const int32_t *etgt, const double *ew, const uint8_t *estrand, const double *eabd,
+                       const int32_t *esoff, const int32_t *sid, const double *sabd,
+                       const double *vw, const int32_t *lpos, const int32_t *rpos, const int32_t *vtype,
+                       const int32_t *poff, const int32_t *pv, const int32_t *pc, const char *gstrand, const int32_t *ecount, const int32_t *erank,
+                       const int32_t *raw_dist, const int32_t *nph, const int32_t *rpoff, const int32_t *rpcoord, const int32_t *rpcount)
+    {
+        if(n <= 0) return ALD_OK;
+        if(!raw_dist) return add_packed(n, nv, ne, np, voff, etgt, ew, estrand, eabd, esoff, sid, sabd, vw, lpos, rpos, vtype, poff, pv, pc, gstrand, ecount, erank);
+        const Mark m = mark(); const size_t n0 = (size_t)this->n();
+        int rc = add_packed(n, nv, ne, np, voff, etgt, ew, estrand, eabd, esoff, sid, sabd, vw, lpos, rpos, vtype, poff, pv, pc, gstrand, ecount, erank);
+        if(rc != ALD_OK) return rc;
+        // phases: offsets of every graph inside the caller's arrays
+        std::vector<int64_t> ip((size_t)n + 1, 0), ic((size_t)n + 1, 0);
+        for(int i = 0; i < n; i++) {
+            const int P = (raw_dist[i] >= 0 && nph) ? nph[i] : 0;
+            if(P < 0 || (P > 0 && (!rpoff || !rpcount))) { rollback(m); err = "null phase arrays"; return ALD_ERR_INVALID; }
+            ip[(size_t)i + 1] = ip[(size_t)i] + P;
+            const int64_t nc = P > 0 ? rpoff[ip[(size_t)i] + i + P] : 0;
+            if(nc < 0 || (nc > 0 && !rpcoord)) { rollback(m); err = "null phase arrays"; return ALD_ERR_INVALID; }
+            ic[(size_t)i + 1] = ic[(size_t)i] + nc;
+        }
+        unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16;
+        if(const char *ev = getenv("ALD_STAGE_THREADS")) { int k = atoi(ev); if(k >= 1 && k <= 64) nthr = (unsigned)k; }
+        if(n < 4096) nthr = 1;
+        std::vector<int> verdict(nthr, 0);            // 1: a raw graph with phasing lists, 2: malformed phase, 3 / 4: parallel source / sink edges
+        run_threads(nthr, [&](unsigned t) {
+            int worst = 0;
+            for(int i = (int)((int64_t)n * t / nthr); i < (int)((int64_t)n * (t + 1) / nthr) && !worst; i++) {
+                if(raw_dist[i] < 0) continue;
+                const size_t g = n0 + (size_t)i; const int V = g_nv[g]; const int64_t oe = off_e[g], ovo = off_v[g] + (int64_t)g;
+                if(g_np[g] != 0) { worst = 1; break; }
+                const int P = (int)(ip[(size_t)i + 1] - ip[(size_t)i]); const int32_t *po = rpoff ? rpoff + ip[(size_t)i] + i : nullptr;
+                if(P > 0 && po[0] != 0) { worst = 2; break; }
+                for(int p = 0; p < P; p++) { const int a = po[p], b = po[p + 1]; if(b <= a || ((b - a) & 1)) { worst = 2; break; } }      // phase_set::add asserts
+                if(worst) break;
+                for(int k = vertex_offset[ovo] + 1; k < vertex_offset[ovo + 1]; k++) if(edge_target[oe + k] == edge_target[oe + k - 1]) { worst = 3; break; }
+                if(worst) break;
+                int s = 0, last = -1;
+                for(int k = in_offset[ovo + V - 1]; k < in_offset[ovo + V]; k++) { const int e = in_edge[oe + k]; while(vertex_offset[ovo + s + 1] <= e) s++; if(s == last) { worst = 4; break; } last = s; }   // in-CSR ids ascend: so do their sources
+            }
+            verdict[t] = worst;
+        });
+        int worst = 0; for(unsigned t = 0; t < nthr; t++) worst = std::max(worst, verdict[t]);
+        if(worst) { rollback(m); err = worst == 1 ? "a raw graph brings phases, not phasing lists" : worst == 2 ? "a phase is a non-empty list of exon coordinate PAIRS"
+                                       : worst == 3 ? "parallel edges out of the source: the reference's boundary grouping is undefined on them" : "parallel edges into the sink: the reference's boundary grouping is undefined on them"; return ALD_ERR_INVALID; }
+        // the raw bookkeeping of the new graphs, laid out again with their phases
+        const int64_t rp0 = off_rp[n0], rc0 = off_rc[n0];
+        rphase_offset.resize(m.a[31] + (size_t)ip[(size_t)n] + (size_t)n); rphase_coord.resize(m.a[32] + (size_t)ic[(size_t)n]); rphase_count.resize(m.a[33] + (size_t)ip[(size_t)n]);
+        for(int i = 0; i < n; i++) {
+            g_rawdist[n0 + (size_t)i] = raw_dist[i] >= 0 ? raw_dist[i] : -1;
+            off_rp[n0 + (size_t)i + 1] = rp0 + ip[(size_t)i + 1]; off_rc[n0 + (size_t)i + 1] = rc0 + ic[(size_t)i + 1];
+            const int P = (int)(ip[(size_t)i + 1] - ip[(size_t)i]);
+            int32_t *dst = &rphase_offset[m.a[31] + (size_t)ip[(size_t)i] + (size_t)i];
+            if(P > 0) memcpy(dst, rpoff + ip[(size_t)i] + i, 4 * ((size_t)P + 1)); else dst[0] = 0;
+            if(P > 0) memcpy(&rphase_count[m.a[33] + (size_t)ip[(size_t)i]], rpcount + ip[(size_t)i], 4 * (size_t)P);
+            const int64_t nc = ic[(size_t)i + 1] - ic[(size_t)i];
+            if(nc > 0) memcpy(&rphase_coord[m.a[32] + (size_t)ic[(size_t)i]], rpcoord + ic[(size_t)i], 4 * (size_t)nc);
+            if(raw_dist[i] >= 0) has_raw = true;
+        }
+        return ALD_OK;
+    }
     template<class F> static void run_threads(unsigned nthr, F &&f)
     {
         if(nthr <= 1) { f(0u); return; }
@@ -369,7 +470,8 @@ struct HostBatch {
     // ---- one contiguous buffer; section offsets are 256-byte aligned ----
     struct Section { const void *src; uint64_t bytes; uint64_t off; };
     enum { S_NV, S_NE, S_NP, S_OFFV, S_OFFE, S_OFFS, S_OFFP, S_OFFPV, S_VOFF, S_ETGT, S_EW, S_ESTRAND, S_EABD, S_ESOFF, S_SID, S_SABD,
-           S_VW, S_LPOS, S_RPOS, S_VTYPE, S_INOFF, S_INEDGE, S_POFF, S_PV, S_PC, S_GSTRAND, S_ECOUNT, S_ERANK, S_COUNT };
+           S_VW, S_LPOS, S_RPOS, S_VTYPE, S_INOFF, S_INEDGE, S_POFF, S_PV, S_PC, S_GSTRAND, S_ECOUNT, S_ERANK,
+           S_RAWDIST, S_OFFRP, S_OFFRC, S_RPOFF, S_RPCOORD, S_RPCOUNT, S_COUNT };
     uint64_t layout(Section sec[S_COUNT]) const
     {
         auto set = [&](int i, const void *p, uint64_t b) { sec[i].src = p; sec[i].bytes = b; };
@@ -384,6 +486,8 @@ struct HostBatch {
         set(S_POFF, phasing_offset.data(), 4ull * phasing_offset.size()); set(S_PV, phasing_vertex.data(), 4ull * phasing_vertex.size()); set(S_PC, phasing_count.data(), 4ull * phasing_count.size());
         set(S_GSTRAND, graph_strand.data(), graph_strand.size()); set(S_ECOUNT, edge_count.data(), 4ull * edge_count.size());
         set(S_ERANK, edge_rank.data(), has_rank ? 4ull * edge_rank.size() : 0);      // travels only when some caller supplied a creation rank
+        set(S_RAWDIST, g_rawdist.data(), has_raw ? 4ull * g_rawdist.size() : 0); set(S_OFFRP, off_rp.data(), has_raw ? 8ull * off_rp.size() : 0); set(S_OFFRC, off_rc.data(), has_raw ? 8ull * off_rc.size() : 0);
+        set(S_RPOFF, rphase_offset.data(), has_raw ? 4ull * rphase_offset.size() : 0); set(S_RPCOORD, rphase_coord.data(), has_raw ? 4ull * rphase_coord.size() : 0); set(S_RPCOUNT, rphase_count.data(), has_raw ? 4ull * rphase_count.size() : 0);
         uint64_t o = 0;
         for(int i = 0; i < S_COUNT; i++) { sec[i].off = o; o = (o + sec[i].bytes + 255) / 256 * 256; }
         return o < 256 ? 256 : o;
@@ -427,6 +531,8 @@ struct HostBatch {
         b.in_offset = ALD_P(int32_t, S_INOFF); b.in_edge = ALD_P(int32_t, S_INEDGE);
         b.phasing_offset = ALD_P(int32_t, S_POFF); b.phasing_vertex = ALD_P(int32_t, S_PV); b.phasing_count = ALD_P(int32_t, S_PC); b.graph_strand = ALD_P(char, S_GSTRAND); b.edge_count = ALD_P(int32_t, S_ECOUNT);
         b.edge_rank = has_rank ? ALD_P(int32_t, S_ERANK) : nullptr;
+        b.g_rawdist = has_raw ? ALD_P(int32_t, S_RAWDIST) : nullptr; b.off_rp = ALD_P(int64_t, S_OFFRP); b.off_rc = ALD_P(int64_t, S_OFFRC);
+        b.rphase_offset = ALD_P(int32_t, S_RPOFF); b.rphase_coord = ALD_P(int32_t, S_RPCOORD); b.rphase_count = ALD_P(int32_t, S_RPCOUNT);
 #undef ALD_P
         return b;
     }

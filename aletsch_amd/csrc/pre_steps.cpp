@@ -246,16 +246,26 @@ int ald_staged_boundary_maps(const ald_staged *S, int32_t *n_smap, const int32_t
 
 int ald_staged_free(ald_staged *S) { delete S; return ALD_OK; }
 
+// The graph goes into the batch AS IT IS, with its phases in exon coordinates: the pre-steps run on the device, in the wave that loads the
+// graph (decomp_device.h: pre_assemble_device).  Where the reference would have asserted in them the graph ends with status
+// ALD_ST_INVARIANT + ALD_INV_OTHER, like any other assert on the path.  (ALD_RAW_ON_HOST=1: the host routine above stages the graph
+// instead -- a debugging aid; a positive return then means that assert, and nothing is added.)
 int ald_batch_add_graph_raw(ald_batch *b, const ald_graph_view *g, const ald_phase_view *phases, int32_t max_group_boundary_distance)
 {
-    if(!b) return ALD_ERR_INVALID;
-    ald_staged *S = nullptr;
-    int rc = ald_pre_assemble(g, phases, max_group_boundary_distance, &S);
-    if(rc != ALD_OK) return rc;
-    ald_graph_view v; ald_staged_view(S, &v);
-    rc = ald_batch_add_graph(b, &v);
-    delete S;
-    return rc;
+    if(!b || !g) return ALD_ERR_INVALID;
+    if(getenv("ALD_RAW_ON_HOST")) {
+        ald_staged *S = nullptr;
+        int rc = ald_pre_assemble(g, phases, max_group_boundary_distance, &S);
+        if(rc != ALD_OK) return rc;
+        ald_graph_view v; ald_staged_view(S, &v);
+        rc = ald_batch_add_graph(b, &v);
+        delete S;
+        return rc;
+    }
+    b->uploaded = b->ran = b->downloaded = false;
+    const int rc = b->hb.add_graph_raw(*g, phases, max_group_boundary_distance);
+    if(rc != ALD_OK) return ald_set_err(rc, b->hb.err);
+    return ALD_OK;
 }
 
 } // extern "C"

@@ -53,7 +53,27 @@ int ald_batch_features(const ald_batch *b, int32_t graph, const ald_graph_extras
     if(!b || !features || graph < 0 || graph >= b->hb.n()) return ALD_ERR_INVALID;
     if(!b->downloaded) return ald_set_err(ALD_ERR_STATE, "ald_batch_features before ald_batch_download");
     { int rc = ald_ensure_index(b); if(rc != ALD_OK) return rc; }
-    const GraphRO G(b->hb, graph);
+    // gr_ori is the graph as scallop received it, i.e. AFTER the pre-steps of assemble(): a raw graph was grouped on the device, so
+    // its staged form is made here, on demand, by the host restatement of the same steps (pre_steps.cpp)
+    HostBatch staged_copy; int gi = graph;
+    if(b->hb.g_rawdist[(size_t)graph] >= 0) {
+        const HostBatch &h = b->hb; const int64_t ov = h.off_v[graph], ovo = ov + graph, oe = h.off_e[graph], oeo = oe + graph, os = h.off_s[graph], orp = h.off_rp[graph], orc = h.off_rc[graph];
+        ald_graph_view gv; memset(&gv, 0, sizeof(gv));
+        gv.num_vertices = h.g_nv[graph]; gv.num_edges = h.g_ne[graph]; gv.vertex_offset = &h.vertex_offset[ovo]; gv.edge_target = h.edge_target.data() + oe; gv.edge_weight = h.edge_weight.data() + oe;
+        gv.edge_strand = h.edge_strand.data() + oe; gv.edge_abd = h.edge_abd.data() + oe; gv.edge_sample_offset = &h.edge_sample_offset[oeo]; gv.sample_id = h.sample_id.data() + os; gv.sample_abd = h.sample_abd.data() + os;
+        gv.vertex_weight = h.vertex_weight.data() + ov; gv.vertex_lpos = h.vertex_lpos.data() + ov; gv.vertex_rpos = h.vertex_rpos.data() + ov; gv.vertex_type = h.vertex_type.data() + ov;
+        gv.strand = h.graph_strand[(size_t)graph]; gv.edge_count = h.edge_count.data() + oe; gv.edge_creation_rank = h.has_rank ? h.edge_rank.data() + oe : nullptr;
+        ald_phase_view pv; pv.num_phases = (int32_t)(h.off_rp[graph + 1] - orp); pv.phase_offset = &h.rphase_offset[(size_t)(orp + graph)]; pv.phase_coord = h.rphase_coord.data() + orc; pv.phase_count = h.rphase_count.data() + orp;
+        ald_staged *S = nullptr;
+        const int rc = ald_pre_assemble(&gv, &pv, h.g_rawdist[(size_t)graph], &S);
+        if(rc != ALD_OK) return rc;
+        ald_graph_view sv; ald_staged_view(S, &sv);
+        const int rc2 = staged_copy.add_graph(sv);
+        ald_staged_free(S);
+        if(rc2 != ALD_OK) return ald_set_err(rc2, staged_copy.err);
+        gi = 0;
+    }
+    const GraphRO G(gi == graph && b->hb.g_rawdist[(size_t)graph] < 0 ? b->hb : staged_copy, gi);
     const int64_t p0 = b->res.path_begin[graph]; const int np = (int)(b->res.path_begin[graph + 1] - p0);
     std::vector<std::vector<Junc>> junc((size_t)np);
     for(int k = 0; k < np; k++) { const PathRec p = b->res.path((int64_t)((size_t)(p0 + k))); junctions(G, b->res.vertices(p), p.nv, junc[(size_t)k]); }

@@ -40,13 +40,15 @@ struct packed_chunk {
     std::vector<int32_t> g_nv, g_ne, g_np, vertex_offset, edge_target, edge_sample_offset, sample_id, vertex_lpos, vertex_rpos, vertex_type,
                          phasing_offset, phasing_vertex, phasing_count, edge_count, edge_rank, sid;
     std::vector<double> edge_weight, edge_abd, sample_abd, vertex_weight; std::vector<uint8_t> edge_strand; std::vector<char> graph_strand;
+    // raw graphs (submit_raw): per graph -1 or the max_group_boundary_distance of a graph whose pre-steps run on the device, its phases
+    std::vector<int32_t> raw_dist, nphase, rphase_offset, rphase_coord, rphase_count; bool any_raw = false;
     long first = 0;                                               // ticket of the first graph, set when the chunk is handed over
     int n() const { return (int)g_nv.size(); }
     template<class T> static void cat(std::vector<T> &d, const std::vector<T> &s) { d.insert(d.end(), s.begin(), s.end()); }
     void append(const staged_graph &s, int sample)
     {
         g_nv.push_back((int32_t)s.vertex_weight.size()); g_ne.push_back((int32_t)s.edge_target.size()); g_np.push_back((int32_t)s.phasing_count.size());
-        graph_strand.push_back(s.strand); sid.push_back((int32_t)sample);
+        graph_strand.push_back(s.strand); sid.push_back((int32_t)sample); raw_dist.push_back(-1); nphase.push_back(0); rphase_offset.push_back(0);
         cat(vertex_offset, s.vertex_offset); cat(edge_target, s.edge_target); cat(edge_weight, s.edge_weight); cat(edge_strand, s.edge_strand); cat(edge_abd, s.edge_abd);
         cat(edge_sample_offset, s.edge_sample_offset); cat(sample_id, s.sample_id); cat(sample_abd, s.sample_abd);
         cat(vertex_weight, s.vertex_weight); cat(vertex_lpos, s.vertex_lpos); cat(vertex_rpos, s.vertex_rpos); cat(vertex_type, s.vertex_type);
@@ -77,7 +79,7 @@ struct packed_chunk {
             while(pos > lo && tmp.dst[(size_t)perm[(size_t)pos - 1]] > tmp.dst[(size_t)k]) { perm[(size_t)pos] = perm[(size_t)pos - 1]; pos--; }      // stable: equal targets keep walk order
             perm[(size_t)pos] = k;
         }
-        g_nv.push_back(V); g_ne.push_back(E); graph_strand.push_back(gr.strand); sid.push_back((int32_t)sample);
+        g_nv.push_back(V); g_ne.push_back(E); graph_strand.push_back(gr.strand); sid.push_back((int32_t)sample); raw_dist.push_back(-1); nphase.push_back(0); rphase_offset.push_back(0);
         vertex_offset.insert(vertex_offset.end(), tmp.row.begin(), tmp.row.end());
         const size_t e0 = edge_target.size(), s0 = edge_sample_offset.size();
         edge_target.resize(e0 + (size_t)E); edge_weight.resize(e0 + (size_t)E); edge_strand.resize(e0 + (size_t)E); edge_abd.resize(e0 + (size_t)E); edge_count.resize(e0 + (size_t)E); edge_rank.resize(e0 + (size_t)E);
@@ -100,6 +102,15 @@ struct packed_chunk {
         for(const auto &kv : hs.nodes) { for(int x : kv.first) phasing_vertex.push_back(x); phasing_offset.push_back((int32_t)(phasing_vertex.size() - pv0)); phasing_count.push_back(kv.second); np++; }
         g_np.push_back(np);
     }
+    // the graph appended last is RAW: its pre-steps (meta/assembler.cc:1075-1086) run on the device; PhaseSet: .pmap (map<vector<int32_t>, int>)
+    template<class PhaseSet>
+    void last_is_raw(const PhaseSet &px, int max_group_boundary_distance)
+    {
+        raw_dist.back() = max_group_boundary_distance; any_raw = true;
+        const size_t c0 = rphase_coord.size(); int np = 0;
+        for(const auto &kv : px.pmap) { rphase_coord.insert(rphase_coord.end(), kv.first.begin(), kv.first.end()); rphase_offset.push_back((int32_t)(rphase_coord.size() - c0)); rphase_count.push_back((int32_t)kv.second); np++; }
+        nphase.back() = np;
+    }
     void reserve_like(const packed_chunk &o)                      // the next chunk of a thread is about as large as its last one
     {
         g_nv.reserve(o.g_nv.size()); g_ne.reserve(o.g_ne.size()); g_np.reserve(o.g_np.size()); graph_strand.reserve(o.graph_strand.size()); sid.reserve(o.sid.size());
@@ -113,10 +124,16 @@ struct packed_chunk {
         static const int32_t zero_i = 0; static const double zero_d = 0;     // empty arrays still need valid pointers
         auto pi = [](const std::vector<int32_t> &v) { return v.empty() ? &zero_i : v.data(); };
         auto pd = [](const std::vector<double> &v) { return v.empty() ? &zero_d : v.data(); };
+        if(!any_raw)
         return ald_batch_add_packed(b, n(), g_nv.data(), g_ne.data(), g_np.data(), vertex_offset.data(), pi(edge_target), pd(edge_weight),
                                     edge_strand.empty() ? (const uint8_t*)&zero_i : edge_strand.data(), pd(edge_abd), edge_sample_offset.data(), pi(sample_id), pd(sample_abd),
                                     pd(vertex_weight), pi(vertex_lpos), pi(vertex_rpos), pi(vertex_type), phasing_offset.data(), pi(phasing_vertex), pi(phasing_count),
                                     graph_strand.data(), pi(edge_count), edge_rank.size() == edge_target.size() && !edge_rank.empty() ? edge_rank.data() : nullptr);
+        return ald_batch_add_packed_raw(b, n(), g_nv.data(), g_ne.data(), g_np.data(), vertex_offset.data(), pi(edge_target), pd(edge_weight),
+                                    edge_strand.empty() ? (const uint8_t*)&zero_i : edge_strand.data(), pd(edge_abd), edge_sample_offset.data(), pi(sample_id), pd(sample_abd),
+                                    pd(vertex_weight), pi(vertex_lpos), pi(vertex_rpos), pi(vertex_type), phasing_offset.data(), pi(phasing_vertex), pi(phasing_count),
+                                    graph_strand.data(), pi(edge_count), edge_rank.size() == edge_target.size() && !edge_rank.empty() ? edge_rank.data() : nullptr,
+                                    raw_dist.data(), nphase.data(), rphase_offset.data(), pi(rphase_coord), pi(rphase_count));
     }
 };
 
@@ -191,16 +208,18 @@ private:
     }
 public:
 
-    // The call shape of assembler::assemble(gx, px, sid) itself (meta/assembler.cc:1075): the pre-steps (extend_strands, boundary
-    // grouping, phase projection, hyper_set ctor + filter_nodes) run in the calling thread through the library, then the graph is queued.
-    // Returns false when the reference would have asserted in the pre-steps (the graph is counted as failed, nothing is queued).
+    // The call shape of assembler::assemble(gx, px, sid) itself (meta/assembler.cc:1075): the graph is queued AS IT IS with its phase set;
+    // the pre-steps (extend_strands, boundary grouping, phase projection, hyper_set ctor + filter_nodes) run on the device, in the wave
+    // that loads the graph.  A graph on which the reference would have asserted in them is counted in failed_graphs() like any other.
     template<class PhaseSet>
     bool submit_raw(SpliceGraph &gx, const PhaseSet &px, int sid, int max_group_boundary_distance = 10000)
     {
-        int st = 0;
-        staged_graph s = stage_raw(gx, px, max_group_boundary_distance, st);
-        if(st > 0) { std::lock_guard<std::mutex> lk(m_); failed_++; return false; }
-        submit_staged(s, sid);
+        struct no_hyper_set { std::map<std::vector<int>, int> nodes; } none;
+        lane *L = my_lane();
+        std::unique_lock<std::mutex> ll(L->m);
+        L->c.append_graph(gx, none, sid, L->tmp);
+        L->c.last_is_raw(px, max_group_boundary_distance);
+        hand_over_if_full(L, ll);
         return true;
     }
 

@@ -172,16 +172,19 @@ public:
         lpos_.push_back(std::move(s.vertex_lpos)); rpos_.push_back(std::move(s.vertex_rpos));
         return (int)lpos_.size() - 1;
     }
-    // the same for a graph as assembler::assemble(gx, px, sid) receives it: its pre-steps (meta/assembler.cc:1075-1086) run first.
-    // Returns the ticket, or -1 - status where the reference would have asserted in them (nothing is enqueued then).
+    // the same for a graph as assembler::assemble(gx, px, sid) receives it: its pre-steps (meta/assembler.cc:1075-1086) run on the device,
+    // in the wave that loads the graph.  Returns the ticket; where the reference would have asserted in them status(ticket) says so.
     template<class PhaseSet>
     int enqueue_raw(SpliceGraph &gx, const PhaseSet &px, int max_group_boundary_distance = 10000) {
-        int st = 0;
-        staged_graph s = stage_raw(gx, px, max_group_boundary_distance, st);
-        if(st > 0) return -1 - st;
+        struct no_hyper_set { std::map<std::vector<int>, int> nodes; } none;
+        staged_graph s = stage_graph(gx, none);                      // the graph as it is; the pre-steps run on the device (ald_batch_add_graph_raw)
+        std::vector<int32_t> off(1, 0), coord, cnt;
+        for(const auto &kv : px.pmap) { coord.insert(coord.end(), kv.first.begin(), kv.first.end()); off.push_back((int32_t)coord.size()); cnt.push_back((int32_t)kv.second); }
+        static const int32_t zero = 0;
+        ald_phase_view pv; pv.num_phases = (int32_t)cnt.size(); pv.phase_offset = off.data(); pv.phase_coord = coord.empty() ? &zero : coord.data(); pv.phase_count = cnt.empty() ? &zero : cnt.data();
         ald_graph_view g = s.view();
-        int rc = ald_batch_add_graph(b_, &g);
-        if(rc != ALD_OK) throw gpu_error(rc, "ald_batch_add_graph");
+        int rc = ald_batch_add_graph_raw(b_, &g, &pv, max_group_boundary_distance);
+        if(rc != ALD_OK) throw gpu_error(rc, "ald_batch_add_graph_raw");
         lpos_.push_back(std::move(s.vertex_lpos)); rpos_.push_back(std::move(s.vertex_rpos));
         return (int)lpos_.size() - 1;
     }

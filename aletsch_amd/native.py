@@ -297,9 +297,24 @@ class DecompBatch:
     def add(self, pg: PackedGraphs):
         _check(self._lib.ald_batch_add_packed(self._h, *pg.c_args()))
 
+    def add_packed_raw(self, pg: PackedGraphs, max_group_boundary_distance: int = 10000, phases=None):
+        """every graph of `pg` as a RAW graph (pre-steps on the device): ald_batch_add_packed_raw; phases: per graph a list of
+        ([l0, r0, l1, r1, ...], count) or None"""
+        n = pg.n
+        dist = np.full(n, max_group_boundary_distance, np.int32)
+        nph = np.zeros(n, np.int32); off = []; co = []; cnt = []
+        for g in range(n):
+            ph = phases[g] if phases is not None else []
+            nph[g] = len(ph); off.append(0); base = len(co)
+            for coords, c in ph:
+                co += list(coords); off.append(len(co) - base); cnt.append(c)
+        off = np.array(off, np.int32); co = np.array(co if co else [0], np.int32); cnt = np.array(cnt if cnt else [0], np.int32)
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        _check(self._lib.ald_batch_add_packed_raw(self._h, *pg.c_args(), p(dist), p(nph), p(off), p(co), p(cnt)))
+
     def add_raw(self, pg: PackedGraphs, phases, max_group_boundary_distance: int = 10000, g: int = 0) -> int:
-        """assemble(gx, px, sid) up to the scallop ctor, then staged: ald_batch_add_graph_raw.  Returns 0, or the positive status where
-        the reference would have asserted in the pre-steps (nothing is added then)."""
+        """assemble(gx, px, sid) as received: ald_batch_add_graph_raw stages graph g of `pg` raw, with its phases; the pre-steps run on the
+        device.  Returns 0 (a graph on which the reference would have asserted in them ends with an invariant status)."""
         gv = GraphView.from_packed(pg, g); pv = PhaseView.from_lists(phases)
         rc = self._lib.ald_batch_add_graph_raw(self._h, C.byref(gv), C.byref(pv), C.c_int32(max_group_boundary_distance))
         if rc < 0:

@@ -328,7 +328,7 @@ def main() -> int:
             dist.barrier()
         return time.perf_counter()
 
-    def run_steps(w, k, staged):
+    def run_steps(w, k, staged, raw=False):
         """w untimed + k timed passes through ONE pipeline.  staged=True: host arrays in -> host results out, three stages on three
         threads (adder: caller's arrays -> the batch's host arrays; uploader: pack + H2D + first-pass work lists; this thread: kernel
         launch + D2H), batch objects rotating; staged=False: the batches are resident, kernel + D2H only.
@@ -386,7 +386,11 @@ def main() -> int:
                     b = free.get()
                     t_ = time.perf_counter()
                     if staged:
-                        b.clear(); b.add(pg)
+                        b.clear()
+                        if raw:
+                            b.add_packed_raw(pg, 10000)      # the graphs as assemble(gx, px, sid) receives them: the pre-steps run in the kernel
+                        else:
+                            b.add(pg)
                     stage_s[0] += time.perf_counter() - t_
                     added.put(b)
             except BaseException as e:                           # surface the failure in the main thread instead of a hang
@@ -514,6 +518,13 @@ def main() -> int:
                 msf, badf, clsf = kernel_only(A, dev, flow)
                 sec["flow_weights"] = {"workload": f"{args.graphs} x {args.vertices}v/{args.edges}e, flow-conserving weights (SURVEY.md 8d's second distribution)",
                                        "kernel_ms": msf, "bundles_per_s": args.graphs / (msf / 1e3), "failed_graphs": badf, "graphs_per_class": clsf}
+            if elapsed_h2d:
+                # row f1: the same host-arrays-in loop with every graph handed over RAW (ald_batch_add_packed_raw: extend_strands, boundary
+                # grouping, phase projection, hyper_set ctor and filter_nodes run in the wave that loads the graph)
+                el_raw, kms_raw = run_steps(2, args.steps, True, raw=True)
+                sec["raw_form"] = {"workload": "the headline workload handed over as raw graphs (pre-steps of assembler::assemble on the device), host arrays in -> host results out",
+                                   "bundles_per_s": args.graphs * args.steps / el_raw, "ms_per_step": el_raw / args.steps * 1e3, "kernel_ms": float(np.mean(kms_raw)),
+                                   "vs_packed_form": (args.graphs * args.steps / el_raw) / (args.graphs * args.steps / elapsed_h2d)}
             sec["end_to_end_with_sink"] = sink_pipeline(A, pg, args.graphs)
             line["secondary"] = sec
         if args.cpu_sample > 0 and world == 1:           # reported at N = 1 only

@@ -167,8 +167,22 @@ int  ald_pre_assemble(const ald_graph_view *g, const ald_phase_view *phases, int
 int  ald_staged_view(const ald_staged *s, ald_graph_view *out);      /* borrowed pointers into s; edge_creation_rank is set */
 int  ald_staged_boundary_maps(const ald_staged *s, int32_t *n_smap, const int32_t **smap_pairs, int32_t *n_tmap, const int32_t **tmap_pairs);   /* (from, to) pairs */
 int  ald_staged_free(ald_staged *s);
-/* ald_pre_assemble + ald_batch_add_graph in one call: the batched form of `assemble(gx, px, sid)` up to `scallop sx(gx, hx, pa)` */
+/* The batched form of `assemble(gx, px, sid)` (meta/assembler.cc:1075): the graph goes into the batch AS RECEIVED, its phase set in exon
+ * coordinates, and the pre-steps named above run ON THE DEVICE, in the wave that loads the graph (decomp_device.h: pre_assemble_device),
+ * before that wave decomposes it -- no host pass per graph.  g->num_phasing / phasing_* are ignored.  Returns ALD_OK or ALD_ERR_INVALID
+ * (malformed input, incl. parallel source / sink edges); where the reference would have asserted in the pre-steps the graph ENDS with
+ * status ALD_ST_INVARIANT + ALD_INV_OTHER, like any other assert on the path. */
 int  ald_batch_add_graph_raw(ald_batch *b, const ald_graph_view *g, const ald_phase_view *phases, int32_t max_group_boundary_distance);
+/* The bulk form: ald_batch_add_packed's arrays + per graph raw_max_group_boundary_distance[i] (>= 0: graph i is raw and brings g_nphase[i]
+ * phases -- phase_offset is a local CSR of g_nphase[i] + 1 entries per graph, phase_coord / phase_count concatenated --; < 0: graph i is
+ * an ordinary staged graph with its phasing lists).  Replaces the same call, one graph after the other. */
+int  ald_batch_add_packed_raw(ald_batch *b, int32_t n, const int32_t *g_nv, const int32_t *g_ne, const int32_t *g_np,
+                              const int32_t *vertex_offset, const int32_t *edge_target, const double *edge_weight, const uint8_t *edge_strand, const double *edge_abd,
+                              const int32_t *edge_sample_offset, const int32_t *sample_id, const double *sample_abd,
+                              const double *vertex_weight, const int32_t *vertex_lpos, const int32_t *vertex_rpos, const int32_t *vertex_type,
+                              const int32_t *phasing_offset, const int32_t *phasing_vertex, const int32_t *phasing_count, const char *graph_strand, const int32_t *edge_count,
+                              const int32_t *edge_creation_rank,
+                              const int32_t *raw_max_group_boundary_distance, const int32_t *g_nphase, const int32_t *phase_offset, const int32_t *phase_coord, const int32_t *phase_count);
 
 /* ---- execution (replaces `sx.assemble()`, scallop.cc:38-188) ---- */
 int  ald_batch_upload(ald_batch *b);      /* H2D of the wire buffer (one coalesced copy)      */

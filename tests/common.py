@@ -90,6 +90,33 @@ def emu_run(pg: PackedGraphs, trace_cap: int = 0, force_class: int = 0, params=N
     return r, it, cl
 
 
+def emu_run_raw(items, params=None):
+    """items: [(single-graph PackedGraphs, phases, max_group_boundary_distance), ...] as assembler::assemble(gx, px, sid) receives them;
+    staged raw (HostBatch::add_graph_raw) and run through the single-lane emulation of the engine, whose load phase does the pre-steps
+    -> (DecompResult, iterations[n])"""
+    from aletsch_amd.native import GraphView, PhaseView
+    E = emu_lib()
+    E.emu_batch_new.restype = C.c_void_p
+    E.emu_batch_free.argtypes = [C.c_void_p]; E.emu_batch_add_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    E.emu_batch_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    B = C.c_void_p(E.emu_batch_new())
+    try:
+        for pg, phases, dist in items:
+            gv = GraphView.from_packed(pg, 0); pv = PhaseView.from_lists(phases)
+            rc = E.emu_batch_add_raw(B, C.byref(gv), C.byref(pv), C.c_int32(dist))
+            assert rc == 0, rc
+        h = C.c_void_p()
+        rc = E.emu_batch_run(B, C.byref(params) if params is not None else None, C.c_int32(0), C.c_int32(0), C.byref(h))
+        assert rc == 0, rc
+        r = export_via(E.emu_result_export, h, len(items))
+        it = np.zeros(len(items), np.int32); cl = np.zeros(len(items), np.int32)
+        E.emu_result_iters(h, it.ctypes.data_as(C.POINTER(C.c_int32)), cl.ctypes.data_as(C.POINTER(C.c_int32)))
+        E.emu_result_free(h)
+    finally:
+        E.emu_batch_free(B)
+    return r, it
+
+
 def emu_transcripts(pg: PackedGraphs):
     """coverage + exon lists per path as the engine's records carry them (single-lane emulation) -> (DecompResult, cov, exon_offset, exons[.,2])"""
     E = emu_lib()

@@ -18,6 +18,7 @@ struct emu_result { HostResults R; int n = 0; std::vector<int32_t> trace_n, trac
 
 extern "C" {
 
+static int emu_run_batch(HostBatch &B, const ald_params *prm, int32_t trace_cap, int32_t force_class, emu_result **out);
 int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_t *np,
                    const int32_t *voff, const int32_t *etgt, const double *ew, const uint8_t *estrand, const double *eabd,
                    const int32_t *esoff, const int32_t *sid, const double *sabd,
@@ -28,6 +29,17 @@ int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_
     HostBatch B;
     int rc = B.add_packed(n, nv, ne, np, voff, etgt, ew, estrand, eabd, esoff, sid, sabd, vw, lpos, rpos, vtype, poff, pv, pc, gstrand, ecount, erank);
     if(rc != ALD_OK) { fprintf(stderr, "emu: add_packed failed: %s\n", B.err.c_str()); return rc; }
+    return emu_run_batch(B, prm, trace_cap, force_class, out);
+}
+/* a batch built graph by graph, raw graphs (pre-steps in the engine's load phase) included: the staging calls are the product's own */
+HostBatch *emu_batch_new() { return new HostBatch(); }
+void emu_batch_free(HostBatch *B) { delete B; }
+int emu_batch_add_raw(HostBatch *B, const ald_graph_view *g, const ald_phase_view *ph, int32_t dist) { return B->add_graph_raw(*g, ph, dist); }
+int emu_batch_add(HostBatch *B, const ald_graph_view *g) { return B->add_graph(*g); }
+int emu_batch_run(HostBatch *B, const ald_params *prm, int32_t trace_cap, int32_t force_class, emu_result **out) { return emu_run_batch(*B, prm, trace_cap, force_class, out); }
+static int emu_run_batch(HostBatch &B, const ald_params *prm, int32_t trace_cap, int32_t force_class, emu_result **out)
+{
+    const int n = B.n(); int rc = 0;
     HostBatch::Section sec[HostBatch::S_COUNT];
     uint64_t bytes = B.layout(sec);
     std::vector<uint8_t> buf(bytes);
@@ -55,6 +67,7 @@ int emu_run_packed(int32_t n, const int32_t *nv, const int32_t *ne, const int32_
     if(trace_cap > 0) std::fill(E->trace_n.begin(), E->trace_n.end(), 0);
     for(int g = 0; g < n; g++) {
         int64_t ns = B.off_s[g + 1] - B.off_s[g], npv = B.off_pv[g + 1] - B.off_pv[g];
+        if(B.g_rawdist[g] >= 0) npv += 2 * (B.off_rc[g + 1] - B.off_rc[g]);
         cls[g] = debug_underclass(pick_class(B.g_nv[g], B.g_ne[g], ns, npv, force_class));
         if(cls[g] < 0) status[g] = ALD_ST_CAPACITY; else work[cls[g]].push_back(g);
     }

@@ -59,6 +59,55 @@ def test_pre_steps_match_the_oracle_and_feed_the_engine():
     assert np.array_equal(it[ok], st[ok, 3]) and ok.sum() > 90
 
 
+def test_pre_steps_in_the_load_phase_of_the_engine():
+    """SURVEY 8f row f1 where it belongs: the graph goes to the device AS assemble(gx, px, sid) receives it, its phase set in exon
+    coordinates, and the wave that loads it runs extend_strands / boundary grouping / phase projection / hyper_set ctor / filter_nodes
+    (decomp_device.h: pre_assemble_device; here through the single-lane emulation).  The decomposition must equal the oracle's
+    pre-steps + decomposition graph for graph -- and a graph on which the reference would have asserted ends with an invariant status."""
+    rng = np.random.default_rng(1077)
+    items = []; staged = []; asserted = []
+    for t in range(260):
+        g, phases = common.gene_like_raw(rng, n_runs=int(rng.integers(3, 10)), strand="+-."[t % 3])
+        if t % 7 == 0:
+            phases = phases + phases[:2]                                            # duplicate phases: equal lists fold their counts
+        pg = PackedGraphs.from_graphs([g])
+        pg.edge_rank = np.array(sorted(range(len(g["edges"])), key=lambda k: (g["edges"][k][0], g["edges"][k][1])), np.int32)
+        pg.edge_count = (pg.sample_counts() + rng.integers(0, 3, pg.edge_target.size)).astype(np.int32)
+        dist = int(rng.choice([10000, 10000, 150, 0]))
+        O = common.oracle_lib()
+        O.ora_pre_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+        O.ora_staged_view.argtypes = [C.c_void_p, C.c_void_p]; O.ora_staged_free.argtypes = [C.c_void_p]; O.ora_staged_boundary_maps.argtypes = [C.c_void_p] * 5
+        want, sm, tm, rc_o = A.pre_assemble(pg, phases, dist, _lib=O, _prefix="ora")
+        items.append((pg, phases, dist)); asserted.append(rc_o != 0)
+        if rc_o == 0:
+            staged.append(want)
+    got, it = common.emu_run_raw(items)
+    asserted = np.array(asserted)
+    assert (got.status[asserted] >= 100).all() and 0 < asserted.sum() < 60
+    batch = PackedGraphs.concat(staged)
+    want, st, _, _ = common.oracle_run(batch)
+    ok = ~asserted
+    # compare graph by graph: the emulated batch holds the asserted graphs too
+    sub = common_select_results(got, np.nonzero(ok)[0])
+    assert not common.compare_results(want, sub, batch.n)
+    good = want.status == 0
+    assert np.array_equal(it[ok][good], st[good, 3]) and good.sum() > 150
+
+
+def common_select_results(r, keep):
+    """the results of graphs `keep` (ascending) as a DecompResult of their own"""
+    from aletsch_amd.packed import DecompResult
+    po = r.path_offset; pv = r.pv_offset
+    paths = np.concatenate([np.arange(po[g], po[g + 1]) for g in keep]) if len(keep) else np.zeros(0, np.int64)
+    cnt = np.array([po[g + 1] - po[g] for g in keep], np.int64)
+    new_po = np.concatenate([[0], np.cumsum(cnt)]).astype(r.path_offset.dtype)
+    lens = (pv[paths + 1] - pv[paths]) if len(paths) else np.zeros(0, np.int64)
+    new_pv = np.concatenate([[0], np.cumsum(lens)]).astype(r.pv_offset.dtype)
+    verts = np.concatenate([r.path_vertices[pv[p]:pv[p + 1]] for p in paths]) if len(paths) else np.zeros(0, r.path_vertices.dtype)
+    return DecompResult(status=r.status[keep], path_offset=new_po, weight=r.weight[paths], abd=r.abd[paths], conf=r.conf[paths], reads=r.reads[paths],
+                        length=r.length[paths], count=r.count[paths], strand=r.strand[paths], pv_offset=new_pv, path_vertices=verts)
+
+
 def test_pre_steps_by_hand():
     """one small case worked out by hand: three start boundaries on a run of touching partial exons, the third too far away"""
     #            0      1          2          3          4          5      6
