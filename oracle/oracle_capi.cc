@@ -363,6 +363,52 @@ int ora_graph_script(const char *script, char *out, int32_t cap)
     return (int)o.size();
 }
 
+/* Router script runner: the same case language and the same '@' output lines as oracle/ref_drivers/ref_router_main.cc (the REFERENCE's
+ * scallop/router.cc built from source), executed by the oracle's Router -- so that classify + thread, the isolate attachments, the
+ * confidence side effect and the clamp can be diffed against the reference's own object code (tests/golden/ref_router.json). */
+int ora_router_script(const char *script, char *out, int32_t cap)
+{
+    std::string o; char buf[160];
+    const char *p = script;
+    auto skip = [&]() { while(*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r') p++; };
+    auto next_int = [&](int &v) { skip(); char *e; v = (int)strtol(p, &e, 10); p = e; };
+    auto next_dbl = [&](double &v) { skip(); char *e; v = strtod(p, &e); p = e; };
+    for(;;) {
+        skip();
+        if(*p != 'R') break;
+        p++;
+        int nv, root, ne, nr; double minw;
+        next_int(nv); next_int(root); next_int(ne); next_int(nr); next_dbl(minw);
+        ora::Graph gr; for(int i = 0; i < nv; i++) gr.add_vertex();
+        for(int k = 0; k < ne; k++) {
+            int s, t, strand, count, ns; double w;
+            next_int(s); next_int(t); next_dbl(w); next_int(strand); next_int(count); next_int(ns);
+            const int e = gr.add_edge(s, t);                      // ids are creation-numbered: e == k
+            ora::EdgeInfo &ei = gr.einf[e]; ei.strand = strand; ei.count = count; ei.confidence = 0; ei.abd = 0;
+            for(int j = 0; j < ns; j++) { int sp; double a; next_int(sp); next_dbl(a); ei.samples.insert(sp); ei.spAbd[sp] = a; ei.abd += a; }
+            gr.ewrt[e] = w;
+        }
+        ora::MPII mpi;
+        for(int k = 0; k < nr; k++) { int a, b, c; next_int(a); next_int(b); next_int(c); mpi[{a, b}] += c; }
+        ora::Params cfg; cfg.min_guaranteed_edge_weight = minw;
+        try {
+            ora::Router rt(root, gr, mpi, cfg);
+            rt.classify();
+            snprintf(buf, sizeof buf, "@case type %d degree %d\n", rt.type, rt.degree); o += buf;
+            if(rt.type == ora::UNSPLITTABLE_SINGLE || rt.type == ora::SPLITTABLE_PURE) {
+                rt.build();
+                snprintf(buf, sizeof buf, "@ratio %.17g\n", rt.ratio); o += buf;
+                for(auto &kv : rt.pe2w) { snprintf(buf, sizeof buf, "@pair %d %d %.17g\n", kv.first.first, kv.first.second, kv.second); o += buf; }
+                for(int k = 0; k < ne; k++) { snprintf(buf, sizeof buf, "@conf %d %.17g\n", k, gr.einf[k].confidence); o += buf; }
+            }
+        } catch(const ora::AssertFail &f) { snprintf(buf, sizeof buf, "@assert %d\n", f.cls); o += buf; }
+        o += "@end\n";
+    }
+    if((int)o.size() + 1 > cap) return -1;
+    memcpy(out, o.c_str(), o.size() + 1);
+    return (int)o.size();
+}
+
 /* subset-sum restatement (oracle/subsetsum_oracle.hpp), one instance */
 int ora_subsetsum(int32_t ns, int32_t nt, const int32_t *src_val, const int32_t *src_lab, const int32_t *tgt_val, const int32_t *tgt_lab,
                   double *err, int32_t *out_ns, int32_t *out_nt, int32_t *out_s, int32_t *out_t)

@@ -11,12 +11,16 @@
   ref_tset.json       transcript groups + the merged set produced by oracle/_ref/ref_tset (the REFERENCE's
                       rnacore/transcript_set.cc + gtf/transcript.cc)  -> pins the result sink (ald_tset_*)
 
+  ref_router.json     one-vertex cases (edges in creation order, supporting samples, phasing routes) and what the REFERENCE's
+                      scallop/router.cc makes of them (oracle/_ref/ref_router: type, degree, ratio, pe2w, edge confidences)
+                      -> pins the oracle's Router (classify + thread + isolate attachment)
+
   ref_gtf.json        transcripts (+ feature blocks) and the bytes the REFERENCE's writers emit for them: transcript::write,
                       write_features(ostream), write_features(int) (gtf/transcript.cc:318-494, oracle/_ref/ref_gtf)
                       -> pins ald_gtf_format_transcript / ald_gtf_format_features
 
 Needs /root/reference (for the _ref binaries); run from the repo root:  python tests/golden/make_golden.py
-(`python tests/golden/make_golden.py gtf` regenerates ref_gtf.json only)
+(`python tests/golden/make_golden.py gtf` / `router` regenerate ref_gtf.json / ref_router.json only)
 """
 import json
 import os
@@ -161,10 +165,59 @@ def make_gtf():
     return len(cases)
 
 
+def router_case(rng):
+    """One vertex with its in- and out-edges as scallop hands it to the router: 1..6 edges a side created in a random order (parallel
+    edges included), weights with deliberate ties, 1..4 supporting samples per edge with sample 0 everywhere (so that every isolated
+    node finds a partner: the reference asserts otherwise), a random set of phasing routes.  -> script text of oracle/ref_drivers/ref_router_main.cc"""
+    nin = rng.choice([1, 2, 2, 2, 3, 3, 4, 5, 6]); nout = rng.choice([1, 2, 2, 2, 3, 3, 4, 5, 6])
+    nfar_in = rng.randint(1, nin); nfar_out = rng.randint(1, nout)
+    root = nfar_in; nv = nfar_in + 1 + nfar_out
+    strand = rng.choice([0, 0, 0, 1, 2])
+    wpool = [float(rng.randint(1, 40)) for _ in range(3)] + [rng.uniform(0.5, 90.0) for _ in range(3)]
+    edges = []
+    for i in range(nin):
+        edges.append((rng.randrange(nfar_in) if i >= nfar_in else i, root))
+    for j in range(nout):
+        edges.append((root, root + 1 + (rng.randrange(nfar_out) if j >= nfar_out else j)))
+    rng.shuffle(edges)                                           # creation order
+    lines = []
+    for s, t in edges:
+        w = rng.choice(wpool) if rng.random() < 0.5 else rng.uniform(0.5, 120.0)
+        smp = sorted(set([0] + [rng.randint(1, 4) for _ in range(rng.randint(0, 3))]))
+        ab = [rng.choice([3.0, 7.5, 12.0]) if rng.random() < 0.4 else rng.uniform(0.2, 60.0) for _ in smp]
+        lines.append("%d %d %r %d %d %d %s" % (s, t, w, strand if rng.random() < 0.7 else 0, rng.randint(1, 3), len(smp), " ".join("%d %r" % (a, b) for a, b in zip(smp, ab))))
+    ins = [k for k, (s, t) in enumerate(edges) if t == root]; outs = [k for k, (s, t) in enumerate(edges) if s == root]
+    routes = []
+    dens = rng.choice([0.0, 0.0, 0.15, 0.4, 0.8])
+    for a in ins:
+        for b in outs:
+            if rng.random() < dens:
+                routes.append((a, b, rng.randint(1, 9)))
+    head = "R %d %d %d %d %r" % (nv, root, len(edges), len(routes), rng.choice([0.01, 0.01, 0.5]))
+    return "\n".join([head] + lines + ["%d %d %d" % r for r in routes]) + "\n"
+
+
+def make_router(n_cases=240):
+    rng = random.Random(73811)
+    cases = []
+    while len(cases) < n_cases:
+        sc = router_case(rng)
+        r = subprocess.run([os.path.join(ROOT, "oracle/_ref/ref_router")], input=sc, capture_output=True, text=True)      # one process per case: an assert aborts it
+        if r.returncode != 0:
+            continue
+        out = "".join(ln + "\n" for ln in r.stdout.splitlines() if ln.startswith("@"))
+        cases.append({"script": sc, "out": out})
+    json.dump(cases, open(os.path.join(HERE, "ref_router.json"), "w"), indent=0)
+    return len(cases)
+
+
 def main():
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
     if len(sys.argv) > 1 and sys.argv[1] == "gtf":
         print("ref_gtf.json:", make_gtf(), "transcripts")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "router":
+        print("ref_router.json:", make_router(), "cases")
         return
     rng = random.Random(20250211)
     # ---- graph layer ----
@@ -197,6 +250,7 @@ def main():
         tcases.append({"groups": groups, "items": tset_parse(out)})
     json.dump(tcases, open(os.path.join(HERE, "ref_tset.json"), "w"))
     make_gtf()
+    make_router()
     # ---- oracle regression fixture ----
     import aletsch_amd as A
     import common
