@@ -2802,7 +2802,15 @@ ALD_FN void finish_graph()
 }
 
 // ---------------------------------------------------------------- scallop::assemble (scallop.cc:38-188)
+// A real call from the kernel root (one per graph): the root then only holds the wave's work loop, and nothing of it has to stay in
+// registers across the calls INSIDE the cascade.  (Inlined into the root, the device pre-steps of raw graphs -- a large callee reached
+// through load_graph -- took the caller-saved registers the cascade had been keeping its long-lived values in: 43 VGPR spills spread over
+// every sweep, 42.7 -> 56.2 ms for the bench batch.)
+#ifdef ALD_RUNGRAPH_INLINE
 ALD_INL void run_graph()
+#else
+ALD_FN void run_graph()
+#endif
 {
     PROF_DECL;
 #ifdef ALD_PROF

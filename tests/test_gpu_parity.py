@@ -596,7 +596,7 @@ def test_raw_graphs_through_the_pre_steps_on_gpu():
         assert b.n == 300 and 0 < asserted.sum() < 60
         b.upload(); b.run(); b.download()
         got = b.result()
-        feats = {g: b.features(g) for g in np.nonzero(~asserted)[0][:40]}
+        feats = {int(g): b.features(int(g)) for g in np.nonzero(~asserted)[0][:40]}
     assert (got.status[asserted] >= 100).all()
     batch = PackedGraphs.concat(want_parts)
     want = common.oracle_run(batch, threads=4)[0]
@@ -614,7 +614,7 @@ def test_raw_graphs_through_the_pre_steps_on_gpu():
         b.add(batch); b.upload(); b.run(); b.download()
         keep = np.nonzero(~asserted)[0]
         for k, g in enumerate(keep[:40]):
-            assert [f.as_dict() for f in b.features(k)[0]] == [f.as_dict() for f in feats[g][0]], g
+            assert [f.as_dict() for f in b.features(k)[0]] == [f.as_dict() for f in feats[int(g)][0]], g
 
 
 def test_rccl_gather_behind_the_c_abi():
