@@ -15,7 +15,8 @@
 #include <cmath>
 
 extern "C" {
-#define ALD_DECL(ID) int ald_launch_c##ID(const KernelArgs *, int, hipStream_t); int ald_occupancy_c##ID(); unsigned long long ald_hot_slab_bytes_c##ID();
+#define ALD_DECL(ID) int ald_launch_c##ID(const KernelArgs *, int, hipStream_t); int ald_occupancy_c##ID(); unsigned long long ald_hot_slab_bytes_c##ID(); \
+                     int ald_launch_raw_c##ID(const KernelArgs *, int, hipStream_t); int ald_occupancy_raw_c##ID(); unsigned long long ald_hot_slab_bytes_raw_c##ID();
 ALD_FOR_EACH_CLASS(ALD_DECL)
 #undef ALD_DECL
 }
@@ -32,12 +33,19 @@ typedef unsigned long long (*hot_fn)();
 #define ALD_L(ID) ald_launch_c##ID,
 #define ALD_O(ID) ald_occupancy_c##ID,
 #define ALD_H(ID) ald_hot_slab_bytes_c##ID,
-const launch_fn k_launch[ALD_NUM_CLASSES] = { ALD_FOR_EACH_CLASS(ALD_L) };
-const occ_fn k_occ[ALD_NUM_CLASSES] = { ALD_FOR_EACH_CLASS(ALD_O) };
-const hot_fn k_hot[ALD_NUM_CLASSES] = { ALD_FOR_EACH_CLASS(ALD_H) };
+#define ALD_LR(ID) ald_launch_raw_c##ID,
+#define ALD_OR(ID) ald_occupancy_raw_c##ID,
+#define ALD_HR(ID) ald_hot_slab_bytes_raw_c##ID,
+// indexed by kernel slot: the plain builds of the classes, then their raw builds (ald_internal.h: ALD_NUM_SLOTS)
+const launch_fn k_launch[ALD_NUM_SLOTS] = { ALD_FOR_EACH_CLASS(ALD_L) ALD_FOR_EACH_CLASS(ALD_LR) };
+const occ_fn k_occ[ALD_NUM_SLOTS] = { ALD_FOR_EACH_CLASS(ALD_O) ALD_FOR_EACH_CLASS(ALD_OR) };
+const hot_fn k_hot[ALD_NUM_SLOTS] = { ALD_FOR_EACH_CLASS(ALD_H) ALD_FOR_EACH_CLASS(ALD_HR) };
 #undef ALD_L
 #undef ALD_O
 #undef ALD_H
+#undef ALD_LR
+#undef ALD_OR
+#undef ALD_HR
 
 } // namespace
 
@@ -70,7 +78,7 @@ int push_pass(ald_batch *b, const StagedPass &P)         // work lists + argumen
 {
     if(P.tot == 0) return ALD_OK;
     HIPCHK(hipMemcpyAsync(b->d_work.p, P.flat.data(), 4 * P.tot, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(b->d_args.p, P.args.data(), sizeof(KernelArgs) * ALD_NUM_CLASSES, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_args.p, P.args.data(), sizeof(KernelArgs) * ALD_NUM_SLOTS, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return ALD_OK;
 }
@@ -82,52 +90,60 @@ int stage_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], i
     P.nord = 0;
     if(P.tot == 0) return ALD_OK;
     if(b->d_work.ensure(4 * (size_t)n + 64)) return set_err(ALD_ERR_NOMEM, "work list");
-    if(b->d_counter.ensure(4 * ALD_NUM_CLASSES * 64)) return set_err(ALD_ERR_NOMEM, "counters");
-    if(b->d_args.ensure(sizeof(KernelArgs) * ALD_NUM_CLASSES)) return set_err(ALD_ERR_NOMEM, "kernel args");
+    if(b->d_counter.ensure(4 * ALD_NUM_SLOTS * 64)) return set_err(ALD_ERR_NOMEM, "counters");
+    if(b->d_args.ensure(sizeof(KernelArgs) * ALD_NUM_SLOTS)) return set_err(ALD_ERR_NOMEM, "kernel args");
     size_t woff = 0;
-    P.args.assign(ALD_NUM_CLASSES, KernelArgs()); P.flat.resize(P.tot);
+    P.args.assign(ALD_NUM_SLOTS, KernelArgs()); P.flat.resize(P.tot);
+    // the work list of a class splits into its staged graphs (plain build of the class) and its raw graphs (raw build: the pre-steps of
+    // assembler::assemble run in the loading wave), each in the order it was given
+    std::vector<int32_t> part[ALD_NUM_SLOTS];
     for(int c = 0; c < ALD_NUM_CLASSES; c++) {
-        P.nblk[c] = 0;
-        if(work[c].empty()) continue;
+        if(!b->hb.has_raw) { part[c] = work[c]; continue; }
+        for(int32_t g : work[c]) part[b->hb.g_rawdist[(size_t)g] >= 0 ? ALD_NUM_CLASSES + c : c].push_back(g);
+    }
+    for(int k = 0; k < ALD_NUM_SLOTS; k++) {
+        P.nblk[k] = 0;
+        if(part[k].empty()) continue;
+        const int c = k % ALD_NUM_CLASSES;
         ClassInfo ci = class_info(c);
-        int per_cu = occupancy_for(b, c);
-        if(const char *ov = getenv("ALD_WG_PER_CU")) { int k = atoi(ov); if(k >= 1 && k < per_cu) per_cu = k; }     // tuning knob: cap the persistent grid
+        int per_cu = occupancy_for(b, k);
+        if(const char *ov = getenv("ALD_WG_PER_CU")) { int q = atoi(ov); if(q >= 1 && q < per_cu) per_cu = q; }     // tuning knob: cap the persistent grid
         int want = b->n_cus * per_cu;
-        const uint64_t stride = ci.slab_bytes + k_hot[c]();           // catch-all class: hot state + cold state per wave
+        const uint64_t stride = ci.slab_bytes + k_hot[k]();           // catch-all class: hot state + cold state per wave
         if(c == ALD_CATCH_ALL_CLASS && want > b->n_cus) want = b->n_cus;      // ~13 MB per wave: one wave per CU is plenty
-        if((size_t)want > work[c].size()) want = (int)work[c].size();
+        if((size_t)want > part[k].size()) want = (int)part[k].size();
         if(want < 1) want = 1;
-        if(b->d_slabs[c].ensure((size_t)want * stride)) return set_err(ALD_ERR_NOMEM, "class slab");
-        P.nblk[c] = want;
-        memcpy(P.flat.data() + woff, work[c].data(), 4 * work[c].size());
-        KernelArgs &A = P.args[c]; memset(&A, 0, sizeof(A));
+        if(b->d_slabs[k].ensure((size_t)want * stride)) return set_err(ALD_ERR_NOMEM, "class slab");
+        P.nblk[k] = want;
+        memcpy(P.flat.data() + woff, part[k].data(), 4 * part[k].size());
+        KernelArgs &A = P.args[k]; memset(&A, 0, sizeof(A));
         A.in = b->hb.make_batch_in((uint8_t*)b->d_in.p, b->sec);
         A.out.status = (int32_t*)b->d_status.p; A.out.n_paths = (int32_t*)b->d_npaths.p; A.out.n_iters = (int32_t*)b->d_niters.p;
         A.out.pool_used = (unsigned long long*)b->d_poolused.p; A.out.pool = (uint32_t*)b->d_pool.p; A.out.pool_cap = b->pool_cap_words;
         A.out.index_used = (unsigned long long*)b->d_poolused.p + 1; A.out.index = (unsigned long long*)b->d_index.p; A.out.index_cap = b->index_cap; A.out.graph_first = (long long*)b->d_gfirst.p;
         A.out.trace_cap = b->trace_cap; A.out.trace_n = (int32_t*)b->d_trace_n.p; A.out.trace_codes = (int32_t*)b->d_trace_codes.p; A.out.trace_vals = (double*)b->d_trace_vals.p;
         A.prm = b->prm;
-        A.work = (const int32_t*)b->d_work.p + woff; A.n_work = (int32_t)work[c].size(); A.attempt = pass;
-        A.counter = (int32_t*)b->d_counter.p + 64 * c;
-        A.slabs = (uint8_t*)b->d_slabs[c].p; A.slab_stride = stride;
-        woff += work[c].size();
+        A.work = (const int32_t*)b->d_work.p + woff; A.n_work = (int32_t)part[k].size(); A.attempt = pass;
+        A.counter = (int32_t*)b->d_counter.p + 64 * k;
+        A.slabs = (uint8_t*)b->d_slabs[k].p; A.slab_stride = stride;
+        woff += part[k].size();
     }
-    // classes with work are dealt to the side streams, heaviest first onto the least loaded stream (cost ~ sum of V * E: the rule
+    // kernels with work are dealt to the side streams, heaviest first onto the least loaded stream (cost ~ sum of V * E: the rule
     // cascade is superlinear in the graph size)
-    double cost[ALD_NUM_CLASSES];
-    for(int c = 0; c < ALD_NUM_CLASSES; c++) {
-        cost[c] = 0;
-        if(P.nblk[c] == 0) continue;
-        for(int32_t g : work[c]) cost[c] += (double)b->hb.g_nv[g] * (double)b->hb.g_ne[g];
-        cost[c] /= (double)P.nblk[c];                     // per resident wave
-        P.order[P.nord++] = c;
+    double cost[ALD_NUM_SLOTS];
+    for(int k = 0; k < ALD_NUM_SLOTS; k++) {
+        cost[k] = 0;
+        if(P.nblk[k] == 0) continue;
+        for(int32_t g : part[k]) cost[k] += (double)b->hb.g_nv[g] * (double)b->hb.g_ne[g];
+        cost[k] /= (double)P.nblk[k];                     // per resident wave
+        P.order[P.nord++] = k;
     }
     std::sort(P.order, P.order + P.nord, [&](int x, int y) { return cost[x] > cost[y]; });
     double load[ALD_SIDE_STREAMS_MAX] = {0};
-    for(int k = 0; k < P.nord; k++) {
-        const int c = P.order[k];
-        int st = 0; for(int q = 1; q < b->n_cstream; q++) if(load[q] < load[st]) st = q;
-        load[st] += cost[c]; P.stream_of[c] = st;
+    for(int q = 0; q < P.nord; q++) {
+        const int k = P.order[q];
+        int st = 0; for(int z = 1; z < b->n_cstream; z++) if(load[z] < load[st]) st = z;
+        load[st] += cost[k]; P.stream_of[k] = st;
     }
     return push_pass(b, P);
 }
@@ -137,7 +153,7 @@ int stage_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], i
 bool refresh_pass_args(ald_batch *b, StagedPass &P)
 {
     bool changed = false;
-    for(int c = 0; c < ALD_NUM_CLASSES; c++) {
+    for(int c = 0; c < ALD_NUM_SLOTS; c++) {
         if(P.nblk[c] == 0 || P.args.empty()) continue;
         KernelArgs &A = P.args[c];
         if(A.slabs != (uint8_t*)b->d_slabs[c].p) { A.slabs = (uint8_t*)b->d_slabs[c].p; changed = true; }
@@ -150,7 +166,7 @@ bool refresh_pass_args(ald_batch *b, StagedPass &P)
 int fire_pass(ald_batch *b, const StagedPass &P)          // fork on the side streams behind ev0, join on the batch stream before ev1
 {
     if(P.tot == 0) return ALD_OK;
-    HIPCHK(hipMemsetAsync(b->d_counter.p, 0, 4 * ALD_NUM_CLASSES * 64, b->stream));
+    HIPCHK(hipMemsetAsync(b->d_counter.p, 0, 4 * ALD_NUM_SLOTS * 64, b->stream));
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     for(int k = 0; k < P.nord; k++) {
         const int c = P.order[k], st = P.stream_of[c];
@@ -205,7 +221,7 @@ int ald_batch_create(const ald_params *p, int device, ald_batch **out)
     bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev1) == hipSuccess;
     if(const char *ev = getenv("ALD_SIDE_STREAMS")) { const int k = atoi(ev); if(k >= 1 && k <= ALD_SIDE_STREAMS_MAX) b->n_cstream = k; }      // tuning knob
     for(int q = 0; q < b->n_cstream && ok; q++) ok = hipStreamCreateWithFlags(&b->cstream[q], hipStreamNonBlocking) == hipSuccess;
-    for(int c = 0; c < ALD_NUM_CLASSES && ok; c++) ok = hipEventCreateWithFlags(&b->cdone[c], hipEventDisableTiming) == hipSuccess;
+    for(int c = 0; c < ALD_NUM_SLOTS && ok; c++) ok = hipEventCreateWithFlags(&b->cdone[c], hipEventDisableTiming) == hipSuccess;
     if(!ok) { ald_batch_destroy(b); return set_err(ALD_ERR_HIP, "stream/event creation failed"); }
     *out = b;
     return ALD_OK;
@@ -219,12 +235,12 @@ int ald_batch_destroy(ald_batch *b)
     b->pin_in.release(); b->pin_out.release(); b->pin_small.release(); b->pin_index.release(); delete b->pass0; b->pass0 = nullptr;
     DevBuf *bufs[] = {&b->d_in, &b->d_status, &b->d_npaths, &b->d_niters, &b->d_pool, &b->d_poolused, &b->d_index, &b->d_gfirst, &b->d_pbegin, &b->d_ordoff, &b->d_trace_n, &b->d_trace_codes, &b->d_trace_vals, &b->d_work, &b->d_counter, &b->d_args};
     for(DevBuf *d : bufs) d->release();
-    for(int c = 0; c < ALD_NUM_CLASSES; c++) b->d_slabs[c].release();
+    for(int c = 0; c < ALD_NUM_SLOTS; c++) b->d_slabs[c].release();
     for(DevBuf &d : b->red) d.release();
     for(DevBuf &d : b->dts) d.release();
     for(PinBuf &d : b->red_pin) d.release();
     for(int q = 0; q < ALD_SIDE_STREAMS_MAX; q++) if(b->cstream[q]) { hipStreamSynchronize(b->cstream[q]); hipStreamDestroy(b->cstream[q]); }
-    for(int c = 0; c < ALD_NUM_CLASSES; c++) if(b->cdone[c]) hipEventDestroy(b->cdone[c]);
+    for(int c = 0; c < ALD_NUM_SLOTS; c++) if(b->cdone[c]) hipEventDestroy(b->cdone[c]);
     if(b->ev0) hipEventDestroy(b->ev0);
     if(b->ev1) hipEventDestroy(b->ev1);
     if(b->stream) hipStreamDestroy(b->stream);
@@ -656,6 +672,14 @@ template<class Make> void merge_groups(ald_tset *t, unsigned nthr, int64_t n_gro
             // a graph that puts a single transcript into this thread's tables needs no per-graph set: merging a one-item set is the same
             // as adding the item (transcript_set.cc:149-175)
             if(cnt == 1) { make(first, x); const uint32_t h = bucket[(size_t)first]; t->shard[h % ALD_TSET_SHARDS].add_hashed(x, h, 1, s_id); continue; }
+            // ... and so is merging a set whose items all sit in DIFFERENT buckets: transcript_set::add(set) goes bucket by bucket
+            // (transcript_set.cc:156-175), and a bucket that receives one item is zipped exactly as add() would place that item.  Only
+            // transcripts of one graph that share a bucket (equal intron chains, single-exon clusters) need the graph's own set first.
+            if(cnt <= 16) {
+                int64_t idx[16]; int k = 0; bool distinct = true;
+                for(int64_t i = first; i < grp[g + 1] && k < cnt; i++) if(mine(bucket[(size_t)i])) { for(int q = 0; q < k && distinct; q++) distinct = bucket[(size_t)idx[q]] != bucket[(size_t)i]; idx[k++] = i; }
+                if(distinct) { for(int q = 0; q < k; q++) { make(idx[q], x); const uint32_t h = bucket[(size_t)idx[q]]; t->shard[h % ALD_TSET_SHARDS].add_hashed(x, h, 1, s_id); } continue; }
+            }
             aletsch::transcript_sink ts(t->overlap);
             for(int64_t i = first; i < grp[g + 1]; i++) {
                 if(!mine(bucket[(size_t)i])) continue;

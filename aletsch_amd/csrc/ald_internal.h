@@ -24,11 +24,14 @@ struct PinBuf {
     void release() { if(p) hipHostFree(p); p = nullptr; cap = 0; }
 };
 
-enum { ALD_SIDE_STREAMS = 3, ALD_SIDE_STREAMS_MAX = 8 };     // default / upper bound of the side streams the classes of a pass are dealt to
+enum { ALD_SIDE_STREAMS = 3, ALD_SIDE_STREAMS_MAX = 8 };
+// kernel slots of a pass: slot c = the plain build of size class c (staged graphs), slot ALD_NUM_CLASSES + c = its raw build (graphs whose
+// pre-steps run on the device); a batch without raw graphs only ever uses the first half
+enum { ALD_NUM_SLOTS = 2 * ALD_NUM_CLASSES };     // default / upper bound of the side streams the classes of a pass are dealt to
 // one pass of a batch, staged: work lists, kernel arguments, grid sizes, stream assignment (see stage_pass)
 struct StagedPass {
     std::vector<int32_t> flat; std::vector<KernelArgs> args;
-    int nblk[ALD_NUM_CLASSES]; int order[ALD_NUM_CLASSES]; int stream_of[ALD_NUM_CLASSES]; int nord = 0; size_t tot = 0;
+    int nblk[ALD_NUM_SLOTS]; int order[ALD_NUM_SLOTS]; int stream_of[ALD_NUM_SLOTS]; int nord = 0; size_t tot = 0;
 };
 
 struct ald_batch {
@@ -41,16 +44,16 @@ struct ald_batch {
     // the size classes run concurrently on a few side streams.  Not one per class: a process only gets a handful of hardware queues
     // (4 by default) and streams beyond that share them in creation order, which can put the two heaviest classes behind each other
     hipStream_t cstream[ALD_SIDE_STREAMS_MAX] = {}; int n_cstream = ALD_SIDE_STREAMS;
-    hipEvent_t cdone[ALD_NUM_CLASSES] = {};
+    hipEvent_t cdone[ALD_NUM_SLOTS] = {};
     PinBuf pin_in, pin_out, pin_small, pin_index;          // wire buffer / record landing area / status + counters landing area / the result index
     DevBuf d_in, d_status, d_npaths, d_niters, d_pool, d_poolused, d_trace_n, d_trace_codes, d_trace_vals, d_work, d_counter, d_args;
     DevBuf d_index, d_gfirst;                              // result index written by the kernel: index[graph_first[g] + p] = pool offset of record (g, p)
     DevBuf d_pbegin, d_ordoff;                             // the same in (graph, path) order, built on the device on demand (tset_reduce.hip: device_path_table)
     uint64_t index_cap = 0; int64_t total_paths = 0; bool paths_on_device = false;
     double dl_ms[4] = {0, 0, 0, 0}; int64_t dl_bytes = 0;   // last download: waiting for the kernel / status + retries / D2H copies / decode (diagnostics)
-    DevBuf d_slabs[ALD_NUM_CLASSES];
-    int blocks[ALD_NUM_CLASSES] = {};
-    int occ[ALD_NUM_CLASSES]; ald_batch() { for(int c = 0; c < ALD_NUM_CLASSES; c++) occ[c] = -1; }
+    DevBuf d_slabs[ALD_NUM_SLOTS];
+    int blocks[ALD_NUM_SLOTS] = {};
+    int occ[ALD_NUM_SLOTS]; ald_batch() { for(int c = 0; c < ALD_NUM_SLOTS; c++) occ[c] = -1; }
     StagedPass *pass0 = nullptr; bool pass0_on_device = false; std::vector<int32_t> cls0;      // first pass of the uploaded batch, staged at upload time
     uint64_t pool_cap_words = 0;
     int trace_cap = 0;
@@ -61,7 +64,7 @@ struct ald_batch {
     std::vector<int32_t> trace_n, trace_codes; std::vector<double> trace_vals;
     HostResults res;
     int passes = 0;
-    const void *launched_slab[ALD_NUM_CLASSES] = {};      // test hook (ald_batch_debug_slab)
+    const void *launched_slab[ALD_NUM_SLOTS] = {};      // test hook (ald_batch_debug_slab)
     rvec<uint32_t> tstream;                                // last transcript stream built from this batch (ald_batch_transcript_stream)
     DevBuf red[20]; PinBuf red_pin[8];                     // scratch of ald_batch_reduce_transcripts, kept across calls (tset_reduce.hip)
     DevBuf dts[3];                                         // ald_batch_device_transcript_stream: lengths / offsets / the stream itself

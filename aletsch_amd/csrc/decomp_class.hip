@@ -6,7 +6,13 @@
 #include <hip/hip_runtime.h>
 #include "decomp_device.h"
 
+#ifdef ALD_RAW_VARIANT
+#define ALD_KERNEL_NAME ALD_CAT(ald_decomp_kernel_raw_c, ALD_CLASS_ID)
+#define ALD_ENTRY(x) ALD_CAT(ALD_CAT(x, _raw_c), ALD_CLASS_ID)
+#else
 #define ALD_KERNEL_NAME ALD_CAT(ald_decomp_kernel_c, ALD_CLASS_ID)
+#define ALD_ENTRY(x) ALD_CAT(ALD_CAT(x, _c), ALD_CLASS_ID)
+#endif
 #ifndef ALD_WAVES_PER_EU
 #define ALD_WAVES_PER_EU 4      /* register budget: 512 / 4 = 128 VGPRs per lane (MI355X_MICROARCH.md, Register files) */
 #endif
@@ -16,7 +22,7 @@ extern "C" __global__ void __launch_bounds__(64, ALD_WAVES_PER_EU) ALD_KERNEL_NA
     ALD_CLASS_NS::wave_main((ALD_GLOBAL const ald::KernelArgs*)A, (int)blockIdx.x);
 }
 
-extern "C" int ALD_CAT(ald_launch_c, ALD_CLASS_ID)(const ald::KernelArgs *dA, int blocks, hipStream_t stream)
+extern "C" int ALD_ENTRY(ald_launch)(const ald::KernelArgs *dA, int blocks, hipStream_t stream)
 {
     (void)hipGetLastError();                       // drop any stale sticky error of this thread before judging the launch
     hipLaunchKernelGGL(ALD_KERNEL_NAME, dim3(blocks), dim3(64), 0, stream, dA);
@@ -24,7 +30,7 @@ extern "C" int ALD_CAT(ald_launch_c, ALD_CLASS_ID)(const ald::KernelArgs *dA, in
 }
 
 // bytes of hot state that live in the wave's slab (0 for the LDS classes)
-extern "C" unsigned long long ALD_CAT(ald_hot_slab_bytes_c, ALD_CLASS_ID)()
+extern "C" unsigned long long ALD_ENTRY(ald_hot_slab_bytes)()
 {
 #if ALD_CLASS_ID >= ALD_FIRST_GLOBAL_CLASS
     return (sizeof(ALD_CLASS_NS::Hot) + 255) / 256 * 256;
@@ -33,7 +39,7 @@ extern "C" unsigned long long ALD_CAT(ald_hot_slab_bytes_c, ALD_CLASS_ID)()
 #endif
 }
 
-extern "C" int ALD_CAT(ald_occupancy_c, ALD_CLASS_ID)()
+extern "C" int ALD_ENTRY(ald_occupancy)()
 {
     int nb = 0;
     if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ALD_KERNEL_NAME, 64, 0) != hipSuccess) return 0;

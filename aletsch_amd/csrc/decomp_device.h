@@ -41,7 +41,14 @@
 #endif
 #define ALD_CAT2(a, b) a##b
 #define ALD_CAT(a, b) ALD_CAT2(a, b)
+// Two builds of every class: the PLAIN kernel (staged graphs only: no call to the device pre-steps anywhere in it, the rule cascade
+// inlined into the kernel root) and, with -DALD_RAW_VARIANT, the kernel that also takes RAW graphs (pre_assemble_device reached through
+// load_graph, run_graph a call).  The host sends a class's raw graphs to the second one; a batch without raw graphs never launches it.
+#ifdef ALD_RAW_VARIANT
+#define ALD_CLASS_NS ALD_CAT(ald_r, ALD_CLASS_ID)
+#else
 #define ALD_CLASS_NS ALD_CAT(ald_c, ALD_CLASS_ID)
+#endif
 
 namespace ALD_CLASS_NS {
 using namespace ald;
@@ -2474,6 +2481,7 @@ ALD_FN void build_phasing_lists(ALD_GLOBAL const int32_t *vo, int V, int NP, ALD
     HC.hl_used = used; HC.hl_n = nl;
 }
 
+#ifdef ALD_RAW_VARIANT
 // ---------------------------------------------------------------- raw graphs: what assembler::assemble(gx, px, sid)
 // does to a graph and its phase set BEFORE it builds the scallop object (meta/assembler.cc:1075-1086), in the wave that just loaded it:
 //   gx.extend_strands()                            rnacore/splice_graph.cc:1338-1373      one candidate edge per lane
@@ -2707,6 +2715,9 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
     wsync();
     return true;
 }
+#else
+enum { RAW_TV = 0, RAW_TV_CAP = 0 };          // (named by load_graph's raw branch, which the plain build never takes)
+#endif
 
 // ---------------------------------------------------------------- load: packed wire arrays -> working state (wave-parallel)
 ALD_FN bool load_graph()
@@ -2760,8 +2771,13 @@ ALD_FN bool load_graph()
     // a raw graph: the pre-steps of assembler::assemble(gx, px, sid) first
     const int rawdist = A->in.g_rawdist ? uni(A->in.g_rawdist[g]) : -1;
     if(rawdist >= 0) {
+#ifdef ALD_RAW_VARIANT
         const int64_t orp = A->in.off_rp[g], orc = A->in.off_rc[g];
         if(!uni(pre_assemble_device(rawdist, V, E, vo, io, ie, (int)(A->in.off_rp[g + 1] - orp), A->in.rphase_offset + orp + g, A->in.rphase_coord + orc, A->in.rphase_count + orp))) { wsync(); return false; }
+#else
+        if(lane == 0) HC.status = ALD_ST_INVARIANT + ALD_INV_OTHER;          // cannot happen: the host sends raw graphs to the raw build of the class
+        wsync(); return false;
+#endif
     }
     if(lane == 0) {
         if(rawdist < 0) build_phasing_lists(vo, V, NP, A->in.phasing_offset + opo, A->in.phasing_vertex + opv, A->in.phasing_count + op);
@@ -2802,11 +2818,11 @@ ALD_FN void finish_graph()
 }
 
 // ---------------------------------------------------------------- scallop::assemble (scallop.cc:38-188)
-// A real call from the kernel root (one per graph): the root then only holds the wave's work loop, and nothing of it has to stay in
-// registers across the calls INSIDE the cascade.  (Inlined into the root, the device pre-steps of raw graphs -- a large callee reached
-// through load_graph -- took the caller-saved registers the cascade had been keeping its long-lived values in: 43 VGPR spills spread over
-// every sweep, 42.7 -> 56.2 ms for the bench batch.)
-#ifdef ALD_RUNGRAPH_INLINE
+// Plain build: inlined into the kernel root.  Raw build: a real call from the root (one per graph) -- with the device pre-steps, a large
+// callee reached through load_graph, in the same function as the cascade, the register allocator lost the caller-saved registers the
+// cascade keeps its long-lived values in (43 VGPR spills spread over every sweep: 42.7 -> 56.2 ms for the bench batch); as a callee the
+// cascade is allocated on its own (42.9 ms) at the price of saving 32 callee-saved VGPRs per graph (8 KB of scratch traffic each way).
+#ifndef ALD_RAW_VARIANT
 ALD_INL void run_graph()
 #else
 ALD_FN void run_graph()

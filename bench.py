@@ -60,6 +60,7 @@ def parse_args(argv=None):
                     help="edge weights: uniform = U[1,100) f64 (BASELINE configs), flow = flow-conserving sums of s-t paths (SURVEY.md 8d's second distribution)")
     ap.add_argument("--cpu-sample", type=int, default=32768, help="graphs in the bounded all-cores cpu_baseline sample (0 = skip both CPU legs)")
     ap.add_argument("--skip-h2d-loop", action="store_true", help="profiling runs: make the batches resident with one plain pass each and skip the host-arrays-in loop (value_h2d_inclusive = null)")
+    ap.add_argument("--serial-steps", action="store_true", help="profiling runs: download every batch before the next kernel starts (under rocprofv3 the D2H copies run as blit kernels on the CUs and would share them with the decomposition kernel)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 / flow-weight kernel timings (the `secondary` block)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: CPU rehearsal of the multi-rank plumbing (needs --dry-run)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: every rank stages its shard and enters the exchange with an empty stream (CPU tier)")
@@ -425,6 +426,10 @@ def main() -> int:
             if prev is not None:
                 prev.sync()                             # the previous kernel is done ...
             t1_ = time.perf_counter(); main_s[0] += t1_ - t_
+            if args.serial_steps and prev is not None:
+                x = finish(prev); release(prev); prev = None
+                if step > w:
+                    ms.append(x)
             cur.run()                                   # ... the next one starts ...
             t2_ = time.perf_counter(); main_s[1] += t2_ - t1_
             if prev is not None:

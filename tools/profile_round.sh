@@ -6,7 +6,9 @@
 R=$GRAFT_REPO_ROOT; tag=$1; cd /tmp; export TMPDIR=/tmp
 # 4 plain passes make the batches resident (cold allocations: dropped by summarize.py --skip-first 4), then 5 warm-up + 20 timed steps
 # of the resident loop: the average over those 25 launches IS the steady state bench.py's `value` is measured in
-ARGS="--steps 20 --warmup 5 --cpu-sample 0 --no-secondary --skip-h2d-loop"
+# --serial-steps: under rocprofv3 the runtime moves D2H copies with blit kernels (__amd_rocclr_copyBuffer) instead of the SDMA engines; overlapped
+# with the decomposition kernel they take CUs from it (45.4 ms per launch against 42.7 ms alone and 42.9 ms in an unprofiled pipelined run)
+ARGS="--steps 20 --warmup 5 --cpu-sample 0 --no-secondary --skip-h2d-loop --serial-steps"
 PMC_ARGS="--steps 6 --warmup 2 --cpu-sample 0 --no-secondary --skip-h2d-loop"      # counters are per launch: no need for a long run
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_stats -o s -- python3 $R/bench.py $ARGS > $R/gpurun_out/${tag}_stats.log 2>&1 || exit 1
 i=0
