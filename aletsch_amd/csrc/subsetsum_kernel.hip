@@ -7,7 +7,7 @@
 // cross pair is a wave arg-min.  Tables are u8 back-pointers in LDS (2 sides x 33 rows x 1000 sums = 66 KB).
 //
 // This component is dead in the reference's live path and is wired here exactly as a separately
-// KAT-checked kernel (tests/test_subsetsum.py: reference KAT subsetsum.cc:263-282 + oracle/_ref/ref_subsetsum).
+// KAT-checked kernel (tests/test_gpu_parity.py::test_subsetsum_kernel_matches_reference_golden, tests/test_oracle_pins.py: reference KAT subsetsum.cc:263-282 + oracle/_ref/ref_subsetsum).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>

@@ -51,10 +51,11 @@ int main(int argc, char **argv)
     mock_parameters cfg;
     try {
         aletsch::gpu_assembly_queue<mock_graph, mock_hyper_set, mock_parameters> q(cfg, tm, false, 0, B, S);
-        for(int pass = 0; pass < 2; pass++) {                     // pass 0 warms the buffers (pinned / device allocations)
+        double p0 = 0, g0 = 0, m0 = 0;
+        for(int pass = 0; pass < 2; pass++) {                     // pass 0 warms the buffers (pinned / device allocations) of EVERY slot
             auto t0 = std::chrono::steady_clock::now();
             std::vector<std::thread> th;
-            const int rounds = pass == 0 ? 1 : R;
+            const int rounds = pass == 0 ? (int)(((long)B * (S + 2) + N - 1) / N) : R;
             for(int t = 0; t < T; t++) th.emplace_back([&, t] { for(int r = 0; r < rounds; r++) for(int n = t; n < N; n += T) q.submit(G[(size_t)n], H[(size_t)n], n % 4); });
             for(auto &x : th) x.join();
             auto t1 = std::chrono::steady_clock::now();
@@ -62,7 +63,8 @@ int main(int argc, char **argv)
             auto t2 = std::chrono::steady_clock::now();
             const double s_sub = std::chrono::duration<double>(t1 - t0).count(), s_all = std::chrono::duration<double>(t2 - t0).count();
             double tp, tg, tm2; q.stage_seconds(tp, tg, tm2);
-            printf("   stages so far: pack %.3f s, upload+kernel+download %.3f s, merge %.3f s\n", tp, tg, tm2);
+            printf("   busy seconds of the stages in this pass: pack %.3f s, upload+kernel+download %.3f s, merge %.3f s\n", tp - p0, tg - g0, tm2 - m0);
+            p0 = tp; g0 = tg; m0 = tm2;
             printf("%s: %ld graphs, %d submitters, batches of %d, %d slots: submit %.3f s, drained %.3f s -> %.0f graphs/s (failed %ld, batches %ld)\n",
                    pass == 0 ? "warm-up" : "measured", (long)N * rounds, T, B, S, s_sub, s_all, (double)N * rounds / s_all, q.failed_graphs(), q.batches());
         }
