@@ -111,6 +111,7 @@ int stage_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], i
         int want = b->n_cus * per_cu;
         const uint64_t stride = ci.slab_bytes + k_hot[k]();           // catch-all class: hot state + cold state per wave
         if(c == ALD_CATCH_ALL_CLASS && want > b->n_cus) want = b->n_cus;      // ~13 MB per wave: one wave per CU is plenty
+        if(c == ALD_HUGE_CLASS && want > ALD_HUGE_CLASS_WAVES) want = ALD_HUGE_CLASS_WAVES;      // ~105 MB per wave
         if((size_t)want > part[k].size()) want = (int)part[k].size();
         if(want < 1) want = 1;
         if(b->d_slabs[k].ensure((size_t)want * stride)) return set_err(ALD_ERR_NOMEM, "class slab");
@@ -447,7 +448,7 @@ int ald_batch_download(ald_batch *b)
         // graphs whose working set overflowed their class are retried one class up (records carry the pass number)
         std::vector<int32_t> work[ALD_NUM_CLASSES]; bool any = false;
         for(int g = 0; g < n; g++) {
-            if(b->cls[g] < 0) { b->status[g] = ALD_ST_CAPACITY; continue; }
+            if(b->cls[g] < 0) { b->status[g] = ALD_ST_TOO_LARGE; continue; }
             if(b->attempt[g] != pass) continue;                 // not part of this pass
             b->status[g] = st[g];
             if(st[g] == ALD_ST_POOL_FULL) pool_full = true;

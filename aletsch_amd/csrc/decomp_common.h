@@ -181,11 +181,16 @@ struct KernelArgs {                               // lives in device memory; eve
 // the wave's HBM slab instead of LDS: a graph runs 2-3 times longer there, but twelve workgroups fit a CU instead of three and none
 // of them takes LDS away from the other classes -- the host moves a class's graphs to its twin when there are more of them than the
 // LDS form can hold at once (ald_abi.cpp: ald_batch_upload).
+// Class 13 takes what is beyond the catch-all: graphs of up to 10 240 vertices (the reference runs its rule loop up to max_num_exons =
+// 10 000 vertices, util/parameters.cc; beyond that it only runs the greedy phase) and 58 752 edges, hot state in the slab like class 10,
+// creation ids in 32 bits (a graph of that size makes more than 65 535 edges in its life).  ~105 MB of slab per wave, at most 32 waves.
 #define ALD_NUM_PICK_CLASSES 11
-#define ALD_NUM_CLASSES 13
+#define ALD_NUM_CLASSES 14
 #define ALD_CATCH_ALL_CLASS 10
+#define ALD_HUGE_CLASS 13
+#define ALD_HUGE_CLASS_WAVES 32
 #define ALD_FOR_EACH_PICK_CLASS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
-#define ALD_FOR_EACH_CLASS(X) ALD_FOR_EACH_PICK_CLASS(X) X(11) X(12)
+#define ALD_FOR_EACH_CLASS(X) ALD_FOR_EACH_PICK_CLASS(X) X(11) X(12) X(13)
 template<int ID> struct ClassDims;
 template<> struct ClassDims<0>  { enum { MAXV = 64,   MAXE = 160,  NW = 1 }; };     // V <= 32
 template<> struct ClassDims<1>  { enum { MAXV = 128,  MAXE = 288,  NW = 1 }; };     // V <= 64   (the bench workload: 20 workgroups per CU)
@@ -200,11 +205,13 @@ template<> struct ClassDims<9>  { enum { MAXV = 2048, MAXE = 6600, NW = 32 }; };
 template<> struct ClassDims<10> { enum { MAXV = 4096, MAXE = 16384, NW = 64 }; };   // catch-all: hot state in the wave's HBM slab, not LDS
 template<> struct ClassDims<11> { enum { MAXV = 896,  MAXE = 2000, NW = 7 }; };     // twin of class 7, hot state in the slab
 template<> struct ClassDims<12> { enum { MAXV = 1024, MAXE = 2280, NW = 8 }; };     // twin of class 8, hot state in the slab
+template<> struct ClassDims<13> { enum { MAXV = 20480, MAXE = 65280, NW = 160 }; }; // V <= 10240, E <= 58752: hot state in the slab, 32-bit creation ids
 static inline int class_twin(int c) { return c == 7 ? 11 : c == 8 ? 12 : -1; }       // slab-resident twin of an LDS class (-1: none)
 static inline int class_retry_up(int c)                                              // where a graph goes when its working set overflowed class c
 {
     if(c == 11) return 12;
     if(c == 12) return 9;
+    if(c == ALD_CATCH_ALL_CLASS) return ALD_HUGE_CLASS;
     return c + 1 < ALD_NUM_PICK_CLASSES ? c + 1 : -1;
 }
 #ifndef ALD_FIRST_GLOBAL_CLASS
@@ -255,11 +262,11 @@ static inline ClassInfo class_info(int c)
 // plus the intersections created by merges.
 static inline int pick_class(int V, int E, int64_t n_samples, int64_t n_phasing_vertices, int first = 0)
 {
-    for(int c = first < 0 ? 0 : first; c < ALD_NUM_PICK_CLASSES; c++) {
-        ClassInfo k = class_info(c);
-        if(V <= k.nw * 64 && 2 * V <= k.maxv && E + k.maxe / 10 <= k.maxe && 2 * n_samples <= (int64_t)k.sp_cap && 4 * n_phasing_vertices <= (int64_t)k.hl_cap) return c;
-    }
-    return -1;
+    auto fits = [&](int c) { ClassInfo k = class_info(c);
+        return V <= k.nw * 64 && 2 * V <= k.maxv && E + k.maxe / 10 <= k.maxe && 2 * n_samples <= (int64_t)k.sp_cap && 4 * n_phasing_vertices <= (int64_t)k.hl_cap; };
+    for(int c = first < 0 ? 0 : first; c < ALD_NUM_PICK_CLASSES; c++) if(fits(c)) return c;
+    if(fits(ALD_HUGE_CLASS)) return ALD_HUGE_CLASS;
+    return -1;                                    // beyond every class: status ALD_ST_TOO_LARGE
 }
 
 #if !defined(__HIP_DEVICE_COMPILE__)

@@ -62,6 +62,13 @@ struct CntPrinter { ~CntPrinter() { if(g_cnt_unsweep) { fprintf(stderr, "[emu-co
 enum { MAXV = ClassDims<ALD_CLASS_ID>::MAXV, MAXE = ClassDims<ALD_CLASS_ID>::MAXE, NW = ClassDims<ALD_CLASS_ID>::NW };
 typedef uint16_t IDX;
 static constexpr IDX NIL = (IDX)0xFFFF;
+#if ALD_CLASS_ID == ALD_HUGE_CLASS
+typedef uint32_t EID;                           // creation ids: a graph of the largest class makes more than 65 535 edges in its life
+enum { EID_LIMIT = 0x7FFFFFF0 };
+#else
+typedef uint16_t EID;
+enum { EID_LIMIT = 0xFFF0 };
+#endif
 typedef ColdLayoutT<MAXV, MAXE, NW> CL;
 enum { LP = 16, ARENA_I = 96, ARENA_D = 48, SCR_I = 4 * LP + ARENA_I, SCR_D = 2 * LP + ARENA_D };   // LDS scratch geometry (ints / doubles)
 
@@ -73,7 +80,7 @@ struct Hot {
                                                 // out-list (both sorted); one 8-byte word so that a list step is ONE LDS round trip
     struct alignas(16) EdgeHot { double w; Link lk; };     // splice_graph::ewrt + the links: 16 bytes, so a walk that needs the weight too
     EdgeHot  ed[MAXE];                          // (sums, balance, smallest-edge evaluation) still makes one LDS access per step
-    uint16_t eid[MAXE];                         // creation id == scallop edge index (ids >= 65535 -> the graph moves up a class)
+    EID      eid[MAXE];                         // creation id == scallop edge index (16 bits; ids beyond -> the graph moves up a class; 32 bits in the largest class)
     IDX      in_head[MAXV], out_head[MAXV], in_deg[MAXV], out_deg[MAXV];
     uint8_t  nz[MAXV];                          // bit 0: scallop::nonzeroset membership; bits 1..5: router class of the vertex on the CURRENT graph (NZ_MEMO_*)
     uint8_t  hflag[MAXE];                       // HF_* (phasing occupancy / extend flags / protect)
@@ -380,8 +387,8 @@ ALD_INL int add_edge_i(int s, int t)
     else if(hw < MAXE) { e = hw; HC.slot_hw = hw + 1; }
     else { fail(ALD_ST_CAPACITY); return -1; }
     int id = uni(HC.next_id); HC.next_id = id + 1;
-    if(ALD_UNLIKELY(id >= 0xFFFF)) { fail(ALD_ST_CAPACITY); return -1; }
-    H.ed[e].lk.es = (IDX)s; H.ed[e].lk.et = (IDX)t; H.eid[e] = (uint16_t)id; H.hflag[e] = 0; H.ed[e].w = 0;
+    if(ALD_UNLIKELY(id >= EID_LIMIT)) { fail(ALD_ST_CAPACITY); return -1; }
+    H.ed[e].lk.es = (IDX)s; H.ed[e].lk.et = (IDX)t; H.eid[e] = (EID)id; H.hflag[e] = 0; H.ed[e].w = 0;
     link_out(s, e); link_in(t, e);
     return e;
 }
@@ -651,7 +658,7 @@ ALD_INL int merge_adjacent_edges_i(int x, int y, double ww)
     const int meix = uni(C.ed[x].mei), meiy = uni(C.ed[y].mei), cntx = uni(C.ed[x].ecount), cnty = uni(C.ed[y].ecount), lt = uni(C.vx[xt].lpos), rt = uni(C.vx[xt].rpos), ov = uni(C.vx[xt].v2v);
     const int stx = uni(C.ed[x].estrand), sty = uni(C.ed[y].estrand);
     // split_edge(x, ww), split_edge(y, ww): a piece of weight ww gets the next id, the original keeps max(w - ww, min_w)
-    if(ALD_UNLIKELY(uni(HC.next_id) >= 0xFFF0)) { fail(ALD_ST_CAPACITY); return -1; }
+    if(ALD_UNLIKELY(uni(HC.next_id) >= EID_LIMIT)) { fail(ALD_ST_CAPACITY); return -1; }
     if(sx) { HC.next_id++; double r = wx - ww; if(r <= mw) r = mw; H.ed[x].w = r; }
     if(sy) { HC.next_id++; double r = wy - ww; if(r <= mw) r = mw; H.ed[y].w = r; }
     const double wx0 = sx ? ww : wx, wy0 = sy ? ww : wy;                 // weights of the two pieces being merged
@@ -832,7 +839,7 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         const double wcur = H.ed[c].w;                                   // what is left of c
         const bool sc = uni(!(fabs(wcur - ww) <= kSMIN));                        // split_edge(c, ww) cuts a piece off (scallop.cc:2433-2484)
         int nid = uni(HC.next_id);
-        if(nid >= 0xFFF0) { C.vx[x].vw = vwt; fail(ALD_ST_CAPACITY); return; }
+        if(nid >= EID_LIMIT) { C.vx[x].vw = vwt; fail(ALD_ST_CAPACITY); return; }
         double rem = wcur;
         if(sc) { nid++; rem = wcur - ww; if(rem <= mw) rem = mw; H.ed[c].w = rem; }    // the piece takes an id and disappears in the merge
         HC.next_id = nid + 1;                                                // id of the merged edge
@@ -870,7 +877,7 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         PROF_ADD(PF_T_MERGE_SUMS);
         // f becomes the merged edge: newest id, far endpoint of c, weight of the two equal pieces
         const int other = A ? (int)uni(H.ed[f].lk.et) : (int)uni(H.ed[f].lk.es);
-        H.eid[f] = (uint16_t)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
+        H.eid[f] = (EID)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
         // the new edge far -> other sorts behind c = far -> x whenever other's key is above x's (always, except for vertices added by
         // decompose_vertex_extend): the walk starts at c
         if(A) { H.ed[f].lk.es = (IDX)far; relink_in(other, f, (uint32_t)far); if(SMALL) { if(tkey((uint32_t)other) > tkey((uint32_t)x)) link_out_after(far, f, c); else link_out(far, f); } }
@@ -1122,7 +1129,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
         {   // what the sequential form checks when it reaches merge q, in its order: a consumed c, the id counter, the two counts
             int code = 0;
             if(dead) code = ALD_ST_INVARIANT + ALD_INV_OTHER;
-            else if(nid - (sc ? 1 : 0) >= 0xFFF0) code = ALD_ST_CAPACITY;
+            else if(nid - (sc ? 1 : 0) >= EID_LIMIT) code = ALD_ST_CAPACITY;
             else if(!(cntc > 0 && cntf > 0)) code = ALD_ST_INVARIANT + ALD_INV_COUNT;
             inv[q] = code; if(ALD_UNLIKELY(code)) broken = true;
         }
@@ -1135,7 +1142,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
         for(int k = 0; k < NW; k++) { uint64_t mk = (NW <= 2 ? cmask_pf[NW <= 2 ? k : 0] : C.ed[c].mask[k]) | (k == 0 ? pf_mask0 : C.ed[f].mask[k]); if(ov >= 0 && (ov >> 6) == k) mk |= (1ull << (ov & 63)); C.ed[f].mask[k] = mk; }
         const int mi = A ? rt - lt + meic + meif : rt - lt + meif + meic;
         C.ed[f].med = A ? mi * r1 + medc1 + medf : mi * r1 + medf + medc1; C.ed[f].mei = mi;
-        H.eid[f] = (uint16_t)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
+        H.eid[f] = (EID)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
         if(A) H.ed[f].lk.es = (IDX)far; else H.ed[f].lk.et = (IDX)far;
 #ifdef ALD_PROF
         { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[PF_S5_BODY] += t1_ - prof_s5_; prof_s5_ = t1_; }
@@ -2619,7 +2626,7 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
             base += __builtin_popcountll(m);
         }
         wsync();
-        for(int k = lane; k < E; k += ALD_WAVE) if(!(H.hflag[k] & RAW_DEAD)) H.eid[k] = (uint16_t)nrank[H.eid[k]];
+        for(int k = lane; k < E; k += ALD_WAVE) if(!(H.hflag[k] & RAW_DEAD)) H.eid[k] = (EID)nrank[H.eid[k]];
         wsync();
         if(lane == 0) {
             for(int k = 0; k < E; k++) if(H.hflag[k] & RAW_DEAD) { H.hflag[k] = 0; kill_edge_i(k); }
@@ -2754,7 +2761,7 @@ ALD_FN bool load_graph()
     ALD_GLOBAL const int32_t *so = A->in.edge_sample_offset + oeo;
     ALD_GLOBAL const int32_t *rank = A->in.edge_rank;      // scallop::scallop -> get_edge_indices (scallop.cc:24, graph_base.cc:139-153): e2i of the input edges
     for(int k = lane; k < E; k += ALD_WAVE) {
-        H.ed[k].lk.et = (IDX)A->in.edge_target[oe + k]; H.ed[k].w = A->in.edge_weight[oe + k]; H.eid[k] = rank ? (uint16_t)rank[oe + k] : (uint16_t)k; H.hflag[k] = 0;
+        H.ed[k].lk.et = (IDX)A->in.edge_target[oe + k]; H.ed[k].w = A->in.edge_weight[oe + k]; H.eid[k] = rank ? (EID)rank[oe + k] : (EID)k; H.hflag[k] = 0;
         uint8_t st = A->in.edge_strand[oe + k]; C.ed[k].estrand = st; if(st) strand = true;
         C.ed[k].med = 0; C.ed[k].mei = 0; C.ed[k].econf = 0; C.ed[k].eabd = A->in.edge_abd[oe + k];
         C.ed[k].sp_off = (uint32_t)so[k]; C.ed[k].sp_len = (uint32_t)(so[k + 1] - so[k]); C.ed[k].ecount = A->in.edge_count[oe + k];

@@ -161,7 +161,7 @@ def kernel_only(A, dev, pg, reps=2):
             b.run(); b.download()
             ms = b.kernel_ms(); best = ms if best is None else min(best, ms)
         bad = int((b.result().status != 0).sum())
-        classes = {str(c): b.class_info(c)["n_graphs"] for c in range(13) if b.class_info(c)["n_graphs"]}
+        classes = {str(c): b.class_info(c)["n_graphs"] for c in range(14) if b.class_info(c)["n_graphs"]}
     return best, bad, classes
 
 

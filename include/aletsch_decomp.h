@@ -46,9 +46,12 @@ extern "C" {
 /* ---- per-graph status words (ald_result_view.status) ---- */
 #define ALD_ST_OK              0
 #define ALD_ST_SKIPPED_LARGE   1   /* the rule loop left through |V| > max_num_exons (scallop.cc:49: at once, or after the graph grew past it); greedy still ran */
-#define ALD_ST_CAPACITY        2   /* device working-set capacity exceeded after all retries  */
+#define ALD_ST_CAPACITY        2   /* the graph fit a size class at hand-over, but its working set outgrew the largest class while it ran */
 #define ALD_ST_POOL_FULL       3   /* the batch's path-record pool was exhausted while this graph emitted a path; ald_batch_download grows the pool
                                       and decomposes the batch again, so a caller only sees this word if the device cannot hold a larger pool */
+#define ALD_ST_TOO_LARGE       4   /* never run: the graph is beyond the largest size class at hand-over (more than 10 240 vertices or 58 752 edges,
+                                      or sample supports / phasing lists beyond that class's pools).  The reference itself leaves its rule loop
+                                      above max_num_exons = 10 000 vertices */
 #define ALD_ST_INVARIANT     100   /* 100+n: the reference would have hit assert class n      */
 
 /* assert classes (status = ALD_ST_INVARIANT + class) */

@@ -10,6 +10,7 @@
 extern "C" {
 #define ALD_DECL(ID) void emu_run_class_##ID(const ald::KernelArgs *);
 ALD_FOR_EACH_PICK_CLASS(ALD_DECL)
+ALD_DECL(13)
 #undef ALD_DECL
 }
 using namespace ald;
@@ -62,22 +63,22 @@ static int emu_run_batch(HostBatch &B, const ald_params *prm, int32_t trace_cap,
     A.out.trace_cap = trace_cap; A.out.trace_n = E->trace_n.data(); A.out.trace_codes = E->trace_codes.data(); A.out.trace_vals = E->trace_vals.data();
     std::vector<int32_t> cls(n), attempt(n, 0);
   for(int regrow = 0; ; regrow++) {          // the host policy of ald_batch_download: a full record pool grows and the batch runs again
-    std::vector<int32_t> work[ALD_NUM_PICK_CLASSES];
+    std::vector<int32_t> work[ALD_NUM_CLASSES];
     std::fill(status.begin(), status.end(), 0); std::fill(n_paths.begin(), n_paths.end(), 0); std::fill(attempt.begin(), attempt.end(), 0); pool_used = 0; index_used = 0; std::fill(graph_first.begin(), graph_first.end(), -1);
     if(trace_cap > 0) std::fill(E->trace_n.begin(), E->trace_n.end(), 0);
     for(int g = 0; g < n; g++) {
         int64_t ns = B.off_s[g + 1] - B.off_s[g], npv = B.off_pv[g + 1] - B.off_pv[g];
         if(B.g_rawdist[g] >= 0) npv += 2 * (B.off_rc[g + 1] - B.off_rc[g]);
         cls[g] = debug_underclass(pick_class(B.g_nv[g], B.g_ne[g], ns, npv, force_class));
-        if(cls[g] < 0) status[g] = ALD_ST_CAPACITY; else work[cls[g]].push_back(g);
+        if(cls[g] < 0) status[g] = ALD_ST_TOO_LARGE; else work[cls[g]].push_back(g);
     }
     typedef void (*run_fn)(const KernelArgs *);
 #define ALD_R(ID) emu_run_class_##ID,
-    run_fn runs[ALD_NUM_PICK_CLASSES] = { ALD_FOR_EACH_PICK_CLASS(ALD_R) };
+    run_fn runs[ALD_NUM_CLASSES] = { ALD_FOR_EACH_PICK_CLASS(ALD_R) nullptr, nullptr, emu_run_class_13 };      // (the twins 11 / 12 are a placement choice of the GPU host)
 #undef ALD_R
-    for(int pass = 0; pass < ALD_NUM_PICK_CLASSES + 1; pass++) {
+    for(int pass = 0; pass < ALD_NUM_CLASSES + 1; pass++) {
         bool any = false;
-        for(int c = 0; c < ALD_NUM_PICK_CLASSES; c++) {
+        for(int c = 0; c < ALD_NUM_CLASSES; c++) {
             if(work[c].empty()) continue;
             any = true;
             ClassInfo ci = class_info(c);
@@ -87,12 +88,13 @@ static int emu_run_batch(HostBatch &B, const ald_params *prm, int32_t trace_cap,
             runs[c](&A);
         }
         if(!any) break;
-        std::vector<int32_t> next[ALD_NUM_PICK_CLASSES];
-        for(int c = 0; c < ALD_NUM_PICK_CLASSES; c++) for(int g : work[c]) {
+        std::vector<int32_t> next[ALD_NUM_CLASSES];
+        for(int c = 0; c < ALD_NUM_CLASSES; c++) for(int g : work[c]) {
             attempt[g] = pass;
-            if(status[g] == ALD_ST_CAPACITY && c + 1 < ALD_NUM_PICK_CLASSES) { cls[g] = c + 1; next[c + 1].push_back(g); }
+            const int up = class_retry_up(c);
+            if(status[g] == ALD_ST_CAPACITY && up >= 0) { cls[g] = up; next[up].push_back(g); }
         }
-        for(int c = 0; c < ALD_NUM_PICK_CLASSES; c++) work[c].swap(next[c]);
+        for(int c = 0; c < ALD_NUM_CLASSES; c++) work[c].swap(next[c]);
     }
     bool pool_full = false; for(int g = 0; g < n; g++) if(status[g] == ALD_ST_POOL_FULL) pool_full = true;
     if(!pool_full || regrow >= 8) break;

@@ -162,6 +162,25 @@ def test_large_classes():
         assert np.array_equal(it, st[:, 3])
 
 
+def test_class_beyond_the_catch_all():
+    """graphs of more than 2 048 vertices: the largest class (hot state in the slab, 32-bit creation ids); small graphs forced through it
+    as well, so that its id width sees parallel edges, phasing lists and multi-sample supports; a graph beyond it is refused with its
+    own status instead of ALD_ST_CAPACITY (the reference leaves its rule loop above max_num_exons = 10 000 vertices anyway)"""
+    pg = A.synth(seed=78, n_graphs=2, v_min=2500, v_max=2500, edges_per_vertex=3)
+    want = common.oracle_run(pg, threads=2)[0]
+    got, it, cl = common.emu_run(pg)
+    assert (cl == 13).all(), cl
+    assert not common.compare_results(want, got, pg.n)
+    pg = A.synth(seed=77, n_graphs=60, v_min=8, v_max=120, edges_per_vertex=4, phasing_per_graph=5, n_samples=2)
+    want = common.oracle_run(pg, threads=4)[0]
+    got, it, cl = common.emu_run(pg, force_class=13)
+    assert (cl == 13).all()
+    assert not common.compare_results(want, got, pg.n)
+    pg = A.synth(seed=5, n_graphs=1, v_min=10300, v_max=10300, edges_per_vertex=2)
+    got, it, cl = common.emu_run(pg)
+    assert got.status[0] == 4 and cl[0] == -1 and np.diff(got.path_offset)[0] == 0          # ALD_ST_TOO_LARGE
+
+
 def test_explicit_edge_counts():
     """edge_info.count handed over separately from the sample sets (group_start_boundaries adds counts along grouped boundaries,
     graph_reviser.cc:965-975): larger than |samples| on some edges, zero on a few (router.cc:269 treats those as absent; a merge of

@@ -196,6 +196,24 @@ def test_large_classes_on_gpu():
     assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
 
 
+def test_class_beyond_the_catch_all_on_gpu():
+    """2 500-vertex graphs run in the largest class (class 13: hot state in the slab, 32-bit creation ids) and match the oracle; a graph
+    beyond every class is refused with ALD_ST_TOO_LARGE, the rest of its batch is unaffected"""
+    pg = A.synth(seed=78, n_graphs=3, v_min=2500, v_max=2500, edges_per_vertex=3)
+    want = common.oracle_run(pg, threads=3)[0]
+    with A.DecompBatch(0) as b:
+        b.add(pg); b.upload(); b.run(); got = b.download()
+        assert b.class_info(13)["n_graphs"] == 3
+    assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
+    small = A.synth(seed=79, n_graphs=50, v_min=10, v_max=60, edges_per_vertex=3)
+    huge = A.synth(seed=5, n_graphs=1, v_min=10300, v_max=10300, edges_per_vertex=2)
+    want = common.oracle_run(small, threads=4)[0]
+    with A.DecompBatch(0) as b:
+        b.add(small); b.add(huge); b.upload(); b.run(); got = b.download()
+    assert got.status[50] == 4 and np.diff(got.path_offset)[50] == 0
+    assert not common.compare_results(want, got, small.n, conf_tol=1e-9)
+
+
 def test_max_num_exons_on_gpu():
     """|V| > max_num_exons: cascade skipped, greedy phase only (scallop.cc:49), status ALD_ST_SKIPPED_LARGE"""
     p = A.default_params(); p.max_num_exons = 30
@@ -221,7 +239,7 @@ def test_capacity_retry_on_gpu():
                 b.run()
                 # the retry passes of the previous download regrew class slabs (hipFree + hipMalloc): the first pass of this run must
                 # have been launched with the buffers the batch owns NOW, not the addresses staged at upload time
-                for c in range(13):
+                for c in range(14):
                     if b.class_info(c)["blocks_last_run"] > 0:
                         used, owned = C.c_void_p(), C.c_void_p()
                         assert b._lib.ald_batch_debug_slab(b._h, c, C.byref(used), C.byref(owned)) == 0
@@ -356,7 +374,7 @@ def test_slab_twins_of_the_large_lds_classes(monkeypatch):
         with A.DecompBatch(0) as b:
             b.add(pg); b.upload(); b.run(); b.download()
             got = b.result()
-            used = {c: b.class_info(c)["n_graphs"] for c in range(13) if b.class_info(c)["n_graphs"]}
+            used = {c: b.class_info(c)["n_graphs"] for c in range(14) if b.class_info(c)["n_graphs"]}
         assert not common.compare_results(want, got, pg.n, conf_tol=1e-9), force
         assert (set(used) <= {11, 12, 9}) if force == "1" else (set(used) <= {7, 8, 9}), (force, used)
     monkeypatch.setenv("ALD_DEBUG_TWIN", "1"); monkeypatch.setenv("ALD_DEBUG_UNDERCLASS", "1")
@@ -381,7 +399,7 @@ def test_cfg3_mixed_batch_at_spec():
     with A.DecompBatch(0) as b:
         b.add(pg); b.upload(); b.run(); b.download()
         got = b.result()
-        used = {c: b.class_info(c)["n_graphs"] for c in range(13) if b.class_info(c)["n_graphs"]}
+        used = {c: b.class_info(c)["n_graphs"] for c in range(14) if b.class_info(c)["n_graphs"]}
     assert not common.compare_results(want, got, pg.n, conf_tol=1e-9)
     assert (got.status == 0).all() and len(used) >= 8, used
 
@@ -396,7 +414,7 @@ def test_flow_weights_at_full_size():
     with A.DecompBatch(0) as b:
         b.add(pg); b.upload(); b.run(); b.download()
         got = b.result()
-        classes = {c: b.class_info(c)["n_graphs"] for c in range(13) if b.class_info(c)["n_graphs"]}
+        classes = {c: b.class_info(c)["n_graphs"] for c in range(14) if b.class_info(c)["n_graphs"]}
     assert not common.compare_results(want, got, n, conf_tol=1e-9)
     assert (got.status == 0).all()
     assert set(classes) - {1}, f"expected at least one capacity retry out of class 1: {classes}"
@@ -471,14 +489,14 @@ def test_record_pool_regrow_on_gpu(monkeypatch):
     plain = {}
     with A.DecompBatch(0) as b:
         b.add(pg); b.upload(); b.run(); b.download()
-        plain = {c: b.class_info(c)["n_graphs"] for c in range(13)}
+        plain = {c: b.class_info(c)["n_graphs"] for c in range(14)}
     monkeypatch.setenv("ALD_DEBUG_POOL_WORDS", "5000")
     with A.DecompBatch(0) as b:
         b.add(pg); b.upload()
         for rep in range(2):
             b.run(); b.download()
             assert not common.compare_results(want, b.result(), pg.n, conf_tol=1e-9)
-            assert {c: b.class_info(c)["n_graphs"] for c in range(13)} == plain
+            assert {c: b.class_info(c)["n_graphs"] for c in range(14)} == plain
 
 
 def test_transcript_stream_and_its_merge():

@@ -16,7 +16,7 @@ def run(sel, name, twin=None):
         b.add(sub); b.upload(); ms = []
         for rep in range(2):
             b.run(); b.download(); ms.append(b.kernel_ms())
-        info = [(c, b.class_info(c)["n_graphs"], b.class_info(c)["blocks_per_cu"]) for c in range(13) if b.class_info(c)["n_graphs"]]
+        info = [(c, b.class_info(c)["n_graphs"], b.class_info(c)["blocks_per_cu"]) for c in range(14) if b.class_info(c)["n_graphs"]]
         print("   ", name, "twin=%s" % twin, "graphs", sub.n, "kernel_ms %.1f" % min(ms), "classes(n, wg/cu)", info, flush=True)
 run(V <= 64, "V<=64")
 run((V > 64) & (V <= 128), "65..128")
