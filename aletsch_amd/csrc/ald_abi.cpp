@@ -662,30 +662,45 @@ const uint32_t ALD_NO_BUCKET = 0xFFFFFFFFu;       // hashes are below 2^31 + 1
 // `make(i, x)` fills x from transcript i; grp[k] .. grp[k+1] are the transcripts of group k; bucket[i] = its chain key or ALD_NO_BUCKET.
 template<class Make> void merge_groups(ald_tset *t, unsigned nthr, int64_t n_groups, const int64_t *grp, const int32_t *grp_sid, const uint32_t *bucket, Make make)
 {
+    // the transcripts are dealt to their owners first (a counting sort by owner over contiguous ranges, so that every owner's list is in
+    // ascending (graph, path) order): an owner then walks its own sixteenth instead of testing every transcript of the batch
+    const int64_t nt = n_groups > 0 ? grp[n_groups] : 0;
+    auto owner = [&](uint32_t h) { return (unsigned)((h % ALD_TSET_SHARDS) % nthr); };
+    std::vector<int64_t> base((size_t)nthr * nthr, 0), first((size_t)nthr + 1, 0);
+    HostBatch::run_threads(nthr, [&](unsigned r) {
+        int64_t *c = &base[(size_t)r * nthr];
+        for(int64_t i = nt * r / nthr; i < nt * (r + 1) / nthr; i++) if(bucket[(size_t)i] != ALD_NO_BUCKET) c[owner(bucket[(size_t)i])]++;
+    });
+    for(unsigned o = 0; o < nthr; o++) { int64_t run = first[o]; for(unsigned r = 0; r < nthr; r++) { const int64_t c = base[(size_t)r * nthr + o]; base[(size_t)r * nthr + o] = run; run += c; } first[(size_t)o + 1] = run; }
+    std::vector<int64_t> order((size_t)first[nthr]);
+    HostBatch::run_threads(nthr, [&](unsigned r) {
+        int64_t *c = &base[(size_t)r * nthr];
+        for(int64_t i = nt * r / nthr; i < nt * (r + 1) / nthr; i++) if(bucket[(size_t)i] != ALD_NO_BUCKET) order[(size_t)c[owner(bucket[(size_t)i])]++] = i;
+    });
     HostBatch::run_threads(nthr, [&](unsigned th) {
-        auto mine = [&](uint32_t h) { return h != ALD_NO_BUCKET && (h % ALD_TSET_SHARDS) % nthr == th; };
         aletsch::sink_transcript x;
-        for(int64_t g = 0; g < n_groups; g++) {
-            int cnt = 0; int64_t first = -1;
-            for(int64_t i = grp[g]; i < grp[g + 1]; i++) if(mine(bucket[(size_t)i])) { if(cnt++ == 0) first = i; }
-            if(cnt == 0) continue;
+        int64_t g = 0;
+        for(int64_t k = first[th]; k < first[(size_t)th + 1]; ) {
+            while(grp[g + 1] <= order[(size_t)k]) g++;                           // the graph of this owner's next transcript
+            int64_t k1 = k; while(k1 < first[(size_t)th + 1] && order[(size_t)k1] < grp[g + 1]) k1++;
+            const int64_t *idx = &order[(size_t)k]; const int cnt = (int)(k1 - k);
+            k = k1;
             const int s_id = grp_sid ? grp_sid[g] : -1;
             // a graph that puts a single transcript into this thread's tables needs no per-graph set: merging a one-item set is the same
             // as adding the item (transcript_set.cc:149-175)
-            if(cnt == 1) { make(first, x); const uint32_t h = bucket[(size_t)first]; t->shard[h % ALD_TSET_SHARDS].add_hashed(x, h, 1, s_id); continue; }
+            if(cnt == 1) { make(idx[0], x); const uint32_t h = bucket[(size_t)idx[0]]; t->shard[h % ALD_TSET_SHARDS].add_hashed(x, h, 1, s_id); continue; }
             // ... and so is merging a set whose items all sit in DIFFERENT buckets: transcript_set::add(set) goes bucket by bucket
             // (transcript_set.cc:156-175), and a bucket that receives one item is zipped exactly as add() would place that item.  Only
             // transcripts of one graph that share a bucket (equal intron chains, single-exon clusters) need the graph's own set first.
             if(cnt <= 16) {
-                int64_t idx[16]; int k = 0; bool distinct = true;
-                for(int64_t i = first; i < grp[g + 1] && k < cnt; i++) if(mine(bucket[(size_t)i])) { for(int q = 0; q < k && distinct; q++) distinct = bucket[(size_t)idx[q]] != bucket[(size_t)i]; idx[k++] = i; }
-                if(distinct) { for(int q = 0; q < k; q++) { make(idx[q], x); const uint32_t h = bucket[(size_t)idx[q]]; t->shard[h % ALD_TSET_SHARDS].add_hashed(x, h, 1, s_id); } continue; }
+                bool distinct = true;
+                for(int a = 1; a < cnt && distinct; a++) for(int q = 0; q < a && distinct; q++) distinct = bucket[(size_t)idx[q]] != bucket[(size_t)idx[a]];
+                if(distinct) { for(int q = 0; q < cnt; q++) { make(idx[q], x); const uint32_t h = bucket[(size_t)idx[q]]; t->shard[h % ALD_TSET_SHARDS].add_hashed(x, h, 1, s_id); } continue; }
             }
             aletsch::transcript_sink ts(t->overlap);
-            for(int64_t i = first; i < grp[g + 1]; i++) {
-                if(!mine(bucket[(size_t)i])) continue;
-                make(i, x);
-                ts.add_hashed(x, bucket[(size_t)i], 1, s_id);                  // assembler.cc:1120
+            for(int q = 0; q < cnt; q++) {
+                make(idx[q], x);
+                ts.add_hashed(x, bucket[(size_t)idx[q]], 1, s_id);              // assembler.cc:1120
             }
             t->add(ts);                                                        // assembler.cc:1130 (only tables this thread owns are touched)
         }
@@ -757,6 +772,7 @@ int ald_batch_transcript_stream(const ald_batch *cb, const int32_t *sid, int32_t
 int ald_tset_add_stream(ald_tset *t, const uint32_t *words, int64_t n_words, int32_t graph_offset, int64_t tid_base)
 {
     if(!t || n_words < 0 || (n_words > 0 && !words)) return ALD_ERR_INVALID;
+    const auto T0 = std::chrono::steady_clock::now();
     // record boundaries and groups (one serial walk: the lengths are in the records)
     std::vector<int64_t> offs, grp; std::vector<int32_t> grp_sid;
     int64_t last_graph = -1;
@@ -771,6 +787,7 @@ int ald_tset_add_stream(ald_tset *t, const uint32_t *words, int64_t n_words, int
     }
     const int64_t nt = (int64_t)offs.size(); grp.push_back(nt);
     const unsigned nthr = sink_threads(nt);
+    const auto T1 = std::chrono::steady_clock::now();
     std::vector<uint32_t> bucket((size_t)nt);
     HostBatch::run_threads(nthr, [&](unsigned th) {
         for(int64_t i = nt * th / nthr; i < nt * (th + 1) / nthr; i++) { const uint32_t *w = words + offs[(size_t)i]; bucket[(size_t)i] = (uint32_t)aletsch::sink_transcript::chain_key((const int32_t*)(w + TS_HDR), 2 * (size_t)w[5]); }
@@ -782,6 +799,8 @@ int ald_tset_add_stream(ald_tset *t, const uint32_t *words, int64_t n_words, int
         x.tid = tid_base + ((((int64_t)w[0] + graph_offset) << 20) | (int64_t)w[1]);
         x.xs.assign((const int32_t*)(w + TS_HDR), (const int32_t*)(w + TS_HDR) + 2 * (size_t)w[5]);
     });
+    if(getenv("ALD_SINK_PROF")) { const auto T3 = std::chrono::steady_clock::now(); auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+        fprintf(stderr, "[sink] stream of %lld transcripts: boundaries %.1f ms, hash + merge passes %.1f ms (%u threads)\n", (long long)nt, ms(T0, T1), ms(T1, T3), nthr); }
     return ALD_OK;
 }
 
