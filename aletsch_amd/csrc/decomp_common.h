@@ -64,8 +64,14 @@
       const unsigned long long k2 = ((unsigned long long)(unsigned)hi2 << 32) | (unsigned)lo2;
       return k2 < k ? k2 : k;
   }
+  // PRECONDITION: every lane of the wave is active (EXEC all ones) -- a DPP step reads the registers of its source lanes whatever their
+  // EXEC bit, and the final ballot / readlane assume 64 candidates.  Both call sites (scan_trivial, sweep_smallest) sit in code every
+  // lane runs; the -DALD_WSYNC_BARRIER test build traps if that is ever not so.
   __device__ __forceinline__ void     wave_argmin(double &rr, int &vv)
   {
+  #ifdef ALD_WSYNC_BARRIER
+      if(__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();
+  #endif
       const unsigned long long bits = (unsigned long long)__double_as_longlong(rr);
       if(__builtin_expect(__ballot(vv >= 0 && bits > 0x7FF0000000000000ull) != 0, 0)) {
           const int lane = (int)threadIdx.x;

@@ -207,14 +207,21 @@ ALD_FN void trace_emit(int code, int a, int b, double v)
 ALD_INL bool tracing() { return HC.p_trace_cap > 0; }
 ALD_INL void trace(int code, int a, int b, double v) { HC.n_iters++; if(HC.p_trace_cap > 0) trace_emit(code, a, b, v); }
 // u_*: the same accessors for the scalar (lane-0) routines, with the result marked wave-uniform (see uni() in decomp_common.h)
-ALD_INL int u_first_in(int v) { IDX h = uni(H.in_head[v]); return h == NIL ? -1 : (int)h; }
-ALD_INL int u_first_out(int v) { IDX h = uni(H.out_head[v]); return h == NIL ? -1 : (int)h; }
-ALD_INL int u_next_in(int e) { IDX h = uni(H.ed[e].lk.inx); return h == NIL ? -1 : (int)h; }
-ALD_INL int u_next_out(int e) { IDX h = uni(H.ed[e].lk.onx); return h == NIL ? -1 : (int)h; }
-ALD_INL int first_in(int v) { return H.in_head[v] == NIL ? -1 : (int)H.in_head[v]; }
-ALD_INL int first_out(int v) { return H.out_head[v] == NIL ? -1 : (int)H.out_head[v]; }
-ALD_INL int next_in(int e) { return H.ed[e].lk.inx == NIL ? -1 : (int)H.ed[e].lk.inx; }
-ALD_INL int next_out(int e) { return H.ed[e].lk.onx == NIL ? -1 : (int)H.ed[e].lk.onx; }
+// an edge slot or NIL -> slot or -1.  Slots of every class but the largest stay below 2^15, so NIL (0xFFFF) read as a SIGNED 16-bit value
+// is already the -1 the walks test for: the load itself sign-extends (ds_read_i16) and the compare + select per list step goes away.
+#ifndef ALD_NO_SEXT_LINKS
+ALD_INL int slot_or_neg(IDX h) { return MAXE < 32768 ? (int)(int16_t)h : (h == NIL ? -1 : (int)h); }
+#else
+ALD_INL int slot_or_neg(IDX h) { return h == NIL ? -1 : (int)h; }
+#endif
+ALD_INL int u_first_in(int v) { return uni(slot_or_neg(H.in_head[v])); }
+ALD_INL int u_first_out(int v) { return uni(slot_or_neg(H.out_head[v])); }
+ALD_INL int u_next_in(int e) { return uni(slot_or_neg(H.ed[e].lk.inx)); }
+ALD_INL int u_next_out(int e) { return uni(slot_or_neg(H.ed[e].lk.onx)); }
+ALD_INL int first_in(int v) { return slot_or_neg(H.in_head[v]); }
+ALD_INL int first_out(int v) { return slot_or_neg(H.out_head[v]); }
+ALD_INL int next_in(int e) { return slot_or_neg(H.ed[e].lk.inx); }
+ALD_INL int next_out(int e) { return slot_or_neg(H.ed[e].lk.onx); }
 ALD_INL double in_weights(int v) { double w = 0; for(int e = first_in(v); e >= 0; e = next_in(e)) w += H.ed[e].w; return w; }    // splice_graph.cc:187-198
 ALD_INL double out_weights(int v) { double w = 0; for(int e = first_out(v); e >= 0; e = next_out(e)) w += H.ed[e].w; return w; } // splice_graph.cc:174-185
 
@@ -225,7 +232,7 @@ ALD_INL double out_weights(int v) { double w = 0; for(int e = first_out(v); e >=
 ALD_INL uint32_t tkey(uint32_t p) { return (int)p == HC.sinkp ? 0xFFFFu : p; }      // the sink sorts after every other vertex
 ALD_INL int vlog(int p) { return p < HC.V0 - 1 ? p : (p == HC.sinkp ? HC.nv - 1 : p - 1); }   // physical -> reference index (traces)
 ALD_INL uint64_t lkw(int e) { return uni(*(const uint64_t*)&H.ed[e].lk); }            // es | et << 16 | inx << 32 | onx << 48
-ALD_INL int lk_next(uint32_t f) { return f == 0xFFFFu ? -1 : (int)f; }
+ALD_INL int lk_next(uint32_t f) { return slot_or_neg((IDX)f); }
 ALD_INL void link_in(int v, int e)
 {
     v = uni(v); e = uni(e);
@@ -1534,7 +1541,7 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
     }
     if(mode == 1 && code != SC_STOP && code != SC_BAD) {
         double rr = frr; int vv = fvv;
-        wave_argmin(rr, vv);
+        wave_argmin(rr, vv);                                             // (all 64 lanes are here: the loop above leaves through wave-uniform breaks only)
         if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; }      // if(ratio < r) continue;
     }
     if(lane == 0) { HC.sw_best_r = best_r; HC.sw_best_v = best_v; HC.sw_hit = hit; HC.sw_hit_r = hit_r; }
@@ -1656,7 +1663,7 @@ ALD_INL bool sweep_smallest(double max_ratio)
                     const int i = c * ALD_WAVE + lane;
                     if(i >= start && i < lim && ce[c] >= 0 && (vv < 0 || !(rr < cr[c]))) { rr = cr[c]; vv = i; }
                 }
-                wave_argmin(rr, vv);
+                wave_argmin(rr, vv);                                         // (all 64 lanes are here: every branch around it is wave-uniform)
                 if(vv >= 0 && !(best_r < rr)) { best_r = rr; best_v = vv; best_e = wread(cget_e(vv / ALD_WAVE), vv % ALD_WAVE); }   // if(ratio < r) continue;
             }
             }
