@@ -32,7 +32,7 @@
 #endif
 
 #ifndef ALD_CLASS_ID
-#error "compile with -DALD_CLASS_ID=<0..12> (one translation unit per size class)"
+#error "compile with -DALD_CLASS_ID=<0..13> (one translation unit per size class)"
 #endif
 #if defined(__HIP__) || defined(__clang__)
   #define ALD_UNROLL _Pragma("unroll")
@@ -1237,6 +1237,10 @@ ALD_INL void decompose_trivial_vertex_wave(int x)
 {
     x = uni(x);
     const int nin = uni(H.in_deg[x]), nout = uni(H.out_deg[x]);
+#ifdef ALD_STAR_SEQ_MAX
+    // experiment: the smallest fans through the sequential form on lane 0 (no hand-overs at all)
+    if((nin == 1 && nout >= 1 && nout <= ALD_STAR_SEQ_MAX) || (nout == 1 && nin >= 1 && nin <= ALD_STAR_SEQ_MAX)) { if(lane_id() == 0) decompose_trivial_vertex(x); wsync(); return; }
+#endif
     if(nin == 1 && nout >= 1 && nout <= STAR_MAX) star_wave_in(x);
     else if(nout == 1 && nin >= 1 && nin <= STAR_MAX) star_wave_out(x);
     else { if(lane_id() == 0) decompose_trivial_vertex(x); wsync(); }
