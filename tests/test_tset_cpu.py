@@ -80,3 +80,18 @@ def test_sink_matches_live_reference_build():
         out = subprocess.run([os.path.join(os.path.dirname(HERE), "oracle", "_ref", "ref_tset")], input=mg.tset_text(groups), capture_output=True, text=True, check=True).stdout
         s = A.TranscriptSink(0.8); s.add_groups(groups)
         check(s.items(), mg.tset_parse(out))
+
+
+def test_sink_containers_under_sanitizers():
+    """the sink's own containers (small_vec: first elements inside their owner; chain_table: index over entries that never move) against
+    standard-container models under AddressSanitizer + UBSan, object lifetimes counted; then the sink against a plain std::map / std::vector
+    restatement of transcript_set::add / merge_sorted_trans_items on random transcripts incl. chains beyond the inline eight exons and
+    items with many samples (tests/host_adapter/sink_containers_test.cc; C++11 as the reference builds)"""
+    import subprocess
+    out = os.path.join(HERE, "_build"); os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "sink_containers_test")
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-g", "-Wall", "-Wextra", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        os.path.join(HERE, "host_adapter", "sink_containers_test.cc"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "sink containers ok" in r.stdout, r.stdout + r.stderr
