@@ -976,6 +976,9 @@ template<bool A> ALD_INL void star_wave_body(int x)
 {
     COLD;
     PROF_DECL;
+#if defined(ALD_PROF) && defined(ALD_PROF_STAR_BY_SIZE)
+    const unsigned long long prof_star0_ = __builtin_readcyclecounter();
+#endif
     const int lane = lane_id();
     const double mw = HC.p_min_w;
     int32_t *fe = (int32_t*)HC.scr_i, *ord = fe + STAR_MAX, *inv = fe + 2 * STAR_MAX, *oth = fe + 3 * STAR_MAX, *ctx = (int32_t*)HC.scr_i;
@@ -1228,6 +1231,9 @@ template<bool A> ALD_INL void star_wave_body(int x)
     { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[PF_S7] += t1_ - prof_s7_; }
 #endif
     PROF_ADD(PF_T_MERGE_ADD);
+#if defined(ALD_PROF) && defined(ALD_PROF_STAR_BY_SIZE)
+    { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[n == 1 ? PF_T_PAIRS : n == 2 ? PF_T_MERGE_ISECT : n == 3 ? PF_T_MERGE_KILL : n == 4 ? PF_S6_LINK : PF_FINISH] += t1_ - prof_star0_; }
+#endif
     #undef SW_REPLAY
 }
 ALD_INL void star_wave_in(int x) { star_wave_body<true>(uni(x)); }       // inlined into the kernel entry, once (sweep_trivial has ONE decomposition site,

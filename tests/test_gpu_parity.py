@@ -847,3 +847,25 @@ def test_barrier_variant_of_the_hand_overs():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith("TOTAL graphs") and last.endswith("mismatches 0") and int(last.split()[2]) >= 1000, r.stdout[-1500:]
+
+
+def test_bench_line_and_its_exchange_path():
+    """bench.py in a fresh process, as the driver starts it: ONE JSON line carrying the contract's keys, `roofline` and `cpu_baseline`; and
+    once more with the multi-rank exchange forced on for the single rank this box has (ALD_BENCH_FORCE_DIST: process group over RCCL,
+    transcript stream built on the device, gathered to rank 0, merged there) -- the path `--gpus N` takes on a multi-GPU node"""
+    import json, os, subprocess, sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    for force in (False, True):
+        e = dict(env, ALD_BENCH_FORCE_DIST="1") if force else env
+        r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--graphs", "20000", "--no-secondary",
+                            "--cpu-sample", "0" if force else "2000"], capture_output=True, text=True, timeout=280, env=e)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout[-2000:]
+        j = json.loads(lines[0])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in j, k
+        assert j["metric"] == "bundles/sec" and j["value"] > 0 and j["n_gpus"] == 1 and j["steps"] == 3 and j["dtype"] == "f64" and j["vs_baseline"] is None
+        assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1 and j["config"]["failed_graphs"] == 0
+        if not force:
+            assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
