@@ -660,7 +660,8 @@ const uint32_t ALD_NO_BUCKET = 0xFFFFFFFFu;       // hashes are below 2^31 + 1
 // the groups (graphs) in ascending order, builds the per-graph set of ITS buckets and merges it -- the same sequence of
 // trans_item::merge calls per bucket as the serial loop of assembler.cc:1105-1133, hence the same result, without `mylock`.
 // `make(i, x)` fills x from transcript i; grp[k] .. grp[k+1] are the transcripts of group k; bucket[i] = its chain key or ALD_NO_BUCKET.
-template<class Make> void merge_groups(ald_tset *t, unsigned nthr, int64_t n_groups, const int64_t *grp, const int32_t *grp_sid, const uint32_t *bucket, Make make)
+struct no_prefetch { void operator()(int64_t) const {} };
+template<class Make, class Pre = no_prefetch> void merge_groups(ald_tset *t, unsigned nthr, int64_t n_groups, const int64_t *grp, const int32_t *grp_sid, const uint32_t *bucket, Make make, Pre pre = Pre())
 {
     // the transcripts are dealt to their owners first (a counting sort by owner over contiguous ranges, so that every owner's list is in
     // ascending (graph, path) order): an owner then walks its own sixteenth instead of testing every transcript of the batch
@@ -680,10 +681,19 @@ template<class Make> void merge_groups(ald_tset *t, unsigned nthr, int64_t n_gro
     HostBatch::run_threads(nthr, [&](unsigned th) {
         aletsch::sink_transcript x;
         int64_t g = 0;
-        for(int64_t k = first[th]; k < first[(size_t)th + 1]; ) {
+        // the loop is bound by cache misses (source record -> index slot -> table entry): what transcript k + 12 / k + 8 / k + 4 will touch is
+        // asked for while transcript k is merged
+        const int64_t end = first[(size_t)th + 1];
+        auto ahead = [&](int64_t k) {
+            if(k + 12 < end) pre(order[(size_t)(k + 12)]);
+            if(k + 8 < end) { const uint32_t h = bucket[(size_t)order[(size_t)(k + 8)]]; t->shard[h % ALD_TSET_SHARDS].mt.prefetch_slot(h); }
+            if(k + 4 < end) { const uint32_t h = bucket[(size_t)order[(size_t)(k + 4)]]; t->shard[h % ALD_TSET_SHARDS].mt.prefetch_entry(h); }
+        };
+        for(int64_t k = first[th]; k < end; ) {
             while(grp[g + 1] <= order[(size_t)k]) g++;                           // the graph of this owner's next transcript
-            int64_t k1 = k; while(k1 < first[(size_t)th + 1] && order[(size_t)k1] < grp[g + 1]) k1++;
+            int64_t k1 = k; while(k1 < end && order[(size_t)k1] < grp[g + 1]) k1++;
             const int64_t *idx = &order[(size_t)k]; const int cnt = (int)(k1 - k);
+            for(int64_t q = k; q < k1; q++) ahead(q);
             k = k1;
             const int s_id = grp_sid ? grp_sid[g] : -1;
             // a graph that puts a single transcript into this thread's tables needs no per-graph set: merging a one-item set is the same
@@ -717,14 +727,11 @@ int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int6
     const int n = b->hb.n();
     const int64_t np = b->res.n_paths();
     const unsigned nthr = sink_threads(np);
-    // pass 1: bucket of every transcript (the exons are in the records, joined by the kernel)
+    // pass 1: bucket of every transcript -- the key was taken by the download while it decoded the record (HostResults::build)
     std::vector<uint32_t> bucket((size_t)np, ALD_NO_BUCKET);
     HostBatch::run_threads(nthr, [&](unsigned th) {
-        for(int64_t i = np * th / nthr; i < np * (th + 1) / nthr; i++) {
-            const PathRec p = b->res.path((int64_t)((size_t)i));
-            if(p.nexw <= 2 && skip_single_exon) continue;                      // assembler.cc:1117
-            bucket[(size_t)i] = (uint32_t)aletsch::sink_transcript::chain_key(b->res.exons(p), (size_t)p.nexw);
-        }
+        for(int64_t i = np * th / nthr; i < np * (th + 1) / nthr; i++)
+            if(!(b->res.n_exon_words[(size_t)i] <= 2 && skip_single_exon)) bucket[(size_t)i] = b->res.chain_key[(size_t)i];      // assembler.cc:1117
     });
     auto T2 = std::chrono::steady_clock::now();
     // pass 2: thread th owns the tables th, th + nthr, ...
@@ -734,7 +741,7 @@ int ald_tset_add_batch(ald_tset *t, const ald_batch *b, const int32_t *sid, int6
         x.tid = tid_base + (((int64_t)p.graph << 20) | (int64_t)p.index);
         const int32_t *ex = b->res.exons(p);
         x.xs.assign(ex, ex + p.nexw);
-    });
+    }, [&](int64_t i) { __builtin_prefetch(b->res.rec(i)); __builtin_prefetch(b->res.rec(i) + 16); });
     if(getenv("ALD_SINK_PROF")) { auto T3 = std::chrono::steady_clock::now(); auto ms = [](auto a, auto b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); }; fprintf(stderr, "[sink] hash pass %.1f ms, merge pass %.1f ms (%u threads)\n", ms(T0, T2), ms(T2, T3), nthr); }
     return ALD_OK;
 }
@@ -792,15 +799,16 @@ int ald_tset_add_stream(ald_tset *t, const uint32_t *words, int64_t n_words, int
     HostBatch::run_threads(nthr, [&](unsigned th) {
         for(int64_t i = nt * th / nthr; i < nt * (th + 1) / nthr; i++) { const uint32_t *w = words + offs[(size_t)i]; bucket[(size_t)i] = (uint32_t)aletsch::sink_transcript::chain_key((const int32_t*)(w + TS_HDR), 2 * (size_t)w[5]); }
     });
+    const auto T2 = std::chrono::steady_clock::now();
     merge_groups(t, nthr, (int64_t)grp_sid.size(), grp.data(), grp_sid.data(), bucket.data(), [&](int64_t i, aletsch::sink_transcript &x) {
         const uint32_t *w = words + offs[(size_t)i];
         double weight, conf, abd; memcpy(&weight, w + 6, 8); memcpy(&conf, w + 8, 8); memcpy(&abd, w + 10, 8);
         x.strand = (char)w[3]; x.coverage = log(1.0 + weight); x.top.cov2 = x.coverage; x.top.conf = conf; x.top.abd = abd; x.top.count1 = (int32_t)w[4]; x.count2 = 1;
         x.tid = tid_base + ((((int64_t)w[0] + graph_offset) << 20) | (int64_t)w[1]);
         x.xs.assign((const int32_t*)(w + TS_HDR), (const int32_t*)(w + TS_HDR) + 2 * (size_t)w[5]);
-    });
+    }, [&](int64_t i) { __builtin_prefetch(words + offs[(size_t)i]); __builtin_prefetch(words + offs[(size_t)i] + 16); });
     if(getenv("ALD_SINK_PROF")) { const auto T3 = std::chrono::steady_clock::now(); auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
-        fprintf(stderr, "[sink] stream of %lld transcripts: boundaries %.1f ms, hash + merge passes %.1f ms (%u threads)\n", (long long)nt, ms(T0, T1), ms(T1, T3), nthr); }
+        fprintf(stderr, "[sink] stream of %lld transcripts: boundaries %.1f ms, hash pass %.1f ms, merge pass %.1f ms (%u threads)\n", (long long)nt, ms(T0, T1), ms(T1, T2), ms(T2, T3), nthr); }
     return ALD_OK;
 }
 

@@ -10,6 +10,7 @@
 //   * an in-CSR (edge ids ordered by (target, source, id)) so that the kernel links in-lists without sorting.
 #pragma once
 #include "decomp_common.h"
+#include "../host/transcript_sink.hpp"      // sink_transcript::chain_key: the bucket key of a transcript, taken while its record is decoded
 #include <vector>
 #include <algorithm>
 #include <numeric>
@@ -554,10 +555,12 @@ struct HostResults {
     std::vector<int64_t> path_begin;                     // [n+1] into rec_off / coverage (paths sorted by graph, index)
     rvec<uint64_t> rec_off;                              // [paths] pool offset of the record of every path
     rvec<double> coverage;                               // [paths] log(1 + weight)
+    rvec<uint32_t> chain_key;                            // [paths] bucket of the transcript in a transcript_set (transcript.cc:183-201): the decode has the exons in hand
+    rvec<uint16_t> n_exon_words;                         // [paths] min(#exon words, 65535): who is a single-exon transcript without touching the record again
     std::vector<uint32_t> pool;                          // raw record words (vertex and exon lists are read in place) ...
     const uint32_t *ext_pool = nullptr; uint64_t ext_words = 0;   // ... or a borrowed buffer (the batch's pinned D2H landing area)
     int64_t out_bytes = 0;                               // algorithmic output bytes: sum(4*len + 40)
-    void clear() { status.clear(); n_iters.clear(); attempt.clear(); path_begin.clear(); rec_off.clear(); coverage.clear(); pool.clear(); ext_pool = nullptr; ext_words = 0; out_bytes = 0; }
+    void clear() { status.clear(); n_iters.clear(); attempt.clear(); path_begin.clear(); rec_off.clear(); coverage.clear(); chain_key.clear(); n_exon_words.clear(); pool.clear(); ext_pool = nullptr; ext_words = 0; out_bytes = 0; }
     const uint32_t *pool_data() const { return ext_pool ? ext_pool : pool.data(); }
     uint64_t pool_size() const { return ext_pool ? ext_words : (uint64_t)pool.size(); }
     int64_t n_paths() const { return (int64_t)rec_off.size(); }
@@ -579,7 +582,7 @@ struct HostResults {
     // no copy of the records' fields: per path one offset (checked against the record it names) and the coverage.
     int build(int n, const int32_t *n_paths_dev, const unsigned long long *index, uint64_t index_n, const long long *graph_first)
     {
-        rec_off.clear(); coverage.clear(); out_bytes = 0;
+        rec_off.clear(); coverage.clear(); chain_key.clear(); n_exon_words.clear(); out_bytes = 0;
         const uint64_t W = pool_size(); const uint32_t *pw = pool_data();
         path_begin.assign((size_t)n + 1, 0); attempt.assign((size_t)n, 0);
         for(int g = 0; g < n; g++) {
@@ -590,7 +593,7 @@ struct HostResults {
             path_begin[(size_t)g + 1] = path_begin[(size_t)g] + c;
         }
         const int64_t total = path_begin[(size_t)n];
-        rec_off.resize((size_t)total); coverage.resize((size_t)total);
+        rec_off.resize((size_t)total); coverage.resize((size_t)total); chain_key.resize((size_t)total); n_exon_words.resize((size_t)total);
         unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16;
         if(const char *ev = getenv("ALD_STAGE_THREADS")) { int k = atoi(ev); if(k >= 1 && k <= 64) nthr = (unsigned)k; }
         if(total < 50000) nthr = 1;
@@ -609,6 +612,7 @@ struct HostResults {
                 if(nv < 2 || (nexw & 1) || nexw > 2 * nv || o + rec_words(nv, nexw) > W || (int32_t)r[0] != g || (int32_t)r[1] != idx) { bad[t] = 2; return; }
                 double w; memcpy(&w, r + 6, 8);
                 rec_off[(size_t)i] = o; coverage[(size_t)i] = log(1.0 + w);
+                chain_key[(size_t)i] = (uint32_t)aletsch::sink_transcript::chain_key((const int32_t*)(r + REC_HDR_WORDS + nv), (size_t)nexw); n_exon_words[(size_t)i] = (uint16_t)(nexw < 65535u ? nexw : 65535u);
                 if(idx == 0) attempt[(size_t)g] = (int)((r[5] >> 8) & 0xFF);
                 obt += 4ll * nv + 40;
             }

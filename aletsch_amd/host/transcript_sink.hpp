@@ -112,6 +112,15 @@ public:
     iterator find(size_t key) const { const size_t i = probe(key); return iterator(const_cast<chain_table*>(this), i == NONE ? n_ : i); }
     B &operator[](size_t key) { const size_t i = probe(key); return i != NONE ? at(i).second : append(key)->second; }
     void emplace(size_t key, B &&b) { if(probe(key) == NONE) append(key)->second = std::move(b); }
+    // a merge loop that knows the keys it will ask for next can have the slot, then the entry, on their way into the cache before it
+    // needs them (two dependent misses per lookup otherwise): prefetch_slot(key) some iterations ahead, prefetch_entry(key) a few
+    void prefetch_slot(size_t key) const { if(!slot_.empty()) __builtin_prefetch(&slot_[mix(key) & (slot_.size() - 1)]); }
+    void prefetch_entry(size_t key) const {
+        if(slot_.empty()) return;
+        const size_t i = probe(key); if(i == NONE) return;
+        const char *e = reinterpret_cast<const char*>(&const_cast<chain_table*>(this)->at(i));
+        __builtin_prefetch(e); __builtin_prefetch(e + 64); __builtin_prefetch(e + 128); __builtin_prefetch(e + 192);
+    }
     void clear() {
         for(size_t i = 0; i < n_; i++) at(i).~entry();
         for(auto &c : chunks_) ::operator delete((void*)c);
