@@ -280,7 +280,16 @@ public:
     void add_bucket(size_t key, bucket &incoming) {                                           // one iteration of that loop
         auto z = mt.find(key);
         if(z == mt.end()) mt.emplace(key, std::move(incoming));
+        else if(incoming.size() == 1) place(z->second, incoming[0]);
         else zip(z->second, incoming);
+    }
+    // zip() when the incoming bucket holds ONE item (nearly always): the forward walk passes the items that sort first and stops at the
+    // one that compares equal (merge) or sorts behind (the item goes in front of it) -- in place, nothing else moves
+    void place(bucket &b, sink_item &it) {
+        size_t at = 0; int c = +1;
+        while(at < b.size() && (c = b[at].trst.order_against(it.trst, overlap_)) == +1) at++;
+        if(at < b.size() && c == 0) b[at].merge(it);
+        else b.emplace(b.begin() + at, std::move(it));
     }
     size_t size() const { size_t n = 0; for(auto &x : mt) n += x.second.size(); return n; }
     void clear() { mt.clear(); }
