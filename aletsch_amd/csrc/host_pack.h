@@ -301,15 +301,34 @@ struct HostBatch {
         unsigned nthr = std::thread::hardware_concurrency(); if(nthr == 0) nthr = 1; if(nthr > 16) nthr = 16;
         if(const char *ev = getenv("ALD_STAGE_THREADS")) { int k = atoi(ev); if(k >= 1 && k <= 64) nthr = (unsigned)k; }
         if((int64_t)nthr > (TE >> 16) + 1) nthr = (unsigned)((TE >> 16) + 1);                      // not worth a thread below ~64k edges
-        // ---- pass 1 (parallel): is every graph canonical and valid?
+        // ---- ONE parallel pass: every thread checks a graph (canonical and valid?) and, while its arrays are still in the cache, copies
+        // it to its place (all sizes are known up front, so every thread writes its own disjoint ranges).  A graph that is not canonical
+        // or not valid ends the pass: the batch goes back to what it was and the per-graph path normalises, or names the defect.
+        const Mark m0 = mark();
+        if(erank) enable_rank();                     // carried tentatively; dropped again below when it is the identity everywhere
+        const size_t n0 = g_nv.size(), v0 = vertex_weight.size(), vo0 = vertex_offset.size(), e0 = edge_target.size(), eo0 = edge_sample_offset.size(), s0 = sample_id.size(),
+                     p0 = phasing_count.size(), po0 = phasing_offset.size(), pv0 = phasing_vertex.size();
+        g_nv.insert(g_nv.end(), nv, nv + n); g_ne.insert(g_ne.end(), ne, ne + n);
+        if(np) g_np.insert(g_np.end(), np, np + n); else g_np.resize(n0 + n, 0);
+        graph_strand.resize(n0 + n); for(int i = 0; i < n; i++) graph_strand[n0 + i] = (gstrand && gstrand[i]) ? gstrand[i] : '.';
+        off_v.resize(n0 + n + 1); off_e.resize(n0 + n + 1); off_s.resize(n0 + n + 1); off_p.resize(n0 + n + 1); off_pv.resize(n0 + n + 1);
+        { const int64_t rp = off_rp.back(), rc = off_rc.back(); g_rawdist.resize(n0 + n); off_rp.resize(n0 + n + 1); off_rc.resize(n0 + n + 1); const size_t r0 = rphase_offset.size(); rphase_offset.resize(r0 + n);
+          for(int i = 0; i < n; i++) { g_rawdist[n0 + i] = -1; off_rp[n0 + i + 1] = rp; off_rc[n0 + i + 1] = rc; rphase_offset[r0 + i] = 0; } }
+        for(int i = 0; i < n; i++) { off_v[n0 + i + 1] = off_v[n0] + iv[i + 1]; off_e[n0 + i + 1] = off_e[n0] + ie[i + 1]; off_s[n0 + i + 1] = off_s[n0] + is[i + 1]; off_p[n0 + i + 1] = off_p[n0] + ip[i + 1]; off_pv[n0 + i + 1] = off_pv[n0] + ipv[i + 1]; }
+        vertex_offset.resize(vo0 + TV + n); in_offset.resize(vo0 + TV + n);
+        edge_target.resize(e0 + TE); edge_weight.resize(e0 + TE); edge_strand.resize(e0 + TE); edge_abd.resize(e0 + TE); edge_count.resize(e0 + TE); in_edge.resize(e0 + TE); if(has_rank) edge_rank.resize(e0 + TE);
+        edge_sample_offset.resize(eo0 + TE + n); sample_id.resize(s0 + TS); sample_abd.resize(s0 + TS);
+        vertex_weight.resize(v0 + TV); vertex_lpos.resize(v0 + TV); vertex_rpos.resize(v0 + TV); vertex_type.resize(v0 + TV);
+        phasing_offset.resize(po0 + TP + n); phasing_vertex.resize(pv0 + TPV); phasing_count.resize(p0 + TP);
         std::vector<int> verdict(nthr, 0);           // 0 ok, 1 not canonical, 2 invalid
         std::vector<int> permuted(nthr, 0);          // some graph of the slice carries a creation rank other than the CSR position
-        auto check = [&](unsigned t) {
+        auto work = [&](unsigned t) {
             const int g0 = (int)((int64_t)n * t / nthr), g1 = (int)((int64_t)n * (t + 1) / nthr);
-            int worst = 0; std::vector<uint8_t> seen;
-            for(int g = g0; g < g1 && worst < 2; g++) {
+            int worst = 0; std::vector<uint8_t> seen; std::vector<int32_t> cur;
+            for(int g = g0; g < g1; g++) {
                 const int V = nv[g], E = ne[g], P = np ? np[g] : 0;
                 const int32_t *vo = voff + iv[g] + g, *tg = etgt + ie[g], *so = esoff + ie[g] + g;
+                // ---- the checks ----
                 if(vo[0] != 0 || vo[V] != E || (E > 0 && so[0] != 0)) { worst = 2; break; }
                 for(int s = 0; s < V && worst < 2; s++) {
                     if(vo[s + 1] < vo[s]) { worst = 2; break; }
@@ -332,55 +351,25 @@ struct HostBatch {
                         if(p > 0 && !std::lexicographical_compare(v + po[p - 1], v + po[p], v + po[p], v + po[p + 1])) worst = 1;
                     }
                 }
-            }
-            verdict[t] = worst;
-        };
-        run_threads(nthr, check);
-        int worst = 0; for(unsigned t = 0; t < nthr; t++) worst = std::max(worst, verdict[t]);
-        if(erank && worst == 0) { bool any = false; for(unsigned t = 0; t < nthr; t++) any = any || permuted[t]; if(!any) erank = nullptr; }     // identity everywhere: nothing to carry
-        if(worst != 0)      // the per-graph path normalises, or names the defect
-            return add_packed_serial(n, nv, ne, np, voff, etgt, ew, estrand, eabd, esoff, sid, sabd, vw, lpos, rpos, vtype, poff, pv, pc, gstrand, ecount, erank);
-        if(erank) enable_rank();
-        // ---- pass 2: size everything once, then fill disjoint ranges in parallel
-        const size_t n0 = g_nv.size(), v0 = vertex_weight.size(), vo0 = vertex_offset.size(), e0 = edge_target.size(), eo0 = edge_sample_offset.size(), s0 = sample_id.size(),
-                     p0 = phasing_count.size(), po0 = phasing_offset.size(), pv0 = phasing_vertex.size();
-        g_nv.insert(g_nv.end(), nv, nv + n); g_ne.insert(g_ne.end(), ne, ne + n);
-        if(np) g_np.insert(g_np.end(), np, np + n); else g_np.resize(n0 + n, 0);
-        graph_strand.resize(n0 + n); for(int i = 0; i < n; i++) graph_strand[n0 + i] = (gstrand && gstrand[i]) ? gstrand[i] : '.';
-        off_v.resize(n0 + n + 1); off_e.resize(n0 + n + 1); off_s.resize(n0 + n + 1); off_p.resize(n0 + n + 1); off_pv.resize(n0 + n + 1);
-        { const int64_t rp = off_rp.back(), rc = off_rc.back(); g_rawdist.resize(n0 + n); off_rp.resize(n0 + n + 1); off_rc.resize(n0 + n + 1); const size_t r0 = rphase_offset.size(); rphase_offset.resize(r0 + n);
-          for(int i = 0; i < n; i++) { g_rawdist[n0 + i] = -1; off_rp[n0 + i + 1] = rp; off_rc[n0 + i + 1] = rc; rphase_offset[r0 + i] = 0; } }
-        for(int i = 0; i < n; i++) { off_v[n0 + i + 1] = off_v[n0] + iv[i + 1]; off_e[n0 + i + 1] = off_e[n0] + ie[i + 1]; off_s[n0 + i + 1] = off_s[n0] + is[i + 1]; off_p[n0 + i + 1] = off_p[n0] + ip[i + 1]; off_pv[n0 + i + 1] = off_pv[n0] + ipv[i + 1]; }
-        vertex_offset.resize(vo0 + TV + n); in_offset.resize(vo0 + TV + n);
-        edge_target.resize(e0 + TE); edge_weight.resize(e0 + TE); edge_strand.resize(e0 + TE); edge_abd.resize(e0 + TE); edge_count.resize(e0 + TE); in_edge.resize(e0 + TE); if(has_rank) edge_rank.resize(e0 + TE);
-        edge_sample_offset.resize(eo0 + TE + n); sample_id.resize(s0 + TS); sample_abd.resize(s0 + TS);
-        vertex_weight.resize(v0 + TV); vertex_lpos.resize(v0 + TV); vertex_rpos.resize(v0 + TV); vertex_type.resize(v0 + TV);
-        phasing_offset.resize(po0 + TP + n); phasing_vertex.resize(pv0 + TPV); phasing_count.resize(p0 + TP);
-        auto fill = [&](unsigned t) {
-            const int g0 = (int)((int64_t)n * t / nthr), g1 = (int)((int64_t)n * (t + 1) / nthr);
-            if(g0 >= g1) return;
-            // whole-range block copies for the arrays that need no per-graph work
-            const int64_t a_v = iv[g0], b_v = iv[g1], a_e = ie[g0], b_e = ie[g1], a_s = is[g0], b_s = is[g1], a_p = ip[g0], b_p = ip[g1], a_pv = ipv[g0], b_pv = ipv[g1];
-            memcpy(&vertex_offset[vo0 + a_v + g0], voff + a_v + g0, 4 * (size_t)(b_v - a_v + (g1 - g0)));
-            memcpy(&edge_sample_offset[eo0 + a_e + g0], esoff + a_e + g0, 4 * (size_t)(b_e - a_e + (g1 - g0)));
-            if(b_e > a_e) {
-                memcpy(&edge_target[e0 + a_e], etgt + a_e, 4 * (size_t)(b_e - a_e)); memcpy(&edge_weight[e0 + a_e], ew + a_e, 8 * (size_t)(b_e - a_e));
-                if(estrand) memcpy(&edge_strand[e0 + a_e], estrand + a_e, (size_t)(b_e - a_e)); else memset(&edge_strand[e0 + a_e], 0, (size_t)(b_e - a_e));
-                if(eabd) memcpy(&edge_abd[e0 + a_e], eabd + a_e, 8 * (size_t)(b_e - a_e));
-                if(ecount) memcpy(&edge_count[e0 + a_e], ecount + a_e, 4 * (size_t)(b_e - a_e));
-                if(has_rank && erank) memcpy(&edge_rank[e0 + a_e], erank + a_e, 4 * (size_t)(b_e - a_e));
-            }
-            if(b_s > a_s) { memcpy(&sample_id[s0 + a_s], sid + a_s, 4 * (size_t)(b_s - a_s)); memcpy(&sample_abd[s0 + a_s], sabd + a_s, 8 * (size_t)(b_s - a_s)); }
-            memcpy(&vertex_weight[v0 + a_v], vw + a_v, 8 * (size_t)(b_v - a_v)); memcpy(&vertex_lpos[v0 + a_v], lpos + a_v, 4 * (size_t)(b_v - a_v)); memcpy(&vertex_rpos[v0 + a_v], rpos + a_v, 4 * (size_t)(b_v - a_v));
-            if(vtype) memcpy(&vertex_type[v0 + a_v], vtype + a_v, 4 * (size_t)(b_v - a_v)); else for(int64_t k = a_v; k < b_v; k++) vertex_type[v0 + k] = -1;
-            if(poff) memcpy(&phasing_offset[po0 + a_p + g0], poff + a_p + g0, 4 * (size_t)(b_p - a_p + (g1 - g0))); else memset(&phasing_offset[po0 + a_p + g0], 0, 4 * (size_t)(b_p - a_p + (g1 - g0)));
-            if(b_pv > a_pv) memcpy(&phasing_vertex[pv0 + a_pv], pv + a_pv, 4 * (size_t)(b_pv - a_pv));
-            if(b_p > a_p) memcpy(&phasing_count[p0 + a_p], pc + a_p, 4 * (size_t)(b_p - a_p));
-            // per graph: defaults that depend on the sample lists, and the in-CSR (counting sort of edge ids by target)
-            std::vector<int32_t> cur;
-            for(int g = g0; g < g1; g++) {
-                const int V = nv[g], E = ne[g];
-                const int32_t *so = esoff + ie[g] + g, *tg = etgt + ie[g];
+                if(worst) break;                                    // the batch is rolled back: nothing more to stage here
+                // ---- the copy: graph g to its place ----
+                const int64_t a_v = iv[g], a_e = ie[g], a_s = is[g], a_p = ip[g], a_pv = ipv[g]; const int64_t NS = is[g + 1] - a_s, NPV = ipv[g + 1] - a_pv;
+                memcpy(&vertex_offset[vo0 + a_v + g], vo, 4 * ((size_t)V + 1));
+                memcpy(&edge_sample_offset[eo0 + a_e + g], so, 4 * ((size_t)E + 1));
+                if(E > 0) {
+                    memcpy(&edge_target[e0 + a_e], tg, 4 * (size_t)E); memcpy(&edge_weight[e0 + a_e], ew + a_e, 8 * (size_t)E);
+                    if(estrand) memcpy(&edge_strand[e0 + a_e], estrand + a_e, (size_t)E); else memset(&edge_strand[e0 + a_e], 0, (size_t)E);
+                    if(eabd) memcpy(&edge_abd[e0 + a_e], eabd + a_e, 8 * (size_t)E);
+                    if(ecount) memcpy(&edge_count[e0 + a_e], ecount + a_e, 4 * (size_t)E);
+                    if(has_rank && erank) memcpy(&edge_rank[e0 + a_e], erank + a_e, 4 * (size_t)E);
+                }
+                if(NS > 0) { memcpy(&sample_id[s0 + a_s], sid + a_s, 4 * (size_t)NS); memcpy(&sample_abd[s0 + a_s], sabd + a_s, 8 * (size_t)NS); }
+                memcpy(&vertex_weight[v0 + a_v], vw + a_v, 8 * (size_t)V); memcpy(&vertex_lpos[v0 + a_v], lpos + a_v, 4 * (size_t)V); memcpy(&vertex_rpos[v0 + a_v], rpos + a_v, 4 * (size_t)V);
+                if(vtype) memcpy(&vertex_type[v0 + a_v], vtype + a_v, 4 * (size_t)V); else for(int64_t k = a_v; k < a_v + V; k++) vertex_type[v0 + k] = -1;
+                if(poff) memcpy(&phasing_offset[po0 + a_p + g], poff + a_p + g, 4 * ((size_t)P + 1)); else memset(&phasing_offset[po0 + a_p + g], 0, 4 * ((size_t)P + 1));
+                if(NPV > 0) memcpy(&phasing_vertex[pv0 + a_pv], pv + a_pv, 4 * (size_t)NPV);
+                if(P > 0) memcpy(&phasing_count[p0 + a_p], pc + a_p, 4 * (size_t)P);
+                // defaults that depend on the sample lists, and the in-CSR (counting sort of edge ids by target)
                 if(!eabd) for(int k = 0; k < E; k++) { double sum = 0; for(int j = so[k]; j < so[k + 1]; j++) sum += sabd[is[g] + j]; edge_abd[e0 + ie[g] + k] = sum; }
                 if(!ecount) for(int k = 0; k < E; k++) edge_count[e0 + ie[g] + k] = so[k + 1] - so[k];
                 if(has_rank && !erank) for(int k = 0; k < E; k++) edge_rank[e0 + ie[g] + k] = k;
@@ -391,8 +380,15 @@ struct HostBatch {
                 cur.assign(io, io + V);
                 for(int k = 0; k < E; k++) ied[cur[tg[k]]++] = k;
             }
+            verdict[t] = worst;
         };
-        run_threads(nthr, fill);
+        run_threads(nthr, work);
+        int worst = 0; for(unsigned t = 0; t < nthr; t++) worst = std::max(worst, verdict[t]);
+        if(worst != 0) {      // the per-graph path normalises, or names the defect
+            rollback(m0);
+            return add_packed_serial(n, nv, ne, np, voff, etgt, ew, estrand, eabd, esoff, sid, sabd, vw, lpos, rpos, vtype, poff, pv, pc, gstrand, ecount, erank);
+        }
+        if(erank && !m0.has_rank) { bool any = false; for(unsigned t = 0; t < nthr; t++) any = any || permuted[t]; if(!any) { edge_rank.clear(); has_rank = false; } }     // identity everywhere: nothing to carry
         return ALD_OK;
     }
     // add_packed for a run of graphs some (or all) of which are RAW: raw_dist[i] >= 0 marks graph i as one (its max_group_boundary_distance),

@@ -166,16 +166,16 @@ def kernel_only(A, dev, pg, reps=2):
 
 
 def sink_pipeline(A, pg, n, rounds=6):
-    """host arrays in -> merged transcript set out, stages overlapped on three host threads (stage | kernel + download | merge into ONE
+    """host arrays in -> merged transcript set out, stages overlapped on four host threads (stage | kernel | download | merge into ONE
     persistent set that keeps growing): the rate an integrator's whole loop would see, for both merge paths"""
     import numpy as np
     out = {}
     sid = (np.arange(n) % 8).astype(np.int32)
     for mode in ("host_sink", "gpu_reduction"):
-        batches = [A.DecompBatch(0) for _ in range(3)]
+        batches = [A.DecompBatch(0) for _ in range(4)]
         for b in batches:
             b.add(pg); b.upload(); b.run(); b.download(); b.clear()
-        free = queue.Queue(); staged = queue.Queue(maxsize=1); done = queue.Queue(maxsize=1)
+        free = queue.Queue(); staged = queue.Queue(maxsize=1); ran = queue.Queue(maxsize=1); done = queue.Queue(maxsize=1)
         for b in batches:
             free.put(b)
         sink = A.TranscriptSink(0.8); err = []
@@ -188,13 +188,24 @@ def sink_pipeline(A, pg, n, rounds=6):
                 err.append(e)
             staged.put(None)
 
-        def kern():
+        def kern():                                           # the kernel of batch k + 1 runs while batch k is copied back and decoded
             try:
                 while True:
                     b = staged.get()
                     if b is None:
                         break
-                    b.run(); b.download(); done.put(b)
+                    b.run(); b.sync(); ran.put(b)
+            except BaseException as e:
+                err.append(e)
+            ran.put(None)
+
+        def fetch():
+            try:
+                while True:
+                    b = ran.get()
+                    if b is None:
+                        break
+                    b.download(); done.put(b)
             except BaseException as e:
                 err.append(e)
             done.put(None)
@@ -215,7 +226,7 @@ def sink_pipeline(A, pg, n, rounds=6):
                 err.append(e)
                 while done.get() is not None:
                     pass
-        ths = [threading.Thread(target=f, daemon=True) for f in (stage, kern, merge)]
+        ths = [threading.Thread(target=f, daemon=True) for f in (stage, kern, fetch, merge)]
         t0 = time.perf_counter()
         for t in ths:
             t.start()
@@ -228,7 +239,7 @@ def sink_pipeline(A, pg, n, rounds=6):
         sink.close()
         for b in batches:
             b.close()
-    out["workload"] = f"{rounds} batches of {n} graphs through stage | kernel + download | merge into one persistent transcript set (skip_single_exon as the reference's default), three host threads"
+    out["workload"] = f"{rounds} batches of {n} graphs through stage | kernel | download | merge into one persistent transcript set (skip_single_exon as the reference's default), four host threads"
     return out
 
 
