@@ -207,6 +207,13 @@ int ald_default_params(ald_params *p)
     return ALD_OK;
 }
 
+namespace {
+// pinned host memory for the arrays of a batch (host_pack.h: wire_alloc): portable, so that any device of the process can read it
+void *wire_pinned_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) == hipSuccess ? p : nullptr; }
+void wire_pinned_release(void *p) { if(p) hipHostFree(p); }
+struct WireHooksInstaller { WireHooksInstaller() { wire_hooks().alloc = wire_pinned_alloc; wire_hooks().release = wire_pinned_release; } } g_wire_hooks_installer;
+}
+
 int ald_batch_create(const ald_params *p, int device, ald_batch **out)
 {
     if(!out) return ALD_ERR_INVALID;
@@ -312,19 +319,12 @@ int ald_batch_upload(ald_batch *b)
     HIPCHK(hipSetDevice(b->device));
     const int n = b->hb.n();
     b->in_bytes = b->hb.layout(b->sec);
-    if(b->pin_in.ensure(b->in_bytes)) return set_err(ALD_ERR_NOMEM, "pinned input buffer");
     if(b->d_in.ensure(b->in_bytes)) return set_err(ALD_ERR_NOMEM, "device input buffer");
-    // ONE wire buffer, sent in a few large pieces: the host threads pack piece k+1 into the pinned buffer while the copy engine moves
-    // piece k (packing and the PCIe transfer take about as long as each other -- 20 ms and 25 ms for 1.3 GB; back to back they were the
-    // longest stage of a pipelined caller, longer than the kernel)
-    {
-        const uint64_t piece = std::max<uint64_t>(32ull << 20, (b->in_bytes + 7) / 8 / 256 * 256);
-        for(uint64_t lo = 0; lo < b->in_bytes; lo += piece) {
-            const uint64_t hi = std::min<uint64_t>(b->in_bytes, lo + piece);
-            b->hb.pack_range((uint8_t*)b->pin_in.p, b->sec, lo, hi);
-            HIPCHK(hipMemcpyAsync((uint8_t*)b->d_in.p + lo, (uint8_t*)b->pin_in.p + lo, hi - lo, hipMemcpyHostToDevice, b->stream));
-        }
-    }
+    // ONE buffer on the device, its sections filled straight from the batch's host arrays: they live in pinned memory (wire_alloc, hooks
+    // installed by ald_batch_create), so every section is one asynchronous copy of the DMA engine and no host thread packs anything
+    // (the pack into a second, pinned buffer -- 1.3 GB read and written, 20 ms on sixteen threads -- was as long as the PCIe transfer itself)
+    for(int i = 0; i < HostBatch::S_COUNT; i++)
+        if(b->sec[i].bytes) HIPCHK(hipMemcpyAsync((uint8_t*)b->d_in.p + b->sec[i].off, b->sec[i].src, b->sec[i].bytes, hipMemcpyHostToDevice, b->stream));
     // outputs
     // a heuristic, not a bound (one graph can need about (E - V + 2) * (V + 14) words): a graph that finds the pool full reports
     // ALD_ST_POOL_FULL and ald_batch_download grows the pool.  ALD_DEBUG_POOL_WORDS starts it small so that tests reach that path.

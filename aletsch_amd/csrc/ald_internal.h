@@ -37,7 +37,7 @@ struct StagedPass {
 struct ald_batch {
     int device = 0; int n_cus = 0;
     Params prm;
-    HostBatch hb;
+    HostBatch hb{true};                             // its arrays in pinned memory: ald_batch_upload copies them to the device as they are
     HostBatch::Section sec[HostBatch::S_COUNT];
     uint64_t in_bytes = 0;
     hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;

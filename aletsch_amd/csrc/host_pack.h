@@ -20,6 +20,7 @@
 #include <thread>
 #include <cstdlib>
 #include <cmath>
+#include <new>
 
 namespace ald {
 
@@ -33,22 +34,54 @@ template<class T> struct raw_init_alloc : std::allocator<T> {
 };
 template<class T> using rvec = std::vector<T, raw_init_alloc<T>>;
 
+// The arrays of a batch that travel to the device.  A batch of the GPU library keeps them in PINNED memory (HostBatch(true): ald_abi.cpp
+// installs the two hooks when the library is loaded), so that ald_batch_upload hands them to the copy engine as they are -- no pack into a
+// second buffer; every other HostBatch (the emulation, host-only utilities) uses plain memory.  The choice is a property of the vector's
+// allocator, fixed when the batch is constructed.
+struct wire_hooks_t { void *(*alloc)(size_t) = nullptr; void (*release)(void*) = nullptr; };
+inline wire_hooks_t &wire_hooks() { static wire_hooks_t h; return h; }
+template<class T> struct wire_alloc : raw_init_alloc<T> {
+    template<class U> struct rebind { typedef wire_alloc<U> other; };
+    typedef std::true_type propagate_on_container_move_assignment; typedef std::true_type propagate_on_container_copy_assignment; typedef std::true_type propagate_on_container_swap;
+    bool pinned = false;
+    wire_alloc() = default;
+    explicit wire_alloc(bool p) : pinned(p && wire_hooks().alloc && wire_hooks().release) {}
+    template<class U> wire_alloc(const wire_alloc<U> &o) : pinned(o.pinned) {}
+    T *allocate(size_t n) { const size_t bytes = n * sizeof(T); void *p = pinned ? wire_hooks().alloc(bytes) : ::operator new(bytes); if(!p) throw std::bad_alloc(); return static_cast<T*>(p); }
+    void deallocate(T *p, size_t) { if(pinned) wire_hooks().release((void*)p); else ::operator delete((void*)p); }
+    template<class U> bool operator==(const wire_alloc<U> &o) const { return pinned == o.pinned; }
+    template<class U> bool operator!=(const wire_alloc<U> &o) const { return pinned != o.pinned; }
+};
+template<class T> using wvec = std::vector<T, wire_alloc<T>>;
+
 struct HostBatch {
-    rvec<int32_t> g_nv, g_ne, g_np;
-    rvec<int64_t> off_v{0}, off_e{0}, off_s{0}, off_p{0}, off_pv{0};
-    rvec<int32_t> vertex_offset, edge_target; rvec<double> edge_weight; rvec<uint8_t> edge_strand; rvec<double> edge_abd;
-    rvec<int32_t> edge_sample_offset, sample_id; rvec<double> sample_abd;
-    rvec<double> vertex_weight; rvec<int32_t> vertex_lpos, vertex_rpos, vertex_type;
-    rvec<int32_t> in_offset, in_edge;
-    rvec<int32_t> phasing_offset, phasing_vertex, phasing_count; rvec<char> graph_strand;
-    rvec<int32_t> edge_count;
-    rvec<int32_t> edge_rank; bool has_rank = false;   // creation rank of every input edge (optional: empty until a caller supplies one, then identity-filled for the rest)
+    wvec<int32_t> g_nv, g_ne, g_np;
+    wvec<int64_t> off_v, off_e, off_s, off_p, off_pv;            // [n+1] prefixes, {0} for an empty batch
+    wvec<int32_t> vertex_offset, edge_target; wvec<double> edge_weight; wvec<uint8_t> edge_strand; wvec<double> edge_abd;
+    wvec<int32_t> edge_sample_offset, sample_id; wvec<double> sample_abd;
+    wvec<double> vertex_weight; wvec<int32_t> vertex_lpos, vertex_rpos, vertex_type;
+    wvec<int32_t> in_offset, in_edge;
+    wvec<int32_t> phasing_offset, phasing_vertex, phasing_count; wvec<char> graph_strand;
+    wvec<int32_t> edge_count;
+    wvec<int32_t> edge_rank; bool has_rank = false;   // creation rank of every input edge (optional: empty until a caller supplies one, then identity-filled for the rest)
     // RAW graphs (row f1): a graph as assembler::assemble(gx, px, sid) receives it + its phase set in exon coordinates; the pre-steps
     // (extend_strands, boundary grouping, phase projection, hyper_set ctor, filter_nodes) run in the kernel's load phase.
     // g_rawdist[g] = -1: an ordinary (staged) graph, else max_group_boundary_distance of a raw one.  Kept for every graph (a few bytes);
     // the sections only travel when the batch holds a raw graph.
-    rvec<int32_t> g_rawdist; rvec<int64_t> off_rp{0}, off_rc{0};      // [n] / [n+1] prefix of raw phases / of their coordinates
-    rvec<int32_t> rphase_offset, rphase_coord, rphase_count;          // per graph a local CSR of np + 1 entries (at off_rp[g] + g), coordinates, counts
+    wvec<int32_t> g_rawdist; wvec<int64_t> off_rp, off_rc;           // [n] / [n+1] prefix of raw phases / of their coordinates
+    wvec<int32_t> rphase_offset, rphase_coord, rphase_count;          // per graph a local CSR of np + 1 entries (at off_rp[g] + g), coordinates, counts
+    explicit HostBatch(bool pinned = false)
+        : g_nv(wire_alloc<int32_t>(pinned)), g_ne(wire_alloc<int32_t>(pinned)), g_np(wire_alloc<int32_t>(pinned)),
+          off_v(wire_alloc<int64_t>(pinned)), off_e(wire_alloc<int64_t>(pinned)), off_s(wire_alloc<int64_t>(pinned)), off_p(wire_alloc<int64_t>(pinned)), off_pv(wire_alloc<int64_t>(pinned)),
+          vertex_offset(wire_alloc<int32_t>(pinned)), edge_target(wire_alloc<int32_t>(pinned)), edge_weight(wire_alloc<double>(pinned)), edge_strand(wire_alloc<uint8_t>(pinned)), edge_abd(wire_alloc<double>(pinned)),
+          edge_sample_offset(wire_alloc<int32_t>(pinned)), sample_id(wire_alloc<int32_t>(pinned)), sample_abd(wire_alloc<double>(pinned)),
+          vertex_weight(wire_alloc<double>(pinned)), vertex_lpos(wire_alloc<int32_t>(pinned)), vertex_rpos(wire_alloc<int32_t>(pinned)), vertex_type(wire_alloc<int32_t>(pinned)),
+          in_offset(wire_alloc<int32_t>(pinned)), in_edge(wire_alloc<int32_t>(pinned)),
+          phasing_offset(wire_alloc<int32_t>(pinned)), phasing_vertex(wire_alloc<int32_t>(pinned)), phasing_count(wire_alloc<int32_t>(pinned)), graph_strand(wire_alloc<char>(pinned)),
+          edge_count(wire_alloc<int32_t>(pinned)), edge_rank(wire_alloc<int32_t>(pinned)),
+          g_rawdist(wire_alloc<int32_t>(pinned)), off_rp(wire_alloc<int64_t>(pinned)), off_rc(wire_alloc<int64_t>(pinned)),
+          rphase_offset(wire_alloc<int32_t>(pinned)), rphase_coord(wire_alloc<int32_t>(pinned)), rphase_count(wire_alloc<int32_t>(pinned))
+    { off_v.assign(1, 0); off_e.assign(1, 0); off_s.assign(1, 0); off_p.assign(1, 0); off_pv.assign(1, 0); off_rp.assign(1, 0); off_rc.assign(1, 0); }
     bool has_raw = false;
     std::vector<int32_t> cur_, perm_; std::vector<uint8_t> seen_;          // scratch of add_graph, kept across calls
     std::string err;
@@ -598,8 +631,10 @@ struct HostResults {
             const int64_t lo = total * t / nthr, hi = total * (t + 1) / nthr;            // slices of equal path counts
             int g = (int)(std::upper_bound(path_begin.begin(), path_begin.end(), lo) - path_begin.begin()) - 1; if(g < 0) g = 0;
             int64_t obt = 0;
-            for(int64_t i = lo; i < hi; i++) {
+            int g2 = g;                                                               // the record eight paths ahead is asked for now: records lie in the pool
+            for(int64_t i = lo; i < hi; i++) {                                        // in the order the waves emitted them, every one is a miss of its own
                 while(path_begin[(size_t)g + 1] <= i) g++;
+                if(i + 8 < hi) { while(path_begin[(size_t)g2 + 1] <= i + 8) g2++; const uint64_t o2 = index[(uint64_t)graph_first[g2] + (uint64_t)(i + 8 - path_begin[(size_t)g2])]; if(o2 + REC_HDR_WORDS <= W) { __builtin_prefetch(pw + o2); __builtin_prefetch(pw + o2 + 16); } }
                 const int32_t idx = (int32_t)(i - path_begin[(size_t)g]);
                 const uint64_t o = index[(uint64_t)graph_first[g] + (uint64_t)idx];
                 if(o + REC_HDR_WORDS > W) { bad[t] = 1; return; }
