@@ -503,7 +503,7 @@ def main() -> int:
             "timed_step": "inputs resident in HBM; decomposition kernels (exon join of every path into its record + result index written by the kernel) + D2H of status / records (paths and transcripts) / index + decode into the host path table with coverage = log(1 + weight)"
                           + (" + RCCL gather of the finished transcripts to rank 0" if dist_on else "") + "; kernel k+1 is launched before the results of batch k are downloaded, so copies and decode run under the next kernel",
             "value_h2d_inclusive": (args.graphs * world * args.steps / elapsed_h2d) if elapsed_h2d else None, "ms_per_step_h2d_inclusive": (elapsed_h2d / args.steps * 1e3) if elapsed_h2d else None,
-            "h2d_inclusive_step": "ald_batch_add_packed + pack into the pinned wire buffer + H2D in eight overlapped pieces in front of every step (three-stage pipeline on three host threads, 4 batch objects; K kernels, K downloads and K stagings between the brackets)",
+            "h2d_inclusive_step": "ald_batch_add_packed (into the pinned host arrays of the batch) + H2D of every array in front of every step (three-stage pipeline on three host threads, 4 batch objects; K kernels, K downloads and K stagings between the brackets)",
             "download_ms": {"wait_for_kernel": dl["wait_kernel"], "status_and_retries": dl["status_retries"], "d2h_copies": dl["copy"], "decode_paths_and_transcripts": dl["decode"],
                             "bytes_to_host_per_step": dl["bytes_to_host"]},
             "config": {"workload": f"{args.graphs} synthetic splice graphs per GPU, {args.vertices} vertices / {args.edges} edges each "

@@ -130,7 +130,7 @@ int  ald_batch_create(const ald_params *p, int device, ald_batch **out);
 int  ald_batch_destroy(ald_batch *b);
 int  ald_batch_clear(ald_batch *b);                       /* forget graphs, keep buffers */
 
-/* ---- staging: copy one graph / many packed graphs into the pinned wire buffer ----
+/* ---- staging: copy one graph / many packed graphs into the batch's host arrays (pinned memory) ----
  * A malformed graph (edge not from a lower to a higher vertex index below V, offsets that do not span their arrays, strand
  * outside 0..2, negative count, duplicate sample id on an edge) is refused with ALD_ERR_INVALID and a message in ald_last_error();
  * the batch is left exactly as it was -- for the bulk form all or nothing: no graph of a refused call is added. */
@@ -188,7 +188,7 @@ int  ald_batch_add_packed_raw(ald_batch *b, int32_t n, const int32_t *g_nv, cons
                               const int32_t *raw_max_group_boundary_distance, const int32_t *g_nphase, const int32_t *phase_offset, const int32_t *phase_coord, const int32_t *phase_count);
 
 /* ---- execution (replaces `sx.assemble()`, scallop.cc:38-188) ---- */
-int  ald_batch_upload(ald_batch *b);      /* H2D of the wire buffer (one coalesced copy)      */
+int  ald_batch_upload(ald_batch *b);      /* H2D: the batch's arrays to ONE device buffer (a copy per array, no packing pass) */
 int  ald_batch_run(ald_batch *b);         /* launch decomposition kernels on the batch stream */
 int  ald_batch_sync(ald_batch *b);        /* wait for the stream                              */
 int  ald_batch_download(ald_batch *b);    /* D2H of status, path records (vertices + joined exons) and the kernel-written index; decode */
