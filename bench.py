@@ -7,7 +7,7 @@ the status words, the records -- paths AND transcripts -- and the index + the de
 coverage = log(1 + weight): graphs fully decomposed, paths + transcripts materialised in host memory.  At N > 1 the
 step also holds the RCCL gather of the finished transcripts to rank 0, the path's only exchange step.
 `value` is that rate.  `value_h2d_inclusive` is the rate of a second loop that starts from the caller's host arrays
-(ald_batch_add_packed + pack into the pinned wire buffer + H2D in front of every step, three pipeline stages on three host threads,
+(ald_batch_add_packed into the pinned host arrays of the batch + H2D of every array in front of every step, three pipeline stages on three host threads,
 four batch objects rotating); kernels never overlap each other, so the per-launch HIP-event time is that of one kernel.
 
 Workload (N=1): BASELINE.json configs[1] -- 100k synthetic splice graphs, 64 vertices / 256 edges each.
@@ -342,7 +342,7 @@ def main() -> int:
 
     def run_steps(w, k, staged, raw=False):
         """w untimed + k timed passes through ONE pipeline.  staged=True: host arrays in -> host results out, three stages on three
-        threads (adder: caller's arrays -> the batch's host arrays; uploader: pack + H2D + first-pass work lists; this thread: kernel
+        threads (adder: caller's arrays -> the batch's host arrays; uploader: H2D + first-pass work lists; this thread: kernel
         launch + D2H), batch objects rotating; staged=False: the batches are resident, kernel + D2H only.
         The timed window is a window over the pipeline's steady state: between the two brackets (GPU idle, all results of the
         previous step on the host, barrier across ranks) exactly k kernels run, k results are downloaded and k batches are staged --
@@ -358,7 +358,7 @@ def main() -> int:
         for _ in range(w + k + ahead):
             todo.put(1)
         added = queue.Queue(); xq = queue.Queue()
-        stage_s = [0.0, 0.0, 0.0, 0.0]                           # busy seconds: host copy / pack + H2D / main thread waiting for a staged batch / exchange
+        stage_s = [0.0, 0.0, 0.0, 0.0]                           # busy seconds: host copy / H2D / main thread waiting for a staged batch / exchange
 
         def exchanger():                                         # stage 4 (multi-GPU only): finished transcripts -> rank 0
             if tdev.type == "cuda":
@@ -408,7 +408,7 @@ def main() -> int:
             except BaseException as e:                           # surface the failure in the main thread instead of a hang
                 err.append(e); added.put(None); ready.put(None)
 
-        def uploader():                                          # stage 2: pack into the pinned wire buffer + H2D in pieces + first-pass work lists
+        def uploader():                                          # stage 2: H2D of the batch arrays + first-pass work lists
             try:
                 while True:
                     b = added.get()
