@@ -263,11 +263,19 @@ int ald_batch_clear(ald_batch *b)
     return ALD_OK;
 }
 
+// the batch's host arrays are pinned memory: an allocation the driver refuses must not leave through the C ABI as an exception
+static int staging_out_of_memory(ald_batch *b)
+{
+    try { b->hb.clear(); } catch(...) {}
+    return set_err(ALD_ERR_NOMEM, "out of (pinned) host memory while staging: the batch was cleared");
+}
+
 int ald_batch_add_graph(ald_batch *b, const ald_graph_view *g)
 {
     if(!b || !g) return ALD_ERR_INVALID;
     b->uploaded = b->ran = b->downloaded = false;
-    int rc = b->hb.add_graph(*g);
+    int rc;
+    try { rc = b->hb.add_graph(*g); } catch(const std::bad_alloc &) { return staging_out_of_memory(b); }
     if(rc != ALD_OK) return set_err(rc, b->hb.err);
     return ALD_OK;
 }
@@ -281,8 +289,10 @@ int ald_batch_add_packed(ald_batch *b, int32_t n, const int32_t *g_nv, const int
 {
     if(!b || n < 0 || !g_nv || !g_ne) return ALD_ERR_INVALID;
     b->uploaded = b->ran = b->downloaded = false;
-    int rc = b->hb.add_packed(n, g_nv, g_ne, g_np, vertex_offset, edge_target, edge_weight, edge_strand, edge_abd, edge_sample_offset, sample_id, sample_abd,
-                              vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand, edge_count, edge_creation_rank);
+    int rc;
+    try { rc = b->hb.add_packed(n, g_nv, g_ne, g_np, vertex_offset, edge_target, edge_weight, edge_strand, edge_abd, edge_sample_offset, sample_id, sample_abd,
+                              vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand, edge_count, edge_creation_rank); }
+    catch(const std::bad_alloc &) { return staging_out_of_memory(b); }
     if(rc != ALD_OK) return set_err(rc, b->hb.err);
     return ALD_OK;
 }
@@ -297,9 +307,11 @@ int ald_batch_add_packed_raw(ald_batch *b, int32_t n, const int32_t *g_nv, const
 {
     if(!b || n < 0 || !g_nv || !g_ne) return ALD_ERR_INVALID;
     b->uploaded = b->ran = b->downloaded = false;
-    int rc = b->hb.add_packed_raw(n, g_nv, g_ne, g_np, vertex_offset, edge_target, edge_weight, edge_strand, edge_abd, edge_sample_offset, sample_id, sample_abd,
+    int rc;
+    try { rc = b->hb.add_packed_raw(n, g_nv, g_ne, g_np, vertex_offset, edge_target, edge_weight, edge_strand, edge_abd, edge_sample_offset, sample_id, sample_abd,
                                   vertex_weight, vertex_lpos, vertex_rpos, vertex_type, phasing_offset, phasing_vertex, phasing_count, graph_strand, edge_count, edge_creation_rank,
-                                  raw_max_group_boundary_distance, g_nphase, phase_offset, phase_coord, phase_count);
+                                  raw_max_group_boundary_distance, g_nphase, phase_offset, phase_coord, phase_count); }
+    catch(const std::bad_alloc &) { return staging_out_of_memory(b); }
     if(rc != ALD_OK) return set_err(rc, b->hb.err);
     return ALD_OK;
 }

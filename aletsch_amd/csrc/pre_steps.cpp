@@ -263,7 +263,9 @@ int ald_batch_add_graph_raw(ald_batch *b, const ald_graph_view *g, const ald_pha
         return rc;
     }
     b->uploaded = b->ran = b->downloaded = false;
-    const int rc = b->hb.add_graph_raw(*g, phases, max_group_boundary_distance);
+    int rc;
+    try { rc = b->hb.add_graph_raw(*g, phases, max_group_boundary_distance); }
+    catch(const std::bad_alloc &) { try { b->hb.clear(); } catch(...) {} return ald_set_err(ALD_ERR_NOMEM, "out of (pinned) host memory while staging: the batch was cleared"); }
     if(rc != ALD_OK) return ald_set_err(rc, b->hb.err);
     return ALD_OK;
 }
