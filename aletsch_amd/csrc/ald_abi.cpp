@@ -696,10 +696,12 @@ template<class Make, class Pre = no_prefetch> void merge_groups(ald_tset *t, uns
         // the loop is bound by cache misses (source record -> index slot -> table entry): what transcript k + 12 / k + 8 / k + 4 will touch is
         // asked for while transcript k is merged
         const int64_t end = first[(size_t)th + 1];
+        static const int dist[3] = { getenv("ALD_SINK_AHEAD_REC") ? atoi(getenv("ALD_SINK_AHEAD_REC")) : 12, getenv("ALD_SINK_AHEAD_SLOT") ? atoi(getenv("ALD_SINK_AHEAD_SLOT")) : 8,
+                                     getenv("ALD_SINK_AHEAD_ENTRY") ? atoi(getenv("ALD_SINK_AHEAD_ENTRY")) : 4 };      // tuning knobs (0 = off)
         auto ahead = [&](int64_t k) {
-            if(k + 12 < end) pre(order[(size_t)(k + 12)]);
-            if(k + 8 < end) { const uint32_t h = bucket[(size_t)order[(size_t)(k + 8)]]; t->shard[h % ALD_TSET_SHARDS].mt.prefetch_slot(h); }
-            if(k + 4 < end) { const uint32_t h = bucket[(size_t)order[(size_t)(k + 4)]]; t->shard[h % ALD_TSET_SHARDS].mt.prefetch_entry(h); }
+            if(dist[0] > 0 && k + dist[0] < end) pre(order[(size_t)(k + dist[0])]);
+            if(dist[1] > 0 && k + dist[1] < end) { const uint32_t h = bucket[(size_t)order[(size_t)(k + dist[1])]]; t->shard[h % ALD_TSET_SHARDS].mt.prefetch_slot(h); }
+            if(dist[2] > 0 && k + dist[2] < end) { const uint32_t h = bucket[(size_t)order[(size_t)(k + dist[2])]]; t->shard[h % ALD_TSET_SHARDS].mt.prefetch_entry(h); }
         };
         for(int64_t k = first[th]; k < end; ) {
             while(grp[g + 1] <= order[(size_t)k]) g++;                           // the graph of this owner's next transcript
