@@ -51,19 +51,28 @@
       const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
       return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
   }
+  // unsigned 32-bit minimum over the wave, result wave-uniform: six v_min_u32 with a DPP source operand (quad, quad, half row, row, row
+  // broadcast x 2 -- the CDNA reduction idiom), lane 63 then holds the minimum.  Written as ONE asm block: the compiler does not fold
+  // a v_mov_b32_dpp into the v_min_u32 that consumes it (four instructions per step instead of one); the block carries the wait
+  // states the hardware asks for itself -- two between a VALU write of a VGPR and a DPP read of it, one before the v_readlane.
+  __device__ __forceinline__ unsigned wave_umin32(unsigned k)
+  {
+      asm volatile("s_nop 1\n\t"
+                   "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                   "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                   "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                   "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                   "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                   "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0"
+                   : "+v"(k));
+      return (unsigned)__builtin_amdgcn_readlane((int)k, 63);
+  }
   // wave_argmin: over the lanes with vv >= 0, the smallest rr; among equal ones the LARGEST vv (the sequential sweeps keep the later
   // vertex on `!(ratio < r)`); every lane receives the winner, vv = -1 when no lane has a candidate.  The ratios are non-negative
-  // doubles, whose order is the order of their bit patterns as unsigned integers: the minimum is a 64-bit unsigned min over the wave in
-  // six DPP steps (register-to-register lane permutes: quad, quad, half row, row, row broadcast x 2 -- the CDNA reduction idiom), the
-  // winner then comes from one ballot.  A butterfly of shuffles costs eighteen ds_bpermute_b32 round trips for the same result.  Any
-  // candidate that is negative or NaN (never produced by the rules; bit pattern above +inf) sends the wave through the butterfly.
-  template<int CTRL, int ROWMASK> __device__ __forceinline__ unsigned long long dpp_umin_step(unsigned long long k)
-  {
-      const int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32);
-      const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xf, false), hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xf, false);
-      const unsigned long long k2 = ((unsigned long long)(unsigned)hi2 << 32) | (unsigned)lo2;
-      return k2 < k ? k2 : k;
-  }
+  // doubles, whose order is the order of their bit patterns as unsigned integers: the minimum is a 64-bit unsigned min over the wave --
+  // two 32-bit DPP reductions (wave_umin32), high word first --, the winner then comes from one ballot.  A butterfly of shuffles costs
+  // eighteen ds_bpermute_b32 round trips for the same result.  Any candidate that is negative or NaN (never produced by the rules; bit
+  // pattern above +inf) sends the wave through the butterfly.
   // PRECONDITION: every lane of the wave is active (EXEC all ones) -- a DPP step reads the registers of its source lanes whatever their
   // EXEC bit, and the final ballot / readlane assume 64 candidates.  Both call sites (scan_trivial, sweep_smallest) sit in code every
   // lane runs; the -DALD_WSYNC_BARRIER test build traps if that is ever not so.
@@ -84,10 +93,10 @@
       }
       unsigned long long k = vv >= 0 ? bits : ~0ull;
       const unsigned long long mine = k;
-      k = dpp_umin_step<0xB1, 0xf>(k);  k = dpp_umin_step<0x4E, 0xf>(k);          // quad_perm [1,0,3,2], [2,3,0,1]
-      k = dpp_umin_step<0x141, 0xf>(k); k = dpp_umin_step<0x140, 0xf>(k);         // row_half_mirror, row_mirror
-      k = dpp_umin_step<0x142, 0xa>(k); k = dpp_umin_step<0x143, 0xc>(k);         // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3
-      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+      // 64-bit minimum = minimum of the high words, then of the low words of the lanes that hold it
+      const unsigned khi = (unsigned)(k >> 32), klo = (unsigned)k;
+      const unsigned hi = wave_umin32(khi);
+      const unsigned lo = wave_umin32(khi == hi ? klo : 0xFFFFFFFFu);
       const unsigned long long kmin = ((unsigned long long)hi << 32) | lo;
       unsigned long long tied = __ballot(vv >= 0 && mine == kmin);
       int best = -1;

@@ -53,9 +53,10 @@
 namespace ALD_CLASS_NS {
 using namespace ald;
 #ifdef ALD_EMU_COUNT
-static long g_cnt_router = 0, g_cnt_unsweep = 0, g_cnt_star[34] = {0}, g_cnt_rdeg[34] = {0}, g_cnt_build = 0, g_cnt_pre[3] = {0};
+static long g_cnt_router = 0, g_cnt_unsweep = 0, g_cnt_star[34] = {0}, g_cnt_rdeg[34] = {0}, g_cnt_build = 0, g_cnt_pre[3] = {0}, g_cnt_fix[8] = {0}, g_cnt_fix_declined = 0;
 struct CntPrinter { ~CntPrinter() { if(g_cnt_unsweep) { fprintf(stderr, "[emu-count] class %d: unsplittable sweeps %ld router runs %ld (of which reach build(): %ld; prepared at level 0/1/2: %ld %ld %ld)\n", ALD_CLASS_ID, g_cnt_unsweep, g_cnt_router, g_cnt_build, g_cnt_pre[0], g_cnt_pre[1], g_cnt_pre[2]);
     fprintf(stderr, "[emu-count]   stars by fan size:"); for(int i = 0; i < 34; i++) if(g_cnt_star[i]) fprintf(stderr, " %d:%ld", i, g_cnt_star[i]); fprintf(stderr, "\n");
+    fprintf(stderr, "[emu-count]   stars through the fixed-size form:"); for(int i = 0; i < 8; i++) if(g_cnt_fix[i]) fprintf(stderr, " %d:%ld", i, g_cnt_fix[i]); fprintf(stderr, " declined:%ld\n", g_cnt_fix_declined);
     fprintf(stderr, "[emu-count]   router runs by degree:"); for(int i = 0; i < 34; i++) if(g_cnt_rdeg[i]) fprintf(stderr, " %d:%ld", i, g_cnt_rdeg[i]); fprintf(stderr, "\n"); } } }; static CntPrinter g_cnt_printer;
 #endif
 
@@ -1238,11 +1239,251 @@ template<bool A> ALD_INL void star_wave_body(int x)
 }
 ALD_INL void star_wave_in(int x) { star_wave_body<true>(uni(x)); }       // inlined into the kernel entry, once (sweep_trivial has ONE decomposition site,
 ALD_INL void star_wave_out(int x) { star_wave_body<false>(uni(x)); }     // run_graph ONE sweep_trivial): no prologue that parks callee-saved registers in scratch
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same decomposition once more, written for a fan of EXACTLY N = 2..4 edges (two thirds of the stars of the bench workload), with
+// nothing handed from lane to lane: every lane gathers the whole fan and runs the whole numeric part -- balance_vertex, pair
+// weights, merge order, what is left of c after every cut, the ids, the sums around x, the vertex-weight chain -- on named values
+// in registers (N is a template parameter, every loop over the fan unrolls); the lanes execute in lock step, so computing it in 64
+// lanes costs what computing it in one does.  Lane j then finishes fan edge j: its cold record (asked for at the top, the round trip
+// runs under the arithmetic), id / weight / endpoint, its place in the list of its other endpoint, and its link into far's list.  The
+// places in far's list come from ONE walk every lane makes for all N keys at once; the same walk finds c's predecessor, so c leaves the
+// list without a walk of its own.  No scratch, no hand-over until the final one.
+// Anything out of the ordinary -- a weight below min_w, two fan edges to the same vertex, an exhausted id space, a zero count, a c that
+// keeps a remainder, an inconsistent list -- is detected BEFORE the first write and makes the form decline (false): the caller then runs
+// star_wave_body, which treats or reports the case exactly as before.  Every floating-point operation is the one the sequential
+// form performs (scallop.cc:2144-2167 -> 2486-2576, 2009-2142, 2394-2484, 2242-2378), on the same operands in the same order.
+#ifndef ALD_STARFIX_MAX
+#define ALD_STARFIX_MAX 2     /* N = 3, 4 inline cost the kernel root 16 / 41 more VGPR spills: 42.4 / 43.4 ms against 42.4 with N = 2 alone (profiles/r03/za_kernel_ab_star_fixed.txt) */
+#endif
+template<int N, class T> ALD_INL T pick(const T (&a)[N], int i) { T v = a[0]; ALD_UNROLL for(int k = 1; k < N; k++) if(i == k) v = a[k]; return v; }
+#ifdef ALD_STARFIX_CALL
+template<bool A, int N> ALD_FN bool star_fixed(int x)
+#else
+template<bool A, int N> ALD_INL bool star_fixed(int x)
+#endif
+{
+    COLD;
+    PROF_DECL;
+    const int lane = lane_id();
+    const double mw = HC.p_min_w;
+    const int c = uni(A ? first_in(x) : first_out(x));
+    int bad = (c < 0) ? 1 : 0;
+    const int cs = c >= 0 ? c : 0;
+    // c's record and the vertex: one broadcast request each, used after the arithmetic
+    const double medc = C.ed[cs].med, cc = C.ed[cs].econf, abc = C.ed[cs].s0abd, vw0 = C.vx[x].vw;
+    const int meic = C.ed[cs].mei, cntc = C.ed[cs].ecount, stc = C.ed[cs].estrand, idc = C.ed[cs].s0id;
+    const uint32_t nsc = C.ed[cs].sp_len;
+    const int lt = C.vx[x].lpos, rt = C.vx[x].rpos, ov = C.vx[x].v2v;
+    uint64_t cmask_pf[NW <= 2 ? NW : 1];
+    if(NW <= 2) for(int k = 0; k < NW; k++) cmask_pf[k] = C.ed[cs].mask[k];
+    // the fan in list order
+    int fe[N], oth[N]; double fw[N]; uint32_t id[N];
+    {
+        int e = A ? first_out(x) : first_in(x);
+        ALD_UNROLL for(int k = 0; k < N; k++) {
+            if(e < 0) bad = 1;
+            const int es = e >= 0 ? e : 0;
+            const double w = H.ed[es].w; const uint64_t lw = *(const uint64_t*)&H.ed[es].lk;
+            fe[k] = es; fw[k] = w; id[k] = H.eid[es];
+            oth[k] = A ? (int)((lw >> 16) & 0xFFFF) : (int)(lw & 0xFFFF);
+            e = A ? lk_next((uint32_t)(lw >> 48)) : lk_next((uint32_t)((lw >> 32) & 0xFFFF));
+        }
+        if(e >= 0) bad = 1;                       // (the caller chose N from the degree)
+    }
+    const uint64_t lwc = *(const uint64_t*)&H.ed[cs].lk;
+    const int far = uni(A ? (int)(lwc & 0xFFFF) : (int)((lwc >> 16) & 0xFFFF));
+    const int c_next = A ? lk_next((uint32_t)(lwc >> 48)) : lk_next((uint32_t)((lwc >> 32) & 0xFFFF));     // c's successor in far's list
+#ifndef ALD_EMU
+    // lane j asks for the record of fan edge j
+    double pf_med, pf_conf, pf_abd; int pf_mei, pf_st, pf_cnt, pf_id; uint32_t pf_ns; uint64_t pf_mask0;
+    { const int f = pick<N>(fe, lane < N ? lane : 0); pf_med = C.ed[f].med; pf_conf = C.ed[f].econf; pf_abd = C.ed[f].s0abd; pf_mei = C.ed[f].mei; pf_st = C.ed[f].estrand;
+      pf_cnt = C.ed[f].ecount; pf_id = C.ed[f].s0id; pf_ns = C.ed[f].sp_len; pf_mask0 = C.ed[f].mask[0]; }
+#endif
+    bool dupf = false;                            // two fan edges to one vertex: their relinks share a list -> sequential, in merge order, at the end
+    ALD_UNROLL for(int k = 0; k < N; k++) for(int k2 = 0; k2 < k; k2++) if(oth[k] == oth[k2]) dupf = true;
+    dupf = uni(dupf);
+    // ---- balance_vertex(x) on the gathered weights (scallop.cc:2486-2576), pair weights
+    double wcen = H.ed[cs].w;
+    if(!(wcen >= mw - kSMIN)) bad = 1;
+    double sfan0 = 0;
+    ALD_UNROLL for(int k = 0; k < N; k++) { if(!(fw[k] >= mw - kSMIN)) bad = 1; sfan0 += fw[k]; }
+    {
+        double scen0 = 0; scen0 += wcen;
+        const double w_in = A ? scen0 : sfan0, w_out = A ? sfan0 : scen0;
+        const double bw = sqrt(w_in * w_out);
+        const double r_in = bw / w_in, r_out = bw / w_out;
+        double m_cen = 0, m_fan = 0;
+        { double wy = wcen * (A ? r_in : r_out); if(wy < mw) { m_cen += mw - wy; wy = mw; } wcen = wy; }
+        ALD_UNROLL for(int k = 0; k < N; k++) { double wy = fw[k] * (A ? r_out : r_in); if(wy < mw) { m_fan += mw - wy; wy = mw; } fw[k] = wy; }
+        const double m1 = A ? m_cen : m_fan, m2 = A ? m_fan : m_cen;
+        if(m1 > m2) { if(A) fw[0] = fw[0] + m1 - m2; else wcen = wcen + m1 - m2; }
+        else if(m1 < m2) { if(A) wcen = wcen + m2 - m1; else fw[0] = fw[0] + m2 - m1; }
+        const double wc = wcen;
+        ALD_UNROLL for(int k = 0; k < N; k++) { const double w2 = fw[k]; fw[k] = A ? (wc <= w2 ? wc : w2) : (w2 <= wc ? w2 : wc); }
+    }
+    // ---- merge order = ascending creation id; pair weights in that order; the weight c starts with
+    int inv[N];                                   // list position -> merge index
+    ALD_UNROLL for(int k = 0; k < N; k++) { int r = 0; ALD_UNROLL for(int k2 = 0; k2 < N; k2++) r += (id[k2] < id[k]) ? 1 : 0; inv[k] = r; }
+    double pw[N]; int fq[N], oq[N];               // merge index -> pair weight, fan edge, its other endpoint
+    ALD_UNROLL for(int q = 0; q < N; q++) { double w = fw[0]; int f = fe[0], o = oth[0]; ALD_UNROLL for(int k = 1; k < N; k++) if(inv[k] == q) { w = fw[k]; f = fe[k]; o = oth[k]; } pw[q] = w; fq[q] = f; oq[q] = o; }
+    double mdc = 0;
+    ALD_UNROLL for(int q = 0; q < N; q++) { if(!(pw[q] >= mw - kSMIN)) bad = 1; mdc = (q == 0) ? pw[q] : mdc + pw[q]; }
+    // ---- what is left of c before merge q, whether merge q cuts a piece off, the id of its merged edge
+    const int id0 = uni(HC.next_id);
+    double wcur_q[N], rem_q[N]; int sc_q[N], nid_q[N];
+    {
+        double wcur = mdc, rem = 0; bool sc = false; int nid = id0;
+        ALD_UNROLL for(int q = 0; q < N; q++) {
+            if(q > 0) { if(!sc) bad = 1; wcur = rem; nid += 1; }                // (a consumed c in front of the last merge)
+            sc = !(fabs(wcur - pw[q]) <= kSMIN);
+            rem = wcur; if(sc) { nid += 1; rem = wcur - pw[q]; if(rem <= mw) rem = mw; }
+            if(nid - (sc ? 1 : 0) >= EID_LIMIT) bad = 1;
+            wcur_q[q] = wcur; rem_q[q] = rem; sc_q[q] = sc ? 1 : 0; nid_q[q] = nid;
+        }
+        if(sc) bad = 1;                                                            // c keeps a remainder: the reference asserts on the degree of x
+    }
+    // ---- the sums around x at merge q and the vertex-weight chain (scallop.cc:2242-2378)
+    double r1_q[N]; double vwt = vw0;
+    ALD_UNROLL for(int q = 0; q < N; q++) {
+        double sfan = 0;
+        ALD_UNROLL for(int k = 0; k < N; k++) if(inv[k] >= q) sfan += fw[k];     // not merged yet, list order
+        const bool sc = sc_q[q] != 0; const double ww = pw[q], wcur = wcur_q[q];
+        double sc_side = 0; sc_side += sc ? rem_q[q] : wcur; if(sc) sc_side += ww;
+        const double sum = A ? (sc_side + sfan) * 0.5 : (sfan + sc_side) * 0.5;
+        const double wc0 = sc ? ww : wcur;
+        const double r1 = A ? vwt * (wc0 + ww) * 0.5 / sum : vwt * (ww + wc0) * 0.5 / sum;
+        vwt = vwt - r1; r1_q[q] = r1;
+    }
+    if(!(cntc > 0)) bad = 1;
+    // ---- far's list (read only): the place of every merged edge -- behind the last entry whose key does not exceed its own (the old
+    // entries carry older ids; new ones with the same key follow each other in merge order) -- and c's predecessor, in one walk
+    const bool counted = uni(A ? (far == 0 && !HC.special_linked) : (far == HC.sinkp && !HC.special_linked));      // out(source) / in(sink) are only counted
+    uint32_t key[N]; int pred[N], succ[N]; int pc = -1;
+    ALD_UNROLL for(int k = 0; k < N; k++) { key[k] = A ? tkey((uint32_t)oth[k]) : (uint32_t)oth[k]; pred[k] = -1; succ[k] = -1; }
+    if(!counted) {
+        int placed[N]; ALD_UNROLL for(int k = 0; k < N; k++) placed[k] = 0;
+        bool seen_c = false; int last = -1, guard = MAXE;
+        int cur = A ? first_out(far) : first_in(far);
+        while(uni(cur >= 0) && guard-- > 0) {
+            const uint64_t w = *(const uint64_t*)&H.ed[cur].lk;
+            const int nx = A ? lk_next((uint32_t)(w >> 48)) : lk_next((uint32_t)((w >> 32) & 0xFFFF));
+            if(cur == cs) { pc = last; seen_c = true; }
+            else {
+                const uint32_t kc = A ? tkey((uint32_t)((w >> 16) & 0xFFFF)) : (uint32_t)(w & 0xFFFF);
+                ALD_UNROLL for(int k = 0; k < N; k++) if(!placed[k] && kc > key[k]) { placed[k] = 1; pred[k] = last; succ[k] = cur; }
+                last = cur;
+            }
+            bool all = seen_c; ALD_UNROLL for(int k = 0; k < N; k++) all = all && placed[k];
+            if(uni(all)) break;
+            cur = nx;
+        }
+        ALD_UNROLL for(int k = 0; k < N; k++) if(!placed[k]) pred[k] = last;       // behind everything
+        if(!seen_c || guard <= 0) bad = 1;
+    }
+    // ---- the decision: nothing has been written so far
+    {
+        bool cnt_bad = false;
+#ifdef ALD_EMU
+        for(int k = 0; k < N; k++) if(!(C.ed[fe[k]].ecount > 0)) cnt_bad = true;
+#else
+        cnt_bad = lane < N && !(pf_cnt > 0);
+#endif
+#ifdef ALD_EMU_COUNT
+        if(cnt_bad || bad) g_cnt_fix_declined++; else { g_cnt_star[N]++; g_cnt_fix[N]++; }
+#endif
+        if(wballot(cnt_bad) != 0 || uni(bad) != 0) return false;
+    }
+    // ---- lane j: fan edge j becomes merged edge inv[j]
+    bool multi = false;
+    for(int j = lane; j < N; j += ALD_WAVE) {
+        const int q = pick<N>(inv, j), f = pick<N>(fe, j), o = pick<N>(oth, j);
+        const double ww = pick<N>(fw, j), wcur = pick<N>(wcur_q, q), r1 = pick<N>(r1_q, q);
+        const bool sc = pick<N>(sc_q, q) != 0; const int nid = pick<N>(nid_q, q);
+        const double wc0 = sc ? ww : wcur;
+        const double medc1 = sc ? medc * ww / wcur : medc;
+#ifdef ALD_EMU
+        const double pf_med = C.ed[f].med, pf_conf = C.ed[f].econf, pf_abd = C.ed[f].s0abd; const int pf_mei = C.ed[f].mei, pf_st = C.ed[f].estrand, pf_id = C.ed[f].s0id;
+        const uint32_t pf_ns = C.ed[f].sp_len; const uint64_t pf_mask0 = C.ed[f].mask[0];
+#endif
+        if(nsc == 1 && pf_ns == 1) {          // one supporting sample on both sides: intersect_samples' inline case
+            if(pf_id == idc) { const double xa = A ? abc : pf_abd, ya = A ? pf_abd : abc; const double mn = (ya < xa) ? ya : xa; C.ed[f].sp_off = 0; C.ed[f].ecount = 1; C.ed[f].eabd = 0.0 + mn; C.ed[f].s0abd = mn; }
+            else { C.ed[f].sp_off = 0; C.ed[f].sp_len = 0; C.ed[f].ecount = 0; C.ed[f].eabd = 0; C.ed[f].s0id = 0; C.ed[f].s0abd = 0; }
+        } else multi = true;                                                  // pool allocation: sequential, below
+        C.ed[f].econf = A ? cc + pf_conf : pf_conf + cc;
+        { const int sty = A ? pf_st : stc, stx = A ? stc : pf_st; C.ed[f].estrand = (uint8_t)(sty != 0 ? sty : stx); }
+        for(int k = 0; k < NW; k++) { uint64_t mk = (NW <= 2 ? cmask_pf[NW <= 2 ? k : 0] : C.ed[cs].mask[k]) | (k == 0 ? pf_mask0 : C.ed[f].mask[k]); if(ov >= 0 && (ov >> 6) == k) mk |= (1ull << (ov & 63)); C.ed[f].mask[k] = mk; }
+        const int mi = A ? rt - lt + meic + pf_mei : rt - lt + pf_mei + meic;
+        C.ed[f].med = A ? mi * r1 + medc1 + pf_med : mi * r1 + pf_med + medc1; C.ed[f].mei = mi;
+        H.eid[f] = (EID)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
+        if(A) H.ed[f].lk.es = (IDX)far; else H.ed[f].lk.et = (IDX)far;
+        if(!dupf) { if(A) relink_in_lane(o, f, (uint32_t)far); else relink_out_lane(o, f, tkey((uint32_t)far)); }
+        if(!counted) {
+            // neighbours in (key) order among the new edges; a run of new edges behind the same old entry is chained
+            const uint32_t kj = pick<N>(key, j); const int pj = pick<N>(pred, j), sj = pick<N>(succ, j);
+            int rj = 0; ALD_UNROLL for(int k = 0; k < N; k++) rj += (key[k] < kj || (key[k] == kj && inv[k] < q)) ? 1 : 0;
+            int prv_pred = -2, nxt_pred = -2, nxt_f = -1;                    // (-2: no such neighbour; a pred is >= -1)
+            ALD_UNROLL for(int k = 0; k < N; k++) { int rk = 0; ALD_UNROLL for(int k2 = 0; k2 < N; k2++) rk += (key[k2] < key[k] || (key[k2] == key[k] && inv[k2] < inv[k])) ? 1 : 0;
+                if(rk == rj - 1) prv_pred = pred[k]; if(rk == rj + 1) { nxt_pred = pred[k]; nxt_f = fe[k]; } }
+            const bool first_of_gap = prv_pred != pj, last_of_gap = nxt_pred != pj;
+            const IDX nx = last_of_gap ? (sj < 0 ? NIL : (IDX)sj) : (IDX)nxt_f;
+            if(A) H.ed[f].lk.onx = nx; else H.ed[f].lk.inx = nx;
+            if(first_of_gap) { if(pj < 0) { if(A) H.out_head[far] = (IDX)f; else H.in_head[far] = (IDX)f; } else { if(A) H.ed[pj].lk.onx = (IDX)f; else H.ed[pj].lk.inx = (IDX)f; } }
+        }
+    }
+    const bool any_multi = wballot(multi) != 0;
+    wsync();
+    // ---- lane 0: c leaves far's list (unless a merged edge took its predecessor's link), the counters, what is inherently ordered
+    if(lane == 0) {
+        IDX *deg = A ? &H.out_deg[far] : &H.in_deg[far];
+        const int dg = (int)*deg - 1;
+        if(!counted) {
+            bool taken = false; ALD_UNROLL for(int k = 0; k < N; k++) if(pred[k] == pc) taken = true;
+            if(!taken) { const IDX nx = c_next < 0 ? NIL : (IDX)c_next; if(pc < 0) { if(A) H.out_head[far] = nx; else H.in_head[far] = nx; } else { if(A) H.ed[pc].lk.onx = nx; else H.ed[pc].lk.inx = nx; } }
+            if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; }     // as unlink_in / unlink_out
+        }
+        *deg = (IDX)(dg + N);
+        C.vx[x].vw = vwt;
+        if(dupf || any_multi || uni(HC.hl_n) != 0) {
+            ALD_UNROLL for(int q = 0; q < N; q++) {
+                const int f = uni(fq[q]);
+                if(dupf) { if(A) relink_in(uni(oq[q]), f, (uint32_t)far); else relink_out(uni(oq[q]), f, tkey((uint32_t)far)); }
+                if(any_multi) { const uint32_t nsf = uni(C.ed[f].sp_len); if(!(uni(nsc) == 1 && nsf == 1)) { if(!(A ? intersect_samples(cs, f, f) : intersect_samples(f, cs, f))) break; } }
+                if(A) hs_replace2(cs, f, f); else hs_replace2(f, cs, f);
+            }
+        }
+        HC.next_id = nid_q[N - 1] + 1;
+        hs_remove(cs);
+        // remove_edge(c); x is left without edges
+        H.ed[cs].lk.es = NIL; H.hflag[cs] = 0;
+        { int fh = uni(HC.free_head); H.ed[cs].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = cs; HC.free_cnt = uni(HC.free_cnt) + 1; }
+        H.in_head[x] = NIL; H.out_head[x] = NIL; H.in_deg[x] = 0; H.out_deg[x] = 0; H.nz[x] = 0;
+    }
+    wsync();
+    PROF_ADD(PF_T_MERGE_ADD);
+    return true;
+}
+template<bool A> ALD_INL bool star_fixed_any(int x, int n)
+{
+#if ALD_STARFIX_MAX >= 2
+    if(n == 2) return uni(star_fixed<A, 2>(x));
+#endif
+#if ALD_STARFIX_MAX >= 3
+    if(n == 3) return uni(star_fixed<A, 3>(x));
+#endif
+#if ALD_STARFIX_MAX >= 4
+    if(n == 4) return uni(star_fixed<A, 4>(x));
+#endif
+    return false;
+}
 // wave-level entry (ALL lanes): fans of up to STAR_MAX edges go lane-parallel, anything else through the sequential form on lane 0
 ALD_INL void decompose_trivial_vertex_wave(int x)
 {
     x = uni(x);
     const int nin = uni(H.in_deg[x]), nout = uni(H.out_deg[x]);
+#if ALD_STARFIX_MAX >= 2
+    if(nin == 1 && nout >= 2 && nout <= ALD_STARFIX_MAX) { if(star_fixed_any<true>(x, nout)) return; }
+    else if(nout == 1 && nin >= 2 && nin <= ALD_STARFIX_MAX) { if(star_fixed_any<false>(x, nin)) return; }
+#endif
 #ifdef ALD_STAR_SEQ_MAX
     // experiment: the smallest fans through the sequential form on lane 0 (no hand-overs at all)
     if((nin == 1 && nout >= 1 && nout <= ALD_STAR_SEQ_MAX) || (nout == 1 && nin >= 1 && nin <= ALD_STAR_SEQ_MAX)) { if(lane_id() == 0) decompose_trivial_vertex(x); wsync(); return; }
@@ -2903,6 +3144,13 @@ ALD_FN void run_graph()
     finish_graph();
 }
 
+#ifdef ALD_ISA_PROBE
+// diagnostic only (tools/isa_stats.py with ISA_EXTRA=-DALD_ISA_PROBE): hot inlined pieces as functions of their own, so that their instruction mix can be read
+__attribute__((used)) ALD_FN void probe_kill_edge_wave(int e) { kill_edge_wave(e); }
+__attribute__((used)) ALD_FN int probe_eval_smallest(int i, double *r) { double rr = 0; int e = eval_smallest(i, rr); *r = rr; return e; }
+__attribute__((used)) ALD_FN void probe_wave_argmin(double *r, int *v) { double rr = *r; int vv = *v; wave_argmin(rr, vv); *r = rr; *v = vv; }
+__attribute__((used)) ALD_FN bool probe_sweep_smallest(double r) { return sweep_smallest(r); }
+#endif
 // one wave's whole life: pull graphs of this size class from the shared counter until the class is drained
 ALD_INL void wave_main(ALD_GLOBAL const KernelArgs *A, int block)
 {
