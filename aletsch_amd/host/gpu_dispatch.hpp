@@ -7,11 +7,11 @@
 // aletsch::gpu_assembly_queue keeps that call shape for the pool tasks -- submit(gx, hx, sid) where the reference has
 // `scallop sx(gx, hx, pa); sx.assemble(); ... tm.add(ts)` -- and batches ACROSS tasks and clusters:
 //
-//   pool threads --submit()--> per-thread chunk --full--> ready chunks --> [pack thread: ald_batch_add_packed into a free batch]
+//   pool threads --submit()--> per-thread chunk --full--> ready chunks --> [pack threads: ald_batch_add_packed into a free batch]
 //        --> [GPU thread: upload, kernel, download] --> [merge thread: ald_tset_add_batch] --> sink
 //
 // A submitting thread converts its graph and appends it to ITS OWN chunk of packed arrays (no shared lock on that path); a full
-// chunk is handed over with one short critical section and gets the next run of tickets.  The pack thread gathers chunks into a
+// chunk is handed over with one short critical section and gets the next run of tickets.  A pack thread gathers chunks into a
 // batch of `batch_graphs`; `slots` batches rotate through the pack, GPU and merge stages, so staging, kernel and merge overlap.  Graphs
 // are merged into the sink in ticket order, batch after batch -- the same per-bucket sequence of trans_item::merge calls as a
 // serial run over the tickets.  With one submitting thread tickets are the submission order and the result is bit-identical to
@@ -19,7 +19,7 @@
 // `mylock` produced.
 //
 // Several MI355X in ONE process (the reference's own shape: one process, one pool -- meta/incubator.cc:609-637): give the queue a device
-// list.  Every device gets its own slots and its own GPU thread; the pack thread deals batches to the least loaded device; the merge
+// list.  Every device gets its own slots and its own GPU thread; a pack thread deals a batch to the least loaded device; the merge
 // thread takes finished batches in the order they were CUT (= ticket order), whichever device finishes first, so the merged set does
 // not depend on the number of devices.  No collective is involved: bundles are independent, the result set lives in host memory.
 //
@@ -32,6 +32,14 @@
 #include <deque>
 #include <memory>
 #include <chrono>
+#include <atomic>
+
+#ifndef ALD_CONVERT_AHEAD_EDGES
+#define ALD_CONVERT_AHEAD_EDGES 12     /* edge objects asked for this many edges ahead of the walk over gr.edges() */
+#endif
+#ifndef ALD_CONVERT_AHEAD_NODES
+#define ALD_CONVERT_AHEAD_NODES 6      /* first nodes of an edge's sample set / abundance map, this many edges ahead of the copy */
+#endif
 
 namespace aletsch {
 
@@ -57,27 +65,42 @@ struct packed_chunk {
     // The same as stage_graph() + append(), without the staged_graph in between: ONE walk over gr.edges(), a counting sort into CSR
     // rows (rows keep the walk's order, i.e. creation order; inside a row a stable insertion by target: rows hold a handful of edges),
     // every field written straight behind the chunk's last graph.  `tmp` is the calling thread's scratch, kept across graphs.
-    struct scratch { std::vector<int32_t> row, at, ord, dst; std::vector<const void*> eh; };
+    // The walk is bound by cache misses on the reference's objects -- an edge object, its edge_info, the first node of its sample
+    // set and of its abundance map are four heap blocks --, so every loop asks for what it will read a few edges ahead: the edge
+    // objects while it walks gr.edges() (a second iterator runs in front), the edge_info records (ONE get_edge_info per edge, the
+    // addresses are kept) while it sorts, the container nodes while it copies.
+    struct scratch { std::vector<int32_t> row, at, ord, dst, perm; std::vector<const void*> eh, inf; };
     template<class SpliceGraph, class HyperSet>
     void append_graph(SpliceGraph &gr, const HyperSet &hs, int sample, scratch &tmp)
     {
         typedef typename std::decay<decltype(*gr.edges().first)>::type edge_t;       // edge_descriptor (a pointer in the reference)
-        const int V = (int)gr.num_vertices();
         static_assert(std::is_pointer<edge_t>::value, "edge_descriptor is expected to be a pointer (graph/edge_base.h)");
-        std::vector<const void*> &eh = tmp.eh;
-        eh.clear(); tmp.dst.clear(); tmp.row.assign((size_t)V + 1, 0);
-        std::vector<int32_t> &src = tmp.ord;                                         // source of edge k (walk order), then reused as the CSR permutation
+        typedef typename std::decay<decltype(gr.get_edge_info(*gr.edges().first))>::type einfo_t;
+        const int V = (int)gr.num_vertices();
+        std::vector<const void*> &eh = tmp.eh, &inf = tmp.inf;
+        eh.clear(); inf.clear(); tmp.dst.clear(); tmp.row.assign((size_t)V + 1, 0);
+        std::vector<int32_t> &src = tmp.ord;                                         // source of edge k (walk order)
         src.clear();
-        { auto pe = gr.edges(); for(auto it = pe.first; it != pe.second; ++it) { const int a = (*it)->source(), b = (*it)->target(); eh.push_back((const void*)*it); src.push_back(a); tmp.dst.push_back(b); tmp.row[(size_t)a + 1]++; } }
+        {
+            auto pe = gr.edges(); auto ahead = pe.first;
+            for(int i = 0; i < ALD_CONVERT_AHEAD_EDGES && ahead != pe.second; i++, ++ahead) __builtin_prefetch((const void*)*ahead);
+            for(auto it = pe.first; it != pe.second; ++it) {
+                if(ahead != pe.second) { __builtin_prefetch((const void*)*ahead); ++ahead; }
+                const int a = (*it)->source(), b = (*it)->target();
+                const einfo_t *p = &gr.get_edge_info(*it); __builtin_prefetch((const void*)p); __builtin_prefetch((const char*)(const void*)p + 64);
+                eh.push_back((const void*)*it); inf.push_back((const void*)p); src.push_back(a); tmp.dst.push_back(b); tmp.row[(size_t)a + 1]++;
+            }
+        }
         const int E = (int)eh.size();
         for(int i = 0; i < V; i++) tmp.row[(size_t)i + 1] += tmp.row[(size_t)i];
         tmp.at.assign(tmp.row.begin(), tmp.row.end() - 1);
-        std::vector<int32_t> perm((size_t)E);                                        // CSR position -> walk position (= scallop's edge index, graph_base.cc:139-153)
+        tmp.perm.resize((size_t)E);                                                  // CSR position -> walk position (= scallop's edge index, graph_base.cc:139-153)
+        int32_t *perm = tmp.perm.data(); const int32_t *dstp = tmp.dst.data();
         for(int k = 0; k < E; k++) {
             const int a = src[(size_t)k]; int pos = tmp.at[(size_t)a]++;
             const int lo = tmp.row[(size_t)a];
-            while(pos > lo && tmp.dst[(size_t)perm[(size_t)pos - 1]] > tmp.dst[(size_t)k]) { perm[(size_t)pos] = perm[(size_t)pos - 1]; pos--; }      // stable: equal targets keep walk order
-            perm[(size_t)pos] = k;
+            while(pos > lo && dstp[perm[pos - 1]] > dstp[k]) { perm[pos] = perm[pos - 1]; pos--; }      // stable: equal targets keep walk order
+            perm[pos] = k;
         }
         g_nv.push_back(V); g_ne.push_back(E); graph_strand.push_back(gr.strand); sid.push_back((int32_t)sample); raw_dist.push_back(-1); nphase.push_back(0); rphase_offset.push_back(0);
         vertex_offset.insert(vertex_offset.end(), tmp.row.begin(), tmp.row.end());
@@ -85,14 +108,19 @@ struct packed_chunk {
         edge_target.resize(e0 + (size_t)E); edge_weight.resize(e0 + (size_t)E); edge_strand.resize(e0 + (size_t)E); edge_abd.resize(e0 + (size_t)E); edge_count.resize(e0 + (size_t)E); edge_rank.resize(e0 + (size_t)E);
         edge_sample_offset.resize(s0 + (size_t)E + 1); edge_sample_offset[s0] = 0;
         const size_t smp0 = sample_id.size();
+        int32_t *o_tgt = edge_target.data() + e0, *o_cnt = edge_count.data() + e0, *o_rank = edge_rank.data() + e0, *o_so = edge_sample_offset.data() + s0 + 1;
+        double *o_w = edge_weight.data() + e0, *o_abd = edge_abd.data() + e0; uint8_t *o_st = edge_strand.data() + e0;
+        const int AHEAD = ALD_CONVERT_AHEAD_NODES;
+        for(int q = 0; q < AHEAD && q < E; q++) { const einfo_t &ea = *(const einfo_t*)inf[(size_t)perm[q]]; if(!ea.samples.empty()) __builtin_prefetch((const void*)&*ea.samples.begin()); if(!ea.spAbd.empty()) __builtin_prefetch((const void*)&*ea.spAbd.begin()); }
         for(int q = 0; q < E; q++) {
-            const int k = perm[(size_t)q]; const edge_t e = (edge_t)const_cast<void*>(eh[(size_t)k]);
-            const auto &ei = gr.get_edge_info(e);
-            edge_target[e0 + (size_t)q] = tmp.dst[(size_t)k]; edge_weight[e0 + (size_t)q] = gr.get_edge_weight(e); edge_strand[e0 + (size_t)q] = (uint8_t)ei.strand; edge_abd[e0 + (size_t)q] = ei.abd;
-            edge_count[e0 + (size_t)q] = (int32_t)ei.count; edge_rank[e0 + (size_t)q] = k;
+            if(q + AHEAD < E) { const einfo_t &ea = *(const einfo_t*)inf[(size_t)perm[q + AHEAD]]; if(!ea.samples.empty()) __builtin_prefetch((const void*)&*ea.samples.begin()); if(!ea.spAbd.empty()) __builtin_prefetch((const void*)&*ea.spAbd.begin()); }
+            const int k = perm[q]; const edge_t e = (edge_t)const_cast<void*>(eh[(size_t)k]);
+            const einfo_t &ei = *(const einfo_t*)inf[(size_t)k];
+            o_tgt[q] = dstp[k]; o_w[q] = gr.get_edge_weight(e); o_st[q] = (uint8_t)ei.strand; o_abd[q] = ei.abd;
+            o_cnt[q] = (int32_t)ei.count; o_rank[q] = k;
             if(ei.samples.size() == 1 && ei.spAbd.size() == 1 && ei.spAbd.begin()->first == *ei.samples.begin()) { sample_id.push_back(*ei.samples.begin()); sample_abd.push_back(ei.spAbd.begin()->second); }     // the common case without a hash lookup
             else for(int sp : ei.samples) { sample_id.push_back(sp); auto f = ei.spAbd.find(sp); sample_abd.push_back(f == ei.spAbd.end() ? 0.0 : f->second); }
-            edge_sample_offset[s0 + (size_t)q + 1] = (int32_t)(sample_id.size() - smp0);
+            o_so[q] = (int32_t)(sample_id.size() - smp0);
         }
         const size_t v0 = vertex_weight.size();
         vertex_weight.resize(v0 + (size_t)V); vertex_lpos.resize(v0 + (size_t)V); vertex_rpos.resize(v0 + (size_t)V); vertex_type.resize(v0 + (size_t)V);
@@ -142,15 +170,17 @@ class gpu_assembly_queue {
 public:
     // sink: the shared result set (the reference's `tmerge`); skip_single_exon: cfg.skip_single_exon_transcripts (assembler.cc:1117);
     // chunk_graphs: graphs a submitting thread collects before it hands them over (capped by batch_graphs)
-    gpu_assembly_queue(const Parameters &cfg, ald_tset *sink, bool skip_single_exon = false, int device = 0, int batch_graphs = 65536, int slots = 4, int chunk_graphs = 2048)
-        : gpu_assembly_queue(cfg, sink, skip_single_exon, std::vector<int>(1, device), batch_graphs, slots, chunk_graphs) {}
-    // devices: HIP device ordinals (an ordinal may repeat: two GPU threads then share that device); slots: batch objects PER device
-    gpu_assembly_queue(const Parameters &cfg, ald_tset *sink, bool skip_single_exon, const std::vector<int> &devices, int batch_graphs = 65536, int slots = 4, int chunk_graphs = 2048)
+    gpu_assembly_queue(const Parameters &cfg, ald_tset *sink, bool skip_single_exon = false, int device = 0, int batch_graphs = 65536, int slots = 4, int chunk_graphs = 2048, int pack_threads = 2)
+        : gpu_assembly_queue(cfg, sink, skip_single_exon, std::vector<int>(1, device), batch_graphs, slots, chunk_graphs, pack_threads) {}
+    // devices: HIP device ordinals (an ordinal may repeat: two GPU threads then share that device); slots: batch objects PER device;
+    // pack_threads: threads that copy handed-over chunks into a batch (batches are CUT one at a time, in ticket order, and packed side by side)
+    gpu_assembly_queue(const Parameters &cfg, ald_tset *sink, bool skip_single_exon, const std::vector<int> &devices, int batch_graphs = 65536, int slots = 4, int chunk_graphs = 2048, int pack_threads = 2)
         : sink_(sink), skip_(skip_single_exon), batch_graphs_(batch_graphs < 1 ? 1 : batch_graphs)
     {
         if(!sink) throw std::invalid_argument("gpu_assembly_queue: null sink");
         if(devices.empty()) throw std::invalid_argument("gpu_assembly_queue: empty device list");
         if(slots < 1) slots = 1;
+        if(pack_threads < 1) pack_threads = 1;
         const int ndev = (int)devices.size();
         chunk_graphs_ = chunk_graphs < 1 ? 1 : chunk_graphs; if(chunk_graphs_ > batch_graphs_) chunk_graphs_ = batch_graphs_;
         ready_cap_ = (long)batch_graphs_ * (slots * ndev + 1);
@@ -162,7 +192,7 @@ public:
             if(rc != ALD_OK) { for(auto &q : slots_) if(q.b) ald_batch_destroy(q.b); throw gpu_error(rc, "ald_batch_create"); }
         }
         cv_gpu_.reset(new std::condition_variable[(size_t)ndev]);
-        pack_thread_ = std::thread([this] { pack_loop(); });
+        for(int t = 0; t < pack_threads; t++) pack_threads_.emplace_back([this] { pack_loop(); });
         for(int d = 0; d < ndev; d++) gpu_threads_.emplace_back([this, d] { gpu_loop(d); });
         merge_thread_ = std::thread([this] { merge_loop(); });
     }
@@ -171,7 +201,9 @@ public:
         try { drain(); } catch(...) {}
         { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
         cv_pack_.notify_all(); for(size_t d = 0; d < gpu_q_.size(); d++) cv_gpu_[d].notify_all(); cv_merge_.notify_all();
-        pack_thread_.join(); for(auto &t : gpu_threads_) t.join(); merge_thread_.join();
+        for(auto &t : pack_threads_) t.join();
+        for(auto &t : gpu_threads_) t.join();
+        merge_thread_.join();
         for(auto &s : slots_) if(s.b) ald_batch_destroy(s.b);
     }
     gpu_assembly_queue(const gpu_assembly_queue &) = delete;
@@ -232,7 +264,7 @@ public:
             if(kv.second->c.n() > 0) { packed_chunk part; std::swap(part, kv.second->c); push_chunk(std::move(part)); }
         }
         flush_ = true; cv_pack_.notify_all();
-        while(!ready_.empty() || gathering_ || in_flight_ > 0) cv_done_.wait(lk);      // (after an error the stages still run dry: batches are dropped, not merged)
+        while(!ready_.empty() || gathering_ > 0 || in_flight_ > 0) cv_done_.wait(lk);      // (after an error the stages still run dry: batches are dropped, not merged)
         flush_ = false;
         if(err_) throw gpu_error(err_, err_msg_.c_str());
     }
@@ -249,13 +281,20 @@ private:
     struct slot { ald_batch *b = nullptr; std::vector<int32_t> sid; long first = 0; int state = FREE; int dev = 0; bool done = false; };
     struct lane { std::mutex m; packed_chunk c; packed_chunk::scratch tmp; };
 
+    // A thread's lane, looked up once: every later submit() of the thread finds it in thread-local storage (the shared map and its lock
+    // were taken once per GRAPH before -- the only lock all submitters shared).  The queue's serial number tells a new queue at the
+    // address of a destroyed one from the old one.
     lane *my_lane()
     {
+        static thread_local const void *tl_queue = nullptr; static thread_local unsigned long tl_serial = 0; static thread_local lane *tl_lane = nullptr;
+        if(tl_queue == (const void*)this && tl_serial == serial_) return tl_lane;
         std::lock_guard<std::mutex> lk(m_);
         std::unique_ptr<lane> &p = lanes_[std::this_thread::get_id()];
         if(!p) p.reset(new lane());
-        return p.get();
+        tl_queue = (const void*)this; tl_serial = serial_; tl_lane = p.get();
+        return tl_lane;
     }
+    static unsigned long next_serial() { static std::atomic<unsigned long> n(0); return ++n; }
     void push_chunk(packed_chunk &&c)                             // m_ held
     {
         c.first = next_; next_ += c.n(); ready_graphs_ += c.n();
@@ -284,7 +323,7 @@ private:
                 }
                 long got = 0;
                 while(!ready_.empty() && got < batch_graphs_) { got += ready_.front().n(); take.push_back(std::move(ready_.front())); ready_.pop_front(); }
-                ready_graphs_ -= got; gathering_ = true; slots_[(size_t)i].state = BUSY; slots_[(size_t)i].done = false; batches_++;
+                ready_graphs_ -= got; gathering_++; slots_[(size_t)i].state = BUSY; slots_[(size_t)i].done = false; batches_++;
                 dev_load_[(size_t)slots_[(size_t)i].dev]++; cut_order_.push_back(i);                      // merged in the order the batches are cut
                 cv_space_.notify_all();
             }
@@ -298,7 +337,7 @@ private:
             std::lock_guard<std::mutex> lk(m_);
             if(rc != ALD_OK) fail(rc, "ald_batch_add_packed");
             t_pack_ += std::chrono::duration<double>(t1 - t0).count();
-            gathering_ = false; in_flight_++;
+            gathering_--; in_flight_++;
             gpu_q_[(size_t)S.dev].push_back(i); cv_gpu_[(size_t)S.dev].notify_one();
         }
     }
@@ -356,16 +395,16 @@ private:
         }
     }
 
-    ald_tset *sink_; bool skip_; int batch_graphs_, chunk_graphs_ = 1; long ready_cap_ = 0;
+    ald_tset *sink_; bool skip_; int batch_graphs_, chunk_graphs_ = 1; long ready_cap_ = 0; const unsigned long serial_ = next_serial();
     mutable std::mutex m_;
     std::condition_variable cv_pack_, cv_merge_, cv_done_, cv_space_;
     std::unique_ptr<std::condition_variable[]> cv_gpu_;           // one per device slot
     std::vector<slot> slots_; std::vector<std::deque<int>> gpu_q_; std::vector<int> dev_load_; std::deque<int> cut_order_; std::deque<packed_chunk> ready_;
     std::map<std::thread::id, std::unique_ptr<lane>> lanes_;
-    long next_ = 0, failed_ = 0, batches_ = 0, ready_graphs_ = 0; int in_flight_ = 0; bool stop_ = false, flush_ = false, gathering_ = false;
+    long next_ = 0, failed_ = 0, batches_ = 0, ready_graphs_ = 0; int in_flight_ = 0, gathering_ = 0; bool stop_ = false, flush_ = false;
     double t_pack_ = 0, t_gpu_ = 0, t_merge_ = 0;
     int err_ = 0; std::string err_msg_;
-    std::thread pack_thread_, merge_thread_; std::vector<std::thread> gpu_threads_;
+    std::thread merge_thread_; std::vector<std::thread> pack_threads_, gpu_threads_;
 };
 
 } // namespace aletsch

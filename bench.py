@@ -243,6 +243,29 @@ def sink_pipeline(A, pg, n, rounds=6):
     return out
 
 
+def dispatcher_rate(submitters=8):
+    """The call site an integrator would write: `submitters` pool threads hand reference-shaped objects (heap edges, std::set /
+    unordered_map members per edge) to aletsch::gpu_assembly_queue, which converts, batches, runs and merges them into one transcript
+    set (tools/dispatch_bench.cc, a C++ program over the C ABI; built here with g++ and run as a child process)."""
+    import re, shutil
+    exe = os.path.join(ROOT, "build", "dispatch_bench")
+    lib = os.path.join(ROOT, "aletsch_amd", "lib")
+    try:
+        if shutil.which("g++") is None:
+            return {"skipped": "no g++ on this box"}
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.run(["g++", "-std=c++11", "-O2", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "dispatch_bench.cc"), "-o", exe,
+                        "-L" + lib, "-laletsch_decomp", "-Wl,-rpath," + lib], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        r = subprocess.run([exe, "20000", "50", str(submitters), "32768", "4", "1", "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        m = re.search(r"measured: (\d+) graphs.*-> (\d+) graphs/s \(failed (\d+)", r.stdout)
+        if r.returncode != 0 or not m:
+            return {"skipped": "dispatch_bench failed", "rc": r.returncode, "tail": r.stdout[-300:]}
+        return {"workload": f"{m.group(1)} graphs of the headline shape as reference-shaped objects, {submitters} submitting threads -> gpu_assembly_queue (batches of 32768, 4 slots, 2 pack threads) -> one transcript set",
+                "bundles_per_s": float(m.group(2)), "failed_graphs": int(m.group(3)), "submitters": submitters}
+    except Exception as e:                                     # a diagnostic leg must not take the bench line down
+        return {"skipped": f"{type(e).__name__}: {e}"}
+
+
 def main() -> int:
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
@@ -542,6 +565,7 @@ def main() -> int:
                                    "bundles_per_s": args.graphs * args.steps / el_raw, "ms_per_step": el_raw / args.steps * 1e3, "kernel_ms": float(np.mean(kms_raw)),
                                    "vs_packed_form": (args.graphs * args.steps / el_raw) / (args.graphs * args.steps / elapsed_h2d)}
             sec["end_to_end_with_sink"] = sink_pipeline(A, pg, args.graphs)
+            sec["dispatcher"] = dispatcher_rate()
             line["secondary"] = sec
         if args.cpu_sample > 0 and world == 1:           # reported at N = 1 only
             line["cpu_baseline"], line["cpu_baseline_1t"] = cpu_baseline_legs(pg, args.cpu_sample)
