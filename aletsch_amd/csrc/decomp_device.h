@@ -82,7 +82,11 @@ struct Hot {
     struct alignas(16) EdgeHot { double w; Link lk; };     // splice_graph::ewrt + the links: 16 bytes, so a walk that needs the weight too
     EdgeHot  ed[MAXE];                          // (sums, balance, smallest-edge evaluation) still makes one LDS access per step
     EID      eid[MAXE];                         // creation id == scallop edge index (16 bits; ids beyond -> the graph moves up a class; 32 bits in the largest class)
-    IDX      in_head[MAXV], out_head[MAXV], in_deg[MAXV], out_deg[MAXV];
+    // the vertex record: list heads and degrees in ONE 8-byte word.  An LDS instruction occupies the CU's LDS pipeline for ~4.5 cycles
+    // whether it moves two bytes for one lane or eight for sixty-four (profiles/r03/zf_lds_issue_microbench.txt), and twenty resident
+    // waves keep that pipeline more than half busy: the sweeps read degrees and heads together, as one access instead of up to four.
+    struct alignas(8) VertexHot { IDX in_head, out_head, in_deg, out_deg; };
+    VertexHot vx[MAXV];
     uint8_t  nz[MAXV];                          // bit 0: scallop::nonzeroset membership; bits 1..5: router class of the vertex on the CURRENT graph (NZ_MEMO_*)
     uint8_t  hflag[MAXE];                       // HF_* (phasing occupancy / extend flags / protect)
 };
@@ -215,12 +219,12 @@ ALD_INL int slot_or_neg(IDX h) { return MAXE < 32768 ? (int)(int16_t)h : (h == N
 #else
 ALD_INL int slot_or_neg(IDX h) { return h == NIL ? -1 : (int)h; }
 #endif
-ALD_INL int u_first_in(int v) { return uni(slot_or_neg(H.in_head[v])); }
-ALD_INL int u_first_out(int v) { return uni(slot_or_neg(H.out_head[v])); }
+ALD_INL int u_first_in(int v) { return uni(slot_or_neg(H.vx[v].in_head)); }
+ALD_INL int u_first_out(int v) { return uni(slot_or_neg(H.vx[v].out_head)); }
 ALD_INL int u_next_in(int e) { return uni(slot_or_neg(H.ed[e].lk.inx)); }
 ALD_INL int u_next_out(int e) { return uni(slot_or_neg(H.ed[e].lk.onx)); }
-ALD_INL int first_in(int v) { return slot_or_neg(H.in_head[v]); }
-ALD_INL int first_out(int v) { return slot_or_neg(H.out_head[v]); }
+ALD_INL int first_in(int v) { return slot_or_neg(H.vx[v].in_head); }
+ALD_INL int first_out(int v) { return slot_or_neg(H.vx[v].out_head); }
 ALD_INL int next_in(int e) { return slot_or_neg(H.ed[e].lk.inx); }
 ALD_INL int next_out(int e) { return slot_or_neg(H.ed[e].lk.onx); }
 ALD_INL double in_weights(int v) { double w = 0; for(int e = first_in(v); e >= 0; e = next_in(e)) w += H.ed[e].w; return w; }    // splice_graph.cc:187-198
@@ -237,9 +241,9 @@ ALD_INL int lk_next(uint32_t f) { return slot_or_neg((IDX)f); }
 ALD_INL void link_in(int v, int e)
 {
     v = uni(v); e = uni(e);
-    if(v == uni(HC.sinkp) && !uni(HC.special_linked)) { H.in_deg[v]++; return; }
+    if(v == uni(HC.sinkp) && !uni(HC.special_linked)) { H.vx[v].in_deg++; return; }
     const uint32_t ks = uni(H.ed[e].lk.es), kid = uni(H.eid[e]);
-    IDX *pp = &H.in_head[v]; IDX cur = *pp;
+    IDX *pp = &H.vx[v].in_head; IDX cur = *pp;
     for(int guard = MAXE; uni(cur != NIL) && guard > 0; guard--) {      // (the guard only matters on a corrupted list: never spin)
         const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; const uint32_t cs = (uint32_t)(w & 0xFFFF);
         bool stop = cs > ks; if(uni(cs == ks)) stop = H.eid[cur] > kid;
@@ -247,16 +251,16 @@ ALD_INL void link_in(int v, int e)
         pp = &H.ed[cur].lk.inx; cur = (IDX)((w >> 32) & 0xFFFF);
     }
     H.ed[e].lk.inx = cur; *pp = (IDX)e;
-    H.in_deg[v]++;
+    H.vx[v].in_deg++;
 }
 ALD_INL void link_out(int v, int e)
 {
     v = uni(v); e = uni(e);
-    if(v == 0 && !uni(HC.special_linked)) { H.out_deg[v]++; return; }
+    if(v == 0 && !uni(HC.special_linked)) { H.vx[v].out_deg++; return; }
     const uint32_t sk = (uint32_t)uni(HC.sinkp);
     uint32_t kt = uni(H.ed[e].lk.et); const uint32_t kid = uni(H.eid[e]);
     if(kt == sk) kt = 0xFFFFu;
-    IDX *pp = &H.out_head[v]; IDX cur = *pp;
+    IDX *pp = &H.vx[v].out_head; IDX cur = *pp;
     for(int guard = MAXE; uni(cur != NIL) && guard > 0; guard--) {      // (the guard only matters on a corrupted list: never spin)
         const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu;
         bool stop = ct > kt; if(uni(ct == kt)) stop = H.eid[cur] > kid;
@@ -264,13 +268,13 @@ ALD_INL void link_out(int v, int e)
         pp = &H.ed[cur].lk.onx; cur = (IDX)(w >> 48);
     }
     H.ed[e].lk.onx = cur; *pp = (IDX)e;
-    H.out_deg[v]++;
+    H.vx[v].out_deg++;
 }
 // link_out with a starting point: `hint` is an edge of v's out-list known to sort before e (its target key is smaller)
 ALD_INL void link_out_after(int v, int e, int hint)
 {
     v = uni(v); e = uni(e); hint = uni(hint);
-    if(v == 0 && !uni(HC.special_linked)) { H.out_deg[v]++; return; }
+    if(v == 0 && !uni(HC.special_linked)) { H.vx[v].out_deg++; return; }
     const uint32_t sk = (uint32_t)uni(HC.sinkp);
     uint32_t kt = uni(H.ed[e].lk.et); const uint32_t kid = uni(H.eid[e]);
     if(kt == sk) kt = 0xFFFFu;
@@ -282,29 +286,29 @@ ALD_INL void link_out_after(int v, int e, int hint)
         pp = &H.ed[cur].lk.onx; cur = (IDX)(w >> 48);
     }
     H.ed[e].lk.onx = cur; *pp = (IDX)e;
-    H.out_deg[v]++;
+    H.vx[v].out_deg++;
 }
 // The walks below keep the cursor in a vector register (an LDS address has to be in one anyway) and follow the ADDRESS of the link
 // that points at the current edge; only the loop condition is made wave-uniform.
 ALD_INL void unlink_in(int v, int e)
 {
     v = uni(v); e = uni(e);
-    if(v == uni(HC.sinkp) && !uni(HC.special_linked)) { H.in_deg[v]--; return; }
-    IDX *pp = &H.in_head[v]; IDX cur = *pp; int guard = MAXE;
+    if(v == uni(HC.sinkp) && !uni(HC.special_linked)) { H.vx[v].in_deg--; return; }
+    IDX *pp = &H.vx[v].in_head; IDX cur = *pp; int guard = MAXE;
     while(uni((int)cur != e && cur != NIL) && guard-- > 0) { pp = &H.ed[cur].lk.inx; cur = *pp; }
     if(ALD_UNLIKELY(uni((int)cur != e))) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }       // cannot happen on a consistent state; never walk off a list
     *pp = H.ed[e].lk.inx;
-    { int dg = (int)uni(H.in_deg[v]) - 1; H.in_deg[v] = (IDX)dg; if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; } }
+    { int dg = (int)uni(H.vx[v].in_deg) - 1; H.vx[v].in_deg = (IDX)dg; if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; } }
 }
 ALD_INL void unlink_out(int v, int e)
 {
     v = uni(v); e = uni(e);
-    if(v == 0 && !uni(HC.special_linked)) { H.out_deg[v]--; return; }
-    IDX *pp = &H.out_head[v]; IDX cur = *pp; int guard = MAXE;
+    if(v == 0 && !uni(HC.special_linked)) { H.vx[v].out_deg--; return; }
+    IDX *pp = &H.vx[v].out_head; IDX cur = *pp; int guard = MAXE;
     while(uni((int)cur != e && cur != NIL) && guard-- > 0) { pp = &H.ed[cur].lk.onx; cur = *pp; }
     if(ALD_UNLIKELY(uni((int)cur != e))) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
     *pp = H.ed[e].lk.onx;
-    { int dg = (int)uni(H.out_deg[v]) - 1; H.out_deg[v] = (IDX)dg; if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; } }
+    { int dg = (int)uni(H.vx[v].out_deg) - 1; H.vx[v].out_deg = (IDX)dg; if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; } }
 }
 // e stays in v's in-list but its key becomes (ks, newest id): one walk finds its predecessor and its new place
 ALD_INL void relink_in(int v, int e, uint32_t ks)
@@ -323,8 +327,8 @@ ALD_INL void relink_in(int v, int e, uint32_t ks)
     if(!placed) ip = last;
     if(ip == pe) return;                                   // same place
     IDX nxe = uni(H.ed[e].lk.inx);
-    if(pe < 0) H.in_head[v] = nxe; else H.ed[pe].lk.inx = nxe;
-    if(ip < 0) { H.ed[e].lk.inx = uni(H.in_head[v]); H.in_head[v] = (IDX)e; } else { H.ed[e].lk.inx = uni(H.ed[ip].lk.inx); H.ed[ip].lk.inx = (IDX)e; }
+    if(pe < 0) H.vx[v].in_head = nxe; else H.ed[pe].lk.inx = nxe;
+    if(ip < 0) { H.ed[e].lk.inx = uni(H.vx[v].in_head); H.vx[v].in_head = (IDX)e; } else { H.ed[e].lk.inx = uni(H.ed[ip].lk.inx); H.ed[ip].lk.inx = (IDX)e; }
 }
 ALD_INL void relink_out(int v, int e, uint32_t kt)         // kt already mapped by tkey()
 {
@@ -343,8 +347,8 @@ ALD_INL void relink_out(int v, int e, uint32_t kt)         // kt already mapped 
     if(!placed) ip = last;
     if(ip == pe) return;
     IDX nxe = uni(H.ed[e].lk.onx);
-    if(pe < 0) H.out_head[v] = nxe; else H.ed[pe].lk.onx = nxe;
-    if(ip < 0) { H.ed[e].lk.onx = uni(H.out_head[v]); H.out_head[v] = (IDX)e; } else { H.ed[e].lk.onx = uni(H.ed[ip].lk.onx); H.ed[ip].lk.onx = (IDX)e; }
+    if(pe < 0) H.vx[v].out_head = nxe; else H.ed[pe].lk.onx = nxe;
+    if(ip < 0) { H.ed[e].lk.onx = uni(H.vx[v].out_head); H.vx[v].out_head = (IDX)e; } else { H.ed[e].lk.onx = uni(H.ed[ip].lk.onx); H.ed[ip].lk.onx = (IDX)e; }
 }
 // The same two moves for the lane-parallel star: every lane works on ITS OWN vertex / edge (distinct vertices -> disjoint lists), so
 // nothing here may be routed through the scalar unit.
@@ -363,8 +367,8 @@ ALD_INL void relink_in_lane(int v, int e, uint32_t ks)
     if(!placed) ip = last;
     if(ip == pe) return;
     const IDX nxe = H.ed[e].lk.inx;
-    if(pe < 0) H.in_head[v] = nxe; else H.ed[pe].lk.inx = nxe;
-    if(ip < 0) { H.ed[e].lk.inx = H.in_head[v]; H.in_head[v] = (IDX)e; } else { H.ed[e].lk.inx = H.ed[ip].lk.inx; H.ed[ip].lk.inx = (IDX)e; }
+    if(pe < 0) H.vx[v].in_head = nxe; else H.ed[pe].lk.inx = nxe;
+    if(ip < 0) { H.ed[e].lk.inx = H.vx[v].in_head; H.vx[v].in_head = (IDX)e; } else { H.ed[e].lk.inx = H.ed[ip].lk.inx; H.ed[ip].lk.inx = (IDX)e; }
 }
 ALD_INL void relink_out_lane(int v, int e, uint32_t kt)    // kt already mapped by tkey()
 {
@@ -382,8 +386,8 @@ ALD_INL void relink_out_lane(int v, int e, uint32_t kt)    // kt already mapped 
     if(!placed) ip = last;
     if(ip == pe) return;
     const IDX nxe = H.ed[e].lk.onx;
-    if(pe < 0) H.out_head[v] = nxe; else H.ed[pe].lk.onx = nxe;
-    if(ip < 0) { H.ed[e].lk.onx = H.out_head[v]; H.out_head[v] = (IDX)e; } else { H.ed[e].lk.onx = H.ed[ip].lk.onx; H.ed[ip].lk.onx = (IDX)e; }
+    if(pe < 0) H.vx[v].out_head = nxe; else H.ed[pe].lk.onx = nxe;
+    if(ip < 0) { H.ed[e].lk.onx = H.vx[v].out_head; H.vx[v].out_head = (IDX)e; } else { H.ed[e].lk.onx = H.ed[ip].lk.onx; H.ed[ip].lk.onx = (IDX)e; }
 }
 ALD_INL int free_slots() { return uni(HC.free_cnt) + (MAXE - uni(HC.slot_hw)); }
 // directed_graph::add_edge (directed_graph.cc:38-48) + i2e.push_back: the new id is the largest
@@ -422,9 +426,9 @@ ALD_INL void kill_edge_wave(int e)
         const int v = out ? (int)(w & 0xFFFF) : (int)((w >> 16) & 0xFFFF);
         const IDX nxe = out ? (IDX)(w >> 48) : (IDX)((w >> 32) & 0xFFFF);
         const bool counted = !special && (out ? v == 0 : v == sinkp);       // out(source) / in(sink): only counted until the final phase
-        IDX *deg = out ? &H.out_deg[v] : &H.in_deg[v];
+        IDX *deg = out ? &H.vx[v].out_deg : &H.vx[v].in_deg;
         if(!counted) {
-            IDX *pp = out ? &H.out_head[v] : &H.in_head[v]; IDX cur = *pp; int guard = MAXE;
+            IDX *pp = out ? &H.vx[v].out_head : &H.vx[v].in_head; IDX cur = *pp; int guard = MAXE;
             while((int)cur != e && cur != NIL && guard-- > 0) { pp = out ? &H.ed[cur].lk.onx : &H.ed[cur].lk.inx; cur = *pp; }
             if(ALD_UNLIKELY((int)cur != e)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); continue; }      // cannot happen on a consistent state
             *pp = nxe;
@@ -700,7 +704,7 @@ ALD_INL int merge_adjacent_edges_i(int x, int y, double ww)
     PROF_ADD(PF_T_MERGE_SUMS);
     if(!sx) kill_edge_i(x);
     if(!sy) kill_edge_i(y);
-    if(H.in_deg[xt] == 0 && uni(H.out_deg[xt]) == 0) H.nz[xt] = 0;
+    if(H.vx[xt].in_deg == 0 && uni(H.vx[xt].out_deg) == 0) H.nz[xt] = 0;
     PROF_ADD(PF_T_MERGE_KILL);
     return n;
 }
@@ -708,7 +712,7 @@ ALD_FN int merge_adjacent_edges(int x, int y, double ww) { return merge_adjacent
 // scallop::balance_vertex (scallop.cc:2486-2576)
 ALD_INL void balance_vertex_i(int v)
 {
-    if(H.in_deg[v] == 0 || uni(H.out_deg[v]) == 0) return;
+    if(H.vx[v].in_deg == 0 || uni(H.vx[v].out_deg) == 0) return;
     const double mw = HC.p_min_w;
     double w1 = 0, w2 = 0;
     for(int e = u_first_in(v); e >= 0; e = u_next_in(e)) { double w = uni(H.ed[e].w); if(ALD_UNLIKELY(!(w >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w1 += w; }
@@ -918,7 +922,7 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         }
         const bool counted = A ? (far == 0 && !uni(HC.special_linked)) : (far == (int)uni(HC.sinkp) && !uni(HC.special_linked));
         if(!counted) {
-            IDX *pp = A ? &H.out_head[far] : &H.in_head[far]; IDX cur = *pp; int guard = MAXE + n;
+            IDX *pp = A ? &H.vx[far].out_head : &H.vx[far].in_head; IDX cur = *pp; int guard = MAXE + n;
             for(int q = 0; q < n; q++) {
                 const int e = src[q]; const uint32_t ke = A ? tkey(H.ed[e].lk.et) : (uint32_t)H.ed[e].lk.es;
                 while(uni(cur != NIL) && guard-- > 0) {       // existing edges with key <= ke stay in front (their ids are older)
@@ -930,7 +934,7 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
                 *pp = (IDX)e; pp = A ? &H.ed[e].lk.onx : &H.ed[e].lk.inx;
             }
         }
-        if(A) H.out_deg[far] = (IDX)((int)uni(H.out_deg[far]) + n); else H.in_deg[far] = (IDX)((int)uni(H.in_deg[far]) + n);
+        if(A) H.vx[far].out_deg = (IDX)((int)uni(H.vx[far].out_deg) + n); else H.vx[far].in_deg = (IDX)((int)uni(H.vx[far].in_deg) + n);
     }
     if(n >= 2) hs_remove(c);
     if(ALD_UNLIKELY(!consumed)) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }      // c kept a remainder: the reference asserts on the degree of x
@@ -938,7 +942,7 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     if(A) unlink_out(far, c); else unlink_in(far, c);
     H.ed[c].lk.es = NIL; H.hflag[c] = 0;
     { int fh = uni(HC.free_head); H.ed[c].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = c; HC.free_cnt = uni(HC.free_cnt) + 1; }
-    H.in_head[x] = NIL; H.out_head[x] = NIL; H.in_deg[x] = 0; H.out_deg[x] = 0; H.nz[x] = 0;
+    H.vx[x].in_head = NIL; H.vx[x].out_head = NIL; H.vx[x].in_deg = 0; H.vx[x].out_deg = 0; H.nz[x] = 0;
     PROF_ADD(PF_T_TAIL);
 }
 // fans above STAR_MAX are rare (hubs next to the source / sink late in the run): out of line, so the common path stays compact
@@ -946,7 +950,7 @@ ALD_FN void decompose_trivial_star_large(int x, int in_side) { x = uni(x); if(un
 ALD_FN void decompose_trivial_vertex(int x)
 {
     x = uni(x);
-    const int nin = uni(H.in_deg[x]), nout = uni(H.out_deg[x]);
+    const int nin = uni(H.vx[x].in_deg), nout = uni(H.vx[x].out_deg);
     if(nin == 1 && nout >= 1 && nout <= STAR_MAX) decompose_trivial_star<true, true>(x);
     else if(nout == 1 && nin >= 1 && nin <= STAR_MAX) decompose_trivial_star<false, true>(x);
     else if(nin == 1 && nout >= 1 && nout <= Cold::w_cap / 8) decompose_trivial_star_large(x, 1);
@@ -1203,7 +1207,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
             const bool first_of_gap = (r == 0) || pred[srt[r - 1]] != pred[q], last_of_gap = (r + 1 >= n) || pred[srt[r + 1]] != pred[q];
             const IDX nx = last_of_gap ? (succ[q] < 0 ? NIL : (IDX)succ[q]) : (IDX)fe[ord[srt[r + 1]]];
             if(A) H.ed[f].lk.onx = nx; else H.ed[f].lk.inx = nx;
-            if(first_of_gap) { if(pred[q] < 0) { if(A) H.out_head[far] = (IDX)f; else H.in_head[far] = (IDX)f; } else { if(A) H.ed[pred[q]].lk.onx = (IDX)f; else H.ed[pred[q]].lk.inx = (IDX)f; } }
+            if(first_of_gap) { if(pred[q] < 0) { if(A) H.vx[far].out_head = (IDX)f; else H.vx[far].in_head = (IDX)f; } else { if(A) H.ed[pred[q]].lk.onx = (IDX)f; else H.ed[pred[q]].lk.inx = (IDX)f; } }
         }
     }
     wsync();
@@ -1212,7 +1216,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
 #endif
     // ---- phase 7 (lane 0): what is left and inherently ordered -- the support pool, the phasing lists, the counters
     if(lane == 0) {
-        if(A) H.out_deg[far] = (IDX)((int)uni(H.out_deg[far]) + n); else H.in_deg[far] = (IDX)((int)uni(H.in_deg[far]) + n);
+        if(A) H.vx[far].out_deg = (IDX)((int)uni(H.vx[far].out_deg) + n); else H.vx[far].in_deg = (IDX)((int)uni(H.vx[far].in_deg) + n);
         if(any_dup || any_multi || uni(HC.hl_n) != 0) for(int q = 0; q < n; q++) {
             const int f = fe[ord[q]];
             if(any_dup) { if(A) relink_in(oth[q], f, (uint32_t)far); else relink_out(oth[q], f, tkey((uint32_t)far)); }
@@ -1225,7 +1229,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
         // remove_edge(c) (already out of far's list); x is left without edges
         H.ed[c].lk.es = NIL; H.hflag[c] = 0;
         { int fh = uni(HC.free_head); H.ed[c].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = c; HC.free_cnt = uni(HC.free_cnt) + 1; }
-        H.in_head[x] = NIL; H.out_head[x] = NIL; H.in_deg[x] = 0; H.out_deg[x] = 0; H.nz[x] = 0;
+        H.vx[x].in_head = NIL; H.vx[x].out_head = NIL; H.vx[x].in_deg = 0; H.vx[x].out_deg = 0; H.nz[x] = 0;
     }
     wsync();
 #ifdef ALD_PROF
@@ -1266,7 +1270,8 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
     PROF_DECL;
     const int lane = lane_id();
     const double mw = HC.p_min_w;
-    const int c = uni(A ? first_in(x) : first_out(x));
+    const Hot::VertexHot vrx = H.vx[x];           // both list heads of x in one LDS read
+    const int c = uni(slot_or_neg(A ? vrx.in_head : vrx.out_head));
     int bad = (c < 0) ? 1 : 0;
     const int cs = c >= 0 ? c : 0;
     // c's record and the vertex: one broadcast request each, used after the arithmetic
@@ -1279,7 +1284,7 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
     // the fan in list order
     int fe[N], oth[N]; double fw[N]; uint32_t id[N];
     {
-        int e = A ? first_out(x) : first_in(x);
+        int e = slot_or_neg(A ? vrx.out_head : vrx.in_head);
         ALD_UNROLL for(int k = 0; k < N; k++) {
             if(e < 0) bad = 1;
             const int es = e >= 0 ? e : 0;
@@ -1427,18 +1432,18 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
             const bool first_of_gap = prv_pred != pj, last_of_gap = nxt_pred != pj;
             const IDX nx = last_of_gap ? (sj < 0 ? NIL : (IDX)sj) : (IDX)nxt_f;
             if(A) H.ed[f].lk.onx = nx; else H.ed[f].lk.inx = nx;
-            if(first_of_gap) { if(pj < 0) { if(A) H.out_head[far] = (IDX)f; else H.in_head[far] = (IDX)f; } else { if(A) H.ed[pj].lk.onx = (IDX)f; else H.ed[pj].lk.inx = (IDX)f; } }
+            if(first_of_gap) { if(pj < 0) { if(A) H.vx[far].out_head = (IDX)f; else H.vx[far].in_head = (IDX)f; } else { if(A) H.ed[pj].lk.onx = (IDX)f; else H.ed[pj].lk.inx = (IDX)f; } }
         }
     }
     const bool any_multi = wballot(multi) != 0;
     wsync();
     // ---- lane 0: c leaves far's list (unless a merged edge took its predecessor's link), the counters, what is inherently ordered
     if(lane == 0) {
-        IDX *deg = A ? &H.out_deg[far] : &H.in_deg[far];
+        IDX *deg = A ? &H.vx[far].out_deg : &H.vx[far].in_deg;
         const int dg = (int)*deg - 1;
         if(!counted) {
             bool taken = false; ALD_UNROLL for(int k = 0; k < N; k++) if(pred[k] == pc) taken = true;
-            if(!taken) { const IDX nx = c_next < 0 ? NIL : (IDX)c_next; if(pc < 0) { if(A) H.out_head[far] = nx; else H.in_head[far] = nx; } else { if(A) H.ed[pc].lk.onx = nx; else H.ed[pc].lk.inx = nx; } }
+            if(!taken) { const IDX nx = c_next < 0 ? NIL : (IDX)c_next; if(pc < 0) { if(A) H.vx[far].out_head = nx; else H.vx[far].in_head = nx; } else { if(A) H.ed[pc].lk.onx = nx; else H.ed[pc].lk.inx = nx; } }
             if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; }     // as unlink_in / unlink_out
         }
         *deg = (IDX)(dg + N);
@@ -1456,7 +1461,7 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
         // remove_edge(c); x is left without edges
         H.ed[cs].lk.es = NIL; H.hflag[cs] = 0;
         { int fh = uni(HC.free_head); H.ed[cs].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = cs; HC.free_cnt = uni(HC.free_cnt) + 1; }
-        H.in_head[x] = NIL; H.out_head[x] = NIL; H.in_deg[x] = 0; H.out_deg[x] = 0; H.nz[x] = 0;
+        H.vx[x].in_head = NIL; H.vx[x].out_head = NIL; H.vx[x].in_deg = 0; H.vx[x].out_deg = 0; H.nz[x] = 0;
     }
     wsync();
     PROF_ADD(PF_T_MERGE_ADD);
@@ -1479,7 +1484,7 @@ template<bool A> ALD_INL bool star_fixed_any(int x, int n)
 ALD_INL void decompose_trivial_vertex_wave(int x)
 {
     x = uni(x);
-    const int nin = uni(H.in_deg[x]), nout = uni(H.out_deg[x]);
+    const int nin = uni(H.vx[x].in_deg), nout = uni(H.vx[x].out_deg);
 #if ALD_STARFIX_MAX >= 2
     if(nin == 1 && nout >= 2 && nout <= ALD_STARFIX_MAX) { if(star_fixed_any<true>(x, nout)) return; }
     else if(nout == 1 && nin >= 2 && nin <= ALD_STARFIX_MAX) { if(star_fixed_any<false>(x, nin)) return; }
@@ -1501,11 +1506,14 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
     COLD;
     const Pairs P = SMALL ? pairs_at(true, false) : pairs_cur();
     int32_t *a = P.a, *b = P.b; double *w = P.w;
-    const int deg = (int)uni(H.in_deg[root]) + (int)uni(H.out_deg[root]);
+    const int deg = (int)uni(H.vx[root].in_deg) + (int)uni(H.vx[root].out_deg);
     // the visiting order of the nested decompositions (jump_ratio > 1 only) must survive them: it always lives in the slab
     const Arena AR = SMALL ? arena_at(true) : arena_at(4 * deg <= ARENA_I && deg <= ARENA_D && !(HC.p_ratio[7] > 1.0));
     if(ALD_UNLIKELY(4 * deg > AR.cap_i || deg > AR.cap_d || deg > C.w_cap / 16)) { fail(ALD_ST_CAPACITY); return; }
     int nloc = 0; int32_t *loc_e = AR.i;
+    // (Tried: asking for the cold records of the root's edges and of the vertices at their far ends right here, with loads nobody waits
+    // for, so that the ~12 serial round trips further down overlap -- 42.2 against 41.95 ms, profiles/r03/ze_kernel_ab_extend_touch.txt:
+    // the routine is bound by its scalar list work, not by those round trips.)
     for(int e = u_first_in(root); e >= 0; e = u_next_in(e)) { loc_e[nloc++] = e; }
     int nin = nloc;
     for(int e = u_first_out(root); e >= 0; e = u_next_out(e)) { loc_e[nloc++] = e; }
@@ -1534,7 +1542,7 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
     for(int i = 0; i < n; i++) { int u1 = PLOC(a[i]), u2 = PLOC(b[i]); if(mdeg[u1] == 1 && mdeg[u2] == 1) evx[u1] = nn++; else if(mdeg[u1] >= 2 && mdeg[u2] >= 2) newedges++; }
     if(ALD_UNLIKELY(nn > MAXV || free_slots() < newedges)) { fail(ALD_ST_CAPACITY); return; }
     HC.maybe_broken = 1; HC.maybe_triv = 1;
-    for(int i = m; i < nn; i++) { H.in_head[i] = NIL; H.out_head[i] = NIL; H.in_deg[i] = 0; H.out_deg[i] = 0; H.nz[i] = 1; C.vx[i].vw = 0; C.vx[i].lpos = 0; C.vx[i].rpos = 0; C.vx[i].vtype = -1; C.vx[i].v2v = -1; }
+    for(int i = m; i < nn; i++) { H.vx[i].in_head = NIL; H.vx[i].out_head = NIL; H.vx[i].in_deg = 0; H.vx[i].out_deg = 0; H.nz[i] = 1; C.vx[i].vw = 0; C.vx[i].lpos = 0; C.vx[i].rpos = 0; C.vx[i].vtype = -1; C.vx[i].v2v = -1; }
     HC.nv = nn;
     for(int i = 0; i < nin; i++) {               // ev1: detach in-edges onto their new vertex
         int k = evx[i]; if(k < 0) continue; int e = loc_e[i];
@@ -1576,7 +1584,7 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
             if(HC.status) return;
         }
     }
-    if(ALD_UNLIKELY(H.in_deg[root] != 0 || uni(H.out_deg[root]) != 0)) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }
+    if(ALD_UNLIKELY(H.vx[root].in_deg != 0 || uni(H.vx[root].out_deg) != 0)) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }
     H.nz[root] = 0;
     // scallop.cc:1976-1985 resolve_single_trivial_vertex(k, jump_ratio) on the new vertices: a no-op unless jump_ratio > 1
     double jump = HC.p_ratio[7];
@@ -1601,7 +1609,7 @@ ALD_FN void decompose_vertex_extend_any(int root, int n) { decompose_vertex_exte
 ALD_INL void decompose_vertex_extend(int root, int n)
 {
     root = uni(root); n = uni(n);
-    const int deg = (int)uni(H.in_deg[root]) + (int)uni(H.out_deg[root]);
+    const int deg = (int)uni(H.vx[root].in_deg) + (int)uni(H.vx[root].out_deg);
     if(uni(HC.pw_lds) != 0 && 4 * deg <= ARENA_I && deg <= ARENA_D && !(uni(HC.p_ratio[7]) > 1.0)) decompose_vertex_extend_small(root, n);
     else decompose_vertex_extend_any(root, n);
 }
@@ -1610,21 +1618,21 @@ ALD_INL void decompose_vertex_extend(int root, int n)
 // scallop::classify_trivial_vertex (scallop.cc:2169-2196); -2 = needs a dominate query on need_e
 ALD_INL int classify_trivial_fastpath(int x, bool fast)
 {
-    int d1 = H.in_deg[x], d2 = H.out_deg[x];
+    int d1 = H.vx[x].in_deg, d2 = H.vx[x].out_deg;
     if(d1 != 1 && d2 != 1) return -1;
     int e1 = first_in(x), e2 = first_out(x);
-    if(d1 == 1) { int s = H.ed[e1].lk.es; if(H.out_deg[s] == 1) return 1; if(fast) { if(!(H.hflag[e1] & HF_OCC)) return 1; return -2; } }
-    if(d2 == 1) { int t = H.ed[e2].lk.et; if(H.in_deg[t] == 1) return 1; if(fast) { if(!(H.hflag[e2] & HF_OCC)) return 1; return -2; } }
+    if(d1 == 1) { int s = H.ed[e1].lk.es; if(H.vx[s].out_deg == 1) return 1; if(fast) { if(!(H.hflag[e1] & HF_OCC)) return 1; return -2; } }
+    if(d2 == 1) { int t = H.ed[e2].lk.et; if(H.vx[t].in_deg == 1) return 1; if(fast) { if(!(H.hflag[e2] & HF_OCC)) return 1; return -2; } }
     return 2;
 }
 ALD_FN int classify_trivial_vertex(int x, bool fast)     // scalar version with the dominate queries
 {
     x = uni(x); fast = uni(fast);
-    int d1 = uni(H.in_deg[x]), d2 = uni(H.out_deg[x]);
+    int d1 = uni(H.vx[x].in_deg), d2 = uni(H.vx[x].out_deg);
     if(d1 != 1 && d2 != 1) return -1;
     int e1 = u_first_in(x), e2 = u_first_out(x);
-    if(d1 == 1) { int s = uni(H.ed[e1].lk.es); if(H.out_deg[s] == 1) return 1; if(fast && hs_dominate(e1, 1)) return 1; }
-    if(d2 == 1) { int t = uni(H.ed[e2].lk.et); if(H.in_deg[t] == 1) return 1; if(fast && hs_dominate(e2, 2)) return 1; }
+    if(d1 == 1) { int s = uni(H.ed[e1].lk.es); if(H.vx[s].out_deg == 1) return 1; if(fast && hs_dominate(e1, 1)) return 1; }
+    if(d2 == 1) { int t = uni(H.ed[e2].lk.et); if(H.vx[t].in_deg == 1) return 1; if(fast && hs_dominate(e2, 2)) return 1; }
     return 2;
 }
 ALD_INL double compute_balance_ratio(int v, bool &ok)    // scallop.cc:2578-2602
@@ -1650,8 +1658,8 @@ ALD_INL double compute_balance_ratio(int v, bool &ok)    // scallop.cc:2578-2602
 ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio)
 {
     i = uni(i); jump_ratio = uni(jump_ratio);
-    if(H.in_deg[i] == 0 || H.out_deg[i] == 0) return false;
-    if(H.in_deg[i] >= 2 && H.out_deg[i] >= 2) return false;
+    if(H.vx[i].in_deg == 0 || H.vx[i].out_deg == 0) return false;
+    if(H.vx[i].in_deg >= 2 && H.vx[i].out_deg >= 2) return false;
     if(mixed_strand_vertex(i)) return false;
     if(classify_trivial_vertex(i, false) != 1) return false;
     bool ok; double r = compute_balance_ratio(i, ok);
@@ -1664,18 +1672,21 @@ ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio)
 // scallop::compute_smallest_edge + the guards of resolve_smallest_edges (scallop.cc:858-896, 2967-3030)
 ALD_INL int eval_smallest(int i, double &r)
 {
+    int hin, hout;
     {   // the vertex record in one round of loads (the short-circuit form waits for each field before it asks for the next)
-        const int nzv = H.nz[i] & NZ_MEMBER, d1 = H.in_deg[i], d2 = H.out_deg[i];
+        const Hot::VertexHot vr = H.vx[i];       // heads and degrees: one 8-byte LDS read
+        const int nzv = H.nz[i] & NZ_MEMBER, d1 = vr.in_deg, d2 = vr.out_deg;
         if((nzv == 0) | (d1 <= 1) | (d2 <= 1)) return -1;
+        hin = slot_or_neg(vr.in_head); hout = slot_or_neg(vr.out_head);
     }
     int e1 = -1, e2 = -1; double sum1 = 0, sum2 = 0, min1 = DBL_MAX, min2 = DBL_MAX;
 #ifndef ALD_HOT_IN_SLAB
-    for(int e = first_in(i); e >= 0; e = next_in(e)) { double w = H.ed[e].w; sum1 += w; if(w > min1) continue; min1 = w; e1 = e; }
-    for(int e = first_out(i); e >= 0; e = next_out(e)) { double w = H.ed[e].w; sum2 += w; if(w > min2) continue; min2 = w; e2 = e; }
+    for(int e = hin; e >= 0; e = next_in(e)) { double w = H.ed[e].w; sum1 += w; if(w > min1) continue; min1 = w; e1 = e; }
+    for(int e = hout; e >= 0; e = next_out(e)) { double w = H.ed[e].w; sum2 += w; if(w > min2) continue; min2 = w; e2 = e; }
 #else
     {   // hot state in the slab (the catch-all class and the twins): every list step is a round trip to L2 -- the two walks advance
         // together, their steps being independent of each other (in LDS the merged loop costs more than the latency it hides)
-        int a = first_in(i), b = first_out(i);
+        int a = hin, b = hout;
         while((a >= 0) | (b >= 0)) {
             const int ea = a >= 0 ? a : 0, eb = b >= 0 ? b : 0;
             const double wa = H.ed[ea].w, wb = H.ed[eb].w; const IDX na = H.ed[ea].lk.inx, nb = H.ed[eb].lk.onx;
@@ -1690,7 +1701,7 @@ ALD_INL int eval_smallest(int i, double &r)
     int e; if(r1 < r2) { r = r1; e = e1; } else { r = r2; e = e2; }
     int s = H.ed[e].lk.es, t = H.ed[e].lk.et;
     uint8_t f = H.hflag[e];
-    { const int ods = H.out_deg[s], idt = H.in_deg[t]; if((ods <= 1) | (idt <= 1)) return -1; }
+    { const int ods = H.vx[s].out_deg, idt = H.vx[t].in_deg; if((ods <= 1) | (idt <= 1)) return -1; }
     if((f & HF_REXT) && (f & HF_LEXT)) return -1;
     if(t == i && (f & HF_REXT)) return -1;
     if(s == i && (f & HF_LEXT)) return -1;
@@ -1712,17 +1723,18 @@ ALD_INL bool resolve_broken_vertex()
     for(int base = 0; base < vend && x < 0; base += ALD_WAVE) {
         int i = base + lane;
         const bool inr = (i >= 1) & (i < vend) & (i != HC.sinkp); const int ii = inr ? i : 0;
-        const int nzv = H.nz[ii] & NZ_MEMBER, d1 = H.in_deg[ii], d2 = H.out_deg[ii];
+        const Hot::VertexHot vr = H.vx[ii];
+        const int nzv = H.nz[ii] & NZ_MEMBER, d1 = vr.in_deg, d2 = vr.out_deg;
         bool p = inr & (nzv != 0) & !((d1 >= 1) & (d2 >= 1));
         uint64_t m = wballot(p);
         if(m) x = base + ffs64(m);
     }
     if(x < 0) { wsync(); if(lane == 0) HC.maybe_broken = 0; wsync(); return false; }
     if(lane == 0) {
-        if(H.in_deg[x] + H.out_deg[x] == 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);      // assert(ve.size() >= 1)
+        if(H.vx[x].in_deg + H.vx[x].out_deg == 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);      // assert(ve.size() >= 1)
         else {
             HC.maybe_triv = 1;
-            trace(OP_BROKEN, vlog(x), H.in_deg[x] + H.out_deg[x], 0);
+            trace(OP_BROKEN, vlog(x), H.vx[x].in_deg + H.vx[x].out_deg, 0);
             int guard = MAXE;
             while(first_in(x) >= 0 && guard-- > 0) { int e = first_in(x); kill_edge(e); hs_remove(e); }
             while(first_out(x) >= 0 && guard-- > 0) { int e = first_out(x); kill_edge(e); hs_remove(e); }
@@ -1757,13 +1769,14 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
             // classify_trivial_fastpath with every load that does not depend on another issued together: three LDS round trips
             // (vertex record / first edges / their far ends) instead of one per condition of the short-circuit form
             const bool inr = (i >= start) & (i < vend); const int ii = inr ? i : 0;
-            const int nzv = H.nz[ii] & NZ_MEMBER, d1 = H.in_deg[ii], d2 = H.out_deg[ii]; const IDX h1 = H.in_head[ii], h2 = H.out_head[ii];
+            const Hot::VertexHot vr = H.vx[ii];       // heads and degrees: one 8-byte LDS read
+            const int nzv = H.nz[ii] & NZ_MEMBER, d1 = vr.in_deg, d2 = vr.out_deg; const IDX h1 = vr.in_head, h2 = vr.out_head;
             bool elig = inr & (nzv != 0) & (d1 >= 1) & (d2 >= 1) & !((d1 >= 2) & (d2 >= 2));
             if(HC.any_strand) elig = elig && !mixed_strand_vertex(i);
             const int e1 = (elig & (h1 != NIL)) ? (int)h1 : 0, e2 = (elig & (h2 != NIL)) ? (int)h2 : 0;
             const IDX sv = H.ed[e1].lk.es, tv = H.ed[e2].lk.et; const uint8_t f1 = H.hflag[e1], f2 = H.hflag[e2];
             const int s_ = (elig & (sv != NIL)) ? (int)sv : 0, t_ = (elig & (tv != NIL)) ? (int)tv : 0;
-            const int ods = H.out_deg[s_], idt = H.in_deg[t_];
+            const int ods = H.vx[s_].out_deg, idt = H.vx[t_].in_deg;
             if(elig) {
                 if(d1 == 1 && ods == 1) cls = 1;
                 else if(d1 == 1 && fast) cls = (f1 & HF_OCC) ? -2 : 1;
@@ -1927,7 +1940,7 @@ ALD_INL bool sweep_smallest(double max_ratio)
             wsync();
             // other vertices only look at ds / dt through the guards out_deg[ds] > 1 and in_deg[dt] > 1 (both held for the edge just
             // removed); if one of them stops holding, or the phasing flags moved, every lane evaluates again
-            const bool all = uni(HC.hs_dirty) != 0 || (int)uni(H.out_deg[ds]) <= 1 || (int)uni(H.in_deg[dt]) <= 1;
+            const bool all = uni(HC.hs_dirty) != 0 || (int)uni(H.vx[ds].out_deg) <= 1 || (int)uni(H.vx[dt].in_deg) <= 1;
             if(uni(HC.hs_dirty)) { if(lane == 0) hs_refresh_flags(); wsync(); }
             if(NC <= 2) { for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (all || i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } } }
             else if(all) { const int nch = (vend + ALD_WAVE - 1) / ALD_WAVE; for(int c = 0; c < nch; c++) eval_chunk(c, true, -1, -1); }
@@ -1983,7 +1996,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
 #endif
     COLD;
     // ---- build_indices (router.cc:225-248)
-    int nin = uni(H.in_deg[root]), nout = uni(H.out_deg[root]), n = nin + nout;
+    int nin = uni(H.vx[root].in_deg), nout = uni(H.vx[root].out_deg), n = nin + nout;
     const int route_bound = (HC.hl_n == 0) ? 0 : nin * nout;          // routes only come from phasing lists
     HC.pw_lds = SMALL ? 1 : 0;
     const Arena AR = arena_at(SMALL);
@@ -2333,7 +2346,7 @@ ALD_FN int router_prepare(int root)
     COLD;
     root = uni(root);
     const int lane = lane_id();
-    const int nin = uni(H.in_deg[root]), nout = uni(H.out_deg[root]), n = nin + nout;
+    const int nin = uni(H.vx[root].in_deg), nout = uni(H.vx[root].out_deg), n = nin + nout;
     const int route_bound = (uni(HC.hl_n) == 0) ? 0 : nin * nout;
     const bool small = (route_bound + n <= LP) && (5 * n + 3 * (route_bound + n) <= ARENA_I) && (3 * n + route_bound + n <= ARENA_D);
     if(!small) return 0;                                                     // (n <= LP <= the wave)
@@ -2376,10 +2389,10 @@ ALD_FN int router_prepare(int root)
 ALD_INL bool router_run(int root, int want_type, int max_degree, int pre = 0)
 {
 #ifdef ALD_EMU_COUNT
-    g_cnt_router++; { int dg_ = (int)H.in_deg[root] + (int)H.out_deg[root]; g_cnt_rdeg[dg_ < 33 ? dg_ : 33]++; }
+    g_cnt_router++; { int dg_ = (int)H.vx[root].in_deg + (int)H.vx[root].out_deg; g_cnt_rdeg[dg_ < 33 ? dg_ : 33]++; }
 #endif
     root = uni(root);
-    const int nin = uni(H.in_deg[root]), nout = uni(H.out_deg[root]), n = nin + nout;
+    const int nin = uni(H.vx[root].in_deg), nout = uni(H.vx[root].out_deg), n = nin + nout;
     const int route_bound = (uni(HC.hl_n) == 0) ? 0 : nin * nout;
     const bool small = (route_bound + n <= LP) && (5 * n + 3 * (route_bound + n) <= ARENA_I) && (3 * n + route_bound + n <= ARENA_D);
 #ifndef ALD_NO_ROUTER22
@@ -2436,7 +2449,8 @@ ALD_INL bool sweep_unsplittable(int type, int degree, double max_ratio)
         for(int base = (cur / ALD_WAVE) * ALD_WAVE; base < vend && i < 0; base += ALD_WAVE) {
             int i0 = base + lane;
             const bool inr = (i0 >= cur) & (i0 < vend); const int ii = inr ? i0 : 0;
-            const int nzv = H.nz[ii] & NZ_MEMBER, d1 = H.in_deg[ii], d2 = H.out_deg[ii];
+            const Hot::VertexHot vr = H.vx[ii];
+            const int nzv = H.nz[ii] & NZ_MEMBER, d1 = vr.in_deg, d2 = vr.out_deg;
             uint64_t m = wballot(inr & (nzv != 0) & (d1 >= 2) & (d2 >= 2));
             if(m) i = base + ffs64(m);
         }
@@ -2543,7 +2557,7 @@ ALD_FN void materialize_special()
     if(HC.special_linked) return;
     HC.special_linked = 1;
     const int sinkp = HC.sinkp;
-    H.out_head[0] = NIL; H.in_head[sinkp] = NIL; H.out_deg[0] = 0; H.in_deg[sinkp] = 0;
+    H.vx[0].out_head = NIL; H.vx[sinkp].in_head = NIL; H.vx[0].out_deg = 0; H.vx[sinkp].in_deg = 0;
     for(int e = 0; e < HC.slot_hw; e++) {
         if(H.ed[e].lk.es == NIL) continue;
         if((int)uni(H.ed[e].lk.es) == 0) link_out(0, e);
@@ -2647,7 +2661,7 @@ ALD_FN double compute_maximum_path()
     int qt = 0;
     const int sinkp = HC.sinkp;
     // queue seeded in the reference's index order: physical order with the sink last
-    for(int i = 0; i < n; i++) { int d = uni(H.in_deg[i]); vd[i] = d; if(d == 0 && i != sinkp) q[qt++] = i; table[i] = -1; back[i] = -1; }
+    for(int i = 0; i < n; i++) { int d = uni(H.vx[i].in_deg); vd[i] = d; if(d == 0 && i != sinkp) q[qt++] = i; table[i] = -1; back[i] = -1; }
     if(vd[sinkp] == 0) q[qt++] = sinkp;
     int k = 0;
     while(k < qt) { int x = q[k++]; for(int e = u_first_out(x); e >= 0; e = u_next_out(e)) { int t = uni(H.ed[e].lk.et); if(--vd[t] == 0) q[qt++] = t; } }
@@ -2658,7 +2672,7 @@ ALD_FN double compute_maximum_path()
     table[0] = DBL_MAX;
     for(int ii = ssi + 1; ii <= tti; ii++) {
         int i = q[ii];
-        if(H.in_deg[i] + uni(H.out_deg[i]) == 0) continue;
+        if(H.vx[i].in_deg + uni(H.vx[i].out_deg) == 0) continue;
         double max_abd = 0; int max_edge = -1;
         for(int e = u_first_in(i); e >= 0; e = u_next_in(e)) {
             int s = uni(H.ed[e].lk.es);
@@ -2683,12 +2697,12 @@ ALD_FN void greedy_decompose()
 {
     COLD;
     bool any = false;
-    for(int i = 0; i < HC.nv && !any; i++) if(H.out_deg[i]) any = true;
+    for(int i = 0; i < HC.nv && !any; i++) if(H.vx[i].out_deg) any = true;
     if(!any) return;
     materialize_special();                         // the DP and the path surgery walk out(0) / in(sink)
     PROF_DECL;
     // (a vertex without in- or out-edges is left alone by balance_vertex, scallop.cc:2488-2489: most of them by now -- no call for those)
-    for(int rep = 0; rep < 2; rep++) for(int i = 1; i < HC.nv; i++) { if(i == HC.sinkp) continue; if(H.in_deg[i] == 0 || uni(H.out_deg[i]) == 0) continue; balance_vertex(i); if(HC.status) return; }
+    for(int rep = 0; rep < 2; rep++) for(int i = 1; i < HC.nv; i++) { if(i == HC.sinkp) continue; if(H.vx[i].in_deg == 0 || uni(H.vx[i].out_deg) == 0) continue; balance_vertex(i); if(HC.status) return; }
     PROF_ADD(PF_G_BALANCE);
     if(ALD_UNLIKELY(3 * HC.nv > C.w_cap / 2)) { fail(ALD_ST_CAPACITY); return; }
     ALD_GLOBAL int32_t *path = C.wi + Cold::w_cap / 2;
@@ -2889,7 +2903,7 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
         if(lane == 0) {
             for(int k = 0; k < E; k++) if(H.hflag[k] & RAW_DEAD) { H.hflag[k] = 0; kill_edge_i(k); }
             HC.next_id = base;
-            for(int i = 1; i < n; i++) if(H.in_deg[i] == 0 && H.out_deg[i] == 0) H.nz[i] = 0;      // (nonzeroset is taken after the pre-steps: scallop.cc:1664-1673)
+            for(int i = 1; i < n; i++) if(H.vx[i].in_deg == 0 && H.vx[i].out_deg == 0) H.nz[i] = 0;      // (nonzeroset is taken after the pre-steps: scallop.cc:1664-1673)
         }
         wsync();
     }
@@ -3007,8 +3021,8 @@ ALD_FN bool load_graph()
     for(int i = lane; i < V; i += ALD_WAVE) {
         int o0 = vo[i], o1 = vo[i + 1], i0 = io[i], i1 = io[i + 1];
         // out(0) and in(sink) are counted, not linked (see link_in / link_out)
-        H.out_head[i] = (o1 > o0 && i != 0) ? (IDX)o0 : NIL; H.out_deg[i] = (IDX)(o1 - o0);
-        H.in_head[i] = (i1 > i0 && i != V - 1) ? (IDX)ie[i0] : NIL; H.in_deg[i] = (IDX)(i1 - i0);
+        H.vx[i].out_head = (o1 > o0 && i != 0) ? (IDX)o0 : NIL; H.vx[i].out_deg = (IDX)(o1 - o0);
+        H.vx[i].in_head = (i1 > i0 && i != V - 1) ? (IDX)ie[i0] : NIL; H.vx[i].in_deg = (IDX)(i1 - i0);
         H.nz[i] = (i >= 1 && i < V - 1 && (o1 - o0) + (i1 - i0) > 0) ? 1 : 0;
         for(int k = o0; k < o1; k++) { H.ed[k].lk.es = (IDX)i; H.ed[k].lk.onx = (k + 1 < o1) ? (IDX)(k + 1) : NIL; }
         for(int k = i0; k < i1; k++) { H.ed[ie[k]].lk.inx = (k + 1 < i1) ? (IDX)ie[k + 1] : NIL; }
