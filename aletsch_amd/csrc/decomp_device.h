@@ -389,6 +389,21 @@ ALD_INL void relink_out_lane(int v, int e, uint32_t kt)    // kt already mapped 
     if(pe < 0) H.vx[v].out_head = nxe; else H.ed[pe].lk.onx = nxe;
     if(ip < 0) { H.ed[e].lk.onx = H.vx[v].out_head; H.vx[v].out_head = (IDX)e; } else { H.ed[e].lk.onx = H.ed[ip].lk.onx; H.ed[ip].lk.onx = (IDX)e; }
 }
+// x is left without edges.  One 8-byte store; the constant is made HERE (the compiler kept the one copy it had made at kernel entry in a
+// spilled register pair and fetched it back from scratch memory -- a round trip to L2 -- at every use)
+ALD_INL void clear_vertex(int x)
+{
+#if defined(ALD_EMU)
+    H.vx[x].in_head = NIL; H.vx[x].out_head = NIL; H.vx[x].in_deg = 0; H.vx[x].out_deg = 0; H.nz[x] = 0;
+#else
+    unsigned lo = 0xFFFFFFFFu, hi = 0u;
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    static_assert(sizeof(Hot::VertexHot) == 8 && NIL == 0xFFFF, "vertex record layout");
+    union { uint64_t u; Hot::VertexHot v; } z; z.u = ((uint64_t)hi << 32) | lo;
+    H.vx[x] = z.v;                                         // in_head = out_head = NIL, in_deg = out_deg = 0
+    H.nz[x] = 0;
+#endif
+}
 ALD_INL int free_slots() { return uni(HC.free_cnt) + (MAXE - uni(HC.slot_hw)); }
 // directed_graph::add_edge (directed_graph.cc:38-48) + i2e.push_back: the new id is the largest
 ALD_INL int add_edge_i(int s, int t)
@@ -942,7 +957,7 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     if(A) unlink_out(far, c); else unlink_in(far, c);
     H.ed[c].lk.es = NIL; H.hflag[c] = 0;
     { int fh = uni(HC.free_head); H.ed[c].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = c; HC.free_cnt = uni(HC.free_cnt) + 1; }
-    H.vx[x].in_head = NIL; H.vx[x].out_head = NIL; H.vx[x].in_deg = 0; H.vx[x].out_deg = 0; H.nz[x] = 0;
+    clear_vertex(x);
     PROF_ADD(PF_T_TAIL);
 }
 // fans above STAR_MAX are rare (hubs next to the source / sink late in the run): out of line, so the common path stays compact
@@ -1229,7 +1244,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
         // remove_edge(c) (already out of far's list); x is left without edges
         H.ed[c].lk.es = NIL; H.hflag[c] = 0;
         { int fh = uni(HC.free_head); H.ed[c].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = c; HC.free_cnt = uni(HC.free_cnt) + 1; }
-        H.vx[x].in_head = NIL; H.vx[x].out_head = NIL; H.vx[x].in_deg = 0; H.vx[x].out_deg = 0; H.nz[x] = 0;
+        clear_vertex(x);
     }
     wsync();
 #ifdef ALD_PROF
@@ -1274,13 +1289,6 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
     const int c = uni(slot_or_neg(A ? vrx.in_head : vrx.out_head));
     int bad = (c < 0) ? 1 : 0;
     const int cs = c >= 0 ? c : 0;
-    // c's record and the vertex: one broadcast request each, used after the arithmetic
-    const double medc = C.ed[cs].med, cc = C.ed[cs].econf, abc = C.ed[cs].s0abd, vw0 = C.vx[x].vw;
-    const int meic = C.ed[cs].mei, cntc = C.ed[cs].ecount, stc = C.ed[cs].estrand, idc = C.ed[cs].s0id;
-    const uint32_t nsc = C.ed[cs].sp_len;
-    const int lt = C.vx[x].lpos, rt = C.vx[x].rpos, ov = C.vx[x].v2v;
-    uint64_t cmask_pf[NW <= 2 ? NW : 1];
-    if(NW <= 2) for(int k = 0; k < NW; k++) cmask_pf[k] = C.ed[cs].mask[k];
     // the fan in list order
     int fe[N], oth[N]; double fw[N]; uint32_t id[N];
     {
@@ -1298,12 +1306,6 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
     const uint64_t lwc = *(const uint64_t*)&H.ed[cs].lk;
     const int far = uni(A ? (int)(lwc & 0xFFFF) : (int)((lwc >> 16) & 0xFFFF));
     const int c_next = A ? lk_next((uint32_t)(lwc >> 48)) : lk_next((uint32_t)((lwc >> 32) & 0xFFFF));     // c's successor in far's list
-#ifndef ALD_EMU
-    // lane j asks for the record of fan edge j
-    double pf_med, pf_conf, pf_abd; int pf_mei, pf_st, pf_cnt, pf_id; uint32_t pf_ns; uint64_t pf_mask0;
-    { const int f = pick<N>(fe, lane < N ? lane : 0); pf_med = C.ed[f].med; pf_conf = C.ed[f].econf; pf_abd = C.ed[f].s0abd; pf_mei = C.ed[f].mei; pf_st = C.ed[f].estrand;
-      pf_cnt = C.ed[f].ecount; pf_id = C.ed[f].s0id; pf_ns = C.ed[f].sp_len; pf_mask0 = C.ed[f].mask[0]; }
-#endif
     bool dupf = false;                            // two fan edges to one vertex: their relinks share a list -> sequential, in merge order, at the end
     ALD_UNROLL for(int k = 0; k < N; k++) for(int k2 = 0; k2 < k; k2++) if(oth[k] == oth[k2]) dupf = true;
     dupf = uni(dupf);
@@ -1326,6 +1328,21 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
         const double wc = wcen;
         ALD_UNROLL for(int k = 0; k < N; k++) { const double w2 = fw[k]; fw[k] = A ? (wc <= w2 ? wc : w2) : (w2 <= wc ? w2 : wc); }
     }
+    // c's record, the vertex (one broadcast request each) and, lane j, the record of fan edge j: asked for HERE -- behind the square root
+    // and the divisions of the balance step, whose temporaries would otherwise share the register file with two dozen pending values
+    // (the kernel root spilled eleven more VGPRs with the requests at the top) -- and used in the write phase; the round trip runs under
+    // the replay, the sums, the vertex-weight chain and the walk over far's list.
+    const double medc = C.ed[cs].med, cc = C.ed[cs].econf, abc = C.ed[cs].s0abd, vw0 = C.vx[x].vw;
+    const int meic_v = C.ed[cs].mei, cntc_v = C.ed[cs].ecount, stc_v = C.ed[cs].estrand, idc_v = C.ed[cs].s0id;
+    const uint32_t nsc_v = C.ed[cs].sp_len;
+    const int lt_v = C.vx[x].lpos, rt_v = C.vx[x].rpos, ov_v = C.vx[x].v2v;
+    uint64_t cmask_pf[NW <= 2 ? NW : 1];
+    if(NW <= 2) for(int k = 0; k < NW; k++) cmask_pf[k] = C.ed[cs].mask[k];
+#ifndef ALD_EMU
+    double pf_med, pf_conf, pf_abd; int pf_mei, pf_st, pf_cnt, pf_id; uint32_t pf_ns; uint64_t pf_mask0;
+    { const int f = pick<N>(fe, lane < N ? lane : 0); pf_med = C.ed[f].med; pf_conf = C.ed[f].econf; pf_abd = C.ed[f].s0abd; pf_mei = C.ed[f].mei; pf_st = C.ed[f].estrand;
+      pf_cnt = C.ed[f].ecount; pf_id = C.ed[f].s0id; pf_ns = C.ed[f].sp_len; pf_mask0 = C.ed[f].mask[0]; }
+#endif
     // ---- merge order = ascending creation id; pair weights in that order; the weight c starts with
     int inv[N];                                   // list position -> merge index
     ALD_UNROLL for(int k = 0; k < N; k++) { int r = 0; ALD_UNROLL for(int k2 = 0; k2 < N; k2++) r += (id[k2] < id[k]) ? 1 : 0; inv[k] = r; }
@@ -1359,7 +1376,6 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
         const double r1 = A ? vwt * (wc0 + ww) * 0.5 / sum : vwt * (ww + wc0) * 0.5 / sum;
         vwt = vwt - r1; r1_q[q] = r1;
     }
-    if(!(cntc > 0)) bad = 1;
     // ---- far's list (read only): the place of every merged edge -- behind the last entry whose key does not exceed its own (the old
     // entries carry older ids; new ones with the same key follow each other in merge order) -- and c's predecessor, in one walk
     const bool counted = uni(A ? (far == 0 && !HC.special_linked) : (far == HC.sinkp && !HC.special_linked));      // out(source) / in(sink) are only counted
@@ -1385,6 +1401,10 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
         ALD_UNROLL for(int k = 0; k < N; k++) if(!placed[k]) pred[k] = last;       // behind everything
         if(!seen_c || guard <= 0) bad = 1;
     }
+    // (wave-uniform values of c's record and of the vertex go to scalar registers now: the loads have had their time)
+    const int meic = uni(meic_v), cntc = uni(cntc_v), stc = uni(stc_v), idc = uni(idc_v), lt = uni(lt_v), rt = uni(rt_v), ov = uni(ov_v);
+    const uint32_t nsc = uni(nsc_v);
+    if(!(cntc > 0)) bad = 1;
     // ---- the decision: nothing has been written so far
     {
         bool cnt_bad = false;
@@ -1461,7 +1481,7 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
         // remove_edge(c); x is left without edges
         H.ed[cs].lk.es = NIL; H.hflag[cs] = 0;
         { int fh = uni(HC.free_head); H.ed[cs].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = cs; HC.free_cnt = uni(HC.free_cnt) + 1; }
-        H.vx[x].in_head = NIL; H.vx[x].out_head = NIL; H.vx[x].in_deg = 0; H.vx[x].out_deg = 0; H.nz[x] = 0;
+        clear_vertex(x);
     }
     wsync();
     PROF_ADD(PF_T_MERGE_ADD);
