@@ -1,4 +1,4 @@
-# quick A/B of library builds: kernel ms for the bench workload (100k x 64v/256e), its flow-weight variant and cfg3 (10k, V in [8,512]);
+# quick A/B of library builds: kernel ms for 100k graphs of cfg1's shape (32v/96e: class 0), the bench workload (100k x 64v/256e), its flow-weight variant and cfg3 (10k, V in [8,512]);
 #   python tools/kernel_ab.py [lib.so ...]      (each library in a fresh child process: ALETSCH_DECOMP_LIB selects the build)
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -6,7 +6,7 @@ CHILD = r'''
 import sys, numpy as np
 sys.path.insert(0, %r)
 import aletsch_amd as A
-for name, kw in (("cfg2", dict(seed=1002, n_graphs=100000, v_min=64, v_max=64, fixed_edges=256)), ("cfg2flow", dict(seed=1002, n_graphs=100000, v_min=64, v_max=64, fixed_edges=256, weight_mode=2)), ("cfg3", dict(seed=1003, n_graphs=10000, v_min=8, v_max=512, edges_per_vertex=4))):
+for name, kw in (("cfg1x1000", dict(seed=1001, n_graphs=100000, v_min=32, v_max=32, fixed_edges=96)), ("cfg2", dict(seed=1002, n_graphs=100000, v_min=64, v_max=64, fixed_edges=256)), ("cfg2flow", dict(seed=1002, n_graphs=100000, v_min=64, v_max=64, fixed_edges=256, weight_mode=2)), ("cfg3", dict(seed=1003, n_graphs=10000, v_min=8, v_max=512, edges_per_vertex=4))):
     pg = A.synth(**kw)
     with A.DecompBatch(0) as b:
         b.add(pg); b.upload()
