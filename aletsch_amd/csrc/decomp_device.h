@@ -1272,9 +1272,22 @@ ALD_INL void star_wave_out(int x) { star_wave_body<false>(uni(x)); }     // run_
 // star_wave_body, which treats or reports the case exactly as before.  Every floating-point operation is the one the sequential
 // form performs (scallop.cc:2144-2167 -> 2486-2576, 2009-2142, 2394-2484, 2242-2378), on the same operands in the same order.
 #ifndef ALD_STARFIX_MAX
-#define ALD_STARFIX_MAX 2     /* N = 3, 4 inline cost the kernel root 16 / 41 more VGPR spills: 42.4 / 43.4 ms against 42.4 with N = 2 alone (profiles/r03/za_kernel_ab_star_fixed.txt) */
+  // classes 2..9 run one to three waves per SIMD (their LDS footprint caps the occupancy) and have 132..272 VGPRs each: fans of up to four
+  // edges go through this form there without a spill; the twins of classes 7 / 8 (168 VGPRs) take it as well (mixed batch 108.7 -> 107.0
+  // -> 106.5 ms, profiles/r03/zk_*).  Class 1 (96 VGPRs at five waves) and class 0 (80 at six) keep it for two edges: three / four inline
+  // cost the kernel root 15 / 55 spilled VGPRs (42.4 / 43.4 against 40.65 ms, profiles/r03/za_*, zh_*).
+  #if ((ALD_CLASS_ID >= 2 && ALD_CLASS_ID <= 9) || ALD_CLASS_ID == 11 || ALD_CLASS_ID == 12) && !defined(ALD_STARFIX_ROOMY_OFF)
+    #define ALD_STARFIX_MAX 4
+  #else
+    #define ALD_STARFIX_MAX 2
+  #endif
 #endif
-template<int N, class T> ALD_INL T pick(const T (&a)[N], int i) { T v = a[0]; ALD_UNROLL for(int k = 1; k < N; k++) if(i == k) v = a[k]; return v; }
+// a[i] for a run-time i as a chain of selects over constant indices.  Written by template recursion, not as a loop: the optimiser turns the loop
+// "for k: if(i == k) v = a[k]" back into an indexed load, and an array indexed at run time lives in scratch memory (what made the fans of
+// three and four edges slow in this form: 48 scratch loads and 104 scratch stores in a kernel without a single spilled register).
+template<int K, int N, class T> struct PickFrom { ALD_INL T get(const T (&a)[N], int i, T v) { return PickFrom<K + 1, N, T>::get(a, i, i == K ? a[K] : v); } };
+template<int N, class T> struct PickFrom<N, N, T> { ALD_INL T get(const T (&)[N], int, T v) { return v; } };
+template<int N, class T> ALD_INL T pick(const T (&a)[N], int i) { return PickFrom<1, N, T>::get(a, i, a[0]); }
 #ifdef ALD_STARFIX_CALL
 template<bool A, int N> ALD_FN bool star_fixed(int x)
 #else
@@ -1307,7 +1320,7 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
     const int far = uni(A ? (int)(lwc & 0xFFFF) : (int)((lwc >> 16) & 0xFFFF));
     const int c_next = A ? lk_next((uint32_t)(lwc >> 48)) : lk_next((uint32_t)((lwc >> 32) & 0xFFFF));     // c's successor in far's list
     bool dupf = false;                            // two fan edges to one vertex: their relinks share a list -> sequential, in merge order, at the end
-    ALD_UNROLL for(int k = 0; k < N; k++) for(int k2 = 0; k2 < k; k2++) if(oth[k] == oth[k2]) dupf = true;
+    ALD_UNROLL for(int k = 0; k < N; k++) { ALD_UNROLL for(int k2 = 0; k2 < N; k2++) if(k2 < k && oth[k] == oth[k2]) dupf = true; }      // (every loop over the fan must unroll: an array indexed at run time lives in scratch memory)
     dupf = uni(dupf);
     // ---- balance_vertex(x) on the gathered weights (scallop.cc:2486-2576), pair weights
     double wcen = H.ed[cs].w;
@@ -1337,7 +1350,7 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
     const uint32_t nsc_v = C.ed[cs].sp_len;
     const int lt_v = C.vx[x].lpos, rt_v = C.vx[x].rpos, ov_v = C.vx[x].v2v;
     uint64_t cmask_pf[NW <= 2 ? NW : 1];
-    if(NW <= 2) for(int k = 0; k < NW; k++) cmask_pf[k] = C.ed[cs].mask[k];
+    if(NW <= 2) { ALD_UNROLL for(int k = 0; k < (NW <= 2 ? NW : 1); k++) cmask_pf[k] = C.ed[cs].mask[k]; }
 #ifndef ALD_EMU
     double pf_med, pf_conf, pf_abd; int pf_mei, pf_st, pf_cnt, pf_id; uint32_t pf_ns; uint64_t pf_mask0;
     { const int f = pick<N>(fe, lane < N ? lane : 0); pf_med = C.ed[f].med; pf_conf = C.ed[f].econf; pf_abd = C.ed[f].s0abd; pf_mei = C.ed[f].mei; pf_st = C.ed[f].estrand;
