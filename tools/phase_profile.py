@@ -1,5 +1,5 @@
 import os, sys, numpy as np
-os.environ["ALETSCH_DECOMP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aletsch_amd/lib/libaletsch_decomp_prof.so")
+os.environ["ALETSCH_DECOMP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aletsch_amd/lib", os.environ.get("PROF_LIB", "libaletsch_decomp_prof.so"))     # PROF_LIB=libaletsch_decomp_<variant>.so: another profiling build (e.g. make VARIANT=profsize VDEFS="-DALD_PROF -DALD_PROF_STAR_BY_SIZE")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import aletsch_amd as A
