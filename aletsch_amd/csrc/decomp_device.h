@@ -1845,7 +1845,19 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
     wsync();
     return code;
 }
+// The count of rule firings (HotCtx::n_iters, reported per graph) is kept in a register while a sweep runs and added once when it ends, and
+// the arguments of an op-trace event are only formed when a trace is being taken: trace() itself costs a read-modify-write of the counter
+// and a read of the trace capacity in LDS per firing, and its arguments (creation id, reference index of the vertex) four more reads --
+// seven LDS instructions per firing, each one ~4.5 cycles of the CU's LDS pipeline, for nothing in an untraced run.
+ALD_INL bool sweep_trivial_body(int mode, int type, double jump_ratio, int &fired, const bool tr);
 ALD_INL bool sweep_trivial(int mode, int type, double jump_ratio)
+{
+    int fired = 0; const bool tr = uni(HC.p_trace_cap) > 0;
+    const bool rv = sweep_trivial_body(mode, type, jump_ratio, fired, tr);
+    if(fired && lane_id() == 0) HC.n_iters += fired;
+    return rv;
+}
+ALD_INL bool sweep_trivial_body(int mode, int type, double jump_ratio, int &fired, const bool tr)
 {
     mode = uni(mode); type = uni(type); jump_ratio = uni(jump_ratio);
     const int lane = lane_id();
@@ -1885,7 +1897,8 @@ ALD_INL bool sweep_trivial(int mode, int type, double jump_ratio)
             if(uni(HC.sw_best_v) < 0) { if(skippable) { if(lane == 0) HC.maybe_triv = 0; wsync(); } return false; }
             target = uni(HC.sw_best_v); last = true;
         }
-        if(lane == 0) { if(last) trace(OP_TRIVIAL_BEST, vlog(target), type, HC.sw_best_r); else trace(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, vlog(target), mode == 1 ? type : 0, HC.sw_hit_r); }
+        fired++;
+        if(tr && lane == 0) { if(last) trace_emit(OP_TRIVIAL_BEST, vlog(target), type, HC.sw_best_r); else trace_emit(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, vlog(target), mode == 1 ? type : 0, HC.sw_hit_r); }
         decompose_trivial_vertex_wave(target);
         if(last) { wsync(); PROF_ADD(PF_TRIV_MUT); return true; }
         if(lane == 0) {
@@ -1905,7 +1918,15 @@ ALD_INL bool sweep_trivial(int mode, int type, double jump_ratio)
 // only change with hs_dirty), so after a removal just those two lanes evaluate again.  And while nothing else can fire -- no
 // broken vertex, no type-1 trivial vertex, phasing flags untouched: exactly what R1..R3 would find out -- the next sweep of the
 // reference's outer loop (scallop.cc:38-188) starts right here instead of going back through the cascade.
+ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr);
 ALD_INL bool sweep_smallest(double max_ratio)
+{
+    int fired = 0; const bool tr = uni(HC.p_trace_cap) > 0;
+    const bool rv = sweep_smallest_body(max_ratio, fired, tr);
+    if(fired && lane_id() == 0) HC.n_iters += fired;
+    return rv;
+}
+ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr)
 {
     max_ratio = uni(max_ratio);
     const int lane = lane_id();
@@ -1967,7 +1988,8 @@ ALD_INL bool sweep_smallest(double max_ratio)
             PROF_ADD(PF_SMALL_EVAL);
             if(hit < 0) break;
             const int ds = H.ed[hit_e].lk.es, dt = H.ed[hit_e].lk.et;         // the two vertices whose lists change
-            if(lane == 0) trace(OP_SMALL_NOW, (int)H.eid[hit_e], vlog(hit), hit_r);
+            fired++;
+            if(tr && lane == 0) trace_emit(OP_SMALL_NOW, (int)H.eid[hit_e], vlog(hit), hit_r);
             kill_edge_wave(hit_e);
             if(lane == 0) hs_remove(hit_e);
             wsync();
@@ -1989,7 +2011,8 @@ ALD_INL bool sweep_smallest(double max_ratio)
         if(!flag) {
             if(best_e < 0) return any;
             const int ds = H.ed[best_e].lk.es, dt = H.ed[best_e].lk.et;
-            if(lane == 0) trace(OP_SMALLEST, (int)H.eid[best_e], vlog(best_v), best_r);
+            fired++;
+            if(tr && lane == 0) trace_emit(OP_SMALLEST, (int)H.eid[best_e], vlog(best_v), best_r);
             kill_edge_wave(best_e);
             if(lane == 0) hs_remove(best_e);
             wsync();
