@@ -96,3 +96,21 @@ def test_host_adapters_compile_as_cxx11_against_the_header():
                             os.path.join(ROOT, "tests", "host_adapter", src), "-o", os.path.join(out, src[:-3] + "_cpu_check"),
                             "-L" + lib, "-laletsch_decomp", "-Wl,-rpath," + lib], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_dispatcher_conversion_matches_the_two_step_form():
+    """aletsch::packed_chunk::append_graph (what a submitting thread of gpu_assembly_queue runs: one walk over gr.edges(), counting sort
+    into CSR rows, the reference's heap objects asked for ahead of the walks) must fill a chunk exactly as stage_graph + append do --
+    random DAGs in random creation order, parallel edges, 0 / 1 / several samples, abundances without their sample, phasing nodes.
+    Host code only (no GPU); built with ASan + UBSan (tests/host_adapter/convert_test.cc)."""
+    import subprocess
+    ROOT = common.ROOT
+    lib = os.path.join(ROOT, "aletsch_amd", "lib")
+    out = os.path.join(ROOT, "tests", "_build"); os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "convert_test")
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-g", "-Wall", "-Wextra", "-Werror", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "host_adapter", "convert_test.cc"), "-o", exe,
+                        "-L" + lib, "-laletsch_decomp", "-Wl,-rpath," + lib], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "400"], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
