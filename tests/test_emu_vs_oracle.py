@@ -255,3 +255,24 @@ def test_full_record_pool_grows_and_the_batch_runs_again(monkeypatch):
     got, _, cl = common.emu_run(pg)
     assert not common.compare_results(want, got, pg.n)
     assert np.array_equal(cl, cl_plain)                  # nobody changed class because of the pool
+
+
+def test_fixed_size_star_declines_where_the_reference_asserts():
+    """The fixed-size form of the trivial decomposition (star_fixed) checks everything the sequential form would trip over -- a weight
+    below min_guaranteed_edge_weight, a zero edge count, an exhausted id space, a centre edge that keeps a remainder -- BEFORE its first
+    write and hands such a star to the whole-wave form: graphs with zero counts and with a minimum weight far above the balanced weights
+    must end exactly as the oracle's (status words of the reference's asserts included)."""
+    rng = np.random.default_rng(77)
+    for k in range(6):
+        kw = dict(seed=int(rng.integers(1, 1 << 30)), v_min=int(rng.choice([8, 32, 64])), v_max=int(rng.choice([64, 100])), edges_per_vertex=int(rng.choice([3, 4])),
+                  weight_mode=int(rng.choice([0, 1, 2])), n_samples=int(rng.choice([1, 2])), phasing_per_graph=int(rng.choice([0, 5])), n_graphs=120)
+        p = A.default_params()
+        if k % 2 == 0: p.min_guaranteed_edge_weight = float(rng.choice([5.0, 30.0]))
+        pg = A.synth(**kw)
+        if k % 3 != 0:
+            cnt = pg.sample_counts() - rng.integers(0, 2, pg.edge_target.size).astype(np.int32); pg.edge_count = np.maximum(cnt, 0).astype(np.int32)
+        want = common.oracle_run(pg, params=p)[0]
+        got = common.emu_run(pg, params=p)[0]
+        bad = common.compare_results(want, got, pg.n, conf_tol=1e-9)
+        assert not bad, f"round {k}: {len(bad)} mismatches, first {bad[:3]}"
+        if k % 3 != 0: assert int((want.status >= 100).sum()) > 0          # the case is really exercised: some graphs end on an assert class
