@@ -1862,12 +1862,14 @@ ALD_INL bool sweep_trivial_body(int mode, int type, double jump_ratio, int &fire
     mode = uni(mode); type = uni(type); jump_ratio = uni(jump_ratio);
     const int lane = lane_id();
     PROF_DECL;
-    if(lane == 0) { if(uni(HC.hs_dirty)) hs_refresh_flags(); HC.sw_vend = HC.nv; HC.sw_best_r = DBL_MAX; HC.sw_best_v = -1; HC.sw_dom_base = -1; }
-    wsync();
     // R3 (mode 1, type 1) acts whenever a type-1 vertex exists.  After a sweep that found none, one can only appear when a degree
     // drops to <= 1, the phasing flags change or vertices are created -- all of which raise maybe_triv; until then the scan is
     // skipped.  (Stranded graphs also gain candidates when a removal un-mixes a vertex: they always scan.)
-    const bool skippable = (mode == 1 && type == 1 && !uni(HC.any_strand));
+    const int hsd_q = HC.hs_dirty, strand_q = HC.any_strand, triv_q = HC.maybe_triv, nv_q = HC.nv;      // one round of LDS reads for the tests below
+    const bool skippable = (mode == 1 && type == 1 && !uni(strand_q));
+    if(skippable && !uni(hsd_q) && !uni(triv_q)) return false;                // (a pending flag refresh raises maybe_triv itself: not skipped then)
+    if(lane == 0) { if(uni(hsd_q)) hs_refresh_flags(); HC.sw_vend = nv_q; HC.sw_best_r = DBL_MAX; HC.sw_best_v = -1; HC.sw_dom_base = -1; }
+    wsync();
     if(skippable && !uni(HC.maybe_triv)) return false;
     bool flag = false;
     int start = 1;
@@ -1918,6 +1920,13 @@ ALD_INL bool sweep_trivial_body(int mode, int type, double jump_ratio, int &fire
 // only change with hs_dirty), so after a removal just those two lanes evaluate again.  And while nothing else can fire -- no
 // broken vertex, no type-1 trivial vertex, phasing flags untouched: exactly what R1..R3 would find out -- the next sweep of the
 // reference's outer loop (scallop.cc:38-188) starts right here instead of going back through the cascade.
+// "anything R1..R3 would react to": four context words asked for TOGETHER and combined -- as a chain of `||` each word was read, waited for and
+// branched on before the next one was asked for: four dependent LDS round trips at the end of every iteration of the smallest-edge loop
+ALD_INL bool back_to_cascade()
+{
+    const int a = HC.status, b = HC.maybe_broken, c = HC.maybe_triv, d = HC.hs_dirty;
+    return uni(a | b | c | d) != 0;
+}
 ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr);
 ALD_INL bool sweep_smallest(double max_ratio)
 {
@@ -2022,7 +2031,7 @@ ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr)
 #endif
             any = true;
             // back to the cascade unless R1..R3 provably have nothing to do
-            if(!may_chain || uni(HC.status) || uni(HC.maybe_broken) || uni(HC.maybe_triv) || uni(HC.hs_dirty)) { PROF_ADD(PF_SMALL_MUT); return true; }
+            if(!may_chain || back_to_cascade()) { PROF_ADD(PF_SMALL_MUT); return true; }
             if(NC <= 2) { for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } } }
             else {
                 const int c1 = uni(ds) / ALD_WAVE, c2 = uni(dt) / ALD_WAVE;
@@ -2035,7 +2044,7 @@ ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr)
             PROF_ADD(PF_SMALL_MUT);
         } else {
             any = true;
-            if(!may_chain || uni(HC.status) || uni(HC.maybe_broken) || uni(HC.maybe_triv) || uni(HC.hs_dirty)) return true;
+            if(!may_chain || back_to_cascade()) return true;
         }
     }
     return true;
@@ -3175,10 +3184,12 @@ ALD_FN void run_graph()
     const int max_exons = uni(HC.p_max_exons);
     int guard = 64 * MAXE;                     // every successful rule consumes an edge or a vertex; far above any real count
     while(guard-- > 0) {
-        if(uni(HC.nv) > max_exons) { skipped = true; break; }
-        if(uni(HC.status)) break;
-        PROF_RESET();
-        bool brk = uni(HC.maybe_broken) != 0 && uni(resolve_broken_vertex());
+        bool brk = false;
+        { const int nvq = HC.nv, stq = HC.status, mbq = HC.maybe_broken;      // one round of LDS reads for the three tests
+          if(uni(nvq) > max_exons) { skipped = true; break; }
+          if(uni(stq)) break;
+          PROF_RESET();
+          brk = uni(mbq) != 0 && uni(resolve_broken_vertex()); }
         PROF_ADD(PF_BROKEN);
         if(brk) continue;
         // the rest of the cascade as a stage loop, so that every rule is instantiated ONCE (the trivial-vertex sweep serves three stages:
