@@ -19,12 +19,6 @@
 
 extern "C" __global__ void __launch_bounds__(64, ALD_WAVES_PER_EU) ALD_KERNEL_NAME(const ald::KernelArgs *A)
 {
-#if defined(ALD_PRIO_LDS) && ALD_CLASS_ID < ALD_FIRST_GLOBAL_CLASS
-    // a mixed batch runs the LDS classes (one to five waves per SIMD, the LDS holds no more) beside the slab-resident twins (three waves
-    // per SIMD): with equal priority a SIMD's issue slots go round, and the one LDS wave gets a quarter of them -- the class that
-    // holds the LDS, and with it every class queued behind it, runs four times longer than alone.  The LDS waves go first.
-    __builtin_amdgcn_s_setprio(ALD_PRIO_LDS);
-#endif
     ALD_CLASS_NS::wave_main((ALD_GLOBAL const ald::KernelArgs*)A, (int)blockIdx.x);
 }
 
