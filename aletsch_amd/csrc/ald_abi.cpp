@@ -23,6 +23,13 @@ ALD_FOR_EACH_CLASS(ALD_DECL)
 
 namespace {
 
+// A batch owns four HIP streams and a pipelined caller keeps several batches in flight; the ROCm runtime maps all streams of a process
+// onto FOUR hardware queues by default, so the D2H copy of batch k regularly sat in the same queue as the kernel of batch k + 1 and
+// waited for it (download 24-38 ms instead of 3 ms per step).  The runtime reads GPU_MAX_HW_QUEUES when it initialises, so the library
+// sets it -- unless the caller did -- when it is LOADED: before any HIP call of its own, and before the first HIP call of a program
+// that links it.  (A process that initialised HIP before it dlopen()ed the library keeps what it had)
+__attribute__((constructor)) void ald_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 thread_local std::string g_err;
 int set_err(int code, const std::string &s) { g_err = s; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if(e_ != hipSuccess) return set_err(ALD_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while(0)
@@ -414,6 +421,7 @@ static int start_run(ald_batch *b)
     HIPCHK(hipMemsetAsync(b->d_poolused.p, 0, 64, b->stream));
     HIPCHK(hipMemsetAsync(b->d_status.p, 0, 4 * (size_t)n + 4, b->stream));
     HIPCHK(hipMemsetAsync(b->d_npaths.p, 0, 4 * (size_t)n + 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->d_gfirst.p, 0xFF, 8 * (size_t)n + 8, b->stream));      // graph_first = -1 for every graph no wave ever finishes (ALD_ST_TOO_LARGE: never queued)
     b->cls = b->cls0; b->attempt.assign(n, 0); b->status.assign(n, 0);
     b->passes = 0;
     if(refresh_pass_args(b, *b->pass0)) b->pass0_on_device = false;      // a slab or the pool moved since pass 0 was staged (stale slab pointers)

@@ -54,10 +54,12 @@
   // unsigned 32-bit minimum over the wave, result wave-uniform: six v_min_u32 with a DPP source operand (quad, quad, half row, row, row
   // broadcast x 2 -- the CDNA reduction idiom), lane 63 then holds the minimum.  Written as ONE asm block: the compiler does not fold
   // a v_mov_b32_dpp into the v_min_u32 that consumes it (four instructions per step instead of one); the block carries the wait
-  // states the hardware asks for itself -- two between a VALU write of a VGPR and a DPP read of it, one before the v_readlane.
+  // states the hardware asks for itself -- two between a VALU write of a VGPR and a DPP read of it, one before the v_readlane -- and
+  // opens with FIVE (s_nop 4): the compiler's hazard recognizer cannot see into the block, and a VALU write of EXEC (v_cmpx) scheduled
+  // directly in front of it would need five wait states before the first DPP step.
   __device__ __forceinline__ unsigned wave_umin32(unsigned k)
   {
-      asm volatile("s_nop 1\n\t"
+      asm volatile("s_nop 4\n\t"
                    "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                    "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                    "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"

@@ -51,7 +51,10 @@ public:
     void reserve(size_t want) { if(want > cap_) grow(want); }
     void push_back(const T &v) { emplace_back(v); }
     void push_back(T &&v) { emplace_back(std::move(v)); }
-    template<class... A> T &emplace_back(A &&... a) { if(n_ == cap_) grow((size_t)cap_ * 2); T *q = new(p_ + n_) T(std::forward<A>(a)...); n_++; return *q; }
+    template<class... A> T &emplace_back(A &&... a) {
+        if(n_ == cap_) { T fresh(std::forward<A>(a)...); grow((size_t)cap_ * 2); T *q = new(p_ + n_) T(std::move(fresh)); n_++; return *q; }   // built BEFORE the storage moves: v.push_back(v[i]) must work as it does for std::vector
+        T *q = new(p_ + n_) T(std::forward<A>(a)...); n_++; return *q;
+    }
     template<class It> void assign(It a, It b) { clear(); const size_t k = (size_t)(b - a); reserve(k); for(size_t i = 0; i < k; i++, ++a) new(p_ + i) T(*a); n_ = (uint32_t)k; }
     // a new element in front of `pos`: the tail moves up by one
     template<class... A> iterator emplace(iterator pos, A &&... a) {

@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """bench.py -- bundles/sec of the MI355X splice-graph decomposition path (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch of synthetic splice graphs whose packed input is resident in HBM when the timed
-region starts: the decomposition kernels (which join the exons of every path into its record and write the result index) + D2H of
-the status words, the records -- paths AND transcripts -- and the index + the decode into the host's path table with
-coverage = log(1 + weight): graphs fully decomposed, paths + transcripts materialised in host memory.  At N > 1 the
-step also holds the RCCL gather of the finished transcripts to rank 0, the path's only exchange step.
-`value` is that rate.  `value_h2d_inclusive` is the rate of a second loop that starts from the caller's host arrays
-(ald_batch_add_packed into the pinned host arrays of the batch + H2D of every array in front of every step, three pipeline stages on three host threads,
-four batch objects rotating); kernels never overlap each other, so the per-launch HIP-event time is that of one kernel.
+One "step" = one pass of the hot path over one batch of synthetic splice graphs, H2D + kernel + D2H inclusive: the
+caller's host arrays go into the batch's pinned host arrays (ald_batch_add_packed) and over PCIe into HBM, the decomposition kernels
+run (they join the exons of every path into its record and write the result index), the status words, the records -- paths AND
+transcripts -- and the index come back and are decoded into the host's path table with coverage = log(1 + weight): graphs fully
+decomposed, paths + transcripts materialised in host memory.  The stages are pipelined on three host threads over four rotating batch
+objects, as a caller feeding a stream of batches would run them: when the timed region starts the batches of the first steps are
+already resident in HBM (staged during the warm-up) and the staging of later ones runs under the kernels.  At N > 1 the step also
+holds the RCCL gather of the finished transcripts to rank 0, the path's only exchange step.
+`value` is that rate.  `value_resident` is the rate of a second loop over inputs that stay resident in HBM (kernels + D2H + decode
+only, nothing staged inside the window); kernels never overlap each other, so the per-launch HIP-event time is that of one kernel,
+and `roofline` is computed from the launches of the resident loop.
 
 Workload (N=1): BASELINE.json configs[1] -- 100k synthetic splice graphs, 64 vertices / 256 edges each.
 N > 1: bundles shard embarrassingly; every rank decomposes its own 100k-graph shard (weak scaling, seed 1004+rank).
@@ -59,7 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--weights", choices=("uniform", "int", "flow"), default="uniform",
                     help="edge weights: uniform = U[1,100) f64 (BASELINE configs), flow = flow-conserving sums of s-t paths (SURVEY.md 8d's second distribution)")
     ap.add_argument("--cpu-sample", type=int, default=32768, help="graphs in the bounded all-cores cpu_baseline sample (0 = skip both CPU legs)")
-    ap.add_argument("--skip-h2d-loop", action="store_true", help="profiling runs: make the batches resident with one plain pass each and skip the host-arrays-in loop (value_h2d_inclusive = null)")
+    ap.add_argument("--skip-h2d-loop", action="store_true", help="profiling runs: make the batches resident with one plain pass each and skip the host-arrays-in loop (`value` is then the resident-input rate and the line says so)")
     ap.add_argument("--serial-steps", action="store_true", help="profiling runs: download every batch before the next kernel starts (under rocprofv3 the D2H copies run as blit kernels on the CUs and would share them with the decomposition kernel)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 / flow-weight kernel timings (the `secondary` block)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: CPU rehearsal of the multi-rank plumbing (needs --dry-run)")
@@ -88,6 +91,37 @@ def launch_ranks(args) -> int:
         sys.stderr.write("bench.py: the ranks exited cleanly but rank 0 printed no result line\n")
         return 1
     return r.returncode
+
+
+def source_stamp() -> dict:
+    """Which source this line was measured on: the git HEAD (read from .git here, or from build/git_head.txt -- written by
+    tools/stamp_head.sh before a gpurun call, whose snapshot carries no .git), and content hashes of the kernel source and of the
+    loaded product library.  profiles/summarize.py copies the block into every summary it writes."""
+    import hashlib
+    def sha16(paths):
+        h = hashlib.sha256()
+        for q in paths:
+            try:
+                h.update(open(os.path.join(ROOT, q), "rb").read())
+            except OSError:
+                h.update(b"missing:" + q.encode())
+        return h.hexdigest()[:16]
+    head = None
+    try:
+        r = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10)
+        if r.returncode == 0:
+            d = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10)
+            head = r.stdout.strip()[:12] + ("+dirty" if d.stdout.strip() else "")
+    except (OSError, subprocess.SubprocessError):
+        pass
+    if head is None:
+        try:
+            head = open(os.path.join(ROOT, "build", "git_head.txt")).read().strip()
+        except OSError:
+            head = "unknown"
+    return {"git_head": head,
+            "kernel_source_sha16": sha16(["aletsch_amd/csrc/decomp_device.h", "aletsch_amd/csrc/decomp_common.h", "aletsch_amd/csrc/decomp_class.hip"]),
+            "library_sha16": sha16(["aletsch_amd/lib/libaletsch_decomp.so"]), "bench_sha16": sha16(["bench.py"])}
 
 
 def cpu_model() -> str:
@@ -363,7 +397,7 @@ def main() -> int:
             dist.barrier()
         return time.perf_counter()
 
-    def run_steps(w, k, staged, raw=False):
+    def run_steps(w, k, staged, raw=False, prime=False):
         """w untimed + k timed passes through ONE pipeline.  staged=True: host arrays in -> host results out, three stages on three
         threads (adder: caller's arrays -> the batch's host arrays; uploader: H2D + first-pass work lists; this thread: kernel
         launch + D2H), batch objects rotating; staged=False: the batches are resident, kernel + D2H only.
@@ -495,12 +529,13 @@ def main() -> int:
             sys.stderr.write("[bench]   exchange thread per batch: device stream %.1f ms, gather enqueue %.1f ms, wait until read %.1f ms\n" % (1e3 * xs[0] / xs[3], 1e3 * xs[1] / xs[3], 1e3 * xs[2] / xs[3]))
         return el, ms
 
+    # one plain pass per batch object first (untimed, in front of the W warm-up steps): every pinned / device buffer exists, every batch is resident
+    for b in batches:
+        b.clear(); b.add(pg); b.upload(); b.run(); b.download()
     if args.skip_h2d_loop:
-        for b in batches:
-            b.clear(); b.add(pg); b.upload(); b.run(); b.download()
         elapsed_h2d, kms_h2d = None, [float("nan")]
     else:
-        elapsed_h2d, kms_h2d = run_steps(max(args.warmup, NB), args.steps, True)   # host arrays in -> host results out (also: one pass per batch object, so every pinned / device buffer exists and every batch is resident)
+        elapsed_h2d, kms_h2d = run_steps(args.warmup, args.steps, True, prime=True)   # host arrays in -> host results out (also: one pass per batch object, so every pinned / device buffer exists and every batch is resident)
     for k_ in dl_acc:
         dl_acc[k_] = 0
     elapsed, kms = run_steps(args.warmup, args.steps, False)           # THE timed region: W untimed + K timed steps over inputs resident in HBM
@@ -517,16 +552,22 @@ def main() -> int:
     traffic = pmc.get("traffic_bytes_per_launch")
 
     if rank == 0:
-        value = args.graphs * world * args.steps / elapsed
+        value_resident = args.graphs * world * args.steps / elapsed
+        # the metric is H2D + kernel + D2H inclusive.  (A profiling run with --skip-h2d-loop has no such loop: it reports
+        # the resident-input rate and says so in `value_is`.)
+        el_value = elapsed_h2d if elapsed_h2d else elapsed
+        value = args.graphs * world * args.steps / el_value
         achieved = (in_b + out_b) / (k_ms / 1e3) / 1e9
+        step_text = ("decomposition kernels (exon join of every path into its record + result index written by the kernel) + D2H of status / records (paths and transcripts) / index + decode into the host path table with coverage = log(1 + weight)"
+                     + (" + RCCL gather of the finished transcripts to rank 0" if dist_on else "") + "; kernel k+1 is launched before the results of batch k are downloaded, so copies and decode run under the next kernel")
         line = {
             "metric": "bundles/sec", "value": value, "unit": "bundles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "timed_step": "inputs resident in HBM; decomposition kernels (exon join of every path into its record + result index written by the kernel) + D2H of status / records (paths and transcripts) / index + decode into the host path table with coverage = log(1 + weight)"
-                          + (" + RCCL gather of the finished transcripts to rank 0" if dist_on else "") + "; kernel k+1 is launched before the results of batch k are downloaded, so copies and decode run under the next kernel",
-            "value_h2d_inclusive": (args.graphs * world * args.steps / elapsed_h2d) if elapsed_h2d else None, "ms_per_step_h2d_inclusive": (elapsed_h2d / args.steps * 1e3) if elapsed_h2d else None,
-            "h2d_inclusive_step": "ald_batch_add_packed (into the pinned host arrays of the batch) + H2D of every array in front of every step (three-stage pipeline on three host threads, 4 batch objects; K kernels, K downloads and K stagings between the brackets)",
+            "ms_per_step": el_value / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic", "source": source_stamp(),
+            "value_is": "h2d_inclusive" if elapsed_h2d else "resident (--skip-h2d-loop: profiling run)",
+            "timed_step": ("H2D + kernel + D2H inclusive (SURVEY.md 8d): ald_batch_add_packed into the pinned host arrays of the batch + H2D of every array, three-stage pipeline on three host threads over 4 rotating batch objects -- K kernels, K downloads and K stagings between the brackets; the batches of the first timed steps are resident in HBM when the window opens (staged during the warm-up), later ones are staged under the kernels; " if elapsed_h2d else "inputs resident in HBM; ") + step_text,
+            "value_resident": value_resident, "ms_per_step_resident": elapsed / args.steps * 1e3,
+            "resident_step": "the same step over inputs that stay resident in HBM (nothing staged inside the window): " + step_text,
             "download_ms": {"wait_for_kernel": dl["wait_kernel"], "status_and_retries": dl["status_retries"], "d2h_copies": dl["copy"], "decode_paths_and_transcripts": dl["decode"],
                             "bytes_to_host_per_step": dl["bytes_to_host"]},
             "config": {"workload": f"{args.graphs} synthetic splice graphs per GPU, {args.vertices} vertices / {args.edges} edges each "

@@ -269,7 +269,10 @@ inline void group_end_boundaries(Graph &gr, std::map<int32_t, int32_t> &tmap, in
 }
 struct PhaseSet {                               // rnacore/phase_set.h:21-32
     std::map<std::vector<int32_t>, int> pmap;
-    void add(const std::vector<int32_t> &v, int c) { ORA_ASSERT(INV_OTHER, !v.empty() && v.size() % 2 == 0); if(pmap.find(v) == pmap.end()) pmap.insert(std::make_pair(v, c)); else pmap[v] += c; }   // phase_set.cc:12-25
+    void add(const std::vector<int32_t> &v, int c) {                                                                    // phase_set.cc:12-25
+        if(v.empty()) return;                                    // "error: adding empty vector to phase_set": printed and ignored (phase_set.cc:14-18), not an assert
+        ORA_ASSERT(INV_OTHER, v.size() % 2 == 0);
+        if(pmap.find(v) == pmap.end()) pmap.insert(std::make_pair(v, c)); else pmap[v] += c; }
     void project_boundaries(const std::map<int32_t, int32_t> &smap, const std::map<int32_t, int32_t> &tmap) {             // phase_set.cc:50-67
         PhaseSet ps;
         for(auto &x : pmap) {

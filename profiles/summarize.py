@@ -36,9 +36,21 @@ def stats(db, out, skip_first=0, bench_log=None):
             line = [ln for ln in open(bench_log) if ln.startswith('{"metric"')][-1]
             j = json.loads(line)
             f.write('# bench line of the same run: ms_per_step=%.3f roofline.kernel_ms=%.3f (HIP events) roofline.frac=%.5f\n' % (j["ms_per_step"], j["roofline"]["kernel_ms"], j["roofline"]["frac"]))
+            f.write('# source of the run: %s\n' % json.dumps(j.get("source")))
             if avg * 1e-6 > j["ms_per_step"]:
                 print(open(out).read()); sys.exit("steady-state kernel average %.3f ms exceeds ms_per_step %.3f ms" % (avg * 1e-6, j["ms_per_step"]))
     print(open(out).read())
+
+
+def source_of(bench_log):
+    """the `source` block (git HEAD, kernel source / library hashes) of the bench line in a run's log, or None"""
+    if not bench_log:
+        return None
+    try:
+        line = [ln for ln in open(bench_log) if ln.startswith('{"metric"')][-1]
+        return json.loads(line).get("source")
+    except (OSError, IndexError, ValueError):
+        return None
 
 
 def per_launch(db, counter, kernel_prefix):
@@ -47,13 +59,14 @@ def per_launch(db, counter, kernel_prefix):
     return v
 
 
-def pmc(fetch_db, write_db, out, kernel_prefix="ald_decomp_kernel"):
+def pmc(fetch_db, write_db, out, kernel_prefix="ald_decomp_kernel", bench_log=None):
     f = per_launch(fetch_db, "FETCH_SIZE", kernel_prefix); w = per_launch(write_db, "WRITE_SIZE", kernel_prefix)
     fk = sum(f) / len(f); wk = sum(w) / len(w)
     d = {"kernel": kernel_prefix, "launches": [len(f), len(w)], "FETCH_SIZE_KiB_per_launch": fk, "WRITE_SIZE_KiB_per_launch": wk,
          "read_bytes_per_launch_corrected": 2 * fk * 1024, "write_bytes_per_launch": wk * 1024,
          "traffic_bytes_per_launch": 2 * fk * 1024 + wk * 1024,
-         "note": "gfx950: FETCH_SIZE doubled per the microarch guide (upper bound for narrow accesses); separate --pmc passes"}
+         "note": "gfx950: FETCH_SIZE doubled per the microarch guide (upper bound for narrow accesses); separate --pmc passes",
+         "source": source_of(bench_log)}
     json.dump(d, open(out, "w"), indent=1); print(json.dumps(d, indent=1))
 
 
@@ -64,19 +77,27 @@ def main():
         log = a[a.index("--bench-log") + 1] if "--bench-log" in a else None
         stats(sys.argv[2], sys.argv[3], skip, log)
     elif sys.argv[1] == "sq":
-        sq(sys.argv[2:-1], sys.argv[-1])
+        # sq <db> [<db> ...] <out.json> [--bench-log <log>] [--kernel <prefix>]
+        a = sys.argv[2:]; log = None; kern = "ald_decomp_kernel_c1"
+        if "--bench-log" in a:
+            i = a.index("--bench-log"); log = a[i + 1]; a = a[:i] + a[i + 2:]
+        if "--kernel" in a:
+            i = a.index("--kernel"); kern = a[i + 1]; a = a[:i] + a[i + 2:]
+        sq(a[:-1], a[-1], kernel_prefix=kern, bench_log=log)
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+        # pmc <fetch db> <write db> <out.json> [--bench-log <log>]
+        a = sys.argv[5:]
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], bench_log=(a[a.index("--bench-log") + 1] if "--bench-log" in a else None))
 
 
-def sq(dbs, out, kernel_prefix="ald_decomp_kernel_c1", graphs=100000):
+def sq(dbs, out, kernel_prefix="ald_decomp_kernel_c1", graphs=100000, bench_log=None):
     """SQ instruction / wait counters per launch and per graph from one or more --pmc result databases"""
     vals = {}
     for db in dbs:
         c = sqlite3.connect(db)
         for n, v, k in c.execute("select counter_name, avg(value), count(*) from counters_collection where kernel_name like ? group by counter_name", (kernel_prefix + "%",)):
             vals[n] = v
-    d = {"kernel": kernel_prefix, "graphs_per_launch": graphs, "per_launch": vals, "per_graph": {k: v / graphs for k, v in vals.items()}}
+    d = {"kernel": kernel_prefix, "graphs_per_launch": graphs, "per_launch": vals, "per_graph": {k: v / graphs for k, v in vals.items()}, "source": source_of(bench_log)}
     json.dump(d, open(out, "w"), indent=1); print(json.dumps(d["per_graph"], indent=1))
 
 

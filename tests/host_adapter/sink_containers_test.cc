@@ -41,6 +41,13 @@ static void test_small_vec()
         }
         small_vec<int32_t, 16> xs; for(int i = 0; i < 40; i++) xs.push_back(i); CHECK(xs.size() == 40 && xs.front() == 0 && xs.back() == 39);
         const int32_t few[3] = {5, 6, 7}; xs.assign(few, few + 3); CHECK(xs.size() == 3 && xs.data()[2] == 7);
+        // an element of the list handed to push_back while the list is full: std::vector guarantees it, so does small_vec (the new
+        // element is built before the storage moves) -- run under ASan, which sees a read of the freed block if it is not
+        small_vec<tracked, 2> sv; std::vector<int> sm;
+        for(int i = 0; i < 3; i++) { sv.push_back(tracked(10 + i)); sm.push_back(10 + i); }
+        for(int i = 0; i < 70; i++) { const size_t k = (size_t)i % sv.size(); sv.push_back(sv[k]); sm.push_back(sm[k]); sv.push_back(sv.back()); sm.push_back(sm.back()); }
+        CHECK(sv.size() == sm.size());
+        for(size_t i = 0; i < sm.size(); i++) CHECK(sv[i].v == sm[i] && sv[i].s.size() == 40);
     }
     CHECK(tracked::live == 0);
 }

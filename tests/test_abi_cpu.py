@@ -98,6 +98,22 @@ def test_host_adapters_compile_as_cxx11_against_the_header():
         assert r.returncode == 0, r.stderr
 
 
+def test_host_adapters_compile_against_the_reference_headers():
+    """The same three adapters -- gpu_scallop, gpu_scallop_batch (incl. enqueue_raw), gpu_assembly_queue (incl. submit_raw) --
+    instantiated with the reference's OWN splice_graph / hyper_set / phase_set / parameters / path, from its headers where they lie
+    (tests/host_adapter/real_headers_check.cc; g++ -std=c++11 -fsyntax-only -Wall -Werror as the reference builds).  Compile-only: the
+    reference's .cc files need htslib / Boost / config.h and are not built.  Skipped where the reference tree is absent (the GPU box)."""
+    import subprocess
+    REF = "/root/reference"
+    if not os.path.isdir(os.path.join(REF, "rnacore")):
+        pytest.skip("no reference tree on this box")
+    ROOT = common.ROOT
+    inc = ["-I" + os.path.join(REF, d) for d in ("rnacore", "scallop", "util", "graph", "gtf")]
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "include")] + inc +
+                       [os.path.join(ROOT, "tests", "host_adapter", "real_headers_check.cc")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_dispatcher_conversion_matches_the_two_step_form():
     """aletsch::packed_chunk::append_graph (what a submitting thread of gpu_assembly_queue runs: one walk over gr.edges(), counting sort
     into CSR rows, the reference's heap objects asked for ahead of the walks) must fill a chunk exactly as stage_graph + append do --
