@@ -223,6 +223,12 @@ template<> struct ClassDims<10> { enum { MAXV = 4096, MAXE = 16384, NW = 64 }; }
 template<> struct ClassDims<11> { enum { MAXV = 896,  MAXE = 2000, NW = 7 }; };     // twin of class 7, hot state in the slab
 template<> struct ClassDims<12> { enum { MAXV = 1024, MAXE = 2280, NW = 8 }; };     // twin of class 8, hot state in the slab
 template<> struct ClassDims<13> { enum { MAXV = 20480, MAXE = 65280, NW = 160 }; }; // V <= 10240, E <= 58752: hot state in the slab, 32-bit creation ids
+// Row pool of a class (decomp_device.h: Hot::adj): the adjacency ROWS of all vertices, 16-bit edge slots, in segments of whole
+// 4-entry chunks.  Every live edge has two entries (its source's out-row, its target's in-row), a segment is rounded up to a chunk
+// and a row that outgrows its segment moves to a larger one: three entries per edge slot, compacted when the pool runs out.  Class 9
+// fills its CU's LDS (one workgroup per CU) and gets what is left of the 160 KB.
+template<int ID> struct ClassAdj { enum { ADJ = (3 * ClassDims<ID>::MAXE + 3) / 4 * 4 }; };
+template<> struct ClassAdj<9> { enum { ADJ = 18400 }; };                            // 2.79 x 6600
 static inline int class_twin(int c) { return c == 7 ? 11 : c == 8 ? 12 : -1; }       // slab-resident twin of an LDS class (-1: none)
 static inline int class_retry_up(int c)                                              // where a graph goes when its working set overflowed class c
 {
@@ -236,7 +242,7 @@ static inline int class_retry_up(int c)                                         
 #endif
 
 // per-wave HBM slab, laid out at compile time (so that cold pointers cost no registers)
-template<int MAXV, int MAXE, int NW>
+template<int MAXV, int MAXE, int NW, int ADJ>
 struct ColdLayoutT {
     static constexpr uint64_t al(uint64_t x) { return (x + 15) / 16 * 16; }
     static constexpr uint32_t SP_CAP = 8u * MAXE;        // sample-support pool entries (input + intersections)
@@ -260,14 +266,15 @@ struct ColdLayoutT {
     static constexpr uint64_t o_wd = al(o_wi + 4ull * W_CAP);
     static constexpr int32_t  PO_CAP = MAXE;             // record offsets of the graph at hand, in path order (published by finish_graph)
     static constexpr uint64_t o_po = al(o_wd + 8ull * W_CAP);
-    static constexpr uint64_t total = (o_po + 8ull * PO_CAP + 255) / 256 * 256;
+    static constexpr uint64_t o_adjtmp = al(o_po + 8ull * PO_CAP);        // compaction of the row pool: the rows in their new places (ADJ x u16)
+    static constexpr uint64_t total = (o_adjtmp + 2ull * ADJ + 255) / 256 * 256;
 };
 
 struct ClassInfo { int maxv, maxe, nw; uint32_t sp_cap, hl_cap; uint64_t slab_bytes; };
 static inline ClassInfo class_info(int c)
 {
     switch(c) {
-#define ALD_CI(ID) case ID: { typedef ColdLayoutT<ClassDims<ID>::MAXV, ClassDims<ID>::MAXE, ClassDims<ID>::NW> L; \
+#define ALD_CI(ID) case ID: { typedef ColdLayoutT<ClassDims<ID>::MAXV, ClassDims<ID>::MAXE, ClassDims<ID>::NW, ClassAdj<ID>::ADJ> L; \
         return ClassInfo{ClassDims<ID>::MAXV, ClassDims<ID>::MAXE, ClassDims<ID>::NW, L::SP_CAP, L::HL_CAP, L::total}; }
     ALD_FOR_EACH_CLASS(ALD_CI)
 #undef ALD_CI

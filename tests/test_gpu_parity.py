@@ -210,9 +210,9 @@ def test_class_beyond_the_catch_all_on_gpu():
     want = common.oracle_run(small, threads=4)[0]
     with A.DecompBatch(0) as b:
         b.add(small); b.add(huge); b.upload(); b.run(); b.download(); got = b.result()
-    assert got.status[50] == 4 and np.diff(got.path_offset)[50] == 0
         gf = b.result_index()[1]
-        assert gf[50] == -1 and (gf[:50][np.diff(got.path_offset)[:50] > 0] >= 0).all()      # a graph no wave ever ran: "no records" in the result index, not stale memory
+    assert got.status[50] == 4 and np.diff(got.path_offset)[50] == 0
+    assert gf[50] == -1 and (gf[:50][np.diff(got.path_offset)[:50] > 0] >= 0).all()      # a graph no wave ever ran: "no records" in the result index, not stale memory
     import dataclasses
     first = dataclasses.replace(got, status=got.status[:50], path_offset=got.path_offset[:51])       # (the refused graph has no paths)
     assert not common.compare_results(want, first, small.n, conf_tol=1e-9)
