@@ -4,7 +4,11 @@
 // work counter.  Every wave reaches the `break` in wave_main once the class is drained, so the grid
 // always drains.  No MFMA: integer / pointer-chasing work with FP64 compares.
 #include <hip/hip_runtime.h>
+#ifdef ALD_ROWS
+#include "decomp_device_rows.h"     /* make ROWS=1: the adjacency-row form of the engine (A/B build: profiles/r04/) */
+#else
 #include "decomp_device.h"
+#endif
 
 #ifdef ALD_RAW_VARIANT
 #define ALD_KERNEL_NAME ALD_CAT(ald_decomp_kernel_raw_c, ALD_CLASS_ID)

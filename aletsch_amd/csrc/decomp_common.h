@@ -223,7 +223,7 @@ template<> struct ClassDims<10> { enum { MAXV = 4096, MAXE = 16384, NW = 64 }; }
 template<> struct ClassDims<11> { enum { MAXV = 896,  MAXE = 2000, NW = 7 }; };     // twin of class 7, hot state in the slab
 template<> struct ClassDims<12> { enum { MAXV = 1024, MAXE = 2280, NW = 8 }; };     // twin of class 8, hot state in the slab
 template<> struct ClassDims<13> { enum { MAXV = 20480, MAXE = 65280, NW = 160 }; }; // V <= 10240, E <= 58752: hot state in the slab, 32-bit creation ids
-// Row pool of a class (decomp_device.h: Hot::adj): the adjacency ROWS of all vertices, 16-bit edge slots, in segments of whole
+// Row pool of a class (the ALD_ROWS build, decomp_device_rows.h: Hot::adj): the adjacency ROWS of all vertices, 16-bit edge slots, in segments of whole
 // 4-entry chunks.  Every live edge has two entries (its source's out-row, its target's in-row), a segment is rounded up to a chunk
 // and a row that outgrows its segment moves to a larger one: three entries per edge slot, compacted when the pool runs out.  Class 9
 // fills its CU's LDS (one workgroup per CU) and gets what is left of the 160 KB.
@@ -274,7 +274,12 @@ struct ClassInfo { int maxv, maxe, nw; uint32_t sp_cap, hl_cap; uint64_t slab_by
 static inline ClassInfo class_info(int c)
 {
     switch(c) {
-#define ALD_CI(ID) case ID: { typedef ColdLayoutT<ClassDims<ID>::MAXV, ClassDims<ID>::MAXE, ClassDims<ID>::NW, ClassAdj<ID>::ADJ> L; \
+#ifdef ALD_ROWS
+#define ALD_SLAB_ADJ(ID) ClassAdj<ID>::ADJ
+#else
+#define ALD_SLAB_ADJ(ID) 0
+#endif
+#define ALD_CI(ID) case ID: { typedef ColdLayoutT<ClassDims<ID>::MAXV, ClassDims<ID>::MAXE, ClassDims<ID>::NW, ALD_SLAB_ADJ(ID)> L; \
         return ClassInfo{ClassDims<ID>::MAXV, ClassDims<ID>::MAXE, ClassDims<ID>::NW, L::SP_CAP, L::HL_CAP, L::total}; }
     ALD_FOR_EACH_CLASS(ALD_CI)
 #undef ALD_CI

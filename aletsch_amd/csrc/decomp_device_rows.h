@@ -1,7 +1,8 @@
 // decomp_device.h -- the per-graph decomposition engine executed by ONE 64-lane wavefront.
 //
-// One wavefront owns one splice graph.  The graph's hot state (sorted adjacency lists, endpoints, creation ids, FP64 weights,
-// degrees: struct Hot) and the wave's context + exchange scratch (struct HotCtx) live in LDS; cold per-edge / per-vertex state
+// One wavefront owns one splice graph.  The graph's hot state (per-vertex adjacency ROWS -- a vertex's in-edges and its out-edges as
+// contiguous, sorted arrays of edge slots --, endpoints, creation ids, FP64 weights, degrees: struct Hot) and the wave's context +
+// exchange scratch (struct HotCtx) live in LDS; cold per-edge / per-vertex state
 // (coverage bookkeeping, sample support, phasing lists, path bitmasks) lives in the wave's private HBM slab, laid out at compile
 // time.  The slab-resident classes (the catch-all and the twins) keep Hot in the slab as well, HotCtx stays in LDS.
 //
@@ -29,6 +30,7 @@
 #ifdef ALD_EMU
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 #endif
 
 #ifndef ALD_CLASS_ID
@@ -70,26 +72,36 @@ enum { EID_LIMIT = 0x7FFFFFF0 };
 typedef uint16_t EID;
 enum { EID_LIMIT = 0xFFF0 };
 #endif
-typedef ColdLayoutT<MAXV, MAXE, NW, 0> CL;         // (no row pool in this form: decomp_device_rows.h is the build that has one)
+enum { ADJ_CAP = ClassAdj<ALD_CLASS_ID>::ADJ, ADJ_CAP4 = ADJ_CAP / 4 };      // the row pool: entries / 4-entry chunks
+static_assert(ADJ_CAP % 4 == 0 && ADJ_CAP4 < 0xFFFF, "row pool geometry");
+typedef ColdLayoutT<MAXV, MAXE, NW, ADJ_CAP> CL;
 enum { LP = 16, ARENA_I = 96, ARENA_D = 48, SCR_I = 4 * LP + ARENA_I, SCR_D = 2 * LP + ARENA_D };   // LDS scratch geometry (ints / doubles)
 
 // ---------------------------------------------------------------------------------------------
 // hot state: ONE instance per workgroup (= per wavefront)
 // ---------------------------------------------------------------------------------------------
 struct Hot {
-    struct alignas(8) Link { IDX es, et, inx, onx; };      // endpoints (es == NIL <=> slot dead) + next edge in the target's in-list / the source's
-                                                // out-list (both sorted); one 8-byte word so that a list step is ONE LDS round trip
-    struct alignas(16) EdgeHot { double w; Link lk; };     // splice_graph::ewrt + the links: 16 bytes, so a walk that needs the weight too
-    EdgeHot  ed[MAXE];                          // (sums, balance, smallest-edge evaluation) still makes one LDS access per step
-    EID      eid[MAXE];                         // creation id == scallop edge index (16 bits; ids beyond -> the graph moves up a class; 32 bits in the largest class)
-    // the vertex record: list heads and degrees in ONE 8-byte word.  An LDS instruction occupies the CU's LDS pipeline for ~4.5 cycles
-    // whether it moves two bytes for one lane or eight for sixty-four (profiles/r03/zf_lds_issue_microbench.txt), and twenty resident
-    // waves keep that pipeline more than half busy: the sweeps read degrees and heads together, as one access instead of up to four.
-    struct alignas(8) VertexHot { IDX in_head, out_head, in_deg, out_deg; };
+    // splice_graph::ewrt, the endpoints (es == NIL <=> slot dead; a dead slot keeps the next free slot in et), the creation id ==
+    // scallop edge index (16 bits; ids beyond -> the graph moves up a class; 32 bits in the largest class) and the HF_* flags (phasing
+    // occupancy / extend flags): ONE 16-byte record, so that everything a rule asks about an edge is one LDS access (two 8-byte halves:
+    // the weight, and the "key word" es | et << 16 | eid << 32 | hf << 48 that the sorted rows are ordered by)
+    struct alignas(sizeof(EID) == 2 ? 16 : 8) EdgeHot { double w; IDX es, et; EID eid; uint8_t hf, pad_; };
+    EdgeHot  ed[MAXE];
+    // the vertex record: where its rows are and how long -- ONE 8-byte word.  A vertex owns the segment [4 off4, 4 (off4 + cap4)) of the
+    // row pool: its in-edges (slots, sorted by (source, creation id): graph/edge_base.h:35-45) grow UP from the segment's start, its
+    // out-edges (sorted by (target, creation id)) grow DOWN from its end:
+    //     in-edge  k = adj[4 off4 + k]                  k < in_deg
+    //     out-edge k = adj[4 (off4 + cap4) - 1 - k]     k < out_deg           in_deg + out_deg <= 4 cap4
+    // (both rows start on a 4-entry boundary: a lane reads four entries of either with one aligned 8-byte access; a wave reads a whole
+    // row with one instruction, entry k in lane k -- where the linked lists of the earlier rounds cost one dependent hop per edge).
+    // out(source) and in(sink) grow to dozens of entries and are never iterated by the rule cascade: they are only COUNTED (no row)
+    // until the final collect / greedy phase (materialize_special).
+    struct alignas(8) VertexHot { IDX off4, cap4, in_deg, out_deg; };
     VertexHot vx[MAXV];
+    alignas(8) IDX adj[ADJ_CAP];                // the row pool (segment allocator: seg_alloc / seg_release / adj_compact below)
     uint8_t  nz[MAXV];                          // bit 0: scallop::nonzeroset membership; bits 1..5: router class of the vertex on the CURRENT graph (NZ_MEMO_*)
-    uint8_t  hflag[MAXE];                       // HF_* (phasing occupancy / extend flags / protect)
 };
+static_assert(sizeof(EID) != 2 || sizeof(Hot::EdgeHot) == 16, "edge record layout");
 // Everything else a wave keeps about the graph at hand: scalars, the sweep state, the scratch the lanes exchange values through.
 // ALWAYS in LDS -- also for the classes whose graph arrays live in the wave's HBM slab (the twins, the catch-all class): these ~1.7 KB
 // are what every phase boundary and every branch of the rule cascade reads, and a round trip to L2 / the Infinity Cache for each of
@@ -105,6 +117,8 @@ struct HotCtx {
     int32_t  nv, next_id, slot_hw, free_head, free_cnt, status, any_strand, hs_dirty, n_paths, n_iters, n_trace;
     uint32_t sp_used, hl_used; int32_t hl_n;
     int32_t  s_next;
+    // row pool: chunks handed out so far (bump pointer) and, per segment size of 1..SEG_LISTS chunks, the released segments (NIL: none)
+    int32_t  adj_used4; IDX seg_free[16];
     // parameters cached once per wave (saves a dependent HBM/L2 round per use)
     double   p_min_w, p_min_cov, p_ratio[8]; int32_t p_max_exons, p_trace_cap;
     // small-case scratch: the pe2w pair area (+ a parked copy) and the router / decomposition arenas live here whenever the
@@ -211,211 +225,338 @@ ALD_FN void trace_emit(int code, int a, int b, double v)
 }
 ALD_INL bool tracing() { return HC.p_trace_cap > 0; }
 ALD_INL void trace(int code, int a, int b, double v) { HC.n_iters++; if(HC.p_trace_cap > 0) trace_emit(code, a, b, v); }
-// u_*: the same accessors for the scalar (lane-0) routines, with the result marked wave-uniform (see uni() in decomp_common.h)
-// an edge slot or NIL -> slot or -1.  Slots of every class but the largest stay below 2^15, so NIL (0xFFFF) read as a SIGNED 16-bit value
-// is already the -1 the walks test for: the load itself sign-extends (ds_read_i16) and the compare + select per list step goes away.
-#ifndef ALD_NO_SEXT_LINKS
-ALD_INL int slot_or_neg(IDX h) { return MAXE < 32768 ? (int)(int16_t)h : (h == NIL ? -1 : (int)h); }
-#else
-ALD_INL int slot_or_neg(IDX h) { return h == NIL ? -1 : (int)h; }
-#endif
-ALD_INL int u_first_in(int v) { return uni(slot_or_neg(H.vx[v].in_head)); }
-ALD_INL int u_first_out(int v) { return uni(slot_or_neg(H.vx[v].out_head)); }
-ALD_INL int u_next_in(int e) { return uni(slot_or_neg(H.ed[e].lk.inx)); }
-ALD_INL int u_next_out(int e) { return uni(slot_or_neg(H.ed[e].lk.onx)); }
-ALD_INL int first_in(int v) { return slot_or_neg(H.vx[v].in_head); }
-ALD_INL int first_out(int v) { return slot_or_neg(H.vx[v].out_head); }
-ALD_INL int next_in(int e) { return slot_or_neg(H.ed[e].lk.inx); }
-ALD_INL int next_out(int e) { return slot_or_neg(H.ed[e].lk.onx); }
-ALD_INL double in_weights(int v) { double w = 0; for(int e = first_in(v); e >= 0; e = next_in(e)) w += H.ed[e].w; return w; }    // splice_graph.cc:187-198
-ALD_INL double out_weights(int v) { double w = 0; for(int e = first_out(v); e >= 0; e = next_out(e)) w += H.ed[e].w; return w; } // splice_graph.cc:174-185
+// ---------------------------------------------------------------- edges and rows: accessors
+// the "key word" of an edge -- endpoints, creation id, flags -- in ONE 8-byte LDS access
+struct EKey { uint32_t es, et, eid, hf; };
+ALD_INL EKey ekey(int e)
+{
+    EKey k;
+    if(sizeof(EID) == 2) { const uint64_t w = *(const uint64_t*)&H.ed[e].es; k.es = (uint32_t)(w & 0xFFFF); k.et = (uint32_t)((w >> 16) & 0xFFFF); k.eid = (uint32_t)((w >> 32) & 0xFFFF); k.hf = (uint32_t)((w >> 48) & 0xFF); }
+    else { const uint32_t a = *(const uint32_t*)&H.ed[e].es; k.es = a & 0xFFFF; k.et = a >> 16; k.eid = (uint32_t)H.ed[e].eid; k.hf = H.ed[e].hf; }
+    return k;
+}
+ALD_INL int rin(const Hot::VertexHot &vr) { return 4 * (int)vr.off4; }                              // in-edge k of the vertex: adj[rin + k]
+ALD_INL int rout(const Hot::VertexHot &vr) { return 4 * ((int)vr.off4 + (int)vr.cap4) - 1; }        // out-edge k of the vertex: adj[rout - k]
+// the first edge of a row, or -1 (the rule scans ask for it when the degree is 1)
+ALD_INL int first_in(int v) { const Hot::VertexHot vr = H.vx[v]; return vr.in_deg ? (int)H.adj[rin(vr)] : -1; }
+ALD_INL int first_out(int v) { const Hot::VertexHot vr = H.vx[v]; return vr.out_deg ? (int)H.adj[rout(vr)] : -1; }
+ALD_INL int u_first_in(int v) { return uni(first_in(v)); }
+ALD_INL int u_first_out(int v) { return uni(first_out(v)); }
+// A scalar (lane 0 / wave-uniform) pass over a row: ROW_IN_U(v, e) { ... uses e ... } ROW_END.  The row must not change inside.  The
+// entries' addresses do not depend on each other (a linked list's do): the loads of a short row are all in flight together.
+#define ROW_IN_U(v_, e_)  { const Hot::VertexHot rvr_ = H.vx[(v_)]; const int rb_ = uni(rin(rvr_)), rn_ = uni((int)rvr_.in_deg); for(int rk_ = 0; rk_ < rn_; rk_++) { const int e_ = uni((int)H.adj[rb_ + rk_]);
+#define ROW_OUT_U(v_, e_) { const Hot::VertexHot rvr_ = H.vx[(v_)]; const int rb_ = uni(rout(rvr_)), rn_ = uni((int)rvr_.out_deg); for(int rk_ = 0; rk_ < rn_; rk_++) { const int e_ = uni((int)H.adj[rb_ - rk_]);
+// the same per lane (every lane its own vertex)
+#define ROW_IN_L(v_, e_)  { const Hot::VertexHot rvr_ = H.vx[(v_)]; const int rb_ = rin(rvr_), rn_ = (int)rvr_.in_deg; for(int rk_ = 0; rk_ < rn_; rk_++) { const int e_ = (int)H.adj[rb_ + rk_];
+#define ROW_OUT_L(v_, e_) { const Hot::VertexHot rvr_ = H.vx[(v_)]; const int rb_ = rout(rvr_), rn_ = (int)rvr_.out_deg; for(int rk_ = 0; rk_ < rn_; rk_++) { const int e_ = (int)H.adj[rb_ - rk_];
+#define ROW_END } }
+ALD_INL double in_weights(int v) { double w = 0; ROW_IN_L(v, e) w += H.ed[e].w; ROW_END return w; }      // splice_graph.cc:187-198
+ALD_INL double out_weights(int v) { double w = 0; ROW_OUT_L(v, e) w += H.ed[e].w; ROW_END return w; }    // splice_graph.cc:174-185
 
-// ---------------------------------------------------------------- sorted adjacency lists (scalar code)
-// in-list of v ordered by (source, id); out-list ordered by (target, id): graph/edge_base.h:35-45
-// out(source 0) and in(sink) grow to dozens of entries and are never iterated by the rule cascade: until the final collect /
-// greedy phase (materialize_special) edges are only counted there, not linked.
 ALD_INL uint32_t tkey(uint32_t p) { return (int)p == HC.sinkp ? 0xFFFFu : p; }      // the sink sorts after every other vertex
 ALD_INL int vlog(int p) { return p < HC.V0 - 1 ? p : (p == HC.sinkp ? HC.nv - 1 : p - 1); }   // physical -> reference index (traces)
-ALD_INL uint64_t lkw(int e) { return uni(*(const uint64_t*)&H.ed[e].lk); }            // es | et << 16 | inx << 32 | onx << 48
-ALD_INL int lk_next(uint32_t f) { return slot_or_neg((IDX)f); }
+// how many entries of a vertex's rows exist in the pool: out(source) / in(sink) are only counted until the final phase
+ALD_INL int mat_in(int v, const Hot::VertexHot &vr) { return (v == HC.sinkp && !HC.special_linked) ? 0 : (int)vr.in_deg; }
+ALD_INL int mat_out(int v, const Hot::VertexHot &vr) { return (v == 0 && !HC.special_linked) ? 0 : (int)vr.out_deg; }
+
+// exclusive prefix sum over the lanes + the total (every lane calls; the single-lane emulation runs its "lanes" one after the other)
+#ifdef ALD_EMU
+ALD_INL int wave_excl_scan(int x, int &total) { total = x; return 0; }
+#else
+ALD_INL int wave_excl_scan(int x, int &total)
+{
+    int s = x;
+    for(int off = 1; off < ALD_WAVE; off <<= 1) { const int t = __shfl_up(s, off, ALD_WAVE); if(lane_id() >= off) s += t; }
+    total = __shfl(s, ALD_WAVE - 1, ALD_WAVE);
+    return s - x;
+}
+#endif
+
+// ---------------------------------------------------------------- the row pool: segments
+// Segments are whole 4-entry chunks.  Sizes of 1..SEG_LISTS chunks are exact and a released one goes to the list of its size (its first
+// entry holds the next one); larger ones are powers of two and come back with the next compaction.  Allocation: the list of the size,
+// else the bump pointer, else ONE compaction of the whole pool (every row moved down to a segment of exactly its size, the vertex at
+// hand sized for what it is about to receive), else the graph's working set does not fit its class (ALD_ST_CAPACITY: it is run again one
+// class up).  The allocator's state is wave-uniform; its routines are single-lane code (lane 0, or every lane of a wave-uniform branch).
+enum { SEG_LISTS = 16 };
+#if defined(ALD_EMU) && defined(ALD_EMU_CHECK)
+static long g_adj_grow = 0, g_adj_compact = 0, g_adj_graphs = 0, g_adj_peak = 0, g_adj_peak_sum = 0;
+struct AdjPrinter { ~AdjPrinter() { if(g_adj_graphs) fprintf(stderr, "[emu-adj] class %d (pool %d chunks): %ld graphs, segment moves %.2f / graph, compactions %.4f / graph, peak chunks used: max %ld, mean %.1f\n",
+    ALD_CLASS_ID, (int)ADJ_CAP4, g_adj_graphs, (double)g_adj_grow / g_adj_graphs, (double)g_adj_compact / g_adj_graphs, g_adj_peak, (double)g_adj_peak_sum / g_adj_graphs); } }; static AdjPrinter g_adj_printer;
+#define ADJ_STAT(x) (x)
+#else
+#define ADJ_STAT(x) do {} while(0)
+#endif
+ALD_INL int seg_round4(int c4) { if(c4 <= SEG_LISTS) return c4; int p = 2 * SEG_LISTS; while(p < c4) p <<= 1; return p; }
+ALD_INL int seg_alloc(int c4)                    // c4 = seg_round4(chunks wanted) >= 1  ->  first chunk, or -1
+{
+    if(c4 <= SEG_LISTS) { const IDX h = uni(HC.seg_free[c4 - 1]); if(h != NIL) { HC.seg_free[c4 - 1] = uni(H.adj[4 * (int)h]); return (int)h; } }
+    const int u = uni(HC.adj_used4);
+    if(u + c4 <= ADJ_CAP4) { HC.adj_used4 = u + c4; return u; }
+    return -1;
+}
+ALD_INL void seg_release(int off4, int c4) { if(c4 >= 1 && c4 <= SEG_LISTS) { H.adj[4 * off4] = uni(HC.seg_free[c4 - 1]); HC.seg_free[c4 - 1] = (IDX)off4; } }
+// compaction, single lane: the rows go to the slab in their new places and come back in one sweep.  pv / pextra: the vertex about to
+// receive `pextra` more entries (-1: none).  false = even a pool without a gap cannot hold the rows (status set)
+ALD_FN bool adj_compact_s(int pv, int pextra)
+{
+    pv = uni(pv); pextra = uni(pextra);
+    ADJ_STAT(g_adj_compact++);
+    ALD_GLOBAL IDX *tmp = (ALD_GLOBAL IDX*)(HC.cold + CL::o_adjtmp);
+    const int nv = uni(HC.nv); int used4 = 0;
+    for(int v = 0; v < nv; v++) {
+        const Hot::VertexHot vr = H.vx[v]; const int ni = uni(mat_in(v, vr)), no = uni(mat_out(v, vr));
+        const int c4 = (ni + no + (v == pv ? pextra : 0) + 3) / 4;
+        if(ALD_UNLIKELY(used4 + c4 > ADJ_CAP4)) { fail(ALD_ST_CAPACITY); return false; }
+        const int bi = uni(rin(vr)), bo = uni(rout(vr));
+        for(int k = 0; k < ni; k++) tmp[4 * used4 + k] = H.adj[bi + k];
+        for(int k = 0; k < no; k++) tmp[4 * (used4 + c4) - 1 - k] = H.adj[bo - k];
+        H.vx[v].off4 = (IDX)used4; H.vx[v].cap4 = (IDX)c4;
+        used4 += c4;
+    }
+    for(int k = 0; k < 4 * used4; k++) H.adj[k] = tmp[k];
+    HC.adj_used4 = used4; for(int k = 0; k < SEG_LISTS; k++) HC.seg_free[k] = NIL;
+    return true;
+}
+// the same by the whole wave (ALL lanes call): a vertex per lane, the new offsets by a prefix sum over the wave
+ALD_FN bool adj_compact_w(int pv, int pextra)
+{
+    pv = uni(pv); pextra = uni(pextra);
+    ALD_GLOBAL IDX *tmp = (ALD_GLOBAL IDX*)(HC.cold + CL::o_adjtmp);
+    const int lane = lane_id(), nv = uni(HC.nv); int used4 = 0;
+    ADJ_STAT(g_adj_compact++);
+    wsync();
+    for(int v0 = 0; v0 < nv; v0 += ALD_WAVE) {
+        const int v = v0 + lane; const bool in = v < nv; const Hot::VertexHot vr = H.vx[in ? v : 0];
+        const int ni = in ? mat_in(v, vr) : 0, no = in ? mat_out(v, vr) : 0;
+        const int c4 = in ? (ni + no + (v == pv ? pextra : 0) + 3) / 4 : 0;
+        int tot; const int o4 = used4 + wave_excl_scan(c4, tot);
+        if(in && o4 + c4 <= ADJ_CAP4) {
+            const int bi = rin(vr), bo = rout(vr);
+            for(int k = 0; k < ni; k++) tmp[4 * o4 + k] = H.adj[bi + k];
+            for(int k = 0; k < no; k++) tmp[4 * (o4 + c4) - 1 - k] = H.adj[bo - k];
+            H.vx[v].off4 = (IDX)o4; H.vx[v].cap4 = (IDX)c4;
+        }
+        used4 += tot;
+    }
+    wsync();
+    if(ALD_UNLIKELY(used4 > ADJ_CAP4)) { if(lane == 0) fail(ALD_ST_CAPACITY); wsync(); return false; }
+    for(int k = lane; k < 4 * used4; k += ALD_WAVE) H.adj[k] = tmp[k];
+    if(lane == 0) { HC.adj_used4 = used4; for(int k = 0; k < SEG_LISTS; k++) HC.seg_free[k] = NIL; }
+    wsync();
+    return true;
+}
+// room for `extra` more entries in v's segment, single lane: the rows move to a larger segment (a quarter more than asked for once
+// a row is long), the old one is released.  false = pool exhausted (status set)
+ALD_FN bool adj_grow_s(int v, int extra)
+{
+    v = uni(v); extra = uni(extra);
+    const Hot::VertexHot vr = H.vx[v]; const int ni = uni(mat_in(v, vr)), no = uni(mat_out(v, vr)), need = ni + no + extra;
+    const int c4 = seg_round4((need + 3) / 4 + (need >= 16 ? need / 16 : 0));
+    const int o4 = seg_alloc(c4);
+    ADJ_STAT(g_adj_grow++);
+    if(o4 < 0) return adj_compact_s(v, extra);
+    const int bi = uni(rin(vr)), bo = uni(rout(vr));
+    for(int k = 0; k < ni; k++) H.adj[4 * o4 + k] = H.adj[bi + k];
+    for(int k = 0; k < no; k++) H.adj[4 * (o4 + c4) - 1 - k] = H.adj[bo - k];
+    seg_release(uni((int)vr.off4), uni((int)vr.cap4));
+    H.vx[v].off4 = (IDX)o4; H.vx[v].cap4 = (IDX)c4;
+    return true;
+}
+ALD_INL bool adj_reserve_s(int v, int extra)
+{
+    const Hot::VertexHot vr = H.vx[v];
+    if(uni(mat_in(v, vr) + mat_out(v, vr) + extra <= 4 * (int)vr.cap4)) return true;
+    return adj_grow_s(v, extra);
+}
+// the same decided and carried out by the whole wave (ALL lanes call, v / extra wave-uniform): lane 0 allocates, the lanes copy
+ALD_FN bool adj_grow_w(int v, int extra)
+{
+    v = uni(v); extra = uni(extra);
+    const int lane = lane_id();
+    wsync();
+    const Hot::VertexHot vr = H.vx[v]; const int ni = uni(mat_in(v, vr)), no = uni(mat_out(v, vr)), need = ni + no + extra;
+    const int c4 = seg_round4((need + 3) / 4 + (need >= 16 ? need / 16 : 0));
+    if(lane == 0) HC.tmp0 = seg_alloc(c4);
+    ADJ_STAT(g_adj_grow++);
+    wsync();
+    const int o4 = uni(HC.tmp0);
+    if(o4 < 0) return adj_compact_w(v, extra);
+    const int bi = uni(rin(vr)), bo = uni(rout(vr));
+    for(int k = lane; k < ni; k += ALD_WAVE) H.adj[4 * o4 + k] = H.adj[bi + k];
+    for(int k = lane; k < no; k += ALD_WAVE) H.adj[4 * (o4 + c4) - 1 - k] = H.adj[bo - k];
+    wsync();
+    if(lane == 0) { seg_release(uni((int)vr.off4), uni((int)vr.cap4)); H.vx[v].off4 = (IDX)o4; H.vx[v].cap4 = (IDX)c4; }
+    wsync();
+    return true;
+}
+ALD_INL bool adj_reserve_w(int v, int extra)
+{
+    const Hot::VertexHot vr = H.vx[v];
+    if(uni(mat_in(v, vr) + mat_out(v, vr) + extra <= 4 * (int)vr.cap4)) return true;
+    return uni(adj_grow_w(v, extra));
+}
+
+// ---------------------------------------------------------------- sorted rows: single-lane edits
+// in-row of v ordered by (source, id); out-row ordered by (target, id): graph/edge_base.h:35-45.  U: the arguments are wave-uniform
+// (lane-0 code: loop control and address arithmetic on the scalar unit); !U: every lane edits a row of its OWN vertex.
+// e enters the row at its sorted place; the caller has made room (adj_reserve_*).  Searched from the end: a new edge carries the newest id.
+template<bool U> ALD_INL void row_insert_in(int v, int e)
+{
+    const Hot::VertexHot vr = H.vx[v]; const EKey ke = ekey(e);
+    const int b = U ? uni(rin(vr)) : rin(vr); int p = U ? uni((int)vr.in_deg) : (int)vr.in_deg;
+    const uint32_t ks = U ? uni(ke.es) : ke.es, kid = U ? uni(ke.eid) : ke.eid;
+    H.vx[v].in_deg = (IDX)(p + 1);
+    while(p > 0) {
+        const int c = H.adj[b + p - 1]; const EKey kc = ekey(c);
+        const bool stays = kc.es < ks || (kc.es == ks && kc.eid < kid);
+        if(U ? uni(stays) : stays) break;
+        H.adj[b + p] = (IDX)c; p--;
+    }
+    H.adj[b + p] = (IDX)e;
+}
+template<bool U> ALD_INL void row_insert_out(int v, int e)
+{
+    const Hot::VertexHot vr = H.vx[v]; const EKey ke = ekey(e);
+    const uint32_t sk = (uint32_t)(U ? uni(HC.sinkp) : HC.sinkp);
+    const int b = U ? uni(rout(vr)) : rout(vr); int p = U ? uni((int)vr.out_deg) : (int)vr.out_deg;
+    uint32_t kt = U ? uni(ke.et) : ke.et; const uint32_t kid = U ? uni(ke.eid) : ke.eid;
+    if(kt == sk) kt = 0xFFFFu;
+    H.vx[v].out_deg = (IDX)(p + 1);
+    while(p > 0) {
+        const int c = H.adj[b - (p - 1)]; const EKey kc = ekey(c); const uint32_t ct = kc.et == sk ? 0xFFFFu : kc.et;
+        const bool stays = ct < kt || (ct == kt && kc.eid < kid);
+        if(U ? uni(stays) : stays) break;
+        H.adj[b - p] = (IDX)c; p--;
+    }
+    H.adj[b - p] = (IDX)e;
+}
+// e leaves the row; false: it is not there (cannot happen on a consistent state)
+template<bool U> ALD_INL bool row_remove_in(int v, int e)
+{
+    const Hot::VertexHot vr = H.vx[v]; const int b = U ? uni(rin(vr)) : rin(vr), n = U ? uni((int)vr.in_deg) : (int)vr.in_deg;
+    int p = 0;
+    while(p < n) { const bool hit = (int)H.adj[b + p] == e; if(U ? uni(hit) : hit) break; p++; }
+    if(p >= n) return false;
+    for(int k = p; k + 1 < n; k++) H.adj[b + k] = H.adj[b + k + 1];
+    H.vx[v].in_deg = (IDX)(n - 1);
+    return true;
+}
+template<bool U> ALD_INL bool row_remove_out(int v, int e)
+{
+    const Hot::VertexHot vr = H.vx[v]; const int b = U ? uni(rout(vr)) : rout(vr), n = U ? uni((int)vr.out_deg) : (int)vr.out_deg;
+    int p = 0;
+    while(p < n) { const bool hit = (int)H.adj[b - p] == e; if(U ? uni(hit) : hit) break; p++; }
+    if(p >= n) return false;
+    for(int k = p; k + 1 < n; k++) H.adj[b - k] = H.adj[b - (k + 1)];
+    H.vx[v].out_deg = (IDX)(n - 1);
+    return true;
+}
+// e stays in v's in-row but its key becomes (ks, newest id): it moves in front of the FIRST other entry whose source exceeds ks (the
+// row may hold a second edge whose endpoint has already changed and which still waits for this same move -- two fan edges of a star to
+// one vertex --: "first entry above", not "count of entries below", is what places both of them right, one after the other)
+template<bool U> ALD_INL bool row_rekey_in(int v, int e, uint32_t ks)
+{
+    const Hot::VertexHot vr = H.vx[v]; const int b = U ? uni(rin(vr)) : rin(vr), n = U ? uni((int)vr.in_deg) : (int)vr.in_deg;
+    int pe = -1, q = -1, others = 0;
+    for(int k = 0; k < n; k++) { const int c = H.adj[b + k]; const uint32_t cs = H.ed[c].es; if(c == e) pe = k; else { if(q < 0 && cs > ks) q = others; others++; } }
+    if(q < 0) q = others;
+    if(U) { pe = uni(pe); q = uni(q); }
+    if(pe < 0) return false;
+    if(q > pe) for(int k = pe; k < q; k++) H.adj[b + k] = H.adj[b + k + 1];
+    else for(int k = pe; k > q; k--) H.adj[b + k] = H.adj[b + k - 1];
+    H.adj[b + q] = (IDX)e;
+    return true;
+}
+template<bool U> ALD_INL bool row_rekey_out(int v, int e, uint32_t kt)         // kt already mapped by tkey()
+{
+    const Hot::VertexHot vr = H.vx[v]; const int b = U ? uni(rout(vr)) : rout(vr), n = U ? uni((int)vr.out_deg) : (int)vr.out_deg;
+    const uint32_t sk = (uint32_t)HC.sinkp;
+    int pe = -1, q = -1, others = 0;
+    for(int k = 0; k < n; k++) { const int c = H.adj[b - k]; uint32_t ct = H.ed[c].et; if(ct == sk) ct = 0xFFFFu; if(c == e) pe = k; else { if(q < 0 && ct > kt) q = others; others++; } }
+    if(q < 0) q = others;
+    if(U) { pe = uni(pe); q = uni(q); }
+    if(pe < 0) return false;
+    if(q > pe) for(int k = pe; k < q; k++) H.adj[b - k] = H.adj[b - (k + 1)];
+    else for(int k = pe; k > q; k--) H.adj[b - k] = H.adj[b - (k - 1)];
+    H.adj[b - q] = (IDX)e;
+    return true;
+}
+// the list operations of the scalar routines (lane 0): out(source) / in(sink) only count until the final phase
 ALD_INL void link_in(int v, int e)
 {
     v = uni(v); e = uni(e);
     if(v == uni(HC.sinkp) && !uni(HC.special_linked)) { H.vx[v].in_deg++; return; }
-    const uint32_t ks = uni(H.ed[e].lk.es), kid = uni(H.eid[e]);
-    IDX *pp = &H.vx[v].in_head; IDX cur = *pp;
-    for(int guard = MAXE; uni(cur != NIL) && guard > 0; guard--) {      // (the guard only matters on a corrupted list: never spin)
-        const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; const uint32_t cs = (uint32_t)(w & 0xFFFF);
-        bool stop = cs > ks; if(uni(cs == ks)) stop = H.eid[cur] > kid;
-        if(uni(stop)) break;
-        pp = &H.ed[cur].lk.inx; cur = (IDX)((w >> 32) & 0xFFFF);
-    }
-    H.ed[e].lk.inx = cur; *pp = (IDX)e;
-    H.vx[v].in_deg++;
+    if(!adj_reserve_s(v, 1)) return;
+    row_insert_in<true>(v, e);
 }
 ALD_INL void link_out(int v, int e)
 {
     v = uni(v); e = uni(e);
     if(v == 0 && !uni(HC.special_linked)) { H.vx[v].out_deg++; return; }
-    const uint32_t sk = (uint32_t)uni(HC.sinkp);
-    uint32_t kt = uni(H.ed[e].lk.et); const uint32_t kid = uni(H.eid[e]);
-    if(kt == sk) kt = 0xFFFFu;
-    IDX *pp = &H.vx[v].out_head; IDX cur = *pp;
-    for(int guard = MAXE; uni(cur != NIL) && guard > 0; guard--) {      // (the guard only matters on a corrupted list: never spin)
-        const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu;
-        bool stop = ct > kt; if(uni(ct == kt)) stop = H.eid[cur] > kid;
-        if(uni(stop)) break;
-        pp = &H.ed[cur].lk.onx; cur = (IDX)(w >> 48);
-    }
-    H.ed[e].lk.onx = cur; *pp = (IDX)e;
-    H.vx[v].out_deg++;
+    if(!adj_reserve_s(v, 1)) return;
+    row_insert_out<true>(v, e);
 }
-// link_out with a starting point: `hint` is an edge of v's out-list known to sort before e (its target key is smaller)
-ALD_INL void link_out_after(int v, int e, int hint)
-{
-    v = uni(v); e = uni(e); hint = uni(hint);
-    if(v == 0 && !uni(HC.special_linked)) { H.vx[v].out_deg++; return; }
-    const uint32_t sk = (uint32_t)uni(HC.sinkp);
-    uint32_t kt = uni(H.ed[e].lk.et); const uint32_t kid = uni(H.eid[e]);
-    if(kt == sk) kt = 0xFFFFu;
-    IDX *pp = &H.ed[hint].lk.onx; IDX cur = *pp;
-    for(int guard = MAXE; uni(cur != NIL) && guard > 0; guard--) {      // (the guard only matters on a corrupted list: never spin)
-        const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu;
-        bool stop = ct > kt; if(uni(ct == kt)) stop = H.eid[cur] > kid;
-        if(uni(stop)) break;
-        pp = &H.ed[cur].lk.onx; cur = (IDX)(w >> 48);
-    }
-    H.ed[e].lk.onx = cur; *pp = (IDX)e;
-    H.vx[v].out_deg++;
-}
-// The walks below keep the cursor in a vector register (an LDS address has to be in one anyway) and follow the ADDRESS of the link
-// that points at the current edge; only the loop condition is made wave-uniform.
 ALD_INL void unlink_in(int v, int e)
 {
     v = uni(v); e = uni(e);
     if(v == uni(HC.sinkp) && !uni(HC.special_linked)) { H.vx[v].in_deg--; return; }
-    IDX *pp = &H.vx[v].in_head; IDX cur = *pp; int guard = MAXE;
-    while(uni((int)cur != e && cur != NIL) && guard-- > 0) { pp = &H.ed[cur].lk.inx; cur = *pp; }
-    if(ALD_UNLIKELY(uni((int)cur != e))) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }       // cannot happen on a consistent state; never walk off a list
-    *pp = H.ed[e].lk.inx;
-    { int dg = (int)uni(H.vx[v].in_deg) - 1; H.vx[v].in_deg = (IDX)dg; if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; } }
+    if(ALD_UNLIKELY(!row_remove_in<true>(v, e))) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }       // cannot happen on a consistent state
+    { const int dg = (int)uni(H.vx[v].in_deg); if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; } }
 }
 ALD_INL void unlink_out(int v, int e)
 {
     v = uni(v); e = uni(e);
     if(v == 0 && !uni(HC.special_linked)) { H.vx[v].out_deg--; return; }
-    IDX *pp = &H.vx[v].out_head; IDX cur = *pp; int guard = MAXE;
-    while(uni((int)cur != e && cur != NIL) && guard-- > 0) { pp = &H.ed[cur].lk.onx; cur = *pp; }
-    if(ALD_UNLIKELY(uni((int)cur != e))) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
-    *pp = H.ed[e].lk.onx;
-    { int dg = (int)uni(H.vx[v].out_deg) - 1; H.vx[v].out_deg = (IDX)dg; if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; } }
+    if(ALD_UNLIKELY(!row_remove_out<true>(v, e))) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
+    { const int dg = (int)uni(H.vx[v].out_deg); if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; } }
 }
-// e stays in v's in-list but its key becomes (ks, newest id): one walk finds its predecessor and its new place
+// e stays in v's row but its key becomes (key, newest id)
 ALD_INL void relink_in(int v, int e, uint32_t ks)
 {
     v = uni(v); e = uni(e);
     if(v == uni(HC.sinkp) && !uni(HC.special_linked)) return;
-    int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
-    int guard = MAXE;
-    for(int cur = u_first_in(v); cur >= 0 && guard-- > 0; ) {
-        uint64_t w = lkw(cur); int nx = lk_next((uint32_t)((w >> 32) & 0xFFFF));
-        if(cur == e) { pe = last; seen = true; if(placed) break; }
-        else { if(!placed && (uint32_t)(w & 0xFFFF) > ks) { ip = last; placed = true; if(seen) break; } last = cur; }
-        cur = nx;
-    }
-    if(ALD_UNLIKELY(!seen)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
-    if(!placed) ip = last;
-    if(ip == pe) return;                                   // same place
-    IDX nxe = uni(H.ed[e].lk.inx);
-    if(pe < 0) H.vx[v].in_head = nxe; else H.ed[pe].lk.inx = nxe;
-    if(ip < 0) { H.ed[e].lk.inx = uni(H.vx[v].in_head); H.vx[v].in_head = (IDX)e; } else { H.ed[e].lk.inx = uni(H.ed[ip].lk.inx); H.ed[ip].lk.inx = (IDX)e; }
+    if(ALD_UNLIKELY(!row_rekey_in<true>(v, e, ks))) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);
 }
 ALD_INL void relink_out(int v, int e, uint32_t kt)         // kt already mapped by tkey()
 {
     v = uni(v); e = uni(e);
     if(v == 0 && !uni(HC.special_linked)) return;
-    const uint32_t sk = (uint32_t)uni(HC.sinkp);
-    int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
-    int guard = MAXE;
-    for(int cur = u_first_out(v); cur >= 0 && guard-- > 0; ) {
-        uint64_t w = lkw(cur); int nx = lk_next((uint32_t)(w >> 48));
-        if(cur == e) { pe = last; seen = true; if(placed) break; }
-        else { uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu; if(!placed && ct > kt) { ip = last; placed = true; if(seen) break; } last = cur; }
-        cur = nx;
-    }
-    if(ALD_UNLIKELY(!seen)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
-    if(!placed) ip = last;
-    if(ip == pe) return;
-    IDX nxe = uni(H.ed[e].lk.onx);
-    if(pe < 0) H.vx[v].out_head = nxe; else H.ed[pe].lk.onx = nxe;
-    if(ip < 0) { H.ed[e].lk.onx = uni(H.vx[v].out_head); H.vx[v].out_head = (IDX)e; } else { H.ed[e].lk.onx = uni(H.ed[ip].lk.onx); H.ed[ip].lk.onx = (IDX)e; }
+    if(ALD_UNLIKELY(!row_rekey_out<true>(v, e, kt))) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);
 }
-// The same two moves for the lane-parallel star: every lane works on ITS OWN vertex / edge (distinct vertices -> disjoint lists), so
+// The same two moves for the lane-parallel star: every lane works on ITS OWN vertex / edge (distinct vertices -> disjoint rows), so
 // nothing here may be routed through the scalar unit.
 ALD_INL void relink_in_lane(int v, int e, uint32_t ks)
 {
     if(v == HC.sinkp && !HC.special_linked) return;
-    int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
-    int guard = MAXE;
-    for(int cur = first_in(v); cur >= 0 && guard-- > 0; ) {
-        const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; const int nx = lk_next((uint32_t)((w >> 32) & 0xFFFF));
-        if(cur == e) { pe = last; seen = true; if(placed) break; }
-        else { if(!placed && (uint32_t)(w & 0xFFFF) > ks) { ip = last; placed = true; if(seen) break; } last = cur; }
-        cur = nx;
-    }
-    if(ALD_UNLIKELY(!seen)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
-    if(!placed) ip = last;
-    if(ip == pe) return;
-    const IDX nxe = H.ed[e].lk.inx;
-    if(pe < 0) H.vx[v].in_head = nxe; else H.ed[pe].lk.inx = nxe;
-    if(ip < 0) { H.ed[e].lk.inx = H.vx[v].in_head; H.vx[v].in_head = (IDX)e; } else { H.ed[e].lk.inx = H.ed[ip].lk.inx; H.ed[ip].lk.inx = (IDX)e; }
+    if(ALD_UNLIKELY(!row_rekey_in<false>(v, e, ks))) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);
 }
 ALD_INL void relink_out_lane(int v, int e, uint32_t kt)    // kt already mapped by tkey()
 {
     if(v == 0 && !HC.special_linked) return;
-    const uint32_t sk = (uint32_t)HC.sinkp;
-    int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
-    int guard = MAXE;
-    for(int cur = first_out(v); cur >= 0 && guard-- > 0; ) {
-        const uint64_t w = *(const uint64_t*)&H.ed[cur].lk; const int nx = lk_next((uint32_t)(w >> 48));
-        if(cur == e) { pe = last; seen = true; if(placed) break; }
-        else { uint32_t ct = (uint32_t)((w >> 16) & 0xFFFF); if(ct == sk) ct = 0xFFFFu; if(!placed && ct > kt) { ip = last; placed = true; if(seen) break; } last = cur; }
-        cur = nx;
-    }
-    if(ALD_UNLIKELY(!seen)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
-    if(!placed) ip = last;
-    if(ip == pe) return;
-    const IDX nxe = H.ed[e].lk.onx;
-    if(pe < 0) H.vx[v].out_head = nxe; else H.ed[pe].lk.onx = nxe;
-    if(ip < 0) { H.ed[e].lk.onx = H.vx[v].out_head; H.vx[v].out_head = (IDX)e; } else { H.ed[e].lk.onx = H.ed[ip].lk.onx; H.ed[ip].lk.onx = (IDX)e; }
+    if(ALD_UNLIKELY(!row_rekey_out<false>(v, e, kt))) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);
 }
-// x is left without edges.  One 8-byte store; the constant is made HERE (the compiler kept the one copy it had made at kernel entry in a
-// spilled register pair and fetched it back from scratch memory -- a round trip to L2 -- at every use)
+// x is left without edges: its segment goes back to the pool (single lane)
 ALD_INL void clear_vertex(int x)
 {
-#if defined(ALD_EMU)
-    H.vx[x].in_head = NIL; H.vx[x].out_head = NIL; H.vx[x].in_deg = 0; H.vx[x].out_deg = 0; H.nz[x] = 0;
-#else
-    unsigned lo = 0xFFFFFFFFu, hi = 0u;
-    asm volatile("" : "+v"(lo), "+v"(hi));
-    static_assert(sizeof(Hot::VertexHot) == 8 && NIL == 0xFFFF, "vertex record layout");
-    union { uint64_t u; Hot::VertexHot v; } z; z.u = ((uint64_t)hi << 32) | lo;
-    H.vx[x] = z.v;                                         // in_head = out_head = NIL, in_deg = out_deg = 0
-    H.nz[x] = 0;
-#endif
+    const Hot::VertexHot vr = H.vx[x];
+    seg_release(uni((int)vr.off4), uni((int)vr.cap4));
+    Hot::VertexHot z; z.off4 = 0; z.cap4 = 0; z.in_deg = 0; z.out_deg = 0;
+    H.vx[x] = z; H.nz[x] = 0;
 }
 ALD_INL int free_slots() { return uni(HC.free_cnt) + (MAXE - uni(HC.slot_hw)); }
+ALD_INL void slot_release(int e) { const int fh = uni(HC.free_head); H.ed[e].es = NIL; H.ed[e].et = fh < 0 ? NIL : (IDX)fh; HC.free_head = e; HC.free_cnt = uni(HC.free_cnt) + 1; }
 // directed_graph::add_edge (directed_graph.cc:38-48) + i2e.push_back: the new id is the largest
 ALD_INL int add_edge_i(int s, int t)
 {
     s = uni(s); t = uni(t);
     int e; int fh = uni(HC.free_head), hw = uni(HC.slot_hw);
-    if(fh >= 0) { e = fh; IDX nx = uni(H.ed[e].lk.onx); HC.free_head = nx == NIL ? -1 : (int)nx; HC.free_cnt--; }
+    if(fh >= 0) { e = fh; IDX nx = uni(H.ed[e].et); HC.free_head = nx == NIL ? -1 : (int)nx; HC.free_cnt--; }
     else if(hw < MAXE) { e = hw; HC.slot_hw = hw + 1; }
     else { fail(ALD_ST_CAPACITY); return -1; }
     int id = uni(HC.next_id); HC.next_id = id + 1;
     if(ALD_UNLIKELY(id >= EID_LIMIT)) { fail(ALD_ST_CAPACITY); return -1; }
-    H.ed[e].lk.es = (IDX)s; H.ed[e].lk.et = (IDX)t; H.eid[e] = (EID)id; H.hflag[e] = 0; H.ed[e].w = 0;
+    H.ed[e].es = (IDX)s; H.ed[e].et = (IDX)t; H.ed[e].eid = (EID)id; H.ed[e].hf = 0; H.ed[e].w = 0;
     link_out(s, e); link_in(t, e);
     return e;
 }
@@ -424,46 +565,84 @@ ALD_INL int add_edge_i(int s, int t)
 ALD_INL void kill_edge_i(int e)
 {
     e = uni(e);
-    unlink_out(uni(H.ed[e].lk.es), e); unlink_in(uni(H.ed[e].lk.et), e);
-    H.ed[e].lk.es = NIL;
-    { int fh = uni(HC.free_head); H.ed[e].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = e; HC.free_cnt = uni(HC.free_cnt) + 1; }
+    unlink_out(uni(H.ed[e].es), e); unlink_in(uni(H.ed[e].et), e);
+    slot_release(e);
 }
-// remove_edge by the wave (ALL lanes call, e wave-uniform): the edge leaves its source's out-list and its target's in-list AT THE SAME
-// TIME -- lane 0 walks one list, lane 1 the other, same instruction stream, different links -- where kill_edge_i walks them one after
-// the other.  The two lists share no link field (onx / inx), no head and no degree.
+// remove_edge by the wave (ALL lanes call, e wave-uniform): the edge leaves its source's out-row and its target's in-row with ONE read
+// and ONE write of the two rows -- the lower half of the wave holds the out-row, the upper half the in-row, entry k in lane k of its
+// half; a ballot finds the edge, the entries behind it move up by one.  (A row of more than 32 entries -- a hub -- takes the scalar edit.)
 ALD_INL void kill_edge_wave(int e)
 {
     e = uni(e);
-    const uint64_t w = *(const uint64_t*)&H.ed[e].lk;            // es | et << 16 | inx << 32 | onx << 48, read before anything moves
-    const bool special = HC.special_linked != 0; const int sinkp = HC.sinkp;
-    for(int side = lane_id(); side < 2; side += ALD_WAVE) {
-        const bool out = (side == 0);
-        const int v = out ? (int)(w & 0xFFFF) : (int)((w >> 16) & 0xFFFF);
-        const IDX nxe = out ? (IDX)(w >> 48) : (IDX)((w >> 32) & 0xFFFF);
-        const bool counted = !special && (out ? v == 0 : v == sinkp);       // out(source) / in(sink): only counted until the final phase
-        IDX *deg = out ? &H.vx[v].out_deg : &H.vx[v].in_deg;
-        if(!counted) {
-            IDX *pp = out ? &H.vx[v].out_head : &H.vx[v].in_head; IDX cur = *pp; int guard = MAXE;
-            while((int)cur != e && cur != NIL && guard-- > 0) { pp = out ? &H.ed[cur].lk.onx : &H.ed[cur].lk.inx; cur = *pp; }
-            if(ALD_UNLIKELY((int)cur != e)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); continue; }      // cannot happen on a consistent state
-            *pp = nxe;
-        }
-        const int dg = (int)*deg - 1; *deg = (IDX)dg;
-        if(!counted && dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; }
+    const EKey ke = ekey(e); const int s = uni(ke.es), t = uni(ke.et);
+    const int special = HC.special_linked, sinkp = HC.sinkp;               // (one round of LDS reads with the two vertex records)
+    const Hot::VertexHot vs = H.vx[s], vt = H.vx[t];
+    const bool cs = !uni(special) && s == 0, ct = !uni(special) && t == uni(sinkp);       // out(source) / in(sink): only counted until the final phase
+    const int no = uni((int)vs.out_deg), ni = uni((int)vt.in_deg);
+#ifdef ALD_EMU
+    const bool wide = true;
+#else
+    const bool wide = (!cs && no > 32) || (!ct && ni > 32);
+#endif
+    if(wide) {
+        if(lane_id() == 0) { unlink_out(s, e); unlink_in(t, e); slot_release(e); }
+        return;
     }
-    wsync();
-    if(lane_id() == 0) {
-        H.ed[e].lk.es = NIL;
-        const int fh = uni(HC.free_head); H.ed[e].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = e; HC.free_cnt = uni(HC.free_cnt) + 1;
+#ifndef ALD_EMU
+    const int lane = lane_id(), half = lane >> 5, k = lane & 31;
+    const int n = half ? (ct ? 0 : ni) : (cs ? 0 : no);
+    const int addr = half ? uni(rin(vt)) + k : uni(rout(vs)) - k;
+    const int c = k < n ? (int)H.adj[addr] : -1;
+    const uint64_t m = wballot(c == e);
+    const uint32_t m_out = (uint32_t)m, m_in = (uint32_t)(m >> 32);
+    if(ALD_UNLIKELY((!cs && m_out == 0) || (!ct && m_in == 0))) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }      // cannot happen on a consistent state
+    const int p = half ? __builtin_ctz(m_in | 0x80000000u) : __builtin_ctz(m_out | 0x80000000u);
+    if(k > p && k < n) H.adj[half ? addr - 1 : addr + 1] = (IDX)c;
+    if(lane == 0) {
+        H.vx[s].out_deg = (IDX)(no - 1); H.vx[t].in_deg = (IDX)(ni - 1);
+        if((!cs && no - 1 <= 1) || (!ct && ni - 1 <= 1)) { HC.maybe_triv = 1; if((!cs && no - 1 == 0) || (!ct && ni - 1 == 0)) HC.maybe_broken = 1; }
+        slot_release(e);
     }
+#endif
 }
+#if defined(ALD_EMU) && defined(ALD_EMU_CHECK)
+// test build of the emulation only: every row sorted by (key, creation id), every live edge in exactly the rows it belongs to, every
+// segment inside the pool and disjoint from the others
+static void adj_check(const char *where)
+{
+    const int nv = HC.nv; int bad = 0;
+    static thread_local std::vector<int> owner; owner.assign(ADJ_CAP4, -1);
+    std::vector<int> seen_in(HC.slot_hw, 0), seen_out(HC.slot_hw, 0);
+    for(int v = 0; v < nv; v++) {
+        const Hot::VertexHot vr = H.vx[v]; const int ni = mat_in(v, vr), no = mat_out(v, vr);
+        if(ni + no > 4 * (int)vr.cap4) { fprintf(stderr, "[check %s] g %d v %d: %d + %d entries in %d chunks\n", where, HC.g, v, ni, no, (int)vr.cap4); bad++; continue; }
+        for(int c = vr.off4; c < vr.off4 + vr.cap4; c++) { if(c >= ADJ_CAP4) { bad++; break; } if(owner[c] >= 0) { fprintf(stderr, "[check %s] g %d: chunk %d owned by %d and %d\n", where, HC.g, c, owner[c], v); bad++; } owner[c] = v; }
+        uint32_t pk = 0, pid = 0;
+        for(int k = 0; k < ni; k++) { const int e = H.adj[rin(vr) + k]; if(e >= HC.slot_hw || H.ed[e].es == NIL || (int)H.ed[e].et != v) { fprintf(stderr, "[check %s] g %d v %d in[%d] = %d: not an in-edge\n", where, HC.g, v, k, e); bad++; continue; }
+            seen_in[e]++; const uint32_t kk = H.ed[e].es, id = H.ed[e].eid; if(k > 0 && (kk < pk || (kk == pk && id <= pid))) { fprintf(stderr, "[check %s] g %d v %d in-row out of order at %d\n", where, HC.g, v, k); bad++; } pk = kk; pid = id; }
+        pk = 0; pid = 0;
+        for(int k = 0; k < no; k++) { const int e = H.adj[rout(vr) - k]; if(e >= HC.slot_hw || H.ed[e].es == NIL || (int)H.ed[e].es != v) { fprintf(stderr, "[check %s] g %d v %d out[%d] = %d: not an out-edge\n", where, HC.g, v, k, e); bad++; continue; }
+            seen_out[e]++; const uint32_t kk = tkey(H.ed[e].et), id = H.ed[e].eid; if(k > 0 && (kk < pk || (kk == pk && id <= pid))) { fprintf(stderr, "[check %s] g %d v %d out-row out of order at %d\n", where, HC.g, v, k); bad++; } pk = kk; pid = id; }
+    }
+    for(int e = 0; e < HC.slot_hw; e++) {
+        if(H.ed[e].es == NIL) continue;
+        const int s = H.ed[e].es, t = H.ed[e].et;
+        const int wi = (t == HC.sinkp && !HC.special_linked) ? 0 : 1, wo = (s == 0 && !HC.special_linked) ? 0 : 1;
+        if(seen_in[e] != wi || seen_out[e] != wo) { fprintf(stderr, "[check %s] g %d edge %d (%d -> %d): in rows %d/%d, out rows %d/%d\n", where, HC.g, e, s, t, seen_in[e], wi, seen_out[e], wo); bad++; }
+    }
+    if(bad) abort();
+}
+#define ADJ_CHECK(w) adj_check(w)
+#else
+#define ADJ_CHECK(w) do {} while(0)
+#endif
 ALD_FN int add_edge(int s, int t) { return add_edge_i(uni(s), uni(t)); }
 ALD_FN void kill_edge(int e) { kill_edge_i(uni(e)); }
 ALD_FN void move_edge(int e, int x, int y)      // directed_graph.cc:180-194
 {
     e = uni(e); x = uni(x); y = uni(y);
-    unlink_out(uni(H.ed[e].lk.es), e); unlink_in(uni(H.ed[e].lk.et), e);
-    H.ed[e].lk.es = (IDX)x; H.ed[e].lk.et = (IDX)y;
+    unlink_out(uni(H.ed[e].es), e); unlink_in(uni(H.ed[e].et), e);
+    H.ed[e].es = (IDX)x; H.ed[e].et = (IDX)y;
     link_out(x, e); link_in(y, e);
 }
 
@@ -472,8 +651,8 @@ ALD_INL void strand_degree(int v, int vs[6])
 {
     COLD;
     for(int k = 0; k < 6; k++) vs[k] = 0;
-    for(int e = first_in(v); e >= 0; e = next_in(e)) vs[C.ed[e].estrand]++;
-    for(int e = first_out(v); e >= 0; e = next_out(e)) vs[C.ed[e].estrand + 3]++;
+    ROW_IN_L(v, e) vs[C.ed[e].estrand]++; ROW_END
+    ROW_OUT_L(v, e) vs[C.ed[e].estrand + 3]++; ROW_END
 }
 ALD_INL bool mixed_strand_vertex(int v)
 {
@@ -538,7 +717,7 @@ ALD_FN void hs_refresh_flags()                  // per-slot OCC / LEXT / REXT: h
     if(!HC.hs_dirty) return;
     HC.maybe_triv = 1;
     COLD;
-    for(int e = 0; e < HC.slot_hw; e++) H.hflag[e] = 0;
+    for(int e = 0; e < HC.slot_hw; e++) H.ed[e].hf = 0;
     int nl = HC.hl_n;
     for(int k = 0; k < nl; k++) {
         ALD_GLOBAL int32_t *v = C.hl + uni(C.hl_off[k]); int n = uni(C.hl_len[k]);
@@ -547,7 +726,7 @@ ALD_FN void hs_refresh_flags()                  // per-slot OCC / LEXT / REXT: h
             uint8_t f = HF_OCC;
             if(i >= 1 && v[i - 1] != -1) f |= HF_LEXT;
             if(i + 1 < n && v[i + 1] != -1) f |= HF_REXT;
-            H.hflag[e] |= f;
+            H.ed[e].hf |= f;
         }
     }
     HC.hs_dirty = 0;
@@ -650,7 +829,7 @@ ALD_FN int split_edge(int ei, double w)
     if(ALD_UNLIKELY(!(w >= HC.p_min_w - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
     double ww = uni(H.ed[ei].w);
     if(fabs(ww - w) <= kSMIN) return ei;
-    int s = uni(H.ed[ei].lk.es), t = uni(H.ed[ei].lk.et);
+    int s = uni(H.ed[ei].es), t = uni(H.ed[ei].et);
     int p2 = add_edge(s, t);
     if(p2 < 0) return -1;
     COLD;
@@ -673,9 +852,9 @@ ALD_INL int merge_adjacent_edges_i(int x, int y, double ww)
     const double mw = HC.p_min_w;
     if(ALD_UNLIKELY(!(ww >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return -1; }
     if(x < 0 || y < 0) return -1;
-    if(H.ed[x].lk.et != uni(H.ed[y].lk.es)) { int t = x; x = y; y = t; }
-    const int xs = uni(H.ed[x].lk.es), xt = uni(H.ed[x].lk.et), yt = uni(H.ed[y].lk.et);
-    if((int)uni(H.ed[y].lk.es) != xt) return -1;
+    if(H.ed[x].et != uni(H.ed[y].es)) { int t = x; x = y; y = t; }
+    const int xs = uni(H.ed[x].es), xt = uni(H.ed[x].et), yt = uni(H.ed[y].et);
+    if((int)uni(H.ed[y].es) != xt) return -1;
     PROF_DECL;
     COLD;
     const double wx = uni(H.ed[x].w), wy = uni(H.ed[y].w);
@@ -708,8 +887,8 @@ ALD_INL int merge_adjacent_edges_i(int x, int y, double ww)
     // same far endpoint (its id is the newest), before the first edge with a larger one
     PROF_ADD(PF_T_MERGE_MASK);
     double sum1 = 0, sum2 = 0;
-    { bool ins = !sx; for(int e = u_first_in(xt); e >= 0; e = u_next_in(e)) { if(!ins && (int)uni(H.ed[e].lk.es) > xs) { sum1 += ww; ins = true; } sum1 += uni(H.ed[e].w); } if(!ins) sum1 += ww; }
-    { bool ins = !sy; for(int e = u_first_out(xt); e >= 0; e = u_next_out(e)) { if(!ins && tkey(H.ed[e].lk.et) > tkey(yt)) { sum2 += ww; ins = true; } sum2 += uni(H.ed[e].w); } if(!ins) sum2 += ww; }
+    { bool ins = !sx; ROW_IN_U(xt, e) if(!ins && (int)uni(H.ed[e].es) > xs) { sum1 += ww; ins = true; } sum1 += uni(H.ed[e].w); ROW_END if(!ins) sum1 += ww; }
+    { bool ins = !sy; ROW_OUT_U(xt, e) if(!ins && tkey(H.ed[e].et) > tkey(yt)) { sum2 += ww; ins = true; } sum2 += uni(H.ed[e].w); ROW_END if(!ins) sum2 += ww; }
     const double sum = (sum1 + sum2) * 0.5;
     const double r1 = vwt * (wx0 + wy0) * 0.5 / sum;
     C.vx[xt].vw = vwt - r1;
@@ -730,13 +909,15 @@ ALD_INL void balance_vertex_i(int v)
     if(H.vx[v].in_deg == 0 || uni(H.vx[v].out_deg) == 0) return;
     const double mw = HC.p_min_w;
     double w1 = 0, w2 = 0;
-    for(int e = u_first_in(v); e >= 0; e = u_next_in(e)) { double w = uni(H.ed[e].w); if(ALD_UNLIKELY(!(w >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w1 += w; }
-    for(int e = u_first_out(v); e >= 0; e = u_next_out(e)) { double w = uni(H.ed[e].w); if(ALD_UNLIKELY(!(w >= mw - kSMIN))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; } w2 += w; }
+    bool low = false;
+    ROW_IN_U(v, e) const double w = uni(H.ed[e].w); if(ALD_UNLIKELY(!(w >= mw - kSMIN))) low = true; w1 += w; ROW_END
+    ROW_OUT_U(v, e) const double w = uni(H.ed[e].w); if(ALD_UNLIKELY(!(w >= mw - kSMIN))) low = true; w2 += w; ROW_END
+    if(ALD_UNLIKELY(low)) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
     double ww = sqrt(w1 * w2);
     double r1 = ww / w1, r2 = ww / w2;
     double m1 = 0, m2 = 0;
-    for(int e = u_first_in(v); e >= 0; e = u_next_in(e)) { double wy = uni(H.ed[e].w) * r1; if(wy < mw) { m1 += mw - wy; wy = mw; } H.ed[e].w = wy; }
-    for(int e = u_first_out(v); e >= 0; e = u_next_out(e)) { double wy = uni(H.ed[e].w) * r2; if(wy < mw) { m2 += mw - wy; wy = mw; } H.ed[e].w = wy; }
+    ROW_IN_U(v, e) double wy = uni(H.ed[e].w) * r1; if(wy < mw) { m1 += mw - wy; wy = mw; } H.ed[e].w = wy; ROW_END
+    ROW_OUT_U(v, e) double wy = uni(H.ed[e].w) * r2; if(wy < mw) { m2 += mw - wy; wy = mw; } H.ed[e].w = wy; ROW_END
     if(m1 > m2) { int e = u_first_out(v); H.ed[e].w = uni(H.ed[e].w) + m1 - m2; }
     else if(m1 < m2) { int e = u_first_in(v); H.ed[e].w = uni(H.ed[e].w) + m2 - m1; }
 }
@@ -771,9 +952,9 @@ ALD_INL Arena arena_at(bool lds)
 }
 ALD_INL bool pair_less(int a1, int a2, int b1, int b2)
 {
-    uint32_t x1 = H.eid[a1], y1 = H.eid[b1];
+    uint32_t x1 = H.ed[a1].eid, y1 = H.ed[b1].eid;
     if(x1 != y1) return x1 < y1;
-    return H.eid[a2] < H.eid[b2];
+    return H.ed[a2].eid < H.ed[b2].eid;
 }
 ALD_INL void sort_pairs(const Pairs &P, int n)   // insertion sort by (id(e1), id(e2)); keys are unique
 {
@@ -811,9 +992,13 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     int n = 0; double wcen = H.ed[c].w;          // weights stay in vector registers: they only feed FP arithmetic and LDS stores
     if(ALD_UNLIKELY(uni(!(wcen >= mw - kSMIN)))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
     double sfan0 = 0;
-    for(int e = A ? u_first_out(x) : u_first_in(x); e >= 0; e = A ? u_next_out(e) : u_next_in(e)) {
-        double w2 = H.ed[e].w; if(ALD_UNLIKELY(uni(!(w2 >= mw - kSMIN)))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
-        fe[n] = e; fw[n] = w2; sfan0 += w2; n++;
+    {
+        const Hot::VertexHot vrx = H.vx[x]; const int fb = uni(A ? rout(vrx) : rin(vrx)), fn = uni(A ? (int)vrx.out_deg : (int)vrx.in_deg);
+        for(int k = 0; k < fn; k++) {
+            const int e = uni((int)H.adj[A ? fb - k : fb + k]);
+            double w2 = H.ed[e].w; if(ALD_UNLIKELY(uni(!(w2 >= mw - kSMIN)))) { fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); return; }
+            fe[n] = e; fw[n] = w2; sfan0 += w2; n++;
+        }
     }
     {
         double scen0 = 0; scen0 += wcen;
@@ -834,14 +1019,14 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     double *pfx = SMALL ? nullptr : (double*)(C.wd + Cold::w_cap / 8);     // [n] large form only: prefix sums of fw over the live fan edges (list order)
     if(!SMALL) { double run = 0; for(int k = 0; k < n; k++) { run += fw[k]; pfx[k] = run; } }
     int32_t *aux = SMALL ? nullptr : (int32_t*)(C.wi + 2 * (Cold::w_cap / 8));        // [n] second buffer of the large form (merge sort, deferred inserts)
-    if(SMALL) { for(int i = 0; i < n; i++) { int k = i; uint32_t id = uni(H.eid[fe[i]]); while(k > 0 && (uint32_t)uni(H.eid[fe[ord[k - 1]]]) > id) { ord[k] = ord[k - 1]; k--; } ord[k] = i; } }
+    if(SMALL) { for(int i = 0; i < n; i++) { int k = i; uint32_t id = uni(H.ed[fe[i]].eid); while(k > 0 && (uint32_t)uni(H.ed[fe[ord[k - 1]]].eid) > id) { ord[k] = ord[k - 1]; k--; } ord[k] = i; } }
     else {      // a hub's fan can hold hundreds of edges: bottom-up merge sort of the positions by creation id
         for(int i = 0; i < n; i++) ord[i] = i;
         int32_t *src = ord, *dst = aux;
         for(int wdt = 1; wdt < n; wdt *= 2) {
             for(int lo = 0; lo < n; lo += 2 * wdt) {
                 int mid = lo + wdt < n ? lo + wdt : n, hi = lo + 2 * wdt < n ? lo + 2 * wdt : n, i = lo, j = mid, k = lo;
-                while(i < mid && j < hi) { if((uint32_t)H.eid[fe[src[j]]] < (uint32_t)H.eid[fe[src[i]]]) dst[k++] = src[j++]; else dst[k++] = src[i++]; }
+                while(i < mid && j < hi) { if((uint32_t)H.ed[fe[src[j]]].eid < (uint32_t)H.ed[fe[src[i]]].eid) dst[k++] = src[j++]; else dst[k++] = src[i++]; }
                 while(i < mid) dst[k++] = src[i++];
                 while(j < hi) dst[k++] = src[j++];
             }
@@ -854,7 +1039,7 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     H.ed[c].w = mdc;
     for(int j = 0; j < n; j++) H.ed[fe[j]].w = fw[j];
     PROF_ADD(PF_T_SETUP);
-    const int far = A ? (int)uni(H.ed[c].lk.es) : (int)uni(H.ed[c].lk.et);
+    const int far = A ? (int)uni(H.ed[c].es) : (int)uni(H.ed[c].et);
     const double medc = C.ed[c].med, cc = C.ed[c].econf;
     const int meic = uni(C.ed[c].mei), cntc = uni(C.ed[c].ecount), stc = uni(C.ed[c].estrand);
     const uint32_t nsc = uni(C.ed[c].sp_len); const int idc = uni(C.ed[c].s0id); const double abc = C.ed[c].s0abd;     // c's support never changes
@@ -903,13 +1088,11 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
         C.ed[f].med = A ? mi * r1 + medc1 + medf : mi * r1 + medf + medc1; C.ed[f].mei = mi;
         PROF_ADD(PF_T_MERGE_SUMS);
         // f becomes the merged edge: newest id, far endpoint of c, weight of the two equal pieces
-        const int other = A ? (int)uni(H.ed[f].lk.et) : (int)uni(H.ed[f].lk.es);
-        H.eid[f] = (EID)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
-        // the new edge far -> other sorts behind c = far -> x whenever other's key is above x's (always, except for vertices added by
-        // decompose_vertex_extend): the walk starts at c
-        if(A) { H.ed[f].lk.es = (IDX)far; relink_in(other, f, (uint32_t)far); if(SMALL) { if(tkey((uint32_t)other) > tkey((uint32_t)x)) link_out_after(far, f, c); else link_out(far, f); } }
-        else { H.ed[f].lk.et = (IDX)far; relink_out(other, f, tkey((uint32_t)far)); if(SMALL) link_in(far, f); }
-        if(!SMALL) aux[q] = f;            // large form: the far vertex's list takes all new edges in ONE merge after the loop (nothing reads it meanwhile)
+        const int other = A ? (int)uni(H.ed[f].et) : (int)uni(H.ed[f].es);
+        H.ed[f].eid = (EID)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
+        if(A) { H.ed[f].es = (IDX)far; relink_in(other, f, (uint32_t)far); if(SMALL) link_out(far, f); }
+        else { H.ed[f].et = (IDX)far; relink_out(other, f, tkey((uint32_t)far)); if(SMALL) link_in(far, f); }
+        if(!SMALL) aux[q] = f;            // large form: the far vertex's row takes the new edges after the loop (nothing reads it meanwhile)
         fe[j] = -1;
         if(!SMALL) { double run = j > 0 ? pfx[j - 1] : 0.0; for(int k = j; k < n; k++) { if(fe[k] >= 0) run += fw[k]; pfx[k] = run; } }      // same additions, same order, from j on
         PROF_ADD(PF_T_MERGE_ADD);
@@ -920,43 +1103,17 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
     }
     C.vx[x].vw = vwt;
     if(!SMALL) {
-        // aux[0..n) = the merged edges in creation order; stable merge sort by the list's primary key (target for an out-list, source
-        // for an in-list) gives (key, id) order, then one walk of far's list places them all
-        int32_t *src = aux, *dst = ord;
-        for(int wdt = 1; wdt < n; wdt *= 2) {
-            for(int lo = 0; lo < n; lo += 2 * wdt) {
-                int mid = lo + wdt < n ? lo + wdt : n, hi = lo + 2 * wdt < n ? lo + 2 * wdt : n, i = lo, j = mid, k = lo;
-                while(i < mid && j < hi) {
-                    const uint32_t kj = A ? tkey(H.ed[src[j]].lk.et) : (uint32_t)H.ed[src[j]].lk.es, ki = A ? tkey(H.ed[src[i]].lk.et) : (uint32_t)H.ed[src[i]].lk.es;
-                    if(kj < ki) dst[k++] = src[j++]; else dst[k++] = src[i++];
-                }
-                while(i < mid) dst[k++] = src[i++];
-                while(j < hi) dst[k++] = src[j++];
-            }
-            int32_t *t2 = src; src = dst; dst = t2;
-        }
+        // aux[0..n) = the merged edges in creation order: into far's row one by one, each searched for from the row's end (room for all
+        // of them is made once)
         const bool counted = A ? (far == 0 && !uni(HC.special_linked)) : (far == (int)uni(HC.sinkp) && !uni(HC.special_linked));
-        if(!counted) {
-            IDX *pp = A ? &H.vx[far].out_head : &H.vx[far].in_head; IDX cur = *pp; int guard = MAXE + n;
-            for(int q = 0; q < n; q++) {
-                const int e = src[q]; const uint32_t ke = A ? tkey(H.ed[e].lk.et) : (uint32_t)H.ed[e].lk.es;
-                while(uni(cur != NIL) && guard-- > 0) {       // existing edges with key <= ke stay in front (their ids are older)
-                    const uint32_t kc = A ? tkey(H.ed[cur].lk.et) : (uint32_t)H.ed[cur].lk.es;
-                    if(uni(kc > ke)) break;
-                    pp = A ? &H.ed[cur].lk.onx : &H.ed[cur].lk.inx; cur = *pp;
-                }
-                if(A) H.ed[e].lk.onx = cur; else H.ed[e].lk.inx = cur;
-                *pp = (IDX)e; pp = A ? &H.ed[e].lk.onx : &H.ed[e].lk.inx;
-            }
-        }
-        if(A) H.vx[far].out_deg = (IDX)((int)uni(H.vx[far].out_deg) + n); else H.vx[far].in_deg = (IDX)((int)uni(H.vx[far].in_deg) + n);
+        if(!counted && !adj_reserve_s(far, n)) return;
+        for(int q = 0; q < n; q++) { if(A) link_out(far, aux[q]); else link_in(far, aux[q]); }
     }
     if(n >= 2) hs_remove(c);
     if(ALD_UNLIKELY(!consumed)) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }      // c kept a remainder: the reference asserts on the degree of x
     // remove_edge(c); x is left without edges
     if(A) unlink_out(far, c); else unlink_in(far, c);
-    H.ed[c].lk.es = NIL; H.hflag[c] = 0;
-    { int fh = uni(HC.free_head); H.ed[c].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = c; HC.free_cnt = uni(HC.free_cnt) + 1; }
+    H.ed[c].hf = 0; slot_release(c);
     clear_vertex(x);
     PROF_ADD(PF_T_TAIL);
 }
@@ -1006,7 +1163,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
     double *dctx = fw + 2 * STAR_MAX;                                      // [0] = weight c starts with
     // what the merges need of c's record and of vertex x is asked for NOW, by every lane (one broadcast request each): the round
     // trip to L2 runs under phases 0..2 instead of in front of phase 3
-    const int c_early = A ? first_in(x) : first_out(x);
+    const int c_early = A ? first_in(x) : first_out(x);      // (x has exactly one edge on that side: the caller chose the form from the degrees)
     const double medc = C.ed[c_early].med, cc = C.ed[c_early].econf, abc = C.ed[c_early].s0abd, vw_early = C.vx[x].vw;
     const int meic_v = C.ed[c_early].mei, cntc_v = C.ed[c_early].ecount, stc_v = C.ed[c_early].estrand, idc_v = C.ed[c_early].s0id;
     const uint32_t nsc_v = C.ed[c_early].sp_len;
@@ -1015,13 +1172,18 @@ template<bool A> ALD_INL void star_wave_body(int x)
     if(NW <= 2) for(int k = 0; k < NW; k++) cmask_pf[k] = C.ed[c_early].mask[k];
     // ---- phase 0 (lane 0): gather the fan, balance_vertex(x) on the gathered weights, pair weights -- as in the sequential form
     if(lane == 0) {
-        const int c = A ? u_first_in(x) : u_first_out(x);
+        const Hot::VertexHot vrx = H.vx[x];                               // where both rows of x are: one read
+        const int c = uni((int)H.adj[A ? rin(vrx) : rout(vrx)]);
         int n = 0; double wcen = H.ed[c].w; int bad = 0;
         if(ALD_UNLIKELY(uni(!(wcen >= mw - kSMIN)))) bad = ALD_ST_INVARIANT + ALD_INV_WEIGHT;
         double sfan0 = 0;
-        for(int e = A ? u_first_out(x) : u_first_in(x); e >= 0 && n < STAR_MAX; e = A ? u_next_out(e) : u_next_in(e)) {
-            double w2 = H.ed[e].w; if(ALD_UNLIKELY(uni(!(w2 >= mw - kSMIN)))) bad = ALD_ST_INVARIANT + ALD_INV_WEIGHT;
-            fe[n] = e; fw[n] = w2; sfan0 += w2; n++;
+        {   // the fan = the other row of x: its entries' addresses are known at once, nothing here waits for the edge before
+            const int fb = uni(A ? rout(vrx) : rin(vrx)); int fn = uni(A ? (int)vrx.out_deg : (int)vrx.in_deg); if(fn > STAR_MAX) fn = STAR_MAX;
+            for(int k = 0; k < fn; k++) {
+                const int e = uni((int)H.adj[A ? fb - k : fb + k]);
+                double w2 = H.ed[e].w; if(ALD_UNLIKELY(uni(!(w2 >= mw - kSMIN)))) bad = ALD_ST_INVARIANT + ALD_INV_WEIGHT;
+                fe[n] = e; fw[n] = w2; sfan0 += w2; n++;
+            }
         }
         if(!bad) {
             double scen0 = 0; scen0 += wcen;
@@ -1041,14 +1203,14 @@ template<bool A> ALD_INL void star_wave_body(int x)
 #ifndef ALD_STAR_NO_SMALL
         if(!bad && n <= STAR_SMALL) {           // phases 1 and 2 right here: merge order by creation id (insertion sort), centre weight, the fan edges' new weights
             small = 1;
-            for(int i = 0; i < n; i++) { int k = i; const uint32_t id = uni(H.eid[fe[i]]); while(k > 0 && (uint32_t)uni(H.eid[fe[ord[k - 1]]]) > id) { ord[k] = ord[k - 1]; k--; } ord[k] = i; }
+            for(int i = 0; i < n; i++) { int k = i; const uint32_t id = uni(H.ed[fe[i]].eid); while(k > 0 && (uint32_t)uni(H.ed[fe[ord[k - 1]]].eid) > id) { ord[k] = ord[k - 1]; k--; } ord[k] = i; }
             double mdc = 0;
             for(int q = 0; q < n; q++) { inv[ord[q]] = q; const double w = fw[ord[q]]; if(ALD_UNLIKELY(!(w >= mw - kSMIN))) bad = ALD_ST_INVARIANT + ALD_INV_WEIGHT; mdc = (q == 0) ? w : mdc + w; }
             dctx[0] = mdc;
             for(int j = 0; j < n; j++) H.ed[fe[j]].w = fw[j];
         }
 #endif
-        ctx[SW_N] = n; ctx[SW_C] = c; ctx[SW_FAR] = A ? (int)uni(H.ed[c].lk.es) : (int)uni(H.ed[c].lk.et); ctx[SW_FAIL] = bad; ctx[SW_FAILQ] = -1; ctx[SW_SERIAL] = 0; ctx[SW_SMALL] = small;
+        ctx[SW_N] = n; ctx[SW_C] = c; ctx[SW_FAR] = A ? (int)uni(H.ed[c].es) : (int)uni(H.ed[c].et); ctx[SW_FAIL] = bad; ctx[SW_FAILQ] = -1; ctx[SW_SERIAL] = 0; ctx[SW_SMALL] = small;
     }
     wsync();
     const int n = uni(ctx[SW_N]), c = uni(ctx[SW_C]), far = uni(ctx[SW_FAR]);
@@ -1060,8 +1222,8 @@ template<bool A> ALD_INL void star_wave_body(int x)
     if(!uni(ctx[SW_SMALL])) {
     // ---- phase 1 (lane j): rank of fan edge j by creation id -> ord (merge order) and its inverse
     for(int j = lane; j < n; j += ALD_WAVE) {
-        const uint32_t id = H.eid[fe[j]]; int r = 0;
-        for(int k = 0; k < n; k++) r += ((uint32_t)H.eid[fe[k]] < id) ? 1 : 0;
+        const uint32_t id = H.ed[fe[j]].eid; int r = 0;
+        for(int k = 0; k < n; k++) r += ((uint32_t)H.ed[fe[k]].eid < id) ? 1 : 0;
         ord[r] = j; inv[j] = r;
     }
     wsync();
@@ -1108,7 +1270,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
         for(int k = 0; k < n; k++) if(inv[k] >= q) sfan += fw[k];             // not merged yet, list order
         double sc_side = 0; sc_side += sc ? rem : wcur; if(sc) sc_side += ww;
         sq[q] = A ? (sc_side + sfan) * 0.5 : (sfan + sc_side) * 0.5;
-        oth[q] = A ? (int)H.ed[fe[j]].lk.et : (int)H.ed[fe[j]].lk.es;
+        oth[q] = A ? (int)H.ed[fe[j]].et : (int)H.ed[fe[j]].es;
     }
     wsync();
     PROF_ADD(PF_T_MERGE_LOAD);
@@ -1172,8 +1334,8 @@ template<bool A> ALD_INL void star_wave_body(int x)
         for(int k = 0; k < NW; k++) { uint64_t mk = (NW <= 2 ? cmask_pf[NW <= 2 ? k : 0] : C.ed[c].mask[k]) | (k == 0 ? pf_mask0 : C.ed[f].mask[k]); if(ov >= 0 && (ov >> 6) == k) mk |= (1ull << (ov & 63)); C.ed[f].mask[k] = mk; }
         const int mi = A ? rt - lt + meic + meif : rt - lt + meif + meic;
         C.ed[f].med = A ? mi * r1 + medc1 + medf : mi * r1 + medf + medc1; C.ed[f].mei = mi;
-        H.eid[f] = (EID)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
-        if(A) H.ed[f].lk.es = (IDX)far; else H.ed[f].lk.et = (IDX)far;
+        H.ed[f].eid = (EID)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
+        if(A) H.ed[f].es = (IDX)far; else H.ed[f].et = (IDX)far;
 #ifdef ALD_PROF
         { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[PF_S5_BODY] += t1_ - prof_s5_; prof_s5_ = t1_; }
 #endif
@@ -1196,42 +1358,48 @@ template<bool A> ALD_INL void star_wave_body(int x)
     wsync();
     PROF_ADD(PF_T_MERGE_MASK);
     if(ALD_UNLIKELY(!consumed)) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); wsync(); return; }     // c kept a remainder: the reference asserts on the degree of x
-    // ---- phase 6 (lane q): place of merged edge q in far's list = behind the last old entry whose key does not exceed its own
-    // (old entries carry older ids), and among the new ones by (key, creation order).  Read-only walk; the links are written in 6c.
-    int32_t *pred = inv, *succ = (int32_t*)sq, *srt = (int32_t*)sq + STAR_MAX;
+    // ---- phase 6: the merged edges enter far's row.  Lane j holds old entry j and its key, lane q merged edge q (merge order) and its
+    // key; a merged edge goes behind every old entry whose key does not exceed its own (old entries carry older ids) and among the new
+    // ones by (key, creation order): one pass over the new keys gives every old entry its shift and every new one its place, then ALL
+    // entries are written at once -- no walk, whatever the row's length.  (A row that would not fit the wave: one insertion at a time.)
     if(!counted) {
-        for(int q = lane; q < n; q += ALD_WAVE) {
-            const uint32_t key = A ? tkey((uint32_t)oth[q]) : (uint32_t)oth[q];
-            int last = -1, cur = A ? first_out(far) : first_in(far), guard = MAXE;
-            while(cur >= 0 && guard-- > 0) {
-                const uint64_t w = *(const uint64_t*)&H.ed[cur].lk;
-                const uint32_t kc = A ? tkey((uint32_t)((w >> 16) & 0xFFFF)) : (uint32_t)(w & 0xFFFF);
-                if(kc > key) break;
-                last = cur; cur = A ? lk_next((uint32_t)(w >> 48)) : lk_next((uint32_t)((w >> 32) & 0xFFFF));
+        if(!adj_reserve_w(far, n)) { wsync(); return; }                       // (status set: the graph moves up a class)
+        bool placed = false;
+#ifndef ALD_EMU
+        const Hot::VertexHot vf = H.vx[far]; const int len = uni(A ? (int)vf.out_deg : (int)vf.in_deg), fb = uni(A ? rout(vf) : rin(vf));
+        if(len + n <= ALD_WAVE) {
+            const bool old = lane < len, fresh = lane < n;
+            const int cj = old ? (int)H.adj[A ? fb - lane : fb + lane] : 0;
+            const int fq = fresh ? fe[ord[lane]] : 0;
+            const uint32_t myk = fresh ? (A ? tkey((uint32_t)oth[lane]) : (uint32_t)oth[lane]) : 0u;
+            const uint32_t kj = old ? (A ? tkey((uint32_t)H.ed[cj].et) : (uint32_t)H.ed[cj].es) : 0xFFFFFFFFu;
+            int shift = 0, pos = 0;
+            for(int q = 0; q < n; q++) {
+                const uint32_t kq = (uint32_t)__builtin_amdgcn_readlane((int)myk, q);
+                const int below = __builtin_popcountll(wballot(old && kj <= kq));      // old entries that stay in front of merged edge q
+                if(old && kq < kj) shift++;
+                if(lane == q) pos += below;
+                if(fresh && (kq < myk || (kq == myk && q < lane))) pos++;
             }
-            int r = 0;
-            for(int k = 0; k < n; k++) { const uint32_t kk = A ? tkey((uint32_t)oth[k]) : (uint32_t)oth[k]; r += (kk < key || (kk == key && k < q)) ? 1 : 0; }
-            pred[q] = last; succ[q] = cur; srt[r] = q;
+            if(old && shift) H.adj[A ? fb - (lane + shift) : fb + (lane + shift)] = (IDX)cj;
+            if(fresh) H.adj[A ? fb - pos : fb + pos] = (IDX)fq;
+            placed = true;
         }
-        wsync();
-#ifdef ALD_PROF
-        { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[PF_S6_WALK] += t1_ - prof_t_; }
 #endif
-        for(int r = lane; r < n; r += ALD_WAVE) {
-            const int q = srt[r], f = fe[ord[q]];
-            const bool first_of_gap = (r == 0) || pred[srt[r - 1]] != pred[q], last_of_gap = (r + 1 >= n) || pred[srt[r + 1]] != pred[q];
-            const IDX nx = last_of_gap ? (succ[q] < 0 ? NIL : (IDX)succ[q]) : (IDX)fe[ord[srt[r + 1]]];
-            if(A) H.ed[f].lk.onx = nx; else H.ed[f].lk.inx = nx;
-            if(first_of_gap) { if(pred[q] < 0) { if(A) H.vx[far].out_head = (IDX)f; else H.vx[far].in_head = (IDX)f; } else { if(A) H.ed[pred[q]].lk.onx = (IDX)f; else H.ed[pred[q]].lk.inx = (IDX)f; } }
+        wsync();
+        if(lane == 0) {
+            if(placed) { if(A) H.vx[far].out_deg = (IDX)((int)uni(H.vx[far].out_deg) + n); else H.vx[far].in_deg = (IDX)((int)uni(H.vx[far].in_deg) + n); }
+            else for(int q = 0; q < n; q++) { if(A) row_insert_out<true>(far, fe[ord[q]]); else row_insert_in<true>(far, fe[ord[q]]); }
         }
     }
+    else if(lane == 0) { if(A) H.vx[far].out_deg = (IDX)((int)uni(H.vx[far].out_deg) + n); else H.vx[far].in_deg = (IDX)((int)uni(H.vx[far].in_deg) + n); }
     wsync();
 #ifdef ALD_PROF
+    { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[PF_S6_WALK] += t1_ - prof_t_; }
     unsigned long long prof_s7_ = __builtin_readcyclecounter();
 #endif
     // ---- phase 7 (lane 0): what is left and inherently ordered -- the support pool, the phasing lists, the counters
     if(lane == 0) {
-        if(A) H.vx[far].out_deg = (IDX)((int)uni(H.vx[far].out_deg) + n); else H.vx[far].in_deg = (IDX)((int)uni(H.vx[far].in_deg) + n);
         if(any_dup || any_multi || uni(HC.hl_n) != 0) for(int q = 0; q < n; q++) {
             const int f = fe[ord[q]];
             if(any_dup) { if(A) relink_in(oth[q], f, (uint32_t)far); else relink_out(oth[q], f, tkey((uint32_t)far)); }
@@ -1239,11 +1407,10 @@ template<bool A> ALD_INL void star_wave_body(int x)
             if(A) hs_replace2(c, f, f); else hs_replace2(f, c, f);
             if(n == 1) hs_replace1(c, f);
         }
-        HC.next_id = (int)uni(H.eid[fe[ord[n - 1]]]) + 1;
+        HC.next_id = (int)uni(H.ed[fe[ord[n - 1]]].eid) + 1;
         if(n >= 2) hs_remove(c);
-        // remove_edge(c) (already out of far's list); x is left without edges
-        H.ed[c].lk.es = NIL; H.hflag[c] = 0;
-        { int fh = uni(HC.free_head); H.ed[c].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = c; HC.free_cnt = uni(HC.free_cnt) + 1; }
+        // remove_edge(c) (already out of far's row); x is left without edges
+        H.ed[c].hf = 0; slot_release(c);
         clear_vertex(x);
     }
     wsync();
@@ -1298,27 +1465,25 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
     PROF_DECL;
     const int lane = lane_id();
     const double mw = HC.p_min_w;
-    const Hot::VertexHot vrx = H.vx[x];           // both list heads of x in one LDS read
-    const int c = uni(slot_or_neg(A ? vrx.in_head : vrx.out_head));
-    int bad = (c < 0) ? 1 : 0;
-    const int cs = c >= 0 ? c : 0;
-    // the fan in list order
+    const Hot::VertexHot vrx = H.vx[x];           // where both rows of x are, and how long: one LDS read
+    int bad = ((A ? vrx.in_deg : vrx.out_deg) != 1 || (A ? vrx.out_deg : vrx.in_deg) != N) ? 1 : 0;      // (the caller chose N from the degrees)
+    const int xi = rin(vrx), xo = rout(vrx);
+    const int cs = uni((int)H.adj[A ? xi : xo]);
+    // the fan in row order: its (at most four) slots with ONE aligned 8-byte read, then every edge's record at once -- no entry's
+    // address depends on the entry before (a linked list's did: one round trip per fan edge)
     int fe[N], oth[N]; double fw[N]; uint32_t id[N];
     {
-        int e = slot_or_neg(A ? vrx.out_head : vrx.in_head);
+        static_assert(N <= 4, "the fan is read as one 4-entry chunk");
+        const uint64_t rw = *(const uint64_t*)&H.adj[A ? xo - 3 : xi];
         ALD_UNROLL for(int k = 0; k < N; k++) {
-            if(e < 0) bad = 1;
-            const int es = e >= 0 ? e : 0;
-            const double w = H.ed[es].w; const uint64_t lw = *(const uint64_t*)&H.ed[es].lk;
-            fe[k] = es; fw[k] = w; id[k] = H.eid[es];
-            oth[k] = A ? (int)((lw >> 16) & 0xFFFF) : (int)(lw & 0xFFFF);
-            e = A ? lk_next((uint32_t)(lw >> 48)) : lk_next((uint32_t)((lw >> 32) & 0xFFFF));
+            const int es = (int)((rw >> (16 * (A ? 3 - k : k))) & 0xFFFF);
+            const double w = H.ed[es].w; const EKey ek = ekey(es);
+            fe[k] = es; fw[k] = w; id[k] = ek.eid;
+            oth[k] = A ? (int)ek.et : (int)ek.es;
         }
-        if(e >= 0) bad = 1;                       // (the caller chose N from the degree)
     }
-    const uint64_t lwc = *(const uint64_t*)&H.ed[cs].lk;
-    const int far = uni(A ? (int)(lwc & 0xFFFF) : (int)((lwc >> 16) & 0xFFFF));
-    const int c_next = A ? lk_next((uint32_t)(lwc >> 48)) : lk_next((uint32_t)((lwc >> 32) & 0xFFFF));     // c's successor in far's list
+    const EKey kcs = ekey(cs);
+    const int far = uni(A ? (int)kcs.es : (int)kcs.et);
     bool dupf = false;                            // two fan edges to one vertex: their relinks share a list -> sequential, in merge order, at the end
     ALD_UNROLL for(int k = 0; k < N; k++) { ALD_UNROLL for(int k2 = 0; k2 < N; k2++) if(k2 < k && oth[k] == oth[k2]) dupf = true; }      // (every loop over the fan must unroll: an array indexed at run time lives in scratch memory)
     dupf = uni(dupf);
@@ -1389,30 +1554,30 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
         const double r1 = A ? vwt * (wc0 + ww) * 0.5 / sum : vwt * (ww + wc0) * 0.5 / sum;
         vwt = vwt - r1; r1_q[q] = r1;
     }
-    // ---- far's list (read only): the place of every merged edge -- behind the last entry whose key does not exceed its own (the old
-    // entries carry older ids; new ones with the same key follow each other in merge order) -- and c's predecessor, in one walk
+    // ---- far's row (read only here): lane j takes old entry j and its key -- ONE read of the row, ONE of the records, whatever its
+    // length --, a ballot finds c.  A merged edge goes behind every old entry whose key does not exceed its own (the old entries carry
+    // older ids; new ones with the same key follow each other in merge order); c's entry closes up.  A row too long for one pass or a
+    // segment without room for the N - 1 entries to come makes the form decline (star_wave_body grows the segment).
     const bool counted = uni(A ? (far == 0 && !HC.special_linked) : (far == HC.sinkp && !HC.special_linked));      // out(source) / in(sink) are only counted
-    uint32_t key[N]; int pred[N], succ[N]; int pc = -1;
-    ALD_UNROLL for(int k = 0; k < N; k++) { key[k] = A ? tkey((uint32_t)oth[k]) : (uint32_t)oth[k]; pred[k] = -1; succ[k] = -1; }
+    const Hot::VertexHot vf = H.vx[far];
+    const int flen = uni(A ? (int)vf.out_deg : (int)vf.in_deg), fb = uni(A ? rout(vf) : rin(vf));
+    uint32_t key[N]; int pc = -1;
+    ALD_UNROLL for(int k = 0; k < N; k++) key[k] = A ? tkey((uint32_t)oth[k]) : (uint32_t)oth[k];
+#ifndef ALD_EMU
+    int cj = 0; uint32_t kj = 0xFFFFFFFFu; bool oldj = false;
+#endif
     if(!counted) {
-        int placed[N]; ALD_UNROLL for(int k = 0; k < N; k++) placed[k] = 0;
-        bool seen_c = false; int last = -1, guard = MAXE;
-        int cur = A ? first_out(far) : first_in(far);
-        while(uni(cur >= 0) && guard-- > 0) {
-            const uint64_t w = *(const uint64_t*)&H.ed[cur].lk;
-            const int nx = A ? lk_next((uint32_t)(w >> 48)) : lk_next((uint32_t)((w >> 32) & 0xFFFF));
-            if(cur == cs) { pc = last; seen_c = true; }
-            else {
-                const uint32_t kc = A ? tkey((uint32_t)((w >> 16) & 0xFFFF)) : (uint32_t)(w & 0xFFFF);
-                ALD_UNROLL for(int k = 0; k < N; k++) if(!placed[k] && kc > key[k]) { placed[k] = 1; pred[k] = last; succ[k] = cur; }
-                last = cur;
-            }
-            bool all = seen_c; ALD_UNROLL for(int k = 0; k < N; k++) all = all && placed[k];
-            if(uni(all)) break;
-            cur = nx;
-        }
-        ALD_UNROLL for(int k = 0; k < N; k++) if(!placed[k]) pred[k] = last;       // behind everything
-        if(!seen_c || guard <= 0) bad = 1;
+        if(flen > ALD_WAVE || uni(mat_in(far, vf) + mat_out(far, vf)) + N - 1 > 4 * uni((int)vf.cap4)) bad = 1;
+#ifndef ALD_EMU
+        oldj = lane < flen;
+        cj = oldj ? (int)H.adj[A ? fb - lane : fb + lane] : 0;
+        kj = oldj ? (A ? tkey((uint32_t)H.ed[cj].et) : (uint32_t)H.ed[cj].es) : 0xFFFFFFFFu;
+        const uint64_t mc = wballot(oldj && cj == cs);
+        if(mc == 0) bad = 1; else pc = ffs64(mc);
+#else
+        for(int j = 0; j < flen && j < ALD_WAVE * 64; j++) if((int)H.adj[A ? fb - j : fb + j] == cs) { pc = j; break; }
+        if(pc < 0) bad = 1;
+#endif
     }
     // (wave-uniform values of c's record and of the vertex go to scalar registers now: the loads have had their time)
     const int meic = uni(meic_v), cntc = uni(cntc_v), stc = uni(stc_v), idc = uni(idc_v), lt = uni(lt_v), rt = uni(rt_v), ov = uni(ov_v);
@@ -1431,6 +1596,18 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
 #endif
         if(wballot(cnt_bad) != 0 || uni(bad) != 0) return false;
     }
+    // ---- far's row, written: every old entry but c moves to (its index) - (c in front of it) + (merged edges with a smaller key), a merged
+    // edge to (old entries, c apart, whose key does not exceed its own) + (its rank among the merged ones): a merge of two sorted runs in
+    // one round of independent stores
+#ifndef ALD_EMU
+    int below[N];
+    if(!counted) {
+        ALD_UNROLL for(int k = 0; k < N; k++) below[k] = (int)__builtin_popcountll(wballot(oldj && lane != pc && kj <= key[k]));
+        int shift = 0; ALD_UNROLL for(int k = 0; k < N; k++) shift += (key[k] < kj) ? 1 : 0;
+        const int np = lane - (lane > pc ? 1 : 0) + shift;
+        if(oldj && lane != pc && np != lane) H.adj[A ? fb - np : fb + np] = (IDX)cj;
+    } else { ALD_UNROLL for(int k = 0; k < N; k++) below[k] = 0; }
+#endif
     // ---- lane j: fan edge j becomes merged edge inv[j]
     bool multi = false;
     for(int j = lane; j < N; j += ALD_WAVE) {
@@ -1452,34 +1629,31 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
         for(int k = 0; k < NW; k++) { uint64_t mk = (NW <= 2 ? cmask_pf[NW <= 2 ? k : 0] : C.ed[cs].mask[k]) | (k == 0 ? pf_mask0 : C.ed[f].mask[k]); if(ov >= 0 && (ov >> 6) == k) mk |= (1ull << (ov & 63)); C.ed[f].mask[k] = mk; }
         const int mi = A ? rt - lt + meic + pf_mei : rt - lt + pf_mei + meic;
         C.ed[f].med = A ? mi * r1 + medc1 + pf_med : mi * r1 + pf_med + medc1; C.ed[f].mei = mi;
-        H.eid[f] = (EID)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
-        if(A) H.ed[f].lk.es = (IDX)far; else H.ed[f].lk.et = (IDX)far;
+        H.ed[f].eid = (EID)nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
+        if(A) H.ed[f].es = (IDX)far; else H.ed[f].et = (IDX)far;
         if(!dupf) { if(A) relink_in_lane(o, f, (uint32_t)far); else relink_out_lane(o, f, tkey((uint32_t)far)); }
+#ifndef ALD_EMU
         if(!counted) {
-            // neighbours in (key) order among the new edges; a run of new edges behind the same old entry is chained
-            const uint32_t kj = pick<N>(key, j); const int pj = pick<N>(pred, j), sj = pick<N>(succ, j);
-            int rj = 0; ALD_UNROLL for(int k = 0; k < N; k++) rj += (key[k] < kj || (key[k] == kj && inv[k] < q)) ? 1 : 0;
-            int prv_pred = -2, nxt_pred = -2, nxt_f = -1;                    // (-2: no such neighbour; a pred is >= -1)
-            ALD_UNROLL for(int k = 0; k < N; k++) { int rk = 0; ALD_UNROLL for(int k2 = 0; k2 < N; k2++) rk += (key[k2] < key[k] || (key[k2] == key[k] && inv[k2] < inv[k])) ? 1 : 0;
-                if(rk == rj - 1) prv_pred = pred[k]; if(rk == rj + 1) { nxt_pred = pred[k]; nxt_f = fe[k]; } }
-            const bool first_of_gap = prv_pred != pj, last_of_gap = nxt_pred != pj;
-            const IDX nx = last_of_gap ? (sj < 0 ? NIL : (IDX)sj) : (IDX)nxt_f;
-            if(A) H.ed[f].lk.onx = nx; else H.ed[f].lk.inx = nx;
-            if(first_of_gap) { if(pj < 0) { if(A) H.vx[far].out_head = (IDX)f; else H.vx[far].in_head = (IDX)f; } else { if(A) H.ed[pj].lk.onx = (IDX)f; else H.ed[pj].lk.inx = (IDX)f; } }
+            const uint32_t kk = pick<N>(key, j);
+            int rj = 0; ALD_UNROLL for(int k = 0; k < N; k++) rj += (key[k] < kk || (key[k] == kk && inv[k] < q)) ? 1 : 0;
+            const int pos = pick<N>(below, j) + rj;
+            H.adj[A ? fb - pos : fb + pos] = (IDX)f;
         }
+#endif
     }
     const bool any_multi = wballot(multi) != 0;
     wsync();
-    // ---- lane 0: c leaves far's list (unless a merged edge took its predecessor's link), the counters, what is inherently ordered
+    // ---- lane 0: far's degree (c left its row, N merged edges entered), the counters, what is inherently ordered
     if(lane == 0) {
-        IDX *deg = A ? &H.vx[far].out_deg : &H.vx[far].in_deg;
-        const int dg = (int)*deg - 1;
-        if(!counted) {
-            bool taken = false; ALD_UNROLL for(int k = 0; k < N; k++) if(pred[k] == pc) taken = true;
-            if(!taken) { const IDX nx = c_next < 0 ? NIL : (IDX)c_next; if(pc < 0) { if(A) H.vx[far].out_head = nx; else H.vx[far].in_head = nx; } else { if(A) H.ed[pc].lk.onx = nx; else H.ed[pc].lk.inx = nx; } }
-            if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; }     // as unlink_in / unlink_out
-        }
-        *deg = (IDX)(dg + N);
+        const int dg = flen - 1;
+        if(!counted && dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; }     // as unlink_in / unlink_out
+#ifdef ALD_EMU
+        if(!counted) {      // (the single-lane emulation edits the row one entry at a time: same row in the end)
+            if(A) { row_remove_out<true>(far, cs); ALD_UNROLL for(int q = 0; q < N; q++) row_insert_out<true>(far, fq[q]); }
+            else { row_remove_in<true>(far, cs); ALD_UNROLL for(int q = 0; q < N; q++) row_insert_in<true>(far, fq[q]); }
+        } else
+#endif
+        { if(A) H.vx[far].out_deg = (IDX)(dg + N); else H.vx[far].in_deg = (IDX)(dg + N); }
         C.vx[x].vw = vwt;
         if(dupf || any_multi || uni(HC.hl_n) != 0) {
             ALD_UNROLL for(int q = 0; q < N; q++) {
@@ -1492,8 +1666,7 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
         HC.next_id = nid_q[N - 1] + 1;
         hs_remove(cs);
         // remove_edge(c); x is left without edges
-        H.ed[cs].lk.es = NIL; H.hflag[cs] = 0;
-        { int fh = uni(HC.free_head); H.ed[cs].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = cs; HC.free_cnt = uni(HC.free_cnt) + 1; }
+        H.ed[cs].hf = 0; slot_release(cs);
         clear_vertex(x);
     }
     wsync();
@@ -1547,9 +1720,9 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
     // (Tried: asking for the cold records of the root's edges and of the vertices at their far ends right here, with loads nobody waits
     // for, so that the ~12 serial round trips further down overlap -- 42.2 against 41.95 ms, profiles/r03/ze_kernel_ab_extend_touch.txt:
     // the routine is bound by its scalar list work, not by those round trips.)
-    for(int e = u_first_in(root); e >= 0; e = u_next_in(e)) { loc_e[nloc++] = e; }
+    ROW_IN_U(root, e) loc_e[nloc++] = e; ROW_END
     int nin = nloc;
-    for(int e = u_first_out(root); e >= 0; e = u_next_out(e)) { loc_e[nloc++] = e; }
+    ROW_OUT_U(root, e) loc_e[nloc++] = e; ROW_END
     int32_t *mdeg = AR.i + deg;                   // [nloc]
     int32_t *evx = AR.i + 2 * deg;                // [nloc] new vertex of the edge (ev1 / ev2), or -1
     double *mweight = AR.d;                       // [nloc]
@@ -1575,30 +1748,30 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
     for(int i = 0; i < n; i++) { int u1 = PLOC(a[i]), u2 = PLOC(b[i]); if(mdeg[u1] == 1 && mdeg[u2] == 1) evx[u1] = nn++; else if(mdeg[u1] >= 2 && mdeg[u2] >= 2) newedges++; }
     if(ALD_UNLIKELY(nn > MAXV || free_slots() < newedges)) { fail(ALD_ST_CAPACITY); return; }
     HC.maybe_broken = 1; HC.maybe_triv = 1;
-    for(int i = m; i < nn; i++) { H.vx[i].in_head = NIL; H.vx[i].out_head = NIL; H.vx[i].in_deg = 0; H.vx[i].out_deg = 0; H.nz[i] = 1; C.vx[i].vw = 0; C.vx[i].lpos = 0; C.vx[i].rpos = 0; C.vx[i].vtype = -1; C.vx[i].v2v = -1; }
+    for(int i = m; i < nn; i++) { H.vx[i].off4 = 0; H.vx[i].cap4 = 0; H.vx[i].in_deg = 0; H.vx[i].out_deg = 0; H.nz[i] = 1; C.vx[i].vw = 0; C.vx[i].lpos = 0; C.vx[i].rpos = 0; C.vx[i].vtype = -1; C.vx[i].v2v = -1; }
     HC.nv = nn;
     for(int i = 0; i < nin; i++) {               // ev1: detach in-edges onto their new vertex
         int k = evx[i]; if(k < 0) continue; int e = loc_e[i];
-        int p = uni(C.vx[uni(H.ed[e].lk.es)].rpos);
-        move_edge(e, uni(H.ed[e].lk.es), k); C.vx[k].lpos = p; C.vx[k].rpos = p; C.vx[k].vtype = -1; C.vx[k].vw = 0; C.vx[k].v2v = -2;
+        int p = uni(C.vx[uni(H.ed[e].es)].rpos);
+        move_edge(e, uni(H.ed[e].es), k); C.vx[k].lpos = p; C.vx[k].rpos = p; C.vx[k].vtype = -1; C.vx[k].vw = 0; C.vx[k].v2v = -2;
     }
     for(int i = nin; i < nloc; i++) {            // ev2
         int k = evx[i]; if(k < 0) continue; int e = loc_e[i];
-        int p = uni(C.vx[uni(H.ed[e].lk.et)].lpos);
-        move_edge(e, k, uni(H.ed[e].lk.et)); C.vx[k].lpos = p; C.vx[k].rpos = p; C.vx[k].vtype = -1; C.vx[k].vw = 0; C.vx[k].v2v = -2;
+        int p = uni(C.vx[uni(H.ed[e].et)].lpos);
+        move_edge(e, k, uni(H.ed[e].et)); C.vx[k].lpos = p; C.vx[k].rpos = p; C.vx[k].vtype = -1; C.vx[k].vw = 0; C.vx[k].v2v = -2;
     }
     int rv = uni(C.vx[root].v2v);
     for(int i = 0; i < n; i++) {
         int e1 = PSLOT(a[i]), e2 = PSLOT(b[i]); int u1 = PLOC(a[i]), u2 = PLOC(b[i]); double ww = w[i];
         if(mdeg[u1] == 1 && mdeg[u2] >= 2) {
             borrow_edge_strand(C, e1, e2);
-            move_edge(e1, uni(H.ed[e1].lk.es), evx[u2]);
+            move_edge(e1, uni(H.ed[e1].es), evx[u2]);
             if(rv >= 0) C.ed[e1].mask[(rv >> 6)] |= (1ull << (rv & 63));
             C.ed[e1].med += mweight[u1]; C.ed[e1].mei += rlen;
         } else if(mdeg[u2] == 1) {
             if(ALD_UNLIKELY(evx[u1] < 0)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
             borrow_edge_strand(C, e2, e1);
-            move_edge(e2, evx[u1], uni(H.ed[e2].lk.et));
+            move_edge(e2, evx[u1], uni(H.ed[e2].et));
             if(rv >= 0) C.ed[e2].mask[(rv >> 6)] |= (1ull << (rv & 63));
             C.ed[e2].med += mweight[u2]; C.ed[e2].mei += rlen;
         } else {
@@ -1628,8 +1801,8 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
         for(int part = 0; part < 2; part++) {
             int lo = part == 0 ? 0 : nin, hi = part == 0 ? nin : nloc; int first = no;
             for(int i = lo; i < hi; i++) if(evx[i] >= 0) {
-                int k = evx[i]; uint32_t id = uni(H.eid[loc_e[i]]); int j = no - 1;
-                while(j >= first && uni(H.eid[mdeg[j]]) > id) { order[j + 1] = order[j]; mdeg[j + 1] = mdeg[j]; j--; }      // mdeg is free now: reuse it for the sort keys' edges
+                int k = evx[i]; uint32_t id = uni(H.ed[loc_e[i]].eid); int j = no - 1;
+                while(j >= first && uni(H.ed[mdeg[j]].eid) > id) { order[j + 1] = order[j]; mdeg[j + 1] = mdeg[j]; j--; }      // mdeg is free now: reuse it for the sort keys' edges
                 order[j + 1] = k; mdeg[j + 1] = loc_e[i]; no++;
             }
         }
@@ -1654,8 +1827,8 @@ ALD_INL int classify_trivial_fastpath(int x, bool fast)
     int d1 = H.vx[x].in_deg, d2 = H.vx[x].out_deg;
     if(d1 != 1 && d2 != 1) return -1;
     int e1 = first_in(x), e2 = first_out(x);
-    if(d1 == 1) { int s = H.ed[e1].lk.es; if(H.vx[s].out_deg == 1) return 1; if(fast) { if(!(H.hflag[e1] & HF_OCC)) return 1; return -2; } }
-    if(d2 == 1) { int t = H.ed[e2].lk.et; if(H.vx[t].in_deg == 1) return 1; if(fast) { if(!(H.hflag[e2] & HF_OCC)) return 1; return -2; } }
+    if(d1 == 1) { int s = H.ed[e1].es; if(H.vx[s].out_deg == 1) return 1; if(fast) { if(!(H.ed[e1].hf & HF_OCC)) return 1; return -2; } }
+    if(d2 == 1) { int t = H.ed[e2].et; if(H.vx[t].in_deg == 1) return 1; if(fast) { if(!(H.ed[e2].hf & HF_OCC)) return 1; return -2; } }
     return 2;
 }
 ALD_FN int classify_trivial_vertex(int x, bool fast)     // scalar version with the dominate queries
@@ -1664,26 +1837,31 @@ ALD_FN int classify_trivial_vertex(int x, bool fast)     // scalar version with 
     int d1 = uni(H.vx[x].in_deg), d2 = uni(H.vx[x].out_deg);
     if(d1 != 1 && d2 != 1) return -1;
     int e1 = u_first_in(x), e2 = u_first_out(x);
-    if(d1 == 1) { int s = uni(H.ed[e1].lk.es); if(H.vx[s].out_deg == 1) return 1; if(fast && hs_dominate(e1, 1)) return 1; }
-    if(d2 == 1) { int t = uni(H.ed[e2].lk.et); if(H.vx[t].in_deg == 1) return 1; if(fast && hs_dominate(e2, 2)) return 1; }
+    if(d1 == 1) { int s = uni(H.ed[e1].es); if(H.vx[s].out_deg == 1) return 1; if(fast && hs_dominate(e1, 1)) return 1; }
+    if(d2 == 1) { int t = uni(H.ed[e2].et); if(H.vx[t].in_deg == 1) return 1; if(fast && hs_dominate(e2, 2)) return 1; }
     return 2;
+}
+// The two weight sums of a vertex (and, MIN, the smallest edge of either row: "if(w > min) continue" -- the LAST minimum wins,
+// scallop.cc:2978-2980), every lane its own vertex.  Four entries of a row per step: ONE aligned 8-byte read brings four slots, the
+// four weights are then asked for together -- three dependent round trips for a vertex of up to four edges a side where a linked
+// list took one per edge; both rows advance in the same loop.  The additions run in row order, as the reference's walks do.
+template<bool MIN> ALD_INL void rows_scan(const Hot::VertexHot vr, double &sum1, double &sum2, double &min1, double &min2, int &e1, int &e2)
+{
+    const int bi = rin(vr), bo = rout(vr), d1 = vr.in_deg, d2 = vr.out_deg;
+    for(int k0 = 0; (k0 < d1) | (k0 < d2); k0 += 4) {
+        const bool ia = k0 < d1, oa = k0 < d2;
+        const uint64_t ri = ia ? *(const uint64_t*)&H.adj[bi + k0] : 0ull, ro = oa ? *(const uint64_t*)&H.adj[bo - k0 - 3] : 0ull;
+        int si[4], so[4]; double wi[4], wo[4];
+        ALD_UNROLL for(int j = 0; j < 4; j++) { si[j] = (k0 + j < d1) ? (int)((ri >> (16 * j)) & 0xFFFF) : 0; so[j] = (k0 + j < d2) ? (int)((ro >> (16 * (3 - j))) & 0xFFFF) : 0; }
+        ALD_UNROLL for(int j = 0; j < 4; j++) { wi[j] = H.ed[si[j]].w; wo[j] = H.ed[so[j]].w; }
+        ALD_UNROLL for(int j = 0; j < 4; j++) if(k0 + j < d1) { sum1 += wi[j]; if(MIN && !(wi[j] > min1)) { min1 = wi[j]; e1 = si[j]; } }
+        ALD_UNROLL for(int j = 0; j < 4; j++) if(k0 + j < d2) { sum2 += wo[j]; if(MIN && !(wo[j] > min2)) { min2 = wo[j]; e2 = so[j]; } }
+    }
 }
 ALD_INL double compute_balance_ratio(int v, bool &ok)    // scallop.cc:2578-2602
 {
-#ifndef ALD_HOT_IN_SLAB
-    double w1 = in_weights(v), w2 = out_weights(v);
-#else
-    double w1 = 0, w2 = 0;
-    {   // in_weights(v) and out_weights(v), their list steps taken together (see eval_smallest)
-        int a = first_in(v), b = first_out(v);
-        while((a >= 0) | (b >= 0)) {
-            const int ea = a >= 0 ? a : 0, eb = b >= 0 ? b : 0;
-            const double wa = H.ed[ea].w, wb = H.ed[eb].w; const IDX na = H.ed[ea].lk.inx, nb = H.ed[eb].lk.onx;
-            if(a >= 0) { w1 += wa; a = na == NIL ? -1 : (int)na; }
-            if(b >= 0) { w2 += wb; b = nb == NIL ? -1 : (int)nb; }
-        }
-    }
-#endif
+    double w1 = 0, w2 = 0, m1 = 0, m2 = 0; int a1 = -1, a2 = -1;
+    rows_scan<false>(H.vx[v], w1, w2, m1, m2, a1, a2);
     ok = (w1 >= kSMIN) && (w2 >= kSMIN);
     if(w1 >= w2) return w1 / w2; else return w2 / w1;
 }
@@ -1705,35 +1883,19 @@ ALD_FN bool resolve_single_trivial_vertex(int i, double jump_ratio)
 // scallop::compute_smallest_edge + the guards of resolve_smallest_edges (scallop.cc:858-896, 2967-3030)
 ALD_INL int eval_smallest(int i, double &r)
 {
-    int hin, hout;
-    {   // the vertex record in one round of loads (the short-circuit form waits for each field before it asks for the next)
-        const Hot::VertexHot vr = H.vx[i];       // heads and degrees: one 8-byte LDS read
+    const Hot::VertexHot vr = H.vx[i];           // rows and degrees: one 8-byte LDS read
+    {
         const int nzv = H.nz[i] & NZ_MEMBER, d1 = vr.in_deg, d2 = vr.out_deg;
         if((nzv == 0) | (d1 <= 1) | (d2 <= 1)) return -1;
-        hin = slot_or_neg(vr.in_head); hout = slot_or_neg(vr.out_head);
     }
     int e1 = -1, e2 = -1; double sum1 = 0, sum2 = 0, min1 = DBL_MAX, min2 = DBL_MAX;
-#ifndef ALD_HOT_IN_SLAB
-    for(int e = hin; e >= 0; e = next_in(e)) { double w = H.ed[e].w; sum1 += w; if(w > min1) continue; min1 = w; e1 = e; }
-    for(int e = hout; e >= 0; e = next_out(e)) { double w = H.ed[e].w; sum2 += w; if(w > min2) continue; min2 = w; e2 = e; }
-#else
-    {   // hot state in the slab (the catch-all class and the twins): every list step is a round trip to L2 -- the two walks advance
-        // together, their steps being independent of each other (in LDS the merged loop costs more than the latency it hides)
-        int a = hin, b = hout;
-        while((a >= 0) | (b >= 0)) {
-            const int ea = a >= 0 ? a : 0, eb = b >= 0 ? b : 0;
-            const double wa = H.ed[ea].w, wb = H.ed[eb].w; const IDX na = H.ed[ea].lk.inx, nb = H.ed[eb].lk.onx;
-            if(a >= 0) { sum1 += wa; if(!(wa > min1)) { min1 = wa; e1 = a; } a = na == NIL ? -1 : (int)na; }
-            if(b >= 0) { sum2 += wb; if(!(wb > min2)) { min2 = wb; e2 = b; } b = nb == NIL ? -1 : (int)nb; }
-        }
-    }
-#endif
+    rows_scan<true>(vr, sum1, sum2, min1, min2, e1, e2);
     if(e1 < 0 || e2 < 0) return -1;
     if(!(sum1 >= kSMIN) || !(sum2 >= kSMIN)) return -3;          // reference assert(sum1 >= SMIN)
     double r1 = min1 / sum1, r2 = min2 / sum2;
     int e; if(r1 < r2) { r = r1; e = e1; } else { r = r2; e = e2; }
-    int s = H.ed[e].lk.es, t = H.ed[e].lk.et;
-    uint8_t f = H.hflag[e];
+    int s = H.ed[e].es, t = H.ed[e].et;
+    uint8_t f = H.ed[e].hf;
     { const int ods = H.vx[s].out_deg, idt = H.vx[t].in_deg; if((ods <= 1) | (idt <= 1)) return -1; }
     if((f & HF_REXT) && (f & HF_LEXT)) return -1;
     if(t == i && (f & HF_REXT)) return -1;
@@ -1799,15 +1961,18 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
         int i = base + lane;
         int cls = -9; double r = 0; bool bad = false;
         {
-            // classify_trivial_fastpath with every load that does not depend on another issued together: three LDS round trips
-            // (vertex record / first edges / their far ends) instead of one per condition of the short-circuit form
+            // classify_trivial_fastpath with every load that does not depend on another issued together: four LDS round trips
+            // (vertex record / first entry of either row / the two edges' key words / their far ends) instead of one per condition of the
+            // short-circuit form
             const bool inr = (i >= start) & (i < vend); const int ii = inr ? i : 0;
-            const Hot::VertexHot vr = H.vx[ii];       // heads and degrees: one 8-byte LDS read
-            const int nzv = H.nz[ii] & NZ_MEMBER, d1 = vr.in_deg, d2 = vr.out_deg; const IDX h1 = vr.in_head, h2 = vr.out_head;
+            const Hot::VertexHot vr = H.vx[ii];       // rows and degrees: one 8-byte LDS read
+            const int nzv = H.nz[ii] & NZ_MEMBER, d1 = vr.in_deg, d2 = vr.out_deg;
             bool elig = inr & (nzv != 0) & (d1 >= 1) & (d2 >= 1) & !((d1 >= 2) & (d2 >= 2));
             if(HC.any_strand) elig = elig && !mixed_strand_vertex(i);
-            const int e1 = (elig & (h1 != NIL)) ? (int)h1 : 0, e2 = (elig & (h2 != NIL)) ? (int)h2 : 0;
-            const IDX sv = H.ed[e1].lk.es, tv = H.ed[e2].lk.et; const uint8_t f1 = H.hflag[e1], f2 = H.hflag[e2];
+            const IDX h1 = H.adj[elig ? rin(vr) : 0], h2 = H.adj[elig ? rout(vr) : 0];      // (an eligible vertex has an edge on either side)
+            const int e1 = elig ? (int)h1 : 0, e2 = elig ? (int)h2 : 0;
+            const EKey k1 = ekey(e1), k2 = ekey(e2);
+            const uint32_t sv = k1.es, tv = k2.et; const uint32_t f1 = k1.hf, f2 = k2.hf;
             const int s_ = (elig & (sv != NIL)) ? (int)sv : 0, t_ = (elig & (tv != NIL)) ? (int)tv : 0;
             const int ods = H.vx[s_].out_deg, idt = H.vx[t_].in_deg;
             if(elig) {
@@ -1902,6 +2067,7 @@ ALD_INL bool sweep_trivial_body(int mode, int type, double jump_ratio, int &fire
         fired++;
         if(tr && lane == 0) { if(last) trace_emit(OP_TRIVIAL_BEST, vlog(target), type, HC.sw_best_r); else trace_emit(mode == 1 ? OP_TRIVIAL_NOW : OP_TRIVIAL_FAST, vlog(target), mode == 1 ? type : 0, HC.sw_hit_r); }
         decompose_trivial_vertex_wave(target);
+        ADJ_CHECK("star");
         if(last) { wsync(); PROF_ADD(PF_TRIV_MUT); return true; }
         if(lane == 0) {
             if(uni(HC.hs_dirty)) hs_refresh_flags();
@@ -1996,12 +2162,13 @@ ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr)
             }
             PROF_ADD(PF_SMALL_EVAL);
             if(hit < 0) break;
-            const int ds = H.ed[hit_e].lk.es, dt = H.ed[hit_e].lk.et;         // the two vertices whose lists change
+            const int ds = H.ed[hit_e].es, dt = H.ed[hit_e].et;         // the two vertices whose lists change
             fired++;
-            if(tr && lane == 0) trace_emit(OP_SMALL_NOW, (int)H.eid[hit_e], vlog(hit), hit_r);
+            if(tr && lane == 0) trace_emit(OP_SMALL_NOW, (int)H.ed[hit_e].eid, vlog(hit), hit_r);
             kill_edge_wave(hit_e);
             if(lane == 0) hs_remove(hit_e);
             wsync();
+            ADJ_CHECK("small-now");
             // other vertices only look at ds / dt through the guards out_deg[ds] > 1 and in_deg[dt] > 1 (both held for the edge just
             // removed); if one of them stops holding, or the phasing flags moved, every lane evaluates again
             const bool all = uni(HC.hs_dirty) != 0 || (int)uni(H.vx[ds].out_deg) <= 1 || (int)uni(H.vx[dt].in_deg) <= 1;
@@ -2019,12 +2186,13 @@ ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr)
         }
         if(!flag) {
             if(best_e < 0) return any;
-            const int ds = H.ed[best_e].lk.es, dt = H.ed[best_e].lk.et;
+            const int ds = H.ed[best_e].es, dt = H.ed[best_e].et;
             fired++;
-            if(tr && lane == 0) trace_emit(OP_SMALLEST, (int)H.eid[best_e], vlog(best_v), best_r);
+            if(tr && lane == 0) trace_emit(OP_SMALLEST, (int)H.ed[best_e].eid, vlog(best_v), best_r);
             kill_edge_wave(best_e);
             if(lane == 0) hs_remove(best_e);
             wsync();
+            ADJ_CHECK("smallest");
 #ifdef ALD_PROF
             { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[PF_SM_KILL] += t1_ - prof_t_; }
             const unsigned long long prof_re_ = __builtin_readcyclecounter();
@@ -2069,8 +2237,8 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     const int cap = AR.cap_i;
     if(ALD_UNLIKELY(5 * n > cap)) { fail(ALD_ST_CAPACITY); return false; }
     int32_t *u2e = AR.i;
-    if(!pre) { int k = 0; for(int e = u_first_in(root); e >= 0; e = u_next_in(e)) { u2e[k++] = e; }
-      for(int e = u_first_out(root); e >= 0; e = u_next_out(e)) { u2e[k++] = e; } }
+    if(!pre) { int k = 0; ROW_IN_U(root, e) u2e[k++] = e; ROW_END
+      ROW_OUT_U(root, e) u2e[k++] = e; ROW_END }
     if(ALD_UNLIKELY(mixed_strand_vertex(root))) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }     // router.cc:71-76
     // ---- routes from the phasing lists (hyper_set::get_routes, hyper_set.cc:553-571), gathered in the pair area
     const int half = PW.cap;
@@ -2083,7 +2251,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
             for(int i = 0; i + 1 < len; i++) {
                 int x = v[i], y = v[i + 1];
                 if(x < 0 || y < 0) continue;
-                if(H.ed[x].lk.es == NIL || (int)uni(H.ed[x].lk.et) != root) continue;
+                if(H.ed[x].es == NIL || (int)uni(H.ed[x].et) != root) continue;
                 int f = -1;
                 for(int j = 0; j < nr; j++) if(ra[j] == x && rb[j] == y) { f = j; break; }
                 if(f >= 0) rc[f] += c;
@@ -2109,7 +2277,7 @@ template<bool SMALL> ALD_INL bool router_body(int root, int want_type, int max_d
     for(int i = 0; i < n; i++) udeg[i] = 0;
     for(int j = 0; j < nr; j++) {
         int y = rb[j];
-        if(ALD_UNLIKELY(H.ed[y].lk.es == NIL || (int)uni(H.ed[y].lk.es) != root)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }   // assert(e2u.find(e2) != end)
+        if(ALD_UNLIKELY(H.ed[y].es == NIL || (int)uni(H.ed[y].es) != root)) { fail(ALD_ST_INVARIANT + ALD_INV_ROUTER); return false; }   // assert(e2u.find(e2) != end)
         int s = -1, t = -1;                       // local indices by search (routes exist only with phasing paths)
         for(int q = 0; q < nin; q++) if(u2e[q] == ra[j]) { s = q; break; }
         for(int q = nin; q < n; q++) if(u2e[q] == y) { t = q; break; }
@@ -2420,10 +2588,8 @@ ALD_FN int router_prepare(int root)
     double *ecf = AR.d + ARENA_D - n;             // the edges' confidences, for the end of build(): the last n slots (`small` keeps 4 n + routes <= ARENA_D)
     bool multi = false;
     for(int l = lane; l < n; l += ALD_WAVE) {
-        int e;
-        if(l < nin) { e = first_in(root); for(int k = 0; k < l && e >= 0; k++) e = next_in(e); }
-        else { e = first_out(root); for(int k = nin; k < l && e >= 0; k++) e = next_out(e); }
-        if(e < 0) e = 0;                                                       // cannot happen: the degrees count the lists
+        const Hot::VertexHot vrr = H.vx[root];
+        const int e = (l < nin) ? (int)H.adj[rin(vrr) + l] : (int)H.adj[rout(vrr) - (l - nin)];       // the l-th local edge IS an address: no walk
         const int cnt = (int)C.ed[e].sp_len, ec = C.ed[e].ecount;
         u2e[l] = e; ncnt[l] = cnt; nsid[l] = C.ed[e].s0id; nabd[l] = C.ed[e].s0abd; iso[l] = (ec == 0) ? 2 : 0; ecf[l] = C.ed[e].econf;
         if(ec != 0 && cnt != 1) multi = true;
@@ -2610,23 +2776,26 @@ ALD_FN void collect_path(int e)
         { int q = 0; for(int k = 0; k < NW; k++) { uint64_t mk = uni(C.ed[e].mask[k]); while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; const int l = uni(C.vx[x].lpos), rr = uni(C.vx[x].rpos);
             if(l >= rr) continue; if(q > 0 && (int)pv[w + q - 1] == l) pv[w + q - 1] = (uint32_t)rr; else { pv[w + q] = (uint32_t)l; pv[w + q + 1] = (uint32_t)rr; q += 2; } } } w += q; }
         if((REC_HDR_WORDS + nvp + nexw) & 1) pv[w] = 0;
-        if(tracing()) { int save = HC.n_iters; trace(OP_COLLECT, (int)uni(H.eid[e]), nvp, uni(H.ed[e].w)); HC.n_iters = save; }
+        if(tracing()) { int save = HC.n_iters; trace(OP_COLLECT, (int)uni(H.ed[e].eid), nvp, uni(H.ed[e].w)); HC.n_iters = save; }
         HC.n_paths++;
     }
-    H.hflag[e] = 0;
+    H.ed[e].hf = 0;
     kill_edge(e);
 }
-// Before the final phase walks out(0) / in(sink): link every live edge of those two lists (sorted insertion).
+// Before the final phase walks out(0) / in(sink): every live edge of those two rows enters them (sorted insertion; the segments are
+// sized once, for the counts kept so far).
 ALD_FN void materialize_special()
 {
     if(HC.special_linked) return;
-    HC.special_linked = 1;
     const int sinkp = HC.sinkp;
-    H.vx[0].out_head = NIL; H.vx[sinkp].in_head = NIL; H.vx[0].out_deg = 0; H.vx[sinkp].in_deg = 0;
+    const int n0 = uni((int)H.vx[0].out_deg), nt = uni((int)H.vx[sinkp].in_deg);
+    H.vx[0].out_deg = 0; H.vx[sinkp].in_deg = 0;
+    HC.special_linked = 1;                      // (from here on the two rows count as rows: mat_in / mat_out)
+    if(!adj_reserve_s(0, n0) || !adj_reserve_s(sinkp, nt)) return;
     for(int e = 0; e < HC.slot_hw; e++) {
-        if(H.ed[e].lk.es == NIL) continue;
-        if((int)uni(H.ed[e].lk.es) == 0) link_out(0, e);
-        if((int)uni(H.ed[e].lk.et) == sinkp) link_in(sinkp, e);
+        if(H.ed[e].es == NIL) continue;
+        if((int)uni(H.ed[e].es) == 0) link_out(0, e);
+        if((int)uni(H.ed[e].et) == sinkp) link_in(sinkp, e);
     }
 }
 // scallop::collect_existing_st_paths (scallop.cc:2742-2752): ascending edge index == ascending creation id.
@@ -2640,7 +2809,7 @@ ALD_FN void collect_existing_st_paths()
     ALD_GLOBAL int32_t *lst = C.wi; int n = 0;           // the source -> sink edges (work array of the slab: up to MAXE entries), by every lane
     for(int base = 0; base < hw; base += ALD_WAVE) {
         int e = base + lane;
-        bool p = e < hw && H.ed[e].lk.es == 0 && (int)H.ed[e].lk.et == sink;
+        bool p = e < hw && H.ed[e].es == 0 && (int)H.ed[e].et == sink;
         uint64_t m = wballot(p);
 #ifdef ALD_EMU
         if(p) lst[n] = e;
@@ -2653,7 +2822,7 @@ ALD_FN void collect_existing_st_paths()
     if(n == 0) return;
     if(tracing() || 5 * n > Cold::w_cap || uni(HC.n_paths) + n > Cold::po_cap) {        // the op trace lists the paths in order: one at a time (which also reports a full offset table)
         if(lane == 0) {
-            for(int i = 1; i < n; i++) { int x = lst[i]; uint32_t id = uni(H.eid[x]); int j = i - 1; while(j >= 0 && (uint32_t)uni(H.eid[lst[j]]) > id) { lst[j + 1] = lst[j]; j--; } lst[j + 1] = x; }
+            for(int i = 1; i < n; i++) { int x = lst[i]; uint32_t id = uni(H.ed[x].eid); int j = i - 1; while(j >= 0 && (uint32_t)uni(H.ed[lst[j]].eid) > id) { lst[j + 1] = lst[j]; j--; } lst[j + 1] = x; }
             for(int i = 0; i < n && !HC.status; i++) collect_path(lst[i]);
         }
         wsync();
@@ -2670,7 +2839,7 @@ ALD_FN void collect_existing_st_paths()
         const int e = lst[j]; int cnt = 0, mi = 0, nexw = 0, last_r = INT_MIN; bool empty = ends_empty;
         for(int k = 0; k < NW; k++) { uint64_t mk = C.ed[e].mask[k]; while(mk) { int b = ffs64(mk); mk &= mk - 1; int x = k * 64 + b; cnt++; const int l = C.vx[x].lpos, rr = C.vx[x].rpos; mi += rr - l; if(C.vx[x].vtype == K_EMPTY_VERTEX) empty = true;
             if(l < rr) { if(nexw == 0 || last_r != l) nexw += 2; last_r = rr; } } }
-        ids[j] = (int32_t)H.eid[e]; nvs[j] = cnt; nxs[j] = nexw;
+        ids[j] = (int32_t)H.ed[e].eid; nvs[j] = cnt; nxs[j] = nexw;
         keep[j] = (C.ed[e].mei != mi || cnt == 0) ? -1 : (empty ? 0 : 1);
     }
     wsync();
@@ -2711,7 +2880,7 @@ ALD_FN void collect_existing_st_paths()
         else if(any_full) fail(ALD_ST_POOL_FULL);
         else HC.n_paths += kept_total;
         // remove_edge for all of them: out(source) / in(sink) are only counted at this point, the slots go back to the free list
-        for(int k = 0; k < n; k++) { const int e = lst[k]; H.hflag[e] = 0; kill_edge_i(e); }
+        for(int k = 0; k < n; k++) { const int e = lst[k]; H.ed[e].hf = 0; kill_edge_i(e); }
     }
     wsync();
 }
@@ -2729,7 +2898,7 @@ ALD_FN double compute_maximum_path()
     for(int i = 0; i < n; i++) { int d = uni(H.vx[i].in_deg); vd[i] = d; if(d == 0 && i != sinkp) q[qt++] = i; table[i] = -1; back[i] = -1; }
     if(vd[sinkp] == 0) q[qt++] = sinkp;
     int k = 0;
-    while(k < qt) { int x = q[k++]; for(int e = u_first_out(x); e >= 0; e = u_next_out(e)) { int t = uni(H.ed[e].lk.et); if(--vd[t] == 0) q[qt++] = t; } }
+    while(k < qt) { int x = q[k++]; ROW_OUT_U(x, e) int t = uni(H.ed[e].et); if(--vd[t] == 0) q[qt++] = t; ROW_END }
     HC.tmp0 = 0;
     if(ALD_UNLIKELY(qt != n)) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return -1; }
     int ssi = -1, tti = -1;
@@ -2739,20 +2908,20 @@ ALD_FN double compute_maximum_path()
         int i = q[ii];
         if(H.vx[i].in_deg + uni(H.vx[i].out_deg) == 0) continue;
         double max_abd = 0; int max_edge = -1;
-        for(int e = u_first_in(i); e >= 0; e = u_next_in(e)) {
-            int s = uni(H.ed[e].lk.es);
+        ROW_IN_U(i, e)
+            int s = uni(H.ed[e].es);
             double ts = table[s];
             if(ts <= -1) continue;
             double xw = uni(H.ed[e].w);
             double ww = xw < ts ? xw : ts;
             if(ww >= max_abd) { max_abd = ww; max_edge = e; }
-        }
+        ROW_END
         if(max_edge < 0) continue;
         back[i] = max_edge; table[i] = max_abd;
     }
     int plen = 0;
     int x = sinkp;
-    while(plen < n) { int e = back[x]; if(e < 0) break; path[plen++] = e; x = uni(H.ed[e].lk.es); }
+    while(plen < n) { int e = back[x]; if(e < 0) break; path[plen++] = e; x = uni(H.ed[e].es); }
     for(int i = 0; i < plen / 2; i++) { int t = path[i]; path[i] = path[plen - 1 - i]; path[plen - 1 - i] = t; }
     HC.tmp0 = plen;
     return table[sinkp];
@@ -2815,8 +2984,8 @@ ALD_FN void build_phasing_lists(ALD_GLOBAL const int32_t *vo, int V, int NP, ALD
             int s = pvx[a + k], t = pvx[a + k + 1];
             if(!(s < t) || s < 0 || t >= V) { HC.status = ALD_ST_INVARIANT + ALD_INV_OTHER; ok = false; break; }
             int best = -1;
-            if(s == 0) { for(int e = vo[0]; e < vo[1]; e++) { if(H.ed[e].lk.es == NIL) continue; int tt = H.ed[e].lk.et; if(tt == t) best = e; else if(tt > t) break; } }      // row 0 is not linked: scan the CSR row
-            else for(int e = first_out(s); e >= 0; e = next_out(e)) { int tt = H.ed[e].lk.et; if(tt == t) best = e; else if(tt > t) break; }
+            if(s == 0) { for(int e = vo[0]; e < vo[1]; e++) { if(H.ed[e].es == NIL) continue; int tt = H.ed[e].et; if(tt == t) best = e; else if(tt > t) break; } }      // row 0 is not linked: scan the CSR row
+            else { ROW_OUT_L(s, e) const int tt = H.ed[e].et; if(tt == t) best = e; else if(tt > t) break; ROW_END }
             if(best < 0) ok = false; else C.hl[used + k] = best;
         }
         if(!ok || len - 1 < 2) continue;
@@ -2843,7 +3012,7 @@ static_assert(4 * MAXV <= 4 * MAXE, "boundary maps do not fit their slab region"
 ALD_INL int raw_edge(ALD_GLOBAL const int32_t *vo, int s, int t)      // directed_graph::edge(s, t) on the input rows: the newest live parallel edge, or -1
 {
     int best = -1;
-    for(int k = vo[s]; k < vo[s + 1]; k++) { if(H.hflag[k] & RAW_DEAD) continue; const int tt = H.ed[k].lk.et; if(tt == t) best = k; else if(tt > t) break; }
+    for(int k = vo[s]; k < vo[s + 1]; k++) { if(H.ed[k].hf & RAW_DEAD) continue; const int tt = H.ed[k].et; if(tt == t) best = k; else if(tt > t) break; }
     return best;
 }
 ALD_INL bool raw_continuous(const Cold &C, ALD_GLOBAL const int32_t *vo, int x, int y)      // check_continuous_vertices (essential.cc:436-446)
@@ -2864,9 +3033,9 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
     // are never targets themselves, nothing a lane reads is written by another).
     if(uni(HC.any_strand)) {
         for(int k = lane; k < E; k += ALD_WAVE) {
-            const int a = H.ed[k].lk.es, t = H.ed[k].lk.et;
+            const int a = H.ed[k].es, t = H.ed[k].et;
             if(t != a + 1 || C.ed[k].estrand != 0) continue;
-            if(k + 1 < vo[a + 1] && (int)H.ed[k + 1].lk.et == t) continue;               // not the newest a -> a+1
+            if(k + 1 < vo[a + 1] && (int)H.ed[k + 1].et == t) continue;               // not the newest a -> a+1
             uint32_t best_id = 0xFFFFFFFFu; int best_st = 0;
             for(int leg = 0; leg < 2; leg++) {
                 const int s = leg == 0 ? a : a - 1;                                       // the junction s -> s+2; this edge is its first / second leg
@@ -2875,9 +3044,9 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
                 if(p1 >= p2 || C.vx[s + 1].lpos != p1 || C.vx[s + 1].rpos != p2) continue;
                 const double vmid = C.vx[s + 1].vw;
                 for(int j = vo[s]; j < vo[s + 1]; j++) {
-                    if((int)H.ed[j].lk.et != s + 2) continue;
+                    if((int)H.ed[j].et != s + 2) continue;
                     if(H.ed[j].w <= vmid) continue;
-                    const int st = C.ed[j].estrand; const uint32_t id = H.eid[j];
+                    const int st = C.ed[j].estrand; const uint32_t id = H.ed[j].eid;
                     if(st != 0 && id < best_id) { best_id = id; best_st = st; }
                 }
             }
@@ -2892,9 +3061,9 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
         {   // start boundaries that reach the same run of touching vertices within `dist` fold into the leftmost one
             const int r0 = vo[0], r1 = vo[1];                                           // the source's row: targets ascending (parallel ones were refused at staging)
             if(r1 - r0 > 1) {
-                int v0 = H.ed[r0].lk.et; int32_t p1 = C.vx[v0].lpos, p2 = p1; int k1 = v0, k2 = v0, pa = r0;
+                int v0 = H.ed[r0].et; int32_t p1 = C.vx[v0].lpos, p2 = p1; int k1 = v0, k2 = v0, pa = r0;
                 for(int q = r0 + 1; q < r1 && !bad; q++) {
-                    const int vi = H.ed[q].lk.et, pb = q; const int32_t p = C.vx[vi].lpos;
+                    const int vi = H.ed[q].et, pb = q; const int32_t p = C.vx[vi].lpos;
                     const double wb = H.ed[pb].w; const int cb = C.ed[pb].ecount;
                     bool b = raw_continuous(C, vo, k2, vi);
                     if(p < p2) { bad = 1; break; }                                        // assert(p >= p2)
@@ -2908,20 +3077,20 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
                     }
                     if(bad) break;
                     H.ed[pa].w += wb; C.ed[pa].ecount += cb;
-                    H.hflag[pb] |= RAW_DEAD; removed++;
+                    H.ed[pb].hf |= RAW_DEAD; removed++;
                     k2 = vi; p2 = p;
                 }
             }
         }
         if(!bad) {   // the mirror image from the right -- with the reference's own asymmetries (vertex takes edge weight + wb; no count moves)
             const int i0 = io[n], i1 = io[n + 1];                                       // in-edges of the sink: sources ascending
-            int q = i1 - 1; while(q >= i0 && (H.hflag[ie[q]] & RAW_DEAD)) q--;
+            int q = i1 - 1; while(q >= i0 && (H.ed[ie[q]].hf & RAW_DEAD)) q--;
             if(q >= i0) {
-                int pa = ie[q]; const int v0 = H.ed[pa].lk.es; int32_t p1 = C.vx[v0].rpos, p2 = p1; int k1 = v0, k2 = v0; int live = 0;
-                for(int z = i0; z < i1; z++) if(!(H.hflag[ie[z]] & RAW_DEAD)) live++;
+                int pa = ie[q]; const int v0 = H.ed[pa].es; int32_t p1 = C.vx[v0].rpos, p2 = p1; int k1 = v0, k2 = v0; int live = 0;
+                for(int z = i0; z < i1; z++) if(!(H.ed[ie[z]].hf & RAW_DEAD)) live++;
                 if(live > 1) for(q--; q >= i0 && !bad; q--) {
-                    const int pb = ie[q]; if(H.hflag[pb] & RAW_DEAD) continue;
-                    const int vi = H.ed[pb].lk.es; const int32_t p = C.vx[vi].rpos; const double wb = H.ed[pb].w;
+                    const int pb = ie[q]; if(H.ed[pb].hf & RAW_DEAD) continue;
+                    const int vi = H.ed[pb].es; const int32_t p = C.vx[vi].rpos; const double wb = H.ed[pb].w;
                     bool b = raw_continuous(C, vo, vi, k2);
                     if(p > p2) { bad = 1; break; }                                        // assert(p <= p2)
                     if(p2 - p > dist) b = false;
@@ -2934,7 +3103,7 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
                     }
                     if(bad) break;
                     H.ed[pa].w += wb;
-                    H.hflag[pb] |= RAW_DEAD; removed++;
+                    H.ed[pb].hf |= RAW_DEAD; removed++;
                     k2 = vi; p2 = p;
                 }
             }
@@ -2949,7 +3118,7 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
     // handed out later is larger)
     if(removed) {
         ALD_GLOBAL int32_t *flag = C.wi, *nrank = C.wi + E;
-        for(int k = lane; k < E; k += ALD_WAVE) flag[H.eid[k]] = (H.hflag[k] & RAW_DEAD) ? 0 : 1;
+        for(int k = lane; k < E; k += ALD_WAVE) flag[H.ed[k].eid] = (H.ed[k].hf & RAW_DEAD) ? 0 : 1;
         wsync();
         int base = 0;
         for(int r0 = 0; r0 < E; r0 += ALD_WAVE) {
@@ -2963,10 +3132,10 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
             base += __builtin_popcountll(m);
         }
         wsync();
-        for(int k = lane; k < E; k += ALD_WAVE) if(!(H.hflag[k] & RAW_DEAD)) H.eid[k] = (EID)nrank[H.eid[k]];
+        for(int k = lane; k < E; k += ALD_WAVE) if(!(H.ed[k].hf & RAW_DEAD)) H.ed[k].eid = (EID)nrank[H.ed[k].eid];
         wsync();
         if(lane == 0) {
-            for(int k = 0; k < E; k++) if(H.hflag[k] & RAW_DEAD) { H.hflag[k] = 0; kill_edge_i(k); }
+            for(int k = 0; k < E; k++) if(H.ed[k].hf & RAW_DEAD) { H.ed[k].hf = 0; kill_edge_i(k); }
             HC.next_id = base;
             for(int i = 1; i < n; i++) if(H.vx[i].in_deg == 0 && H.vx[i].out_deg == 0) H.nz[i] = 0;      // (nonzeroset is taken after the pre-steps: scallop.cc:1664-1673)
         }
@@ -3083,22 +3252,36 @@ ALD_FN bool load_graph()
     int64_t ns = A->in.edge_sample_offset[oeo + E];
     if(ns > (int64_t)C.sp_cap) { if(lane == 0) HC.status = ALD_ST_CAPACITY; wsync(); return false; }
     ALD_GLOBAL const int32_t *vo = A->in.vertex_offset + ovo, *io = A->in.in_offset + ovo, *ie = A->in.in_edge + oe;
-    for(int i = lane; i < V; i += ALD_WAVE) {
-        int o0 = vo[i], o1 = vo[i + 1], i0 = io[i], i1 = io[i + 1];
-        // out(0) and in(sink) are counted, not linked (see link_in / link_out)
-        H.vx[i].out_head = (o1 > o0 && i != 0) ? (IDX)o0 : NIL; H.vx[i].out_deg = (IDX)(o1 - o0);
-        H.vx[i].in_head = (i1 > i0 && i != V - 1) ? (IDX)ie[i0] : NIL; H.vx[i].in_deg = (IDX)(i1 - i0);
-        H.nz[i] = (i >= 1 && i < V - 1 && (o1 - o0) + (i1 - i0) > 0) ? 1 : 0;
-        for(int k = o0; k < o1; k++) { H.ed[k].lk.es = (IDX)i; H.ed[k].lk.onx = (k + 1 < o1) ? (IDX)(k + 1) : NIL; }
-        for(int k = i0; k < i1; k++) { H.ed[ie[k]].lk.inx = (k + 1 < i1) ? (IDX)ie[k + 1] : NIL; }
-        C.vx[i].vw = A->in.vertex_weight[ov + i]; C.vx[i].lpos = A->in.vertex_lpos[ov + i]; C.vx[i].rpos = A->in.vertex_rpos[ov + i];
-        C.vx[i].vtype = A->in.vertex_type[ov + i]; C.vx[i].v2v = i;
+    // the rows: a vertex per lane, every vertex a segment of exactly its size (whole 4-entry chunks), the segments laid out in vertex
+    // order by a prefix sum over the wave.  The wire's out-CSR row IS the out-row (sorted by (target, creation)), its in-CSR the in-row.
+    int used4 = 0;
+    for(int ib = 0; ib < V; ib += ALD_WAVE) {
+        const int i = ib + lane; const bool in = i < V;
+        int o0 = 0, o1 = 0, i0 = 0, i1 = 0;
+        if(in) { o0 = vo[i]; o1 = vo[i + 1]; i0 = io[i]; i1 = io[i + 1]; }
+        // out(0) and in(sink) are counted, they have no row (see link_in / link_out)
+        const int no = (in && i != 0) ? o1 - o0 : 0, ni = (in && i != V - 1) ? i1 - i0 : 0;
+        const int c4 = (ni + no + 3) / 4;
+        int tot; const int o4 = used4 + wave_excl_scan(c4, tot);
+        if(in && o4 + c4 <= ADJ_CAP4) {
+            Hot::VertexHot vr; vr.off4 = (IDX)o4; vr.cap4 = (IDX)c4; vr.in_deg = (IDX)(i1 - i0); vr.out_deg = (IDX)(o1 - o0);
+            H.vx[i] = vr;
+            H.nz[i] = (i >= 1 && i < V - 1 && (o1 - o0) + (i1 - i0) > 0) ? 1 : 0;
+            for(int k = 0; k < no; k++) H.adj[4 * (o4 + c4) - 1 - k] = (IDX)(o0 + k);
+            for(int k = 0; k < ni; k++) H.adj[4 * o4 + k] = (IDX)ie[i0 + k];
+            for(int k = o0; k < o1; k++) H.ed[k].es = (IDX)i;
+            C.vx[i].vw = A->in.vertex_weight[ov + i]; C.vx[i].lpos = A->in.vertex_lpos[ov + i]; C.vx[i].rpos = A->in.vertex_rpos[ov + i];
+            C.vx[i].vtype = A->in.vertex_type[ov + i]; C.vx[i].v2v = i;
+        }
+        used4 += tot;
     }
+    if(used4 > ADJ_CAP4) { if(lane == 0) HC.status = ALD_ST_CAPACITY; wsync(); return false; }
+    if(lane == 0) { HC.adj_used4 = used4; for(int k = 0; k < SEG_LISTS; k++) HC.seg_free[k] = NIL; }
     bool strand = false, listed = false;        // listed: some edge has two or more supporting samples (its list lives in the pool)
     ALD_GLOBAL const int32_t *so = A->in.edge_sample_offset + oeo;
     ALD_GLOBAL const int32_t *rank = A->in.edge_rank;      // scallop::scallop -> get_edge_indices (scallop.cc:24, graph_base.cc:139-153): e2i of the input edges
     for(int k = lane; k < E; k += ALD_WAVE) {
-        H.ed[k].lk.et = (IDX)A->in.edge_target[oe + k]; H.ed[k].w = A->in.edge_weight[oe + k]; H.eid[k] = rank ? (EID)rank[oe + k] : (EID)k; H.hflag[k] = 0;
+        H.ed[k].et = (IDX)A->in.edge_target[oe + k]; H.ed[k].w = A->in.edge_weight[oe + k]; H.ed[k].eid = rank ? (EID)rank[oe + k] : (EID)k; H.ed[k].hf = 0;
         uint8_t st = A->in.edge_strand[oe + k]; C.ed[k].estrand = st; if(st) strand = true;
         C.ed[k].med = 0; C.ed[k].mei = 0; C.ed[k].econf = 0; C.ed[k].eabd = A->in.edge_abd[oe + k];
         C.ed[k].sp_off = (uint32_t)so[k]; C.ed[k].sp_len = (uint32_t)(so[k + 1] - so[k]); C.ed[k].ecount = A->in.edge_count[oe + k];
@@ -3133,6 +3316,7 @@ ALD_FN bool load_graph()
 
 ALD_FN void finish_graph()
 {
+    ADJ_STAT((g_adj_graphs++, g_adj_peak_sum += HC.adj_used4, g_adj_peak = HC.adj_used4 > g_adj_peak ? HC.adj_used4 : g_adj_peak));
     // the graph's part of the result index: a graph that ended well reserves n_paths entries (one atomic) and the wave copies the pool
     // offsets of its records there, in path order; a graph that did not end well publishes nothing, so its records are unreachable
     {
@@ -3178,6 +3362,7 @@ ALD_FN void run_graph()
     wsync();
 #endif
     if(!uni(load_graph())) { finish_graph(); return; }
+    ADJ_CHECK("load");
     PROF_ADD(PF_LOAD);
     bool skipped = false;
     const double r_triv = uni(HC.p_ratio[7]), r_small = uni(HC.p_ratio[0]), r_single = uni(HC.p_ratio[5]), r_pure = uni(HC.p_ratio[4]);
@@ -3185,6 +3370,7 @@ ALD_FN void run_graph()
     int guard = 64 * MAXE;                     // every successful rule consumes an edge or a vertex; far above any real count
     while(guard-- > 0) {
         bool brk = false;
+        ADJ_CHECK("cascade");
         { const int nvq = HC.nv, stq = HC.status, mbq = HC.maybe_broken;      // one round of LDS reads for the three tests
           if(uni(nvq) > max_exons) { skipped = true; break; }
           if(uni(stq)) break;

@@ -31,10 +31,28 @@ def oracle_lib():
     return _ORACLE
 
 
+_EMU_ROWS = None
+
+
+def emu_rows_lib():
+    """the single-lane emulation of the ADJACENCY-ROW form of the engine (aletsch_amd/csrc/decomp_device_rows.h, make ROWS=1), built with
+    the row checker: every row sorted, every live edge in exactly the rows it belongs to, verified after every rule"""
+    global _EMU_ROWS
+    if _EMU_ROWS is None:
+        path = os.path.join(ROOT, "tests", "_build", "libkernel_emu_rows.so")
+        src = [os.path.join(ROOT, "aletsch_amd", "csrc", f) for f in ("decomp_device_rows.h", "decomp_common.h")]
+        if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in src):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "kernel_emu"), "-j8", "ROWS=1"], check=True, stdout=subprocess.DEVNULL)
+        _EMU_ROWS = C.CDLL(path)
+        _EMU_ROWS.emu_result_free.argtypes = [C.c_void_p]
+    return _EMU_ROWS
+
+
 def emu_lib():
     global _EMU
     if _EMU is None:
-        _EMU = C.CDLL(_ensure(os.path.join(ROOT, "tests", "_build", "libkernel_emu.so"), "tests/kernel_emu"))
+        # ALD_EMU_LIB: another build of the emulation (e.g. one compiled with -DALD_EMU_CHECK, which verifies the adjacency rows after every rule)
+        _EMU = C.CDLL(os.environ.get("ALD_EMU_LIB") or _ensure(os.path.join(ROOT, "tests", "_build", "libkernel_emu.so"), "tests/kernel_emu"))
         _EMU.emu_result_free.argtypes = [C.c_void_p]
     return _EMU
 
@@ -77,9 +95,9 @@ def oracle_transcripts(pg: PackedGraphs):
     return r, cov, eo, lr[:2 * te.value].reshape(-1, 2)
 
 
-def emu_run(pg: PackedGraphs, trace_cap: int = 0, force_class: int = 0, params=None):
-    """single-lane emulation of the HIP engine -> (DecompResult, iterations[n], class[n])"""
-    E = emu_lib()
+def emu_run(pg: PackedGraphs, trace_cap: int = 0, force_class: int = 0, params=None, rows: bool = False):
+    """single-lane emulation of the HIP engine -> (DecompResult, iterations[n], class[n]); rows: its adjacency-row form (make ROWS=1)"""
+    E = emu_rows_lib() if rows else emu_lib()
     h = C.c_void_p()
     rc = E.emu_run_packed(*pg.c_args(), C.byref(params) if params is not None else None, C.c_int32(trace_cap), C.c_int32(force_class), C.byref(h))
     assert rc == 0, rc

@@ -5,7 +5,11 @@
 #ifndef ALD_EMU
 #error "emulation build only"
 #endif
+#ifdef ALD_ROWS
+#include "../../aletsch_amd/csrc/decomp_device_rows.h"      /* make ROWS=1 -> libkernel_emu_rows.so: the adjacency-row form of the engine */
+#else
 #include "../../aletsch_amd/csrc/decomp_device.h"
+#endif
 
 extern "C" void ALD_CAT(emu_run_class_, ALD_CLASS_ID)(const ald::KernelArgs *A)
 {

@@ -29,6 +29,19 @@ def test_engine_records_carry_the_transcripts(name):
     assert np.array_equal(wcov, gcov)
 
 
+@pytest.mark.parametrize("name", ["cfg1_32v96e", "cfg2_64v256e", "cfg3_mixed", "flow_weights", "multi_sample", "stranded", "phasing", "everything", "real_shaped"])
+def test_row_form_of_the_engine_matches_oracle(name):
+    """The A/B build of round 4 (aletsch_amd/csrc/decomp_device_rows.h, make ROWS=1): per-vertex adjacency ROWS in a segment pool instead
+    of linked lists.  Same results bit for bit, same iteration counts; its emulation is built with the row checker (rows sorted by
+    (endpoint, creation id), every live edge in exactly its two rows, segments disjoint -- verified after every rule firing; a
+    violation aborts the process)."""
+    pg = common.make_batch(name)
+    want, st, _, _ = common.oracle_run(pg)
+    got, it, cl = common.emu_run(pg, rows=True)
+    assert not common.compare_results(want, got, pg.n)
+    assert np.array_equal(it, st[:, 3])
+
+
 def test_engine_joins_touching_and_drops_empty_intervals():
     """hand-made: vertices 1|2 touch (one exon), 3 is an empty interval (vanishes), 4 stands alone"""
     from aletsch_amd.packed import PackedGraphs

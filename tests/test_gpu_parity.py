@@ -851,6 +851,20 @@ def test_barrier_variant_of_the_hand_overs():
     assert last.startswith("TOTAL graphs") and last.endswith("mismatches 0") and int(last.split()[2]) >= 1000, r.stdout[-1500:]
 
 
+def test_row_form_of_the_kernels_on_gpu():
+    """libaletsch_decomp_rows.so (make ROWS=1): the engine with adjacency rows in a segment pool -- whole-row reads by the wave, ballots
+    for the position of an edge, merged edges placed by a merge of two sorted runs -- instead of linked lists.  The A/B build of round 4
+    (slower than the list form: profiles/r04/); kept bit-exact: a fixed-seed fuzz slice against the oracle plus the bench shape."""
+    import subprocess, sys
+    lib = os.path.join(common.ROOT, "aletsch_amd", "lib", "libaletsch_decomp_rows.so")
+    assert os.path.exists(lib), "build it with make -C aletsch_amd/csrc ROWS=1 (python __graft_entry__.py does)"
+    env = dict(os.environ, ALETSCH_DECOMP_LIB=lib, FUZZ_SECONDS="25", FUZZ_SEED="4242")
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "tools", "fuzz_parity.py")], capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("TOTAL graphs") and last.endswith("mismatches 0") and int(last.split()[2]) >= 1000, r.stdout[-1500:]
+
+
 def test_bench_line_and_its_exchange_path():
     """bench.py in a fresh process, as the driver starts it: ONE JSON line carrying the contract's keys, `roofline` and `cpu_baseline`; and
     once more with the multi-rank exchange forced on for the single rank this box has (ALD_BENCH_FORCE_DIST: process group over RCCL,
