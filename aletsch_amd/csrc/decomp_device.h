@@ -1258,6 +1258,215 @@ template<bool A> ALD_INL void star_wave_body(int x)
 }
 ALD_INL void star_wave_in(int x) { star_wave_body<true>(uni(x)); }       // inlined into the kernel entry, once (sweep_trivial has ONE decomposition site,
 ALD_INL void star_wave_out(int x) { star_wave_body<false>(uni(x)); }     // run_graph ONE sweep_trivial): no prologue that parks callee-saved registers in scratch
+#ifndef ALD_EMU
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The decomposition by the whole wave ONCE MORE (round 4), with the fan in REGISTERS: lane k holds fan edge k -- slot, weight, creation id,
+// other endpoint -- for the whole routine, and what one lane needs of another's travels through v_readlane (a few cycles, no memory),
+// not through the LDS scratch.  star_wave_body hands every intermediate array from phase to phase through LDS: eight hand-overs, each a
+// wsync() in front of a loop of DEPENDENT LDS round trips (fw[ord[q]]: two per step), 150-190 cycles a trip at this occupancy -- 20 000
+// cycles for a fan of three, 36 000 for the average fan above four (profiles/r03/zl_phase_star_by_size.txt), 22 % of the kernel.  Here:
+//   * the fan list is walked ONCE, in lock step, lane k keeping the k-th edge; every edge's record is then read in one round;
+//   * sums that the reference takes in list order or in merge order (the balance step's side sums, the weight c starts with) are
+//     uniform loops over readlane'd values -- the same additions in the same order;
+//   * merge order: rank of the lane's creation id among the fan's, by comparing against every lane's id in turn;
+//   * "what is left of c before merge q", the ids, the two sums around x and the vertex-weight chain -- the recurrences that tie the
+//     merges together -- run ONCE, as one uniform loop over the merges (every lane computes the same values in lock step, the lane that
+//     owns merge q keeps them); star_wave_body has every lane replay the recurrence up to its own merge out of LDS and a single lane run
+//     the chain behind another hand-over;
+//   * every lane then finishes ITS merged edge exactly as phase 5 does.
+// Only the places in far's list still go through the scratch (two small hand-overs): the links are written by rank, which is a permutation.
+// Every floating-point operation is the one the sequential form performs (scallop.cc:2144-2167 -> 2486-2576, 2009-2142, 2394-2484,
+// 2242-2378), on the same operands in the same order.  The single-lane emulation cannot run this form (it has no lanes to read from): it
+// runs star_wave_body, the same arithmetic through arrays; the GPU tier checks this one against the oracle.
+template<bool A> ALD_INL void star_reg(int x)
+{
+    COLD;
+    PROF_DECL;
+    const int lane = lane_id();
+    const double mw = HC.p_min_w;
+#if defined(ALD_PROF) && defined(ALD_PROF_STAR_BY_SIZE)
+    const unsigned long long prof_star0_ = __builtin_readcyclecounter();
+#endif
+    const Hot::VertexHot vrx = H.vx[x];
+    const int c = uni(slot_or_neg(A ? vrx.in_head : vrx.out_head));
+    const int n = uni((int)(A ? vrx.out_deg : vrx.in_deg));                  // 1 .. STAR_MAX: the caller chose the form from the degrees
+    // ---- the fan: ONE walk in lock step, lane k keeps fan edge k; then every edge's record in one round of loads
+    int f = c;
+    { int e = uni(slot_or_neg(A ? vrx.out_head : vrx.in_head));
+      for(int k = 0; k < n && e >= 0; k++) { if(lane == k) f = e; e = A ? u_next_out(e) : u_next_in(e); } }
+    const bool act = lane < n;
+    const double w0 = H.ed[f].w; const uint64_t lw = *(const uint64_t*)&H.ed[f].lk; const int id = (int)H.eid[f];
+    const int oth = A ? (int)((lw >> 16) & 0xFFFF) : (int)(lw & 0xFFFF);
+    const uint64_t lwc = lkw(c);
+    const int far = A ? (int)(lwc & 0xFFFF) : (int)((lwc >> 16) & 0xFFFF);
+    double wcen = H.ed[c].w;
+    bool badw = !(wcen >= mw - kSMIN) || wballot(act && !(w0 >= mw - kSMIN)) != 0;
+    // ---- balance_vertex(x) (scallop.cc:2486-2576): the side sums in list order, the scale factors, the clamps, the remainder fix-up
+    double sfan0 = 0;
+    for(int k = 0; k < n; k++) sfan0 += wread(w0, k);
+    double fw;
+    {
+        double scen0 = 0; scen0 += wcen;
+        const double w_in = A ? scen0 : sfan0, w_out = A ? sfan0 : scen0;
+        const double bw = sqrt(w_in * w_out);
+        const double r_in = bw / w_in, r_out = bw / w_out;
+        double m_cen = 0, m_fan = 0;
+        { double wy = wcen * (A ? r_in : r_out); if(wy < mw) { m_cen += mw - wy; wy = mw; } wcen = wy; }
+        fw = w0 * (A ? r_out : r_in);
+        const bool clamped = act && fw < mw; const double deficit = mw - fw;
+        if(clamped) fw = mw;
+        { uint64_t m = wballot(clamped); while(m) { const int l = ffs64(m); m &= m - 1; m_fan += wread(deficit, l); } }      // (list order; nearly always empty)
+        const double m1 = A ? m_cen : m_fan, m2 = A ? m_fan : m_cen;
+        if(m1 > m2) { if(A) { if(lane == 0) fw = fw + m1 - m2; } else wcen = wcen + m1 - m2; }
+        else if(m1 < m2) { if(A) wcen = wcen + m2 - m1; else { if(lane == 0) fw = fw + m2 - m1; } }
+        const double wc = wcen;
+        fw = A ? (wc <= fw ? wc : fw) : (fw <= wc ? fw : wc);                   // pe2w of (c, fan edge): the lane's pair weight
+    }
+    PROF_ADD(PF_T_BALANCE);
+    // ---- merge order = ascending creation id; the weight c starts with = the pair weights summed in that order
+    int inv = 0;
+    for(int k = 0; k < n; k++) { const int idk = wread(id, k); inv += ((uint32_t)idk < (uint32_t)id) ? 1 : 0; }
+    double mdc = 0;
+    for(int q = 0; q < n; q++) {
+        const int src = ffs64(wballot(act && inv == q));
+        const double pw = wread(fw, src < 0 ? 0 : src);
+        if(!(pw >= mw - kSMIN)) badw = true;
+        mdc = (q == 0) ? pw : mdc + pw;
+    }
+    if(ALD_UNLIKELY(uni(badw))) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_WEIGHT); wsync(); return; }      // nothing has been written
+    PROF_ADD(PF_T_SETUP);
+    // c's record and the vertex (one broadcast request each) and the lane's own fan edge: asked for here, used behind the merge loop
+    const double medc = C.ed[c].med, cc = C.ed[c].econf, abc = C.ed[c].s0abd, vw0 = C.vx[x].vw;
+    const int meic_v = C.ed[c].mei, cntc_v = C.ed[c].ecount, stc_v = C.ed[c].estrand, idc_v = C.ed[c].s0id;
+    const uint32_t nsc_v = C.ed[c].sp_len;
+    const int lt_v = C.vx[x].lpos, rt_v = C.vx[x].rpos, ov_v = C.vx[x].v2v;
+    uint64_t cmask_pf[NW <= 2 ? NW : 1];
+    if(NW <= 2) for(int k = 0; k < NW; k++) cmask_pf[k] = C.ed[c].mask[k];
+    const double pf_med = C.ed[f].med, pf_conf = C.ed[f].econf, pf_abd = C.ed[f].s0abd;
+    const int pf_mei = C.ed[f].mei, pf_st = C.ed[f].estrand, pf_cnt = C.ed[f].ecount, pf_id = C.ed[f].s0id;
+    const uint32_t pf_ns = C.ed[f].sp_len; const uint64_t pf_mask0 = C.ed[f].mask[0];
+    // ---- the sum of the fan weights not merged before the lane's own merge, list order (get_in/out_weights(x) at that merge)
+    double mysfan = 0;
+    for(int k = 0; k < n; k++) { const double fwk = wread(fw, k); const int invk = wread(inv, k); if(invk >= inv) mysfan += fwk; }
+    // ---- ONE pass over the merges, in merge order: what is left of c, whether the merge cuts a piece off, the ids, the sums around x, the
+    // weight x loses to the merged edge (scallop.cc:2242-2378).  Uniform work; the lane that owns merge q keeps q's values.
+    const int id0 = uni(HC.next_id);
+    double vwt = vw0, wcur = mdc, rem = 0; bool sc = false; int nid = id0;
+    int failq = -1, failcode = 0;
+    double my_wcur = 0, my_r1 = 0; bool my_sc = false; int my_nid = 0;
+    for(int q = 0; q < n; q++) {
+        const int src0 = ffs64(wballot(act && inv == q)), src = src0 < 0 ? 0 : src0;
+        const double ww = wread(fw, src);
+        if(q > 0) { if(!sc && failq < 0) { failq = q; failcode = ALD_ST_INVARIANT + ALD_INV_OTHER; } wcur = rem; nid += 1; }      // (the general form would be handed a dead edge here)
+        sc = uni(!(fabs(wcur - ww) <= kSMIN));                                // split_edge(c, ww) cuts a piece off (scallop.cc:2433-2484)
+        rem = wcur; if(sc) { nid += 1; rem = wcur - ww; if(rem <= mw) rem = mw; }
+        if(failq < 0 && nid - (sc ? 1 : 0) >= EID_LIMIT) { failq = q; failcode = ALD_ST_CAPACITY; }
+        const double sfan = wread(mysfan, src);
+        double sc_side = 0; sc_side += sc ? rem : wcur; if(sc) sc_side += ww;
+        const double sum = A ? (sc_side + sfan) * 0.5 : (sfan + sc_side) * 0.5;
+        const double wc0 = sc ? ww : wcur;
+        const double r1 = A ? vwt * (wc0 + ww) * 0.5 / sum : vwt * (ww + wc0) * 0.5 / sum;
+        vwt = vwt - r1;
+        if(lane == src) { my_wcur = wcur; my_sc = sc; my_nid = nid; my_r1 = r1; }
+    }
+    const bool consumed = !sc;                                                 // the last merge used c up
+    const int nid_last = nid;
+    PROF_ADD(PF_T_MERGE_SUMS);
+    const int meic = uni(meic_v), cntc = uni(cntc_v), stc = uni(stc_v), idc = uni(idc_v);
+    const uint32_t nsc = uni(nsc_v);
+    const int lt = uni(lt_v), rt = uni(rt_v), ov = uni(ov_v);
+    {   // what the sequential form checks when it reaches merge q, in its order: a consumed c, the id counter, the two counts -- the
+        // failure it meets first is the one of the smallest q
+        int cq = -1;
+        if(!(cntc > 0)) cq = 0;
+        else { uint64_t m = wballot(act && !(pf_cnt > 0)); while(m) { const int l = ffs64(m); m &= m - 1; const int ql = wread(inv, l); if(cq < 0 || ql < cq) cq = ql; } }
+        int code = 0;
+        if(failq >= 0 && (cq < 0 || failq <= cq)) code = failcode; else if(cq >= 0) code = ALD_ST_INVARIANT + ALD_INV_COUNT;
+        if(ALD_UNLIKELY(code != 0)) { if(lane == 0) { C.vx[x].vw = vwt; fail(code); } wsync(); return; }
+    }
+    if(lane == 0) C.vx[x].vw = vwt;
+    if(ALD_UNLIKELY(!consumed)) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); wsync(); return; }     // c kept a remainder: the reference asserts on the degree of x
+    // two fan edges to one vertex: their relinks share a list -> sequential, in merge order, at the end
+    bool dup = false;
+    for(int k = 0; k < n; k++) { const int othk = wread(oth, k); if(act && lane != k && othk == oth) dup = true; }
+    const bool any_dup = wballot(dup) != 0;
+    // ---- lane k: fan edge k becomes merged edge inv -- cold record, id, weight, endpoint, place in the list of its other endpoint
+    int32_t *fem = (int32_t*)HC.scr_i, *othm = fem + STAR_MAX, *pred = fem + 2 * STAR_MAX, *succ = fem + 3 * STAR_MAX, *srt = (int32_t*)HC.scr_d;
+    bool multi = false;
+    if(act) {
+        const double ww = fw, wc0 = my_sc ? ww : my_wcur;
+        const double medc1 = my_sc ? medc * ww / my_wcur : medc;
+        if(nsc == 1 && pf_ns == 1) {
+            if(pf_id == idc) { const double xa = A ? abc : pf_abd, ya = A ? pf_abd : abc; const double mn = (ya < xa) ? ya : xa; C.ed[f].sp_off = 0; C.ed[f].ecount = 1; C.ed[f].eabd = 0.0 + mn; C.ed[f].s0abd = mn; }
+            else { C.ed[f].sp_off = 0; C.ed[f].sp_len = 0; C.ed[f].ecount = 0; C.ed[f].eabd = 0; C.ed[f].s0id = 0; C.ed[f].s0abd = 0; }
+        } else multi = true;                                                  // pool allocation: sequential, below
+        C.ed[f].econf = A ? cc + pf_conf : pf_conf + cc;
+        { const int sty = A ? pf_st : stc, stx = A ? stc : pf_st; C.ed[f].estrand = (uint8_t)(sty != 0 ? sty : stx); }
+        for(int k = 0; k < NW; k++) { uint64_t mk = (NW <= 2 ? cmask_pf[NW <= 2 ? k : 0] : C.ed[c].mask[k]) | (k == 0 ? pf_mask0 : C.ed[f].mask[k]); if(ov >= 0 && (ov >> 6) == k) mk |= (1ull << (ov & 63)); C.ed[f].mask[k] = mk; }
+        const int mi = A ? rt - lt + meic + pf_mei : rt - lt + pf_mei + meic;
+        C.ed[f].med = A ? mi * my_r1 + medc1 + pf_med : mi * my_r1 + pf_med + medc1; C.ed[f].mei = mi;
+        H.eid[f] = (EID)my_nid; H.ed[f].w = A ? wc0 * 0.5 + ww * 0.5 : ww * 0.5 + wc0 * 0.5;
+        if(A) H.ed[f].lk.es = (IDX)far; else H.ed[f].lk.et = (IDX)far;
+        if(!any_dup) { if(A) relink_in_lane(oth, f, (uint32_t)far); else relink_out_lane(oth, f, tkey((uint32_t)far)); }
+        fem[inv] = f; othm[inv] = oth;                                        // (merge order: what the tail and the link pass read)
+    }
+    const bool any_multi = wballot(multi) != 0;
+    PROF_ADD(PF_T_MERGE_LOAD);
+    // far's list: c leaves it now (lane 0, while nothing else touches a list of that kind), the merged edges enter it below
+    const bool counted = A ? (far == 0 && !uni(HC.special_linked)) : (far == (int)uni(HC.sinkp) && !uni(HC.special_linked));     // out(source) / in(sink) are only counted
+    if(lane == 0) { if(A) unlink_out(far, c); else unlink_in(far, c); }
+    wsync();
+    PROF_ADD(PF_T_MERGE_MASK);
+    // ---- the place of merged edge q in far's list = behind the last old entry whose key does not exceed its own (old entries carry older
+    // ids), and among the new ones by (key, creation order).  Read-only walk; the links are written by rank after one hand-over.
+    if(!counted) {
+        const uint32_t key = A ? tkey((uint32_t)oth) : (uint32_t)oth;
+        int r = 0;
+        for(int k = 0; k < n; k++) { const uint32_t kk = (uint32_t)wread((int)key, k); const int invk = wread(inv, k); r += (kk < key || (kk == key && invk < inv)) ? 1 : 0; }
+        if(act) {
+            int last = -1, cur = A ? first_out(far) : first_in(far), guard = MAXE;
+            while(cur >= 0 && guard-- > 0) {
+                const uint64_t w = *(const uint64_t*)&H.ed[cur].lk;
+                const uint32_t kc = A ? tkey((uint32_t)((w >> 16) & 0xFFFF)) : (uint32_t)(w & 0xFFFF);
+                if(kc > key) break;
+                last = cur; cur = A ? lk_next((uint32_t)(w >> 48)) : lk_next((uint32_t)((w >> 32) & 0xFFFF));
+            }
+            pred[inv] = last; succ[inv] = cur; srt[r] = inv;
+        }
+        wsync();
+        for(int r2 = lane; r2 < n; r2 += ALD_WAVE) {
+            const int q = srt[r2], fq = fem[q];
+            const bool first_of_gap = (r2 == 0) || pred[srt[r2 - 1]] != pred[q], last_of_gap = (r2 + 1 >= n) || pred[srt[r2 + 1]] != pred[q];
+            const IDX nx = last_of_gap ? (succ[q] < 0 ? NIL : (IDX)succ[q]) : (IDX)fem[srt[r2 + 1]];
+            if(A) H.ed[fq].lk.onx = nx; else H.ed[fq].lk.inx = nx;
+            if(first_of_gap) { if(pred[q] < 0) { if(A) H.vx[far].out_head = (IDX)fq; else H.vx[far].in_head = (IDX)fq; } else { if(A) H.ed[pred[q]].lk.onx = (IDX)fq; else H.ed[pred[q]].lk.inx = (IDX)fq; } }
+        }
+    }
+    wsync();
+    // ---- lane 0: what is left and inherently ordered -- the support pool, the phasing lists, the counters
+    if(lane == 0) {
+        if(A) H.vx[far].out_deg = (IDX)((int)uni(H.vx[far].out_deg) + n); else H.vx[far].in_deg = (IDX)((int)uni(H.vx[far].in_deg) + n);
+        if(any_dup || any_multi || uni(HC.hl_n) != 0) for(int q = 0; q < n; q++) {
+            const int fq = fem[q];
+            if(any_dup) { if(A) relink_in(othm[q], fq, (uint32_t)far); else relink_out(othm[q], fq, tkey((uint32_t)far)); }
+            if(any_multi) { const uint32_t nsf = uni(C.ed[fq].sp_len); if(!(nsc == 1 && nsf == 1)) { if(!(A ? intersect_samples(c, fq, fq) : intersect_samples(fq, c, fq))) break; } }
+            if(A) hs_replace2(c, fq, fq); else hs_replace2(fq, c, fq);
+            if(n == 1) hs_replace1(c, fq);
+        }
+        HC.next_id = nid_last + 1;
+        if(n >= 2) hs_remove(c);
+        // remove_edge(c) (already out of far's list); x is left without edges
+        H.ed[c].lk.es = NIL; H.hflag[c] = 0;
+        { int fh = uni(HC.free_head); H.ed[c].lk.onx = fh < 0 ? NIL : (IDX)fh; HC.free_head = c; HC.free_cnt = uni(HC.free_cnt) + 1; }
+        clear_vertex(x);
+    }
+    wsync();
+    PROF_ADD(PF_T_MERGE_ADD);
+#if defined(ALD_PROF) && defined(ALD_PROF_STAR_BY_SIZE)
+    { unsigned long long t1_ = __builtin_readcyclecounter(); if(lane_id() == 0) HC.prof[n == 1 ? PF_T_PAIRS : n == 2 ? PF_T_MERGE_ISECT : n == 3 ? PF_T_MERGE_KILL : n == 4 ? PF_S6_LINK : PF_FINISH] += t1_ - prof_star0_; }
+#endif
+}
+#endif
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The same decomposition once more, written for a fan of EXACTLY N = 2..4 edges (two thirds of the stars of the bench workload), with
 // nothing handed from lane to lane: every lane gathers the whole fan and runs the whole numeric part -- balance_vertex, pair
@@ -1526,8 +1735,13 @@ ALD_INL void decompose_trivial_vertex_wave(int x)
     // experiment: the smallest fans through the sequential form on lane 0 (no hand-overs at all)
     if((nin == 1 && nout >= 1 && nout <= ALD_STAR_SEQ_MAX) || (nout == 1 && nin >= 1 && nin <= ALD_STAR_SEQ_MAX)) { if(lane_id() == 0) decompose_trivial_vertex(x); wsync(); return; }
 #endif
+#if !defined(ALD_EMU) && !defined(ALD_STAR_SCRATCH_FORM)
+    if(nin == 1 && nout >= 1 && nout <= STAR_MAX) star_reg<true>(x);         // the fan in registers (the emulation and -DALD_STAR_SCRATCH_FORM: the same
+    else if(nout == 1 && nin >= 1 && nin <= STAR_MAX) star_reg<false>(x);    // arithmetic through arrays in LDS, star_wave_body)
+#else
     if(nin == 1 && nout >= 1 && nout <= STAR_MAX) star_wave_in(x);
     else if(nout == 1 && nin >= 1 && nin <= STAR_MAX) star_wave_out(x);
+#endif
     else { if(lane_id() == 0) decompose_trivial_vertex(x); wsync(); }
 }
 
@@ -3180,8 +3394,18 @@ ALD_FN void run_graph()
     if(!uni(load_graph())) { finish_graph(); return; }
     PROF_ADD(PF_LOAD);
     bool skipped = false;
+#ifndef ALD_SGPR_DIET
     const double r_triv = uni(HC.p_ratio[7]), r_small = uni(HC.p_ratio[0]), r_single = uni(HC.p_ratio[5]), r_pure = uni(HC.p_ratio[4]);
     const int max_exons = uni(HC.p_max_exons);
+#else
+    // experiment (profiles/r04/e_*): the cascade's long-lived wave-uniform values -- four ratios, the vertex limit: nine SGPRs for a graph's
+    // whole life, part of what the kernel root spills to VGPR lanes -- re-read from the LDS context where they are used
+    #define r_triv uni(HC.p_ratio[7])
+    #define r_small uni(HC.p_ratio[0])
+    #define r_single uni(HC.p_ratio[5])
+    #define r_pure uni(HC.p_ratio[4])
+    #define max_exons uni(HC.p_max_exons)
+#endif
     int guard = 64 * MAXE;                     // every successful rule consumes an edge or a vertex; far above any real count
     while(guard-- > 0) {
         bool brk = false;
@@ -3223,6 +3447,13 @@ ALD_FN void run_graph()
     }
     wsync();
     finish_graph();
+#ifdef ALD_SGPR_DIET
+    #undef r_triv
+    #undef r_small
+    #undef r_single
+    #undef r_pure
+    #undef max_exons
+#endif
 }
 
 #ifdef ALD_ISA_PROBE
@@ -3252,6 +3483,9 @@ ALD_INL void wave_main(ALD_GLOBAL const KernelArgs *A, int block)
     }
     wsync();
     while(true) {
+#ifdef ALD_SGPR_DIET
+        A = (ALD_GLOBAL const KernelArgs*)uni((unsigned long long)HC.args);       // (experiment: the argument block's address from LDS instead of two SGPRs held across the graph)
+#endif
         if(lane_id() == 0) HC.s_next = atomic_add_i32(A->counter, 1);
         wsync();
         int k = HC.s_next;
