@@ -2849,6 +2849,7 @@ ALD_FN void materialize_special()
 ALD_FN void collect_existing_st_paths()
 {
     COLD;
+    PROF_DECL;
     const int lane = lane_id();
     const int sink = uni(HC.sinkp), hw = uni(HC.slot_hw);
     ALD_GLOBAL int32_t *lst = C.wi; int n = 0;           // the source -> sink edges (work array of the slab: up to MAXE entries), by every lane
@@ -2864,6 +2865,7 @@ ALD_FN void collect_existing_st_paths()
         n += __builtin_popcountll(m);
     }
     wsync();
+    PROF_ADD(PF_S5_DUP);
     if(n == 0) return;
     if(tracing() || 5 * n > Cold::w_cap || uni(HC.n_paths) + n > Cold::po_cap) {        // the op trace lists the paths in order: one at a time (which also reports a full offset table)
         if(lane == 0) {
@@ -2888,6 +2890,7 @@ ALD_FN void collect_existing_st_paths()
         keep[j] = (C.ed[e].mei != mi || cnt == 0) ? -1 : (empty ? 0 : 1);
     }
     wsync();
+    PROF_ADD(PF_S5_BODY);
     bool bad = false, full = false; int kept_total = 0;
     for(int j = lane; j < n; j += ALD_WAVE) {
         const int e = lst[j]; const int32_t id = ids[j]; int rank = 0; bool later_bad = false;
@@ -2919,6 +2922,7 @@ ALD_FN void collect_existing_st_paths()
     }
     const bool any_bad = wballot(bad) != 0, any_full = wballot(full) != 0;
     wsync();
+    PROF_ADD(PF_S5_RELINK);
     if(lane == 0) {
         for(int k = 0; k < n; k++) if(keep[k] == 1) kept_total++;
         if(any_bad) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);                  // assert(mei[e] == mi) / an empty vertex list (scallop.cc:2783)
@@ -2928,6 +2932,7 @@ ALD_FN void collect_existing_st_paths()
         for(int k = 0; k < n; k++) { const int e = lst[k]; H.hflag[e] = 0; kill_edge_i(e); }
     }
     wsync();
+    PROF_ADD(PF_S6_WALK);
 }
 // splice_graph::compute_maximum_path_w (splice_graph.cc:819-885) + directed_graph::topological_sort (directed_graph.cc:420-451)
 // path edges -> upper half of wi, length -> HC.tmp0
@@ -3444,6 +3449,7 @@ ALD_FN void run_graph()
             if(HC.status == 0) greedy_decompose();
             if(HC.status == 0 && skipped) HC.status = ALD_ST_SKIPPED_LARGE;
         }
+        PROF_ADD(PF_S7);
     }
     wsync();
     finish_graph();
