@@ -50,9 +50,11 @@ Rccl &rccl()
 } // namespace
 
 struct ald_comm {
-    ncclComm_t comm = nullptr; int world = 1, rank = 0, device = 0; hipStream_t stream = nullptr;
-    DevBuf d_send, d_recv, d_sizes; PinBuf h_recv;
-    std::vector<int64_t> offsets; std::vector<int32_t> goffs;
+    ncclComm_t comm = nullptr; int world = 1, rank = 0, device = 0; hipStream_t stream = nullptr, copy_stream = nullptr;
+    DevBuf d_send, d_sizes;
+    // two sets of receive buffers (rank 0): while the host merges what gather k brought, gather k + 1 receives and copies into the other set
+    struct Set { DevBuf d_recv; PinBuf h_recv; std::vector<int64_t> offsets; std::vector<int32_t> goffs; std::vector<hipEvent_t> landed; hipEvent_t received = nullptr; bool open = false; } set[2];
+    int cur = 1;                                   // the set of the gather begun last
 };
 
 extern "C" {
@@ -78,7 +80,8 @@ int ald_comm_create(const uint8_t id[128], int32_t world, int32_t rank, int32_t 
     ncclUniqueId u; memcpy(&u, id, 128);
     ncclResult_t r = R.CommInitRank(&c->comm, world, u, rank);
     if(r != ncclSuccess) { delete c; return ald_set_err(ALD_ERR_HIP, std::string("ncclCommInitRank: ") + R.GetErrorString(r)); }
-    if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { R.CommDestroy(c->comm); delete c; return ald_set_err(ALD_ERR_HIP, "stream creation failed"); }
+    if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { R.CommDestroy(c->comm); delete c; return ald_set_err(ALD_ERR_HIP, "stream creation failed"); }
+    for(auto &st : c->set) { if(hipEventCreateWithFlags(&st.received, hipEventDisableTiming) != hipSuccess) { R.CommDestroy(c->comm); delete c; return ald_set_err(ALD_ERR_HIP, "event creation failed"); } }
     *out = c;
     return ALD_OK;
 }
@@ -88,21 +91,28 @@ int ald_comm_destroy(ald_comm *c)
     if(!c) return ALD_OK;
     hipSetDevice(c->device);
     if(c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    if(c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     if(c->comm) rccl().CommDestroy(c->comm);
-    c->d_send.release(); c->d_recv.release(); c->d_sizes.release(); c->h_recv.release();
+    c->d_send.release(); c->d_sizes.release();
+    for(auto &st : c->set) { st.d_recv.release(); st.h_recv.release(); for(hipEvent_t e : st.landed) hipEventDestroy(e); if(st.received) hipEventDestroy(st.received); }
     delete c;
     return ALD_OK;
 }
 
-/* every rank: its stream + the global id of its first graph; rank 0 gets all streams back to back in rank order (valid until the next
- * call on this communicator), offsets[world + 1] into them, and every rank's graph offset */
-int ald_comm_gather_streams(ald_comm *c, const uint32_t *words, int64_t n_words, int32_t graph_offset,
-                            const uint32_t **all_words, const int64_t **offsets, const int32_t **graph_offsets)
+/* The collective in two halves.  ald_comm_gather_begin: every rank passes its stream + the global id of its first graph; the sizes are
+ * exchanged (one small synchronous round), the payloads are ENQUEUED -- grouped Send / Recv to rank 0 on the communicator's stream -- and
+ * on rank 0 the copy of every received stream to pinned host memory is enqueued behind them on a second stream, one copy per rank with an
+ * event of its own: the call returns while the data is still on its way.  ald_comm_gather_wait(upto): blocks until the streams of ranks
+ * 0..upto (-1: all; a rank other than 0: until its own send has left) have landed, then hands out the pointers.  Rank 0 can so merge
+ * rank r's stream while rank r + 1's is still being copied, and -- the buffers exist twice -- begin gather k + 1 before it has merged
+ * gather k: what a wait handed out stays valid until the SECOND next begin on this communicator. */
+int ald_comm_gather_begin(ald_comm *c, const uint32_t *words, int64_t n_words, int32_t graph_offset)
 {
     if(!c || n_words < 0 || (n_words > 0 && !words)) return ALD_ERR_INVALID;
     Rccl &R = rccl();
     HCHK(hipSetDevice(c->device));
     const int W = c->world;
+    c->cur ^= 1; ald_comm::Set &S = c->set[c->cur];
     // sizes and graph offsets of every rank: one (n_words, graph_offset) pair each
     if(c->d_sizes.ensure(16 * (size_t)(W + 1))) return ald_set_err(ALD_ERR_NOMEM, "size exchange buffer");
     int64_t mine[2] = {n_words, (int64_t)graph_offset};
@@ -111,8 +121,8 @@ int ald_comm_gather_streams(ald_comm *c, const uint32_t *words, int64_t n_words,
     std::vector<int64_t> all(2 * (size_t)W);
     HCHK(hipMemcpyAsync(all.data(), (char*)c->d_sizes.p + 16, 16 * (size_t)W, hipMemcpyDeviceToHost, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
-    c->offsets.assign((size_t)W + 1, 0); c->goffs.assign((size_t)W, 0);
-    for(int r = 0; r < W; r++) { c->offsets[(size_t)r + 1] = c->offsets[(size_t)r] + all[2 * (size_t)r]; c->goffs[(size_t)r] = (int32_t)all[2 * (size_t)r + 1]; }
+    S.offsets.assign((size_t)W + 1, 0); S.goffs.assign((size_t)W, 0);
+    for(int r = 0; r < W; r++) { S.offsets[(size_t)r + 1] = S.offsets[(size_t)r] + all[2 * (size_t)r]; S.goffs[(size_t)r] = (int32_t)all[2 * (size_t)r + 1]; }
     // payloads: every rank sends, rank 0 receives each stream at its offset
     // a stream that already lives in HBM (ald_batch_device_transcript_stream) is sent from where it is; a host stream is staged first
     const void *src = words;
@@ -126,8 +136,11 @@ int ald_comm_gather_streams(ald_comm *c, const uint32_t *words, int64_t n_words,
             src = c->d_send.p;
         }
     }
-    const int64_t total = c->offsets[(size_t)W];
-    if(c->rank == 0) { if(c->d_recv.ensure(4 * (size_t)total + 64) || c->h_recv.ensure(4 * (size_t)total + 64)) return ald_set_err(ALD_ERR_NOMEM, "receive buffers"); }
+    const int64_t total = S.offsets[(size_t)W];
+    if(c->rank == 0) {
+        if(S.d_recv.ensure(4 * (size_t)total + 64) || S.h_recv.ensure(4 * (size_t)total + 64)) return ald_set_err(ALD_ERR_NOMEM, "receive buffers");
+        while((int)S.landed.size() < W) { hipEvent_t e; HCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); S.landed.push_back(e); }
+    }
     // the grouped section never returns between GroupStart and GroupEnd: a failed Send / Recv is remembered, the group is closed (the
     // calling thread must not stay in group mode: every later RCCL call on it would be deferred) and the stream drained -- it still
     // holds the staging copy from the caller's buffer -- before the error goes back
@@ -137,7 +150,7 @@ int ald_comm_gather_streams(ald_comm *c, const uint32_t *words, int64_t n_words,
         if(n_words) { const ncclResult_t r_ = R.Send(src, (size_t)n_words, ncclUint32, 0, c->comm, c->stream); if(r_ != ncclSuccess) { bad = r_; what = "ncclSend"; } }
         if(c->rank == 0) for(int r = 0; r < W && bad == ncclSuccess; r++) {
             const int64_t k = all[2 * (size_t)r]; if(!k) continue;
-            const ncclResult_t r_ = R.Recv((uint32_t*)c->d_recv.p + c->offsets[(size_t)r], (size_t)k, ncclUint32, r, c->comm, c->stream);
+            const ncclResult_t r_ = R.Recv((uint32_t*)S.d_recv.p + S.offsets[(size_t)r], (size_t)k, ncclUint32, r, c->comm, c->stream);
             if(r_ != ncclSuccess) { bad = r_; what = "ncclRecv"; }
         }
         const ncclResult_t ge = R.GroupEnd();
@@ -146,12 +159,43 @@ int ald_comm_gather_streams(ald_comm *c, const uint32_t *words, int64_t n_words,
             return ald_set_err(ALD_ERR_HIP, std::string(bad != ncclSuccess ? what : "ncclGroupEnd") + ": " + R.GetErrorString(bad != ncclSuccess ? bad : ge));
         }
     }
-    if(c->rank == 0 && total) HCHK(hipMemcpyAsync(c->h_recv.p, c->d_recv.p, 4 * (size_t)total, hipMemcpyDeviceToHost, c->stream));
-    HCHK(hipStreamSynchronize(c->stream));
-    if(all_words) *all_words = c->rank == 0 ? (const uint32_t*)c->h_recv.p : nullptr;
-    if(offsets) *offsets = c->offsets.data();
-    if(graph_offsets) *graph_offsets = c->goffs.data();
+    HCHK(hipEventRecord(S.received, c->stream));
+    if(c->rank == 0) {
+        // behind the receives, on the copy stream: one D2H per rank, in rank order, an event after each -- the exchange stream is free for
+        // the next gather's size round at once
+        HCHK(hipStreamWaitEvent(c->copy_stream, S.received, 0));
+        for(int r = 0; r < W; r++) {
+            const int64_t k = all[2 * (size_t)r];
+            if(k) HCHK(hipMemcpyAsync((uint32_t*)S.h_recv.p + S.offsets[(size_t)r], (const uint32_t*)S.d_recv.p + S.offsets[(size_t)r], 4 * (size_t)k, hipMemcpyDeviceToHost, c->copy_stream));
+            HCHK(hipEventRecord(S.landed[(size_t)r], c->copy_stream));
+        }
+    }
+    S.open = true;
     return ALD_OK;
+}
+
+int ald_comm_gather_wait(ald_comm *c, int32_t upto, const uint32_t **all_words, const int64_t **offsets, const int32_t **graph_offsets)
+{
+    if(!c) return ALD_ERR_INVALID;
+    ald_comm::Set &S = c->set[c->cur];
+    if(!S.open) return ald_set_err(ALD_ERR_STATE, "ald_comm_gather_wait without a gather in flight");
+    HCHK(hipSetDevice(c->device));
+    const int W = c->world;
+    if(c->rank == 0) { const int last = (upto < 0 || upto >= W) ? W - 1 : upto; HCHK(hipEventSynchronize(S.landed[(size_t)last])); }
+    else HCHK(hipEventSynchronize(S.received));
+    if(all_words) *all_words = c->rank == 0 ? (const uint32_t*)S.h_recv.p : nullptr;
+    if(offsets) *offsets = S.offsets.data();
+    if(graph_offsets) *graph_offsets = S.goffs.data();
+    return ALD_OK;
+}
+
+/* both halves in one call: rank 0 gets all streams back to back in rank order, offsets[world + 1] into them, and every rank's graph offset */
+int ald_comm_gather_streams(ald_comm *c, const uint32_t *words, int64_t n_words, int32_t graph_offset,
+                            const uint32_t **all_words, const int64_t **offsets, const int32_t **graph_offsets)
+{
+    const int rc = ald_comm_gather_begin(c, words, n_words, graph_offset);
+    if(rc != ALD_OK) return rc;
+    return ald_comm_gather_wait(c, -1, all_words, offsets, graph_offsets);
 }
 
 } // extern "C"

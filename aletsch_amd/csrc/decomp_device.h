@@ -209,8 +209,14 @@ ALD_FN void trace_emit(int code, int a, int b, double v)
     int k = HC.n_trace++;
     if(k < cap) { int64_t o = (int64_t)HC.g * cap + k; A->out.trace_codes[3 * o] = code; A->out.trace_codes[3 * o + 1] = a; A->out.trace_codes[3 * o + 2] = b; A->out.trace_vals[o] = v; }
 }
+#ifdef ALD_PROF
+ALD_INL bool tracing_u() { return false; }
+ALD_INL bool tracing() { return false; }        // the profiling build reports its cycle sums through the trace buffer, but takes no op trace: the phases are timed as the product runs them
+#else
+ALD_INL bool tracing_u() { return uni(HC.p_trace_cap) > 0; }
 ALD_INL bool tracing() { return HC.p_trace_cap > 0; }
-ALD_INL void trace(int code, int a, int b, double v) { HC.n_iters++; if(HC.p_trace_cap > 0) trace_emit(code, a, b, v); }
+#endif
+ALD_INL void trace(int code, int a, int b, double v) { HC.n_iters++; if(tracing()) trace_emit(code, a, b, v); }
 // u_*: the same accessors for the scalar (lane-0) routines, with the result marked wave-uniform (see uni() in decomp_common.h)
 // an edge slot or NIL -> slot or -1.  Slots of every class but the largest stay below 2^15, so NIL (0xFFFF) read as a SIGNED 16-bit value
 // is already the -1 the walks test for: the load itself sign-extends (ds_read_i16) and the compare + select per list step goes away.
@@ -2066,7 +2072,7 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
 ALD_INL bool sweep_trivial_body(int mode, int type, double jump_ratio, int &fired, const bool tr);
 ALD_INL bool sweep_trivial(int mode, int type, double jump_ratio)
 {
-    int fired = 0; const bool tr = uni(HC.p_trace_cap) > 0;
+    int fired = 0; const bool tr = tracing_u();
     const bool rv = sweep_trivial_body(mode, type, jump_ratio, fired, tr);
     if(fired && lane_id() == 0) HC.n_iters += fired;
     return rv;
@@ -2144,7 +2150,7 @@ ALD_INL bool back_to_cascade()
 ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr);
 ALD_INL bool sweep_smallest(double max_ratio)
 {
-    int fired = 0; const bool tr = uni(HC.p_trace_cap) > 0;
+    int fired = 0; const bool tr = tracing_u();
     const bool rv = sweep_smallest_body(max_ratio, fired, tr);
     if(fired && lane_id() == 0) HC.n_iters += fired;
     return rv;
@@ -2174,6 +2180,7 @@ ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr)
     };
     ALD_UNROLL for(int c = 0; c < NC; c++) { cr[c] = 0; ce[c] = -1; }
     { const int nch = (vend + ALD_WAVE - 1) / ALD_WAVE; for(int c = 0; c < nch; c++) eval_chunk(c, true, -1, -1); }
+    PROF_ADD(PF_T_MERGE_KILL);                   // (profiling build: the evaluation of every vertex at the sweep's entry)
     const bool may_chain = !(uni(HC.p_ratio[7]) > 1.0) && !uni(HC.any_strand);
     bool any = false;
     int guard = MAXE + 8;

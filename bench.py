@@ -140,6 +140,24 @@ def cpu_baseline_legs(pg, n_all: int):
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import common
+    cores, affinity, quota = cpu_cores(detail=True)
+    n_all = min(n_all, pg.n); n_one = max(256, min(pg.n, n_all // 12))
+    s_all = pg.select(np.arange(n_all)); s_one = pg.select(np.arange(n_one))
+    _, _, sec_all, _ = common.oracle_run(s_all, threads=cores)
+    _, _, sec_one, _ = common.oracle_run(s_one, threads=1)
+    model = cpu_model()
+    note = ("oracle/ = CPU restatement of the reference scallop core (container-based port; the survey's probe of the reference itself "
+            "measured 157-206 graphs/s per thread on these graphs, BASELINE.md section 2)")
+    allc = {"value": s_all.n / sec_all, "unit": "bundles/s", "cores": cores, "kind": "port", "cpu_model": model,
+            "affinity_cores": affinity, "cgroup_cpu_quota": quota,
+            "sample": f"first {s_all.n} graphs of the same workload, {cores} threads over independent graphs (affinity mask {affinity} hardware threads, cgroup CPU quota {quota}), {sec_all:.2f} s; {note}"}
+    one = {"value": s_one.n / sec_one, "unit": "bundles/s", "cores": 1, "kind": "port", "cpu_model": model,
+           "sample": f"first {s_one.n} graphs of the same workload, 1 thread, {sec_one:.2f} s"}
+    return allc, one
+
+
+def cpu_cores(detail=False):
+    """every core this process may USE (see below): -> cores, or (cores, affinity, quota)"""
     try:
         affinity = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -158,19 +176,7 @@ def cpu_baseline_legs(pg, n_all: int):
     cores = max(1, min(affinity, int(quota + 0.5)) if quota else affinity)
     if os.environ.get("ALD_BENCH_CPU_THREADS"):
         cores = max(1, int(os.environ["ALD_BENCH_CPU_THREADS"]))
-    n_all = min(n_all, pg.n); n_one = max(256, min(pg.n, n_all // 12))
-    s_all = pg.select(np.arange(n_all)); s_one = pg.select(np.arange(n_one))
-    _, _, sec_all, _ = common.oracle_run(s_all, threads=cores)
-    _, _, sec_one, _ = common.oracle_run(s_one, threads=1)
-    model = cpu_model()
-    note = ("oracle/ = CPU restatement of the reference scallop core (container-based port; the survey's probe of the reference itself "
-            "measured 157-206 graphs/s per thread on these graphs, BASELINE.md section 2)")
-    allc = {"value": s_all.n / sec_all, "unit": "bundles/s", "cores": cores, "kind": "port", "cpu_model": model,
-            "affinity_cores": affinity, "cgroup_cpu_quota": quota,
-            "sample": f"first {s_all.n} graphs of the same workload, {cores} threads over independent graphs (affinity mask {affinity} hardware threads, cgroup CPU quota {quota}), {sec_all:.2f} s; {note}"}
-    one = {"value": s_one.n / sec_one, "unit": "bundles/s", "cores": 1, "kind": "port", "cpu_model": model,
-           "sample": f"first {s_one.n} graphs of the same workload, 1 thread, {sec_one:.2f} s"}
-    return allc, one
+    return (cores, affinity, quota) if detail else cores
 
 
 def committed_pmc(args):
@@ -187,7 +193,7 @@ def committed_pmc(args):
 
 
 def kernel_only(A, dev, pg, reps=2):
-    """upload once, run `reps` times, -> (best kernel ms, failed graphs, per-class graph counts)"""
+    """upload once, run `reps` times, -> (best kernel ms, failed graphs, per-class graph counts, algorithmic bytes in + out)"""
     with A.DecompBatch(dev) as b:
         b.add(pg); b.upload()
         best = None
@@ -196,7 +202,33 @@ def kernel_only(A, dev, pg, reps=2):
             ms = b.kernel_ms(); best = ms if best is None else min(best, ms)
         bad = int((b.result().status != 0).sum())
         classes = {str(c): b.class_info(c)["n_graphs"] for c in range(14) if b.class_info(c)["n_graphs"]}
-    return best, bad, classes
+        in_b, out_b = b.algorithmic_bytes()
+    return best, bad, classes, in_b + out_b
+
+
+def secondary_roofline(alg_bytes, ms, n_graphs, kernels):
+    """the same roofline object as the headline's, for a secondary shape: algorithmic bytes of the batch (ald_batch_algorithmic_bytes:
+    packed input + packed path records) over the HIP-event time from the first launch to the last kernel's end"""
+    achieved = alg_bytes / (ms / 1e3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": kernels, "kernel_ms": ms, "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_graph": alg_bytes / max(1, n_graphs)}
+
+
+def secondary_cpu_baseline(pg, cores_hint, seconds=8.0, probe=256):
+    """the oracle ("port") on a bounded sample of a secondary shape: a probe of `probe` graphs sizes the sample to about `seconds` of
+    all-core work (graphs are taken with a stride over the whole batch, so the sample has the batch's size mix)"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import common
+    cores = max(1, cores_hint)
+    idx = np.linspace(0, pg.n - 1, num=min(pg.n, probe)).astype(np.int64)
+    _, _, sec_p, _ = common.oracle_run(pg.select(np.unique(idx)), threads=cores)
+    n = int(min(pg.n, max(probe, len(np.unique(idx)) * seconds / max(sec_p, 1e-3))))
+    idx = np.unique(np.linspace(0, pg.n - 1, num=n).astype(np.int64))
+    s = pg.select(idx)
+    _, _, sec, _ = common.oracle_run(s, threads=cores)
+    return {"value": s.n / sec, "unit": "bundles/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"{s.n} graphs taken with an even stride over the batch (same size mix), {cores} threads over independent graphs, {sec:.2f} s"}
 
 
 def sink_pipeline(A, pg, n, rounds=6):
@@ -559,7 +591,7 @@ def main() -> int:
         value = args.graphs * world * args.steps / el_value
         achieved = (in_b + out_b) / (k_ms / 1e3) / 1e9
         step_text = ("decomposition kernels (exon join of every path into its record + result index written by the kernel) + D2H of status / records (paths and transcripts) / index + decode into the host path table with coverage = log(1 + weight)"
-                     + (" + RCCL gather of the finished transcripts to rank 0" if dist_on else "") + "; kernel k+1 is launched before the results of batch k are downloaded, so copies and decode run under the next kernel")
+                     + (" + RCCL gather of the finished transcripts to rank 0 (device stream -> xGMI -> HBM of rank 0; rank 0's merge of the gathered streams into one transcript_set is NOT inside the step: it is host work at ~2.3 M bundles/s, profiles/r04/m_funnel_rehearsal_w8.txt)" if dist_on else "") + "; kernel k+1 is launched before the results of batch k are downloaded, so copies and decode run under the next kernel")
         line = {
             "metric": "bundles/sec", "value": value, "unit": "bundles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el_value / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -590,14 +622,22 @@ def main() -> int:
             # the other single-GPU shapes of BASELINE.json / SURVEY.md 8d, kernel time only (parity for them: tests/test_gpu_parity.py)
             sec = {}
             cfg3 = A.synth(seed=1003, n_graphs=10000, v_min=8, v_max=512, edges_per_vertex=4)
-            ms3, bad3, cls3 = kernel_only(A, dev, cfg3)
+            ms3, bad3, cls3, alg3 = kernel_only(A, dev, cfg3)
             sec["cfg3_mixed"] = {"workload": "BASELINE.json configs[2]: 10000 graphs, V ~ U{8..512}, E = 4V, seed 1003", "kernel_ms": ms3,
-                                 "bundles_per_s": 10000 / (ms3 / 1e3), "failed_graphs": bad3, "graphs_per_class": cls3}
+                                 "bundles_per_s": 10000 / (ms3 / 1e3), "failed_graphs": bad3, "graphs_per_class": cls3,
+                                 "roofline": secondary_roofline(alg3, ms3, 10000, "ald_decomp_kernel_c0..c12 (one kernel per size class, three streams)")}
+            flow = None
             if args.weights == "uniform":
                 flow = A.synth(seed=seed, n_graphs=args.graphs, v_min=args.vertices, v_max=args.vertices, fixed_edges=args.edges, weight_mode=2)
-                msf, badf, clsf = kernel_only(A, dev, flow)
+                msf, badf, clsf, algf = kernel_only(A, dev, flow)
                 sec["flow_weights"] = {"workload": f"{args.graphs} x {args.vertices}v/{args.edges}e, flow-conserving weights (SURVEY.md 8d's second distribution)",
-                                       "kernel_ms": msf, "bundles_per_s": args.graphs / (msf / 1e3), "failed_graphs": badf, "graphs_per_class": clsf}
+                                       "kernel_ms": msf, "bundles_per_s": args.graphs / (msf / 1e3), "failed_graphs": badf, "graphs_per_class": clsf,
+                                       "roofline": secondary_roofline(algf, msf, args.graphs, "ald_decomp_kernel_c1")}
+            if args.cpu_sample > 0:                          # the port on the host cores for the two shapes, bounded samples (about 8 s each)
+                cores_all = cpu_cores()
+                sec["cfg3_mixed"]["cpu_baseline"] = secondary_cpu_baseline(cfg3, cores_all)
+                if flow is not None:
+                    sec["flow_weights"]["cpu_baseline"] = secondary_cpu_baseline(flow, cores_all)
             if elapsed_h2d:
                 # row f1: the same host-arrays-in loop with every graph handed over RAW (ald_batch_add_packed_raw: extend_strands, boundary
                 # grouping, phase projection, hyper_set ctor and filter_nodes run in the wave that loads the graph)

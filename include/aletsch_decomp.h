@@ -342,6 +342,13 @@ int  ald_comm_unique_id(uint8_t id[128]);
 int  ald_comm_create(const uint8_t id[128], int32_t world, int32_t rank, int32_t device, ald_comm **out);
 int  ald_comm_gather_streams(ald_comm *c, const uint32_t *words, int64_t n_words, int32_t graph_offset,
                              const uint32_t **all_words /* rank 0 */, const int64_t **offsets /* [world + 1] */, const int32_t **graph_offsets /* [world] */);
+/* The same collective in two halves, with the receive buffers held twice.  _begin exchanges the sizes, ENQUEUES the payloads and, on rank
+ * 0, one copy to pinned host memory per received stream (an event behind each) and returns; _wait(upto) blocks until the streams of ranks
+ * 0..upto have landed (-1: all; on a rank other than 0: until its own send has left -- its source may be reused then) and hands out the
+ * pointers.  Rank 0 so merges rank r's stream (ald_tset_add_stream) while rank r + 1's is still on its way, and may begin gather k + 1
+ * before it has merged gather k: what a _wait handed out stays valid until the SECOND next _begin on this communicator. */
+int  ald_comm_gather_begin(ald_comm *c, const uint32_t *words, int64_t n_words, int32_t graph_offset);
+int  ald_comm_gather_wait(ald_comm *c, int32_t upto, const uint32_t **all_words /* rank 0 */, const int64_t **offsets /* [world + 1] */, const int32_t **graph_offsets /* [world] */);
 int  ald_comm_destroy(ald_comm *c);
 /* transcript_set::add(transcript_set&) (transcript_set.cc:156-175): every bucket of src zipped into dst; src is left empty */
 int  ald_tset_merge(ald_tset *dst, ald_tset *src);

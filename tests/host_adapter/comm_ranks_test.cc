@@ -38,7 +38,14 @@ int main(int argc, char **argv)
                 src = (const uint32_t*)dsrc;
             }
             const uint32_t *all = nullptr; const int64_t *offs = nullptr; const int32_t *goffs = nullptr;
-            const int e = ald_comm_gather_streams(c, src, (int64_t)mine.size(), 1000 * r + step, &all, &offs, &goffs);
+            // steps 0 / 2: the one-call form; step 1: the two halves (begin returns with the data still on its way, rank 0 waits stream by stream)
+            int e;
+            if(step != 1) e = ald_comm_gather_streams(c, src, (int64_t)mine.size(), 1000 * r + step, &all, &offs, &goffs);
+            else {
+                e = ald_comm_gather_begin(c, src, (int64_t)mine.size(), 1000 * r + step);
+                if(e == ALD_OK && r == 0) for(int q = 0; q < W && e == ALD_OK; q++) e = ald_comm_gather_wait(c, q, &all, &offs, &goffs);
+                else if(e == ALD_OK) e = ald_comm_gather_wait(c, -1, &all, &offs, &goffs);
+            }
             if(fail_rank >= 0) {
                 // the injected failure: the failing rank must get an error AND be out of group mode; the others must not hang
                 void *h = dlopen(getenv("ALD_RCCL_LIB"), RTLD_NOW | RTLD_NOLOAD);

@@ -236,7 +236,7 @@ def test_adapter_takes_graphs_as_assemble_receives_them():
 
 @pytest.mark.gpu
 def test_comm_gather_with_several_ranks_on_one_gpu():
-    """ald_comm_gather_streams with W = 2 and 3 ranks (the multi-rank offsets / receive sizing had never executed).  RCCL
+    """ald_comm_gather_streams with W = 2, 3 and 8 ranks (the multi-rank offsets / receive sizing had never executed).  RCCL
     refuses two ranks on one device, so the ranks are threads of one process and librccl.so is replaced, through ALD_RCCL_LIB, by
     tests/host_adapter/mock_rccl.cc (device-to-device copies behind the nine nccl* entry points the library binds); then a refused
     ncclSend: the failing rank must report the error with its thread out of group mode, and nobody may hang."""
@@ -247,7 +247,7 @@ def test_comm_gather_with_several_ranks_on_one_gpu():
                     os.path.join(ROOT, "tests", "host_adapter", "comm_ranks_test.cc"), "-o", exe, "-L" + lib, "-laletsch_decomp", "-Wl,-rpath," + lib,
                     "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-pthread"], check=True)
     env = dict(os.environ, ALD_RCCL_LIB=mock)
-    for world in ("2", "3"):
+    for world in ("2", "3", "8"):                               # 8: BASELINE.json configs[3]'s world size (one step goes through ald_comm_gather_begin / _wait)
         r = subprocess.run([exe, world], capture_output=True, text=True, timeout=90, env=env)
         assert r.returncode == 0 and "COMM_RANKS_OK world=" + world in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
     for fail in ("1", "0"):
