@@ -16,6 +16,7 @@ while time.time() < t_end:
               strand_mode=int(rng.choice([0, 0, 1])), layout_mode=int(rng.choice([0, 1])))
     work = (vmin + vmax) / 2 * kw["edges_per_vertex"]
     kw["n_graphs"] = int(max(50, min(20000, 2.5e6 / work)))
+    if os.environ.get("FUZZ_EMU"): kw["n_graphs"] = max(20, kw["n_graphs"] // 25)
     p = A.default_params()
     if rng.random() < 0.3: p.max_decompose_error_ratio[7] = float(rng.choice([1.2, 1.5, 3.0]))
     if rng.random() < 0.3: p.max_decompose_error_ratio[0] = float(rng.choice([0.1, 0.2, 0.5]))
@@ -25,7 +26,7 @@ while time.time() < t_end:
     if rng.random() < 0.3:
         cnt = pg.sample_counts() + rng.integers(0, 3, pg.edge_target.size).astype(np.int32); pg.edge_count = cnt.astype(np.int32)
     want = common.oracle_run(pg, params=p, threads=thr)[0]
-    got = A.decompose(pg, device=0, params=p)
+    got = common.emu_run(pg, params=p)[0] if os.environ.get("FUZZ_EMU") else A.decompose(pg, device=0, params=p)      # FUZZ_EMU=1: the single-lane emulation on the CPU (ALD_EMU_LIB: a build with -DALD_EMU_CHECK verifies its caches / rows as it goes)
     bad = common.compare_results(want, got, pg.n, conf_tol=1e-9)
     ntot += pg.n; nbad += len(bad)
     print(k, "graphs", pg.n, {a: b for a, b in kw.items() if a != "n_graphs"}, "params", [round(x, 2) for x in p.max_decompose_error_ratio], p.min_transcript_coverage, p.max_num_exons,
