@@ -70,7 +70,10 @@ enum { EID_LIMIT = 0x7FFFFFF0 };
 typedef uint16_t EID;
 enum { EID_LIMIT = 0xFFF0 };
 #endif
-typedef ColdLayoutT<MAXV, MAXE, NW, 0> CL;         // (no row pool in this form: decomp_device_rows.h is the build that has one)
+typedef ColdLayoutT<MAXV, MAXE, NW, 0> CL;
+#ifndef ALD_KEEP
+  #define ALD_KEEP (ALD_CLASS_ID >= 2 ? 1 : 0)   /* the per-vertex evaluations of the sweeps kept between sweeps (sweep_smallest): not for the one- and two-chunk classes */
+#endif         // (no row pool in this form: decomp_device_rows.h is the build that has one)
 enum { LP = 16, ARENA_I = 96, ARENA_D = 48, SCR_I = 4 * LP + ARENA_I, SCR_D = 2 * LP + ARENA_D };   // LDS scratch geometry (ints / doubles)
 
 // ---------------------------------------------------------------------------------------------
@@ -100,7 +103,14 @@ struct HotCtx {
     ALD_GLOBAL const KernelArgs *args;
     double   ro_ratio;                          // router result
     int32_t  ro_type, ro_degree, ro_npairs, tmp0;
-    int32_t  ro_epoch;                          // bumps whenever the graph changes between router classifications (see sweep_unsplittable)
+    // Classes 2 and up (ALD_KEEP) keep the smallest-edge evaluation of every vertex (ratio, edge) in the wave's slab BETWEEN the sweeps;
+    // what changed since it was taken is recorded here by the routines that change it: a bit per vertex whose lists / weights / membership
+    // changed -- or whose evaluation looks at a neighbour's degree that crossed the 1 | 2 line (the guards of resolve_smallest_edges) --,
+    // and "everything" for the phasing flags and for new vertices.  (Classes 0 / 1 evaluate their one or two chunks at every sweep.)
+    int32_t  ev_all;
+#if ALD_KEEP
+    uint32_t ev_dirty[(MAXV + 31) / 32];
+#endif
     int32_t  g, V0, gstrand;
     int32_t  nv, next_id, slot_hw, free_head, free_cnt, status, any_strand, hs_dirty, n_paths, n_iters, n_trace;
     uint32_t sp_used, hl_used; int32_t hl_n;
@@ -244,10 +254,41 @@ ALD_INL uint32_t tkey(uint32_t p) { return (int)p == HC.sinkp ? 0xFFFFu : p; }  
 ALD_INL int vlog(int p) { return p < HC.V0 - 1 ? p : (p == HC.sinkp ? HC.nv - 1 : p - 1); }   // physical -> reference index (traces)
 ALD_INL uint64_t lkw(int e) { return uni(*(const uint64_t*)&H.ed[e].lk); }            // es | et << 16 | inx << 32 | onx << 48
 ALD_INL int lk_next(uint32_t f) { return slot_or_neg((IDX)f); }
+// ---- what the kept smallest-edge evaluations must forget (HotCtx::ev_dirty / ev_all).  Classes 0 / 1 keep none: nothing here costs them anything.
+ALD_INL void ev_mark(int v)                     // v's lists, the weights in them or its membership changed
+{
+#if ALD_KEEP
+  #ifdef ALD_EMU
+    HC.ev_dirty[v >> 5] |= 1u << (v & 31);
+  #else
+    __hip_atomic_fetch_or(&HC.ev_dirty[v >> 5], 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);     // (lanes of the star mark different vertices of one word)
+  #endif
+#else
+    (void)v;
+#endif
+}
+ALD_INL void ev_mark_all() { if(ALD_KEEP) HC.ev_all = 1; }
+// v's in- (out = false) or out-degree went from `before` to `after`.  v itself is marked; and when the degree crossed the 1 | 2 line, every
+// vertex at the far end of an edge of that list: its evaluation tests exactly this degree (out_deg(s) > 1 for an in-edge s -> j, in_deg(t)
+// > 1 for an out-edge j -> t: scallop.cc:858-896).  out(source) / in(sink) are not linked before the final phase: "everything" then.
+// Per-lane code (kill_edge_wave calls it from two lanes at once).
+ALD_INL void ev_degree(int v, int before, int after, bool out)
+{
+#if ALD_KEEP
+    ev_mark(v);
+    if((before <= 1) == (after <= 1)) return;
+    if(!HC.special_linked && (out ? v == 0 : v == HC.sinkp)) { HC.ev_all = 1; return; }
+    int guard = MAXE;
+    for(int e = out ? slot_or_neg(H.vx[v].out_head) : slot_or_neg(H.vx[v].in_head); e >= 0 && guard-- > 0; e = out ? slot_or_neg(H.ed[e].lk.onx) : slot_or_neg(H.ed[e].lk.inx))
+        ev_mark(out ? (int)H.ed[e].lk.et : (int)H.ed[e].lk.es);
+#else
+    (void)v; (void)before; (void)after; (void)out;
+#endif
+}
 ALD_INL void link_in(int v, int e)
 {
     v = uni(v); e = uni(e);
-    if(v == uni(HC.sinkp) && !uni(HC.special_linked)) { H.vx[v].in_deg++; return; }
+    if(v == uni(HC.sinkp) && !uni(HC.special_linked)) { const int dg = uni((int)H.vx[v].in_deg); H.vx[v].in_deg = (IDX)(dg + 1); ev_degree(v, dg, dg + 1, false); return; }
     const uint32_t ks = uni(H.ed[e].lk.es), kid = uni(H.eid[e]);
     IDX *pp = &H.vx[v].in_head; IDX cur = *pp;
     for(int guard = MAXE; uni(cur != NIL) && guard > 0; guard--) {      // (the guard only matters on a corrupted list: never spin)
@@ -257,12 +298,12 @@ ALD_INL void link_in(int v, int e)
         pp = &H.ed[cur].lk.inx; cur = (IDX)((w >> 32) & 0xFFFF);
     }
     H.ed[e].lk.inx = cur; *pp = (IDX)e;
-    H.vx[v].in_deg++;
+    { const int dg = uni((int)H.vx[v].in_deg); H.vx[v].in_deg = (IDX)(dg + 1); ev_degree(v, dg, dg + 1, false); }
 }
 ALD_INL void link_out(int v, int e)
 {
     v = uni(v); e = uni(e);
-    if(v == 0 && !uni(HC.special_linked)) { H.vx[v].out_deg++; return; }
+    if(v == 0 && !uni(HC.special_linked)) { const int dg = uni((int)H.vx[v].out_deg); H.vx[v].out_deg = (IDX)(dg + 1); ev_degree(v, dg, dg + 1, true); return; }
     const uint32_t sk = (uint32_t)uni(HC.sinkp);
     uint32_t kt = uni(H.ed[e].lk.et); const uint32_t kid = uni(H.eid[e]);
     if(kt == sk) kt = 0xFFFFu;
@@ -274,13 +315,13 @@ ALD_INL void link_out(int v, int e)
         pp = &H.ed[cur].lk.onx; cur = (IDX)(w >> 48);
     }
     H.ed[e].lk.onx = cur; *pp = (IDX)e;
-    H.vx[v].out_deg++;
+    { const int dg = uni((int)H.vx[v].out_deg); H.vx[v].out_deg = (IDX)(dg + 1); ev_degree(v, dg, dg + 1, true); }
 }
 // link_out with a starting point: `hint` is an edge of v's out-list known to sort before e (its target key is smaller)
 ALD_INL void link_out_after(int v, int e, int hint)
 {
     v = uni(v); e = uni(e); hint = uni(hint);
-    if(v == 0 && !uni(HC.special_linked)) { H.vx[v].out_deg++; return; }
+    if(v == 0 && !uni(HC.special_linked)) { const int dg = uni((int)H.vx[v].out_deg); H.vx[v].out_deg = (IDX)(dg + 1); ev_degree(v, dg, dg + 1, true); return; }
     const uint32_t sk = (uint32_t)uni(HC.sinkp);
     uint32_t kt = uni(H.ed[e].lk.et); const uint32_t kid = uni(H.eid[e]);
     if(kt == sk) kt = 0xFFFFu;
@@ -292,34 +333,35 @@ ALD_INL void link_out_after(int v, int e, int hint)
         pp = &H.ed[cur].lk.onx; cur = (IDX)(w >> 48);
     }
     H.ed[e].lk.onx = cur; *pp = (IDX)e;
-    H.vx[v].out_deg++;
+    { const int dg = uni((int)H.vx[v].out_deg); H.vx[v].out_deg = (IDX)(dg + 1); ev_degree(v, dg, dg + 1, true); }
 }
 // The walks below keep the cursor in a vector register (an LDS address has to be in one anyway) and follow the ADDRESS of the link
 // that points at the current edge; only the loop condition is made wave-uniform.
 ALD_INL void unlink_in(int v, int e)
 {
     v = uni(v); e = uni(e);
-    if(v == uni(HC.sinkp) && !uni(HC.special_linked)) { H.vx[v].in_deg--; return; }
+    if(v == uni(HC.sinkp) && !uni(HC.special_linked)) { const int dg = uni((int)H.vx[v].in_deg); H.vx[v].in_deg = (IDX)(dg - 1); ev_degree(v, dg, dg - 1, false); return; }
     IDX *pp = &H.vx[v].in_head; IDX cur = *pp; int guard = MAXE;
     while(uni((int)cur != e && cur != NIL) && guard-- > 0) { pp = &H.ed[cur].lk.inx; cur = *pp; }
     if(ALD_UNLIKELY(uni((int)cur != e))) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }       // cannot happen on a consistent state; never walk off a list
     *pp = H.ed[e].lk.inx;
-    { int dg = (int)uni(H.vx[v].in_deg) - 1; H.vx[v].in_deg = (IDX)dg; if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; } }
+    { int dg = (int)uni(H.vx[v].in_deg) - 1; H.vx[v].in_deg = (IDX)dg; ev_degree(v, dg + 1, dg, false); if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; } }
 }
 ALD_INL void unlink_out(int v, int e)
 {
     v = uni(v); e = uni(e);
-    if(v == 0 && !uni(HC.special_linked)) { H.vx[v].out_deg--; return; }
+    if(v == 0 && !uni(HC.special_linked)) { const int dg = uni((int)H.vx[v].out_deg); H.vx[v].out_deg = (IDX)(dg - 1); ev_degree(v, dg, dg - 1, true); return; }
     IDX *pp = &H.vx[v].out_head; IDX cur = *pp; int guard = MAXE;
     while(uni((int)cur != e && cur != NIL) && guard-- > 0) { pp = &H.ed[cur].lk.onx; cur = *pp; }
     if(ALD_UNLIKELY(uni((int)cur != e))) { fail(ALD_ST_INVARIANT + ALD_INV_OTHER); return; }
     *pp = H.ed[e].lk.onx;
-    { int dg = (int)uni(H.vx[v].out_deg) - 1; H.vx[v].out_deg = (IDX)dg; if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; } }
+    { int dg = (int)uni(H.vx[v].out_deg) - 1; H.vx[v].out_deg = (IDX)dg; ev_degree(v, dg + 1, dg, true); if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; } }
 }
 // e stays in v's in-list but its key becomes (ks, newest id): one walk finds its predecessor and its new place
 ALD_INL void relink_in(int v, int e, uint32_t ks)
 {
     v = uni(v); e = uni(e);
+    ev_mark(v);
     if(v == uni(HC.sinkp) && !uni(HC.special_linked)) return;
     int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
     int guard = MAXE;
@@ -339,6 +381,7 @@ ALD_INL void relink_in(int v, int e, uint32_t ks)
 ALD_INL void relink_out(int v, int e, uint32_t kt)         // kt already mapped by tkey()
 {
     v = uni(v); e = uni(e);
+    ev_mark(v);
     if(v == 0 && !uni(HC.special_linked)) return;
     const uint32_t sk = (uint32_t)uni(HC.sinkp);
     int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
@@ -360,6 +403,7 @@ ALD_INL void relink_out(int v, int e, uint32_t kt)         // kt already mapped 
 // nothing here may be routed through the scalar unit.
 ALD_INL void relink_in_lane(int v, int e, uint32_t ks)
 {
+    ev_mark(v);
     if(v == HC.sinkp && !HC.special_linked) return;
     int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
     int guard = MAXE;
@@ -378,6 +422,7 @@ ALD_INL void relink_in_lane(int v, int e, uint32_t ks)
 }
 ALD_INL void relink_out_lane(int v, int e, uint32_t kt)    // kt already mapped by tkey()
 {
+    ev_mark(v);
     if(v == 0 && !HC.special_linked) return;
     const uint32_t sk = (uint32_t)HC.sinkp;
     int last = -1, pe = -1, ip = -1; bool seen = false, placed = false;
@@ -399,6 +444,7 @@ ALD_INL void relink_out_lane(int v, int e, uint32_t kt)    // kt already mapped 
 // spilled register pair and fetched it back from scratch memory -- a round trip to L2 -- at every use)
 ALD_INL void clear_vertex(int x)
 {
+    ev_mark(x);
 #if defined(ALD_EMU)
     H.vx[x].in_head = NIL; H.vx[x].out_head = NIL; H.vx[x].in_deg = 0; H.vx[x].out_deg = 0; H.nz[x] = 0;
 #else
@@ -455,6 +501,7 @@ ALD_INL void kill_edge_wave(int e)
             *pp = nxe;
         }
         const int dg = (int)*deg - 1; *deg = (IDX)dg;
+        ev_degree(v, dg + 1, dg, out);           // (the sweep that called evaluates the two vertices again itself -- unless it goes back to the cascade first)
         if(!counted && dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; }
     }
     wsync();
@@ -542,7 +589,7 @@ ALD_FN double common_abd(int e1, int e2)
 ALD_FN void hs_refresh_flags()                  // per-slot OCC / LEXT / REXT: hyper_set.cc:949-983 left/right_extend
 {
     if(!HC.hs_dirty) return;
-    HC.maybe_triv = 1;
+    HC.maybe_triv = 1; ev_mark_all();
     COLD;
     for(int e = 0; e < HC.slot_hw; e++) H.hflag[e] = 0;
     int nl = HC.hl_n;
@@ -955,7 +1002,7 @@ template<bool A, bool SMALL> ALD_INL void decompose_trivial_star(int x)
                 *pp = (IDX)e; pp = A ? &H.ed[e].lk.onx : &H.ed[e].lk.inx;
             }
         }
-        if(A) H.vx[far].out_deg = (IDX)((int)uni(H.vx[far].out_deg) + n); else H.vx[far].in_deg = (IDX)((int)uni(H.vx[far].in_deg) + n);
+        { const int dg = A ? (int)uni(H.vx[far].out_deg) : (int)uni(H.vx[far].in_deg); if(A) H.vx[far].out_deg = (IDX)(dg + n); else H.vx[far].in_deg = (IDX)(dg + n); ev_degree(far, dg, dg + n, A); }
     }
     if(n >= 2) hs_remove(c);
     if(ALD_UNLIKELY(!consumed)) { fail(ALD_ST_INVARIANT + ALD_INV_DEGREE); return; }      // c kept a remainder: the reference asserts on the degree of x
@@ -1237,7 +1284,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
 #endif
     // ---- phase 7 (lane 0): what is left and inherently ordered -- the support pool, the phasing lists, the counters
     if(lane == 0) {
-        if(A) H.vx[far].out_deg = (IDX)((int)uni(H.vx[far].out_deg) + n); else H.vx[far].in_deg = (IDX)((int)uni(H.vx[far].in_deg) + n);
+        { const int dg = A ? (int)uni(H.vx[far].out_deg) : (int)uni(H.vx[far].in_deg); if(A) H.vx[far].out_deg = (IDX)(dg + n); else H.vx[far].in_deg = (IDX)(dg + n); ev_degree(far, dg, dg + n, A); }
         if(any_dup || any_multi || uni(HC.hl_n) != 0) for(int q = 0; q < n; q++) {
             const int f = fe[ord[q]];
             if(any_dup) { if(A) relink_in(oth[q], f, (uint32_t)far); else relink_out(oth[q], f, tkey((uint32_t)far)); }
@@ -1451,7 +1498,7 @@ template<bool A> ALD_INL void star_reg(int x)
     wsync();
     // ---- lane 0: what is left and inherently ordered -- the support pool, the phasing lists, the counters
     if(lane == 0) {
-        if(A) H.vx[far].out_deg = (IDX)((int)uni(H.vx[far].out_deg) + n); else H.vx[far].in_deg = (IDX)((int)uni(H.vx[far].in_deg) + n);
+        { const int dg = A ? (int)uni(H.vx[far].out_deg) : (int)uni(H.vx[far].in_deg); if(A) H.vx[far].out_deg = (IDX)(dg + n); else H.vx[far].in_deg = (IDX)(dg + n); ev_degree(far, dg, dg + n, A); }
         if(any_dup || any_multi || uni(HC.hl_n) != 0) for(int q = 0; q < n; q++) {
             const int fq = fem[q];
             if(any_dup) { if(A) relink_in(othm[q], fq, (uint32_t)far); else relink_out(othm[q], fq, tkey((uint32_t)far)); }
@@ -1694,7 +1741,7 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
             if(!taken) { const IDX nx = c_next < 0 ? NIL : (IDX)c_next; if(pc < 0) { if(A) H.vx[far].out_head = nx; else H.vx[far].in_head = nx; } else { if(A) H.ed[pc].lk.onx = nx; else H.ed[pc].lk.inx = nx; } }
             if(dg <= 1) { HC.maybe_triv = 1; if(dg == 0) HC.maybe_broken = 1; }     // as unlink_in / unlink_out
         }
-        *deg = (IDX)(dg + N);
+        *deg = (IDX)(dg + N); ev_degree(far, dg + 1, dg + N, A);
         C.vx[x].vw = vwt;
         if(dupf || any_multi || uni(HC.hl_n) != 0) {
             ALD_UNROLL for(int q = 0; q < N; q++) {
@@ -1794,7 +1841,7 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
     int newedges = 0;
     for(int i = 0; i < n; i++) { int u1 = PLOC(a[i]), u2 = PLOC(b[i]); if(mdeg[u1] == 1 && mdeg[u2] == 1) evx[u1] = nn++; else if(mdeg[u1] >= 2 && mdeg[u2] >= 2) newedges++; }
     if(ALD_UNLIKELY(nn > MAXV || free_slots() < newedges)) { fail(ALD_ST_CAPACITY); return; }
-    HC.maybe_broken = 1; HC.maybe_triv = 1;
+    HC.maybe_broken = 1; HC.maybe_triv = 1; ev_mark_all();
     for(int i = m; i < nn; i++) { H.vx[i].in_head = NIL; H.vx[i].out_head = NIL; H.vx[i].in_deg = 0; H.vx[i].out_deg = 0; H.nz[i] = 1; C.vx[i].vw = 0; C.vx[i].lpos = 0; C.vx[i].rpos = 0; C.vx[i].vtype = -1; C.vx[i].v2v = -1; }
     HC.nv = nn;
     for(int i = 0; i < nin; i++) {               // ev1: detach in-edges onto their new vertex
@@ -1991,7 +2038,7 @@ ALD_INL bool resolve_broken_vertex()
             int guard = MAXE;
             while(first_in(x) >= 0 && guard-- > 0) { int e = first_in(x); kill_edge(e); hs_remove(e); }
             while(first_out(x) >= 0 && guard-- > 0) { int e = first_out(x); kill_edge(e); hs_remove(e); }
-            H.nz[x] = 0;
+            H.nz[x] = 0; ev_mark(x);
         }
     }
     wsync();
@@ -2147,6 +2194,22 @@ ALD_INL bool back_to_cascade()
     const int a = HC.status, b = HC.maybe_broken, c = HC.maybe_triv, d = HC.hs_dirty;
     return uni(a | b | c | d) != 0;
 }
+// Classes 2 and up (ALD_KEEP, round 4): the per-vertex result (ratio, edge) of compute_smallest_edge + guards STAYS in the wave's slab between
+// the sweeps.  A sweep that comes back after a trivial decomposition or an unsplittable vertex first evaluates the vertices the rules in
+// between have marked (HotCtx::ev_dirty) -- gathered into DENSE lanes, whatever chunk they belong to: lanes run in lock step, so a chunk
+// of 64 costs the same for one marked vertex as for 64 -- writes them to the slab, then loads every chunk with one coalesced read.  Up to
+// round 3 every sweep evaluated every vertex: 15 % of a 500-vertex graph's time (profiles/r04/n_phase_big.txt).
+enum { EV_NC = MAXV / ALD_WAVE };                 // chunks of the class: registers for the small classes, private memory beyond
+// the r-th set bit of m (r < popcount(m)): six halving steps on the popcount of the low part
+ALD_INL int nth_set_bit(uint64_t m, int r)
+{
+    int pos = 0;
+    ALD_UNROLL for(int w = 32; w >= 1; w >>= 1) {
+        const uint64_t low = m & ((1ull << w) - 1ull); const int c = (int)__builtin_popcountll(low);
+        if(r >= c) { r -= c; m >>= w; pos += w; } else m = low;
+    }
+    return pos;
+}
 ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr);
 ALD_INL bool sweep_smallest(double max_ratio)
 {
@@ -2160,12 +2223,58 @@ ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr)
     max_ratio = uni(max_ratio);
     const int lane = lane_id();
     const int vend = uni(HC.nv);
-    constexpr int NC = MAXV / ALD_WAVE;           // per-lane results for every chunk of the class (registers for the small classes, private memory beyond)
+    constexpr int NC = EV_NC;
     if(vend > NC * ALD_WAVE) { if(lane == 0) fail(ALD_ST_CAPACITY); wsync(); return true; }     // cannot happen: nv <= MAXV
     PROF_DECL;
     if(lane == 0 && uni(HC.hs_dirty)) hs_refresh_flags();
     wsync();
-    double cr[NC]; int ce[NC];
+    double cr[NC]; int ce[NC];                    // this lane's vertex of every chunk: (ratio, edge)
+    const int nch0 = (vend + ALD_WAVE - 1) / ALD_WAVE;
+#if ALD_KEEP
+    ALD_GLOBAL double *mr = (ALD_GLOBAL double*)(HC.cold + CL::o_evr); ALD_GLOBAL int32_t *me = (ALD_GLOBAL int32_t*)(HC.cold + CL::o_eve);
+    const bool stale_all = uni(HC.ev_all) != 0;
+  #if defined(ALD_EMU) && defined(ALD_EMU_CHECK)
+    { static long n_entry = 0, n_all = 0, n_marked = 0, n_live = 0; static struct P { long *a, *b, *c, *d; ~P() { if(*a) fprintf(stderr, "[emu-ev] class %d: %ld sweep entries, %.1f %% with everything stale, else %.1f marked of %.1f vertices\n", ALD_CLASS_ID, *a, 100.0 * *b / *a, (double)*c / ((*a - *b) ? (*a - *b) : 1), (double)*d / *a); } } pr{&n_entry, &n_all, &n_marked, &n_live};
+      n_entry++; n_live += vend; if(stale_all) n_all++; else for(int i = 1; i < vend; i++) if((HC.ev_dirty[i >> 5] >> (i & 31)) & 1u) n_marked++; }
+    // test build of the emulation: a kept evaluation that is neither marked nor covered by "everything" must equal a fresh one
+    if(!stale_all) for(int i = 1; i < vend; i++) {
+        if((HC.ev_dirty[i >> 5] >> (i & 31)) & 1u) continue;
+        double r = 0; const int e = eval_smallest(i, r); const double kr_ = mr[i]; const int ke_ = me[i];
+        if(e != ke_ || (e >= 0 && memcmp(&r, &kr_, 8) != 0)) { fprintf(stderr, "[check] graph %d: stale smallest-edge evaluation of vertex %d: kept (%d, %.17g), fresh (%d, %.17g)\n", HC.g, i, ke_, kr_, e, r); abort(); }
+    }
+  #endif
+    if(!stale_all) {
+        // the marked vertices, dense: lane l of a pass takes the (base + l)-th set bit of the mask -- found by walking the chunks' popcounts
+        // (wave-uniform words) and a bit select --, evaluates that vertex and leaves the result in the slab
+  #ifdef ALD_EMU
+        for(int i = 1; i < vend; i++) if((HC.ev_dirty[i >> 5] >> (i & 31)) & 1u) { double r = 0; const int e = eval_smallest(i, r); mr[i] = r; me[i] = e; }
+  #else
+        int total = 0;
+        for(int w = 0; w < (vend + 31) / 32; w++) total += (int)__builtin_popcount(uni(HC.ev_dirty[w]));
+        for(int base = 0; base < total; base += ALD_WAVE) {
+            const int k = base + lane; int run = 0, vtx = -1;
+            for(int w = 0; w < (vend + 31) / 32; w++) {
+                const uint32_t m = uni(HC.ev_dirty[w]); const int pc = (int)__builtin_popcount(m);
+                if(k >= run && k < run + pc) vtx = 32 * w + nth_set_bit((uint64_t)m, k - run);
+                run += pc;
+            }
+            if(vtx >= 1 && vtx < vend) { double r = 0; const int e = eval_smallest(vtx, r); mr[vtx] = r; me[vtx] = e; }
+        }
+  #endif
+        wsync();
+        if(NC <= 16) { ALD_UNROLL for(int c = 0; c < (NC <= 16 ? NC : 1); c++) { const bool in = c < nch0; cr[c] = in ? mr[c * ALD_WAVE + lane] : 0.0; ce[c] = in ? me[c * ALD_WAVE + lane] : -1; } }
+        else for(int c = 0; c < nch0; c++) { cr[c] = mr[c * ALD_WAVE + lane]; ce[c] = me[c * ALD_WAVE + lane]; }
+    }
+    else if(NC <= 16) { ALD_UNROLL for(int c = 0; c < (NC <= 16 ? NC : 1); c++) { cr[c] = 0; ce[c] = -1; } }
+    auto keep = [&]() {                           // the evaluations stay behind for the next sweep
+        if(NC <= 16) { ALD_UNROLL for(int c = 0; c < (NC <= 16 ? NC : 1); c++) if(c < nch0) { mr[c * ALD_WAVE + lane] = cr[c]; me[c * ALD_WAVE + lane] = ce[c]; } }
+        else for(int c = 0; c < nch0; c++) { mr[c * ALD_WAVE + lane] = cr[c]; me[c * ALD_WAVE + lane] = ce[c]; }
+    };
+#else
+    const bool stale_all = true;
+    if(NC <= 16) { ALD_UNROLL for(int c = 0; c < (NC <= 16 ? NC : 1); c++) { cr[c] = 0; ce[c] = -1; } }
+    auto keep = [&]() {};
+#endif
     // Classes of up to 16 chunks keep the arrays in registers: every loop over the chunks is fully unrolled (constant indices) and the few
     // accesses with a run-time chunk number go through a select chain; with a run-time index they would live in scratch memory and
     // every sweep would wait for it chunk by chunk.  Larger classes use private memory.
@@ -2178,10 +2287,16 @@ ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr)
         if(!REG) { if(mine) { cr[c] = r; ce[c] = e; } }
         else { ALD_UNROLL for(int k = 0; k < NC; k++) if(k == c && mine) { cr[k] = r; ce[k] = e; } }
     };
-    ALD_UNROLL for(int c = 0; c < NC; c++) { cr[c] = 0; ce[c] = -1; }
-    { const int nch = (vend + ALD_WAVE - 1) / ALD_WAVE; for(int c = 0; c < nch; c++) eval_chunk(c, true, -1, -1); }
-    PROF_ADD(PF_T_MERGE_KILL);                   // (profiling build: the evaluation of every vertex at the sweep's entry)
+    if(stale_all) { for(int c = 0; c < nch0; c++) eval_chunk(c, true, -1, -1); }
+#if ALD_KEEP
+    wsync();
+    if(lane == 0) HC.ev_all = 0;
+    for(int k = lane; k < (vend + 31) / 32; k += ALD_WAVE) HC.ev_dirty[k] = 0;
+    wsync();
+#endif
+    PROF_ADD(PF_T_MERGE_KILL);                   // (profiling build: bringing the kept evaluations up to date at the sweep's entry)
     const bool may_chain = !(uni(HC.p_ratio[7]) > 1.0) && !uni(HC.any_strand);
+    auto sweeps = [&]() -> bool {
     bool any = false;
     int guard = MAXE + 8;
     while(guard-- > 0) {                          // one sweep of the reference per iteration
@@ -2227,6 +2342,9 @@ ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr)
             // removed); if one of them stops holding, or the phasing flags moved, every lane evaluates again
             const bool all = uni(HC.hs_dirty) != 0 || (int)uni(H.vx[ds].out_deg) <= 1 || (int)uni(H.vx[dt].in_deg) <= 1;
             if(uni(HC.hs_dirty)) { if(lane == 0) hs_refresh_flags(); wsync(); }
+#if ALD_KEEP
+            if(all) { wsync(); if(lane == 0) HC.ev_all = 0; for(int k = lane; k < (vend + 31) / 32; k += ALD_WAVE) HC.ev_dirty[k] = 0; wsync(); }      // every vertex is evaluated again right here
+#endif
             if(NC <= 2) { for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (all || i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } } }
             else if(all) { const int nch = (vend + ALD_WAVE - 1) / ALD_WAVE; for(int c = 0; c < nch; c++) eval_chunk(c, true, -1, -1); }
             else {                                                          // many chunks: go straight to the (one or two) chunks of ds and dt
@@ -2269,6 +2387,10 @@ ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr)
         }
     }
     return true;
+    };
+    const bool rv = sweeps();
+    keep();
+    return rv;
 }
 
 // ---------------------------------------------------------------- router (scallop/router.cc), scalar on lane 0
@@ -3300,7 +3422,7 @@ ALD_FN bool load_graph()
     int64_t ov = A->in.off_v[g], ovo = ov + g, oe = A->in.off_e[g], oeo = oe + g, os = A->in.off_s[g], op = A->in.off_p[g], opo = op + g, opv = A->in.off_pv[g];
     if(lane == 0) {
         HC.V0 = V; HC.gstrand = (int)(unsigned char)A->in.graph_strand[g];
-        HC.sinkp = V - 1; HC.special_linked = 0; HC.maybe_broken = 1; HC.maybe_triv = 1; HC.ro_epoch = 1;
+        HC.sinkp = V - 1; HC.special_linked = 0; HC.maybe_broken = 1; HC.maybe_triv = 1; ev_mark_all();
         HC.nv = V; HC.next_id = E; HC.slot_hw = E; HC.free_head = -1; HC.free_cnt = 0; HC.status = 0; HC.any_strand = 0; HC.hs_dirty = 1;
         HC.n_paths = 0; HC.n_iters = 0; HC.n_trace = 0; HC.sp_used = 0; HC.hl_used = 0; HC.hl_n = 0;
     }
