@@ -21,6 +21,9 @@ ALD_FOR_EACH_CLASS(ALD_DECL)
 #undef ALD_DECL
 }
 
+/* how many graphs of LDS class 6 (q = 0) / 5 (q = 1) go to free slots of the slab twins: all the free slots for class 6, none of class 5
+   (profiles/r04/s_cfg3_twin_spill_sweep.txt: 96.5 -> 94 ms for cfg3; moving class 5 as well, or only the part of class 6 beyond one round, loses) */
+#define ALD_TWIN_SPILL_DEFAULT(q, sz, cap) ((q) == 0 ? (int64_t)1 << 40 : (int64_t)0)
 namespace {
 
 // A batch owns four HIP streams and a pipelined caller keeps several batches in flight; the ROCm runtime maps all streams of a process
@@ -393,6 +396,33 @@ int ald_batch_upload(ald_batch *b)
                 if(tw < 0 || work[c].empty()) continue;
                 for(int32_t g : work[c]) b->cls0[g] = tw;
                 work[tw].swap(work[c]);
+            }
+        }
+        // Round 4: the slab twins keep their sweep records between sweeps and run a 385..512-vertex graph in 67 ms where the LDS form of the
+        // band takes 86; when they run anyway, their kernel has workgroup slots to spare (12 per CU, no LDS) for as long as its longest graph
+        // takes, while the LDS classes beside them queue for LDS (profiles/r04/h_cfg3_timeline.txt: the LDS chain ends 20 ms after the
+        // twins).  So the smallest graphs of classes 6 and 5 -- the two that hold the most LDS for the longest -- go to twin 11 (its
+        // capacities hold any graph of theirs) while free twin slots last.  ALD_TWIN_SPILL="n6,n5" fixes the two counts (0,0: off).
+        if(!work[11].empty() || !work[12].empty()) {
+            int64_t free_tw = (int64_t)b->n_cus * std::max(1, occupancy_for(b, 11)) - (int64_t)work[11].size() - (int64_t)work[12].size();
+            long want[2] = {-1, -1};
+            if(const char *ev = getenv("ALD_TWIN_SPILL")) sscanf(ev, "%ld,%ld", &want[0], &want[1]);
+            const ClassInfo k11 = class_info(11);
+            for(int q = 0; q < 2 && free_tw > 0; q++) {
+                const int c = 6 - q;
+                if(work[c].empty()) continue;
+                const int64_t cap = (int64_t)b->n_cus * std::max(1, occupancy_for(b, c)), sz = (int64_t)work[c].size();
+                int64_t k = want[q] >= 0 ? want[q] : ALD_TWIN_SPILL_DEFAULT(q, sz, cap);
+                k = std::min(k, std::min(free_tw, sz));
+                if(k <= 0) continue;
+                std::stable_sort(work[c].begin(), work[c].end(), [&](int32_t x, int32_t y) { return b->hb.g_ne[x] > b->hb.g_ne[y]; });
+                int64_t moved = 0;
+                while(moved < k && !work[c].empty()) {
+                    const int32_t g = work[c].back();
+                    if(!(b->hb.g_nv[g] <= k11.nw * 64 && 2 * b->hb.g_nv[g] <= k11.maxv && b->hb.g_ne[g] + k11.maxe / 10 <= k11.maxe)) break;
+                    work[c].pop_back(); work[11].push_back(g); b->cls0[g] = 11; moved++;
+                }
+                free_tw -= moved;
             }
         }
         for(int c = 0; c < ALD_NUM_CLASSES; c++)

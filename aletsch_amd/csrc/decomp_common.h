@@ -269,7 +269,9 @@ struct ColdLayoutT {
     static constexpr uint64_t o_adjtmp = al(o_po + 8ull * PO_CAP);        // compaction of the row pool: the rows in their new places (ADJ x u16)
     static constexpr uint64_t o_evr = al(o_adjtmp + 2ull * ADJ);          // the smallest-edge evaluation of every vertex, kept between the sweeps
     static constexpr uint64_t o_eve = al(o_evr + 8ull * MAXV);            // (decomp_device.h: ALD_KEEP, sweep_smallest): ratio f64 / edge i32 per vertex
-    static constexpr uint64_t total = (o_eve + 4ull * MAXV + 255) / 256 * 256;
+    static constexpr uint64_t o_tvr = al(o_eve + 4ull * MAXV);            // the trivial-vertex scan's view of every vertex, kept likewise (scan_trivial): balance
+    static constexpr uint64_t o_tvc = al(o_tvr + 8ull * MAXV);            // ratio f64 / class i32 per vertex
+    static constexpr uint64_t total = (o_tvc + 4ull * MAXV + 255) / 256 * 256;
 };
 
 struct ClassInfo { int maxv, maxe, nw; uint32_t sp_cap, hl_cap; uint64_t slab_bytes; };

@@ -72,7 +72,12 @@ enum { EID_LIMIT = 0xFFF0 };
 #endif
 typedef ColdLayoutT<MAXV, MAXE, NW, 0> CL;
 #ifndef ALD_KEEP
-  #define ALD_KEEP (ALD_CLASS_ID >= 2 ? 1 : 0)   /* the per-vertex evaluations of the sweeps kept between sweeps (sweep_smallest): not for the one- and two-chunk classes */
+  /* the per-vertex records of the two evaluation sweeps kept in the slab between sweeps (sweep_smallest, scan_trivial): for the classes whose
+     graph arrays live in the slab -- there a list step is a round trip to L2 and evaluating a vertex costs tens of them: the twins run the
+     385..512-vertex band of cfg3 in 66.6 ms instead of 79.5 (profiles/r04/r_*).  The LDS classes LOSE with it (a chunk evaluated out of
+     LDS costs less than the marks, the dense pass and the trip to the slab: 16.1 -> 17.4, 40.6 -> 42.5, 86.3 -> 89.7 ms for the three
+     upper bands), classes 0 / 1 evaluate their one or two chunks at every sweep anyway. */
+  #define ALD_KEEP (ALD_CLASS_ID >= ALD_FIRST_GLOBAL_CLASS ? 1 : 0)
 #endif         // (no row pool in this form: decomp_device_rows.h is the build that has one)
 enum { LP = 16, ARENA_I = 96, ARENA_D = 48, SCR_I = 4 * LP + ARENA_I, SCR_D = 2 * LP + ARENA_D };   // LDS scratch geometry (ints / doubles)
 
@@ -110,6 +115,9 @@ struct HotCtx {
     int32_t  ev_all;
 #if ALD_KEEP
     uint32_t ev_dirty[(MAXV + 31) / 32];
+    // the same for the trivial-vertex scan (class + balance ratio of every vertex, scan_trivial): it is brought up to date at other moments
+    // than the smallest-edge evaluations, so it has marks of its own -- set by the same calls
+    int32_t  tv_all; uint32_t tv_dirty[(MAXV + 31) / 32];
 #endif
     int32_t  g, V0, gstrand;
     int32_t  nv, next_id, slot_hw, free_head, free_cnt, status, any_strand, hs_dirty, n_paths, n_iters, n_trace;
@@ -259,15 +267,21 @@ ALD_INL void ev_mark(int v)                     // v's lists, the weights in the
 {
 #if ALD_KEEP
   #ifdef ALD_EMU
-    HC.ev_dirty[v >> 5] |= 1u << (v & 31);
+    HC.ev_dirty[v >> 5] |= 1u << (v & 31); HC.tv_dirty[v >> 5] |= 1u << (v & 31);
   #else
     __hip_atomic_fetch_or(&HC.ev_dirty[v >> 5], 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);     // (lanes of the star mark different vertices of one word)
+    __hip_atomic_fetch_or(&HC.tv_dirty[v >> 5], 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   #endif
 #else
     (void)v;
 #endif
 }
-ALD_INL void ev_mark_all() { if(ALD_KEEP) HC.ev_all = 1; }
+ALD_INL void ev_mark_all()
+{
+#if ALD_KEEP
+    HC.ev_all = 1; HC.tv_all = 1;
+#endif
+}
 // v's in- (out = false) or out-degree went from `before` to `after`.  v itself is marked; and when the degree crossed the 1 | 2 line, every
 // vertex at the far end of an edge of that list: its evaluation tests exactly this degree (out_deg(s) > 1 for an in-edge s -> j, in_deg(t)
 // > 1 for an out-edge j -> t: scallop.cc:858-896).  out(source) / in(sink) are not linked before the final phase: "everything" then.
@@ -277,7 +291,7 @@ ALD_INL void ev_degree(int v, int before, int after, bool out)
 #if ALD_KEEP
     ev_mark(v);
     if((before <= 1) == (after <= 1)) return;
-    if(!HC.special_linked && (out ? v == 0 : v == HC.sinkp)) { HC.ev_all = 1; return; }
+    if(!HC.special_linked && (out ? v == 0 : v == HC.sinkp)) { ev_mark_all(); return; }
     int guard = MAXE;
     for(int e = out ? slot_or_neg(H.vx[v].out_head) : slot_or_neg(H.vx[v].in_head); e >= 0 && guard-- > 0; e = out ? slot_or_neg(H.ed[e].lk.onx) : slot_or_neg(H.ed[e].lk.inx))
         ev_mark(out ? (int)H.ed[e].lk.et : (int)H.ed[e].lk.es);
@@ -2050,7 +2064,44 @@ ALD_INL bool resolve_broken_vertex()
 // The wave-parallel evaluation is a LEAF (scan_trivial: no calls, so no callee-saved registers go to scratch on the ~500 scans
 // a graph takes); what it carries from one scan of a sweep to the next -- the running (ratio, root) of the reference's
 // sequential loop -- lives in the LDS context, and the thin driver below only keeps `start` across the decomposition call.
+// the r-th set bit of m (r < popcount(m)): six halving steps on the popcount of the low part
+ALD_INL int nth_set_bit(uint64_t m, int r)
+{
+    int pos = 0;
+    ALD_UNROLL for(int w = 32; w >= 1; w >>= 1) {
+        const uint64_t low = m & ((1ull << w) - 1ull); const int c = (int)__builtin_popcountll(low);
+        if(r >= c) { r -= c; m >>= w; pos += w; } else m = low;
+    }
+    return pos;
+}
+// classify_trivial_fastpath (fast = true: resolve_trivial_vertex's mode) + compute_balance_ratio for ONE vertex, every lane its own: -> class
+// (-9: not a trivial vertex at all, 1 / 2, -2: needs a dominate query), the ratio (classes 1, 2, -2) and whether its weights are in order.
+// Every load that does not depend on another is issued together: three LDS round trips (vertex record / first edges / their far ends)
+// instead of one per condition of the short-circuit form.
+ALD_INL int classify_with_ratio(int i, bool inr, double &r, bool &bad)
+{
+    int cls = -9; r = 0; bad = false;
+    const int ii = inr ? i : 0;
+    const Hot::VertexHot vr = H.vx[ii];       // heads and degrees: one 8-byte LDS read
+    const int nzv = H.nz[ii] & NZ_MEMBER, d1 = vr.in_deg, d2 = vr.out_deg; const IDX h1 = vr.in_head, h2 = vr.out_head;
+    bool elig = inr & (nzv != 0) & (d1 >= 1) & (d2 >= 1) & !((d1 >= 2) & (d2 >= 2));
+    if(HC.any_strand) elig = elig && !mixed_strand_vertex(i);
+    const int e1 = (elig & (h1 != NIL)) ? (int)h1 : 0, e2 = (elig & (h2 != NIL)) ? (int)h2 : 0;
+    const IDX sv = H.ed[e1].lk.es, tv = H.ed[e2].lk.et; const uint8_t f1 = H.hflag[e1], f2 = H.hflag[e2];
+    const int s_ = (elig & (sv != NIL)) ? (int)sv : 0, t_ = (elig & (tv != NIL)) ? (int)tv : 0;
+    const int ods = H.vx[s_].out_deg, idt = H.vx[t_].in_deg;
+    if(elig) {
+        if(d1 == 1 && ods == 1) cls = 1;
+        else if(d1 == 1) cls = (f1 & HF_OCC) ? -2 : 1;
+        else if(d2 == 1 && idt == 1) cls = 1;
+        else if(d2 == 1) cls = (f2 & HF_OCC) ? -2 : 1;
+        else cls = 2;
+        bool ok; r = compute_balance_ratio(i, ok); bad = !ok;
+    }
+    return cls;
+}
 enum { SC_NONE = 0, SC_HIT = 1, SC_STOP = 2, SC_NEED = 3, SC_BAD = 4 };
+enum { EV_NC_ = MAXV / ALD_WAVE };
 ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
 {
     start = uni(start); mode = uni(mode); type = uni(type); jump_ratio = uni(jump_ratio);
@@ -2062,9 +2113,74 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
     const int dom_base = HC.sw_dom_base;        // chunk whose dominate queries the driver has answered (scr_i[lane]), or -1
     int code = SC_NONE, hit = -1; double hit_r = 0;
     double frr = DBL_MAX; int fvv = -1;          // this lane's best candidate over the chunks scanned (later vertex wins ties)
+#if ALD_KEEP
+    // Classes 2 and up keep (class, balance ratio) of every vertex in the wave's slab between the scans, as the smallest-edge sweep keeps its
+    // evaluations: first the vertices marked since the last scan -- in dense lanes --, or all of them; then every chunk of the scan is one
+    // coalesced read.  (resolve_trivial_vertex's mode only: the classification of resolve_trivial_vertex_fast, fast = false, is another one.)
+    ALD_GLOBAL double *kr = (ALD_GLOBAL double*)(HC.cold + CL::o_tvr); ALD_GLOBAL int32_t *kc = (ALD_GLOBAL int32_t*)(HC.cold + CL::o_tvc);
+    const bool kept = (mode == 1);
+    if(kept) {
+        const int nv_now = uni(HC.nv);
+  #if defined(ALD_EMU) && defined(ALD_EMU_CHECK)
+        if(HC.tv_all == 0) for(int v = 1; v < nv_now; v++) {
+            if((HC.tv_dirty[v >> 5] >> (v & 31)) & 1u) continue;
+            double r2; bool b2; const int c2 = classify_with_ratio(v, true, r2, b2); const int kc_ = kc[v]; const double kr_ = kr[v];
+            if((c2 & 0xFF) != (kc_ & 0xFF) || (int)b2 != ((kc_ >> 8) & 1) || (c2 != -9 && memcmp(&r2, &kr_, 8) != 0)) { fprintf(stderr, "[check] graph %d: stale trivial-scan record of vertex %d: kept (%d, %.17g), fresh (%d, %.17g)\n", HC.g, v, kc_, kr_, c2, r2); abort(); }
+        }
+  #endif
+        if(uni(HC.tv_all) != 0) {
+            for(int b0 = 0; b0 < nv_now; b0 += ALD_WAVE) { const int v = b0 + lane; const bool in = v >= 1 && v < nv_now; double r2; bool b2; const int c2 = classify_with_ratio(v, in, r2, b2); if(v < nv_now) { kr[v] = r2; kc[v] = (c2 & 0xFF) | (b2 ? 0x100 : 0); } }
+        } else {
+  #ifdef ALD_EMU
+            for(int v = 1; v < nv_now; v++) if((HC.tv_dirty[v >> 5] >> (v & 31)) & 1u) { double r2; bool b2; const int c2 = classify_with_ratio(v, true, r2, b2); kr[v] = r2; kc[v] = (c2 & 0xFF) | (b2 ? 0x100 : 0); }
+  #else
+            int total = 0;
+            for(int w = 0; w < (nv_now + 31) / 32; w++) total += (int)__builtin_popcount(uni(HC.tv_dirty[w]));
+            for(int b0 = 0; b0 < total; b0 += ALD_WAVE) {
+                const int k = b0 + lane; int run = 0, vtx = -1;
+                for(int w = 0; w < (nv_now + 31) / 32; w++) {
+                    const uint32_t m = uni(HC.tv_dirty[w]); const int pc = (int)__builtin_popcount(m);
+                    if(k >= run && k < run + pc) vtx = 32 * w + nth_set_bit((uint64_t)m, k - run);
+                    run += pc;
+                }
+                const bool in = vtx >= 1 && vtx < nv_now;
+                double r2; bool b2; const int c2 = classify_with_ratio(vtx, in, r2, b2);
+                if(in) { kr[vtx] = r2; kc[vtx] = (c2 & 0xFF) | (b2 ? 0x100 : 0); }
+            }
+  #endif
+        }
+        wsync();
+        if(lane == 0) HC.tv_all = 0;
+        for(int k = lane; k < (nv_now + 31) / 32; k += ALD_WAVE) HC.tv_dirty[k] = 0;
+        wsync();
+    }
+#else
+    const bool kept = false;
+#endif
+#if ALD_KEEP
+    // every chunk the scan may visit is asked for NOW, all reads in flight together (the scan leaves at its first hit, but a chunk asked for
+    // when the loop reaches it would cost a round trip to L2 each, one after the other); classes of more than sixteen chunks read as they go
+    constexpr int KNC = (EV_NC_ <= 16) ? EV_NC_ : 1;
+    double pr_[KNC]; int pc_[KNC];
+    if(kept && EV_NC_ <= 16) {
+        ALD_UNROLL for(int c = 0; c < KNC; c++) {
+            const int i = c * ALD_WAVE + lane; const bool in = (i >= start) & (i < vend);
+            pr_[c] = in ? kr[i] : 0.0; pc_[c] = in ? kc[i] : (-9 & 0xFF);
+        }
+    }
+#endif
     for(int base = (start / ALD_WAVE) * ALD_WAVE; base < vend; base += ALD_WAVE) {
         int i = base + lane;
-        int cls = -9; double r = 0; bool bad = false;
+        int cls = -9; double r = 0; bool bad = false; bool kbad = false;
+#if ALD_KEEP
+        if(kept) {
+            const bool inr = (i >= start) & (i < vend);
+            int kc_ = (-9 & 0xFF); double kr_ = 0;
+            if(EV_NC_ <= 16) { const int cq = base / ALD_WAVE; ALD_UNROLL for(int c = 0; c < KNC; c++) if(c == cq) { kc_ = pc_[c]; kr_ = pr_[c]; } }
+            else if(inr) { kc_ = kc[i]; kr_ = kr[i]; }
+            if(inr) { r = kr_; cls = (int)(int8_t)(kc_ & 0xFF); kbad = (kc_ & 0x100) != 0; }
+        } else
+#endif
         {
             // classify_trivial_fastpath with every load that does not depend on another issued together: three LDS round trips
             // (vertex record / first edges / their far ends) instead of one per condition of the short-circuit form
@@ -2090,7 +2206,7 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
         uint64_t need = wballot(cls == -2);
         if(need) { if(lane == 0) { HC.sw_dom_base = base; HC.sw_need_lo = (uint32_t)need; HC.sw_need_hi = (uint32_t)(need >> 32); } code = SC_NEED; break; }
         bool cand = (cls == type);
-        if(cand) { bool ok; r = compute_balance_ratio(i, ok); if(!ok) bad = true; }
+        if(cand) { if(kept) bad = kbad; else { bool ok; r = compute_balance_ratio(i, ok); if(!ok) bad = true; } }
         if(wballot(bad)) { code = SC_BAD; break; }
         uint64_t now = wballot(cand && r < now_thr);
         // scallop.cc:1222 `if(ratio < jump_ratio) break;`: the first candidate with 1.02 <= r < jump_ratio becomes the root and ends the sweep
@@ -2200,16 +2316,6 @@ ALD_INL bool back_to_cascade()
 // of 64 costs the same for one marked vertex as for 64 -- writes them to the slab, then loads every chunk with one coalesced read.  Up to
 // round 3 every sweep evaluated every vertex: 15 % of a 500-vertex graph's time (profiles/r04/n_phase_big.txt).
 enum { EV_NC = MAXV / ALD_WAVE };                 // chunks of the class: registers for the small classes, private memory beyond
-// the r-th set bit of m (r < popcount(m)): six halving steps on the popcount of the low part
-ALD_INL int nth_set_bit(uint64_t m, int r)
-{
-    int pos = 0;
-    ALD_UNROLL for(int w = 32; w >= 1; w >>= 1) {
-        const uint64_t low = m & ((1ull << w) - 1ull); const int c = (int)__builtin_popcountll(low);
-        if(r >= c) { r -= c; m >>= w; pos += w; } else m = low;
-    }
-    return pos;
-}
 ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr);
 ALD_INL bool sweep_smallest(double max_ratio)
 {
