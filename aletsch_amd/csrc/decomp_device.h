@@ -2340,7 +2340,7 @@ ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr)
     ALD_GLOBAL double *mr = (ALD_GLOBAL double*)(HC.cold + CL::o_evr); ALD_GLOBAL int32_t *me = (ALD_GLOBAL int32_t*)(HC.cold + CL::o_eve);
     const bool stale_all = uni(HC.ev_all) != 0;
   #if defined(ALD_EMU) && defined(ALD_EMU_CHECK)
-    { static long n_entry = 0, n_all = 0, n_marked = 0, n_live = 0; static struct P { long *a, *b, *c, *d; ~P() { if(*a) fprintf(stderr, "[emu-ev] class %d: %ld sweep entries, %.1f %% with everything stale, else %.1f marked of %.1f vertices\n", ALD_CLASS_ID, *a, 100.0 * *b / *a, (double)*c / ((*a - *b) ? (*a - *b) : 1), (double)*d / *a); } } pr{&n_entry, &n_all, &n_marked, &n_live};
+    { static long n_entry = 0, n_all = 0, n_marked = 0, n_live = 0; static struct P { long *a, *b, *c, *d; ~P() { if(*a && getenv("ALD_EMU_VERBOSE")) fprintf(stderr, "[emu-ev] class %d: %ld sweep entries, %.1f %% with everything stale, else %.1f marked of %.1f vertices\n", ALD_CLASS_ID, *a, 100.0 * *b / *a, (double)*c / ((*a - *b) ? (*a - *b) : 1), (double)*d / *a); } } pr{&n_entry, &n_all, &n_marked, &n_live};
       n_entry++; n_live += vend; if(stale_all) n_all++; else for(int i = 1; i < vend; i++) if((HC.ev_dirty[i >> 5] >> (i & 31)) & 1u) n_marked++; }
     // test build of the emulation: a kept evaluation that is neither marked nor covered by "everything" must equal a fresh one
     if(!stale_all) for(int i = 1; i < vend; i++) {

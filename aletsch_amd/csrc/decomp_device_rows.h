@@ -281,7 +281,7 @@ ALD_INL int wave_excl_scan(int x, int &total)
 enum { SEG_LISTS = 16 };
 #if defined(ALD_EMU) && defined(ALD_EMU_CHECK)
 static long g_adj_grow = 0, g_adj_compact = 0, g_adj_graphs = 0, g_adj_peak = 0, g_adj_peak_sum = 0;
-struct AdjPrinter { ~AdjPrinter() { if(g_adj_graphs) fprintf(stderr, "[emu-adj] class %d (pool %d chunks): %ld graphs, segment moves %.2f / graph, compactions %.4f / graph, peak chunks used: max %ld, mean %.1f\n",
+struct AdjPrinter { ~AdjPrinter() { if(g_adj_graphs && getenv("ALD_EMU_VERBOSE")) fprintf(stderr, "[emu-adj] class %d (pool %d chunks): %ld graphs, segment moves %.2f / graph, compactions %.4f / graph, peak chunks used: max %ld, mean %.1f\n",
     ALD_CLASS_ID, (int)ADJ_CAP4, g_adj_graphs, (double)g_adj_grow / g_adj_graphs, (double)g_adj_compact / g_adj_graphs, g_adj_peak, (double)g_adj_peak_sum / g_adj_graphs); } }; static AdjPrinter g_adj_printer;
 #define ADJ_STAT(x) (x)
 #else

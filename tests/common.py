@@ -48,6 +48,23 @@ def emu_rows_lib():
     return _EMU_ROWS
 
 
+_EMU_KEEP = None
+
+
+def emu_keep_lib():
+    """the emulation with the sweep records kept between sweeps in EVERY size class (make KEEP=1), built with the checker: at every sweep
+    every kept record that is not marked must equal a fresh evaluation (a stale one aborts the process)"""
+    global _EMU_KEEP
+    if _EMU_KEEP is None:
+        path = os.path.join(ROOT, "tests", "_build", "libkernel_emu_keep.so")
+        src = [os.path.join(ROOT, "aletsch_amd", "csrc", f) for f in ("decomp_device.h", "decomp_common.h")]
+        if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in src):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "kernel_emu"), "-j8", "KEEP=1"], check=True, stdout=subprocess.DEVNULL)
+        _EMU_KEEP = C.CDLL(path)
+        _EMU_KEEP.emu_result_free.argtypes = [C.c_void_p]
+    return _EMU_KEEP
+
+
 def emu_lib():
     global _EMU
     if _EMU is None:
@@ -95,9 +112,10 @@ def oracle_transcripts(pg: PackedGraphs):
     return r, cov, eo, lr[:2 * te.value].reshape(-1, 2)
 
 
-def emu_run(pg: PackedGraphs, trace_cap: int = 0, force_class: int = 0, params=None, rows: bool = False):
-    """single-lane emulation of the HIP engine -> (DecompResult, iterations[n], class[n]); rows: its adjacency-row form (make ROWS=1)"""
-    E = emu_rows_lib() if rows else emu_lib()
+def emu_run(pg: PackedGraphs, trace_cap: int = 0, force_class: int = 0, params=None, rows: bool = False, keep: bool = False):
+    """single-lane emulation of the HIP engine -> (DecompResult, iterations[n], class[n]); rows: its adjacency-row form (make ROWS=1);
+    keep: sweep records kept in every class + stale-record checker (make KEEP=1)"""
+    E = emu_rows_lib() if rows else (emu_keep_lib() if keep else emu_lib())
     h = C.c_void_p()
     rc = E.emu_run_packed(*pg.c_args(), C.byref(params) if params is not None else None, C.c_int32(trace_cap), C.c_int32(force_class), C.byref(h))
     assert rc == 0, rc

@@ -42,6 +42,19 @@ def test_row_form_of_the_engine_matches_oracle(name):
     assert np.array_equal(it, st[:, 3])
 
 
+@pytest.mark.parametrize("name", ["cfg2_64v256e", "cfg3_mixed", "flow_weights", "multi_sample", "stranded", "phasing", "everything", "real_shaped"])
+def test_kept_sweep_records_are_never_stale(name):
+    """Round 4: the slab-resident classes keep the per-vertex records of the two evaluation sweeps (smallest-edge evaluation; trivial class +
+    balance ratio) between sweeps and bring only MARKED vertices up to date -- the ones a rule edited and, when a degree crossed the 1 | 2
+    line, the vertices at the far end of that list.  This build keeps them in EVERY class and checks, at every sweep, every record that is
+    not marked against a fresh evaluation (a stale one aborts); results and iteration counts must equal the oracle's as ever."""
+    pg = common.make_batch(name)
+    want, st, _, _ = common.oracle_run(pg)
+    got, it, cl = common.emu_run(pg, keep=True)
+    assert not common.compare_results(want, got, pg.n)
+    assert np.array_equal(it, st[:, 3])
+
+
 def test_engine_joins_touching_and_drops_empty_intervals():
     """hand-made: vertices 1|2 touch (one exon), 3 is an empty interval (vanishes), 4 stands alone"""
     from aletsch_amd.packed import PackedGraphs

@@ -840,7 +840,9 @@ def test_barrier_variant_of_the_hand_overs():
     """wsync() is a wavefront-scope fence (no instruction), so every lane-to-lane hand-over through LDS / the slabs relies on
     same-wave in-order memory.  libaletsch_decomp_wsync.so is the same source with __syncthreads() at every hand-over (make WSYNC=1:
     a full s_waitcnt drain each time).  A fixed-seed fuzz slice through it against the oracle must be as clean as through the product
-    build -- a divergence between the two forms would show here and not only in the ad-hoc fuzz tool."""
+    build -- a divergence between the two forms would show here and not only in the ad-hoc fuzz tool.  Since round 4 the same build keeps
+    the sweep records between sweeps in EVERY size class (-DALD_KEEP=1; the product: slab-resident classes only), so that the marks, the
+    dense pass over the marked vertices and the prefetching scan -- device-only code -- run on every graph of the slice."""
     import subprocess, sys
     lib = os.path.join(common.ROOT, "aletsch_amd", "lib", "libaletsch_decomp_wsync.so")
     assert os.path.exists(lib), "build it with make -C aletsch_amd/csrc WSYNC=1 (python __graft_entry__.py does)"
