@@ -26,7 +26,7 @@ ALD_FOR_EACH_CLASS(ALD_DECL)
 #define ALD_TWIN_SPILL_DEFAULT(q, sz, cap) ((q) == 0 ? (int64_t)1 << 40 : (int64_t)0)
 namespace {
 
-// A batch owns four HIP streams and a pipelined caller keeps several batches in flight; the ROCm runtime maps all streams of a process
+// A batch owns six HIP streams and a pipelined caller keeps several batches in flight; the ROCm runtime maps all streams of a process
 // onto FOUR hardware queues by default, so the D2H copy of batch k regularly sat in the same queue as the kernel of batch k + 1 and
 // waited for it (download 24-38 ms instead of 3 ms per step).  The runtime reads GPU_MAX_HW_QUEUES when it initialises, so the library
 // sets it -- unless the caller did -- when it is LOADED: before any HIP call of its own, and before the first HIP call of a program
