@@ -78,6 +78,9 @@ typedef ColdLayoutT<MAXV, MAXE, NW, 0> CL;
      LDS costs less than the marks, the dense pass and the trip to the slab: 16.1 -> 17.4, 40.6 -> 42.5, 86.3 -> 89.7 ms for the three
      upper bands), classes 0 / 1 evaluate their one or two chunks at every sweep anyway. */
   #define ALD_KEEP (ALD_CLASS_ID >= ALD_FIRST_GLOBAL_CLASS ? 1 : 0)
+#endif
+#ifndef ALD_KEEP_TRIV
+  #define ALD_KEEP_TRIV ALD_KEEP               /* the trivial-scan records as well (experiments: -DALD_KEEP=1 -DALD_KEEP_TRIV=0 keeps the smallest-edge evaluations only) */
 #endif         // (no row pool in this form: decomp_device_rows.h is the build that has one)
 enum { LP = 16, ARENA_I = 96, ARENA_D = 48, SCR_I = 4 * LP + ARENA_I, SCR_D = 2 * LP + ARENA_D };   // LDS scratch geometry (ints / doubles)
 
@@ -117,7 +120,9 @@ struct HotCtx {
     uint32_t ev_dirty[(MAXV + 31) / 32];
     // the same for the trivial-vertex scan (class + balance ratio of every vertex, scan_trivial): it is brought up to date at other moments
     // than the smallest-edge evaluations, so it has marks of its own -- set by the same calls
+  #if ALD_KEEP_TRIV
     int32_t  tv_all; uint32_t tv_dirty[(MAXV + 31) / 32];
+  #endif
 #endif
     int32_t  g, V0, gstrand;
     int32_t  nv, next_id, slot_hw, free_head, free_cnt, status, any_strand, hs_dirty, n_paths, n_iters, n_trace;
@@ -267,10 +272,15 @@ ALD_INL void ev_mark(int v)                     // v's lists, the weights in the
 {
 #if ALD_KEEP
   #ifdef ALD_EMU
-    HC.ev_dirty[v >> 5] |= 1u << (v & 31); HC.tv_dirty[v >> 5] |= 1u << (v & 31);
+    HC.ev_dirty[v >> 5] |= 1u << (v & 31);
+    #if ALD_KEEP_TRIV
+    HC.tv_dirty[v >> 5] |= 1u << (v & 31);
+    #endif
   #else
     __hip_atomic_fetch_or(&HC.ev_dirty[v >> 5], 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);     // (lanes of the star mark different vertices of one word)
+    #if ALD_KEEP_TRIV
     __hip_atomic_fetch_or(&HC.tv_dirty[v >> 5], 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    #endif
   #endif
 #else
     (void)v;
@@ -279,7 +289,10 @@ ALD_INL void ev_mark(int v)                     // v's lists, the weights in the
 ALD_INL void ev_mark_all()
 {
 #if ALD_KEEP
-    HC.ev_all = 1; HC.tv_all = 1;
+    HC.ev_all = 1;
+    #if ALD_KEEP_TRIV
+    HC.tv_all = 1;
+    #endif
 #endif
 }
 // v's in- (out = false) or out-degree went from `before` to `after`.  v itself is marked; and when the degree crossed the 1 | 2 line, every
@@ -2113,8 +2126,8 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
     const int dom_base = HC.sw_dom_base;        // chunk whose dominate queries the driver has answered (scr_i[lane]), or -1
     int code = SC_NONE, hit = -1; double hit_r = 0;
     double frr = DBL_MAX; int fvv = -1;          // this lane's best candidate over the chunks scanned (later vertex wins ties)
-#if ALD_KEEP
-    // Classes 2 and up keep (class, balance ratio) of every vertex in the wave's slab between the scans, as the smallest-edge sweep keeps its
+#if ALD_KEEP_TRIV
+    // The slab-resident classes keep (class, balance ratio) of every vertex in the wave's slab between the scans, as the smallest-edge sweep keeps its
     // evaluations: first the vertices marked since the last scan -- in dense lanes --, or all of them; then every chunk of the scan is one
     // coalesced read.  (resolve_trivial_vertex's mode only: the classification of resolve_trivial_vertex_fast, fast = false, is another one.)
     ALD_GLOBAL double *kr = (ALD_GLOBAL double*)(HC.cold + CL::o_tvr); ALD_GLOBAL int32_t *kc = (ALD_GLOBAL int32_t*)(HC.cold + CL::o_tvc);
@@ -2157,7 +2170,7 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
 #else
     const bool kept = false;
 #endif
-#if ALD_KEEP
+#if ALD_KEEP_TRIV
     // every chunk the scan may visit is asked for NOW, all reads in flight together (the scan leaves at its first hit, but a chunk asked for
     // when the loop reaches it would cost a round trip to L2 each, one after the other); classes of more than sixteen chunks read as they go
     constexpr int KNC = (EV_NC_ <= 16) ? EV_NC_ : 1;
@@ -2172,7 +2185,7 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
     for(int base = (start / ALD_WAVE) * ALD_WAVE; base < vend; base += ALD_WAVE) {
         int i = base + lane;
         int cls = -9; double r = 0; bool bad = false; bool kbad = false;
-#if ALD_KEEP
+#if ALD_KEEP_TRIV
         if(kept) {
             const bool inr = (i >= start) & (i < vend);
             int kc_ = (-9 & 0xFF); double kr_ = 0;
