@@ -26,7 +26,7 @@ ALD_FOR_EACH_CLASS(ALD_DECL)
 #define ALD_TWIN_SPILL_DEFAULT(q, sz, cap) ((q) == 0 ? (int64_t)1 << 40 : (int64_t)0)
 namespace {
 
-// A batch owns six HIP streams and a pipelined caller keeps several batches in flight; the ROCm runtime maps all streams of a process
+// A batch owns seven HIP streams and a pipelined caller keeps several batches in flight; the ROCm runtime maps all streams of a process
 // onto FOUR hardware queues by default, so the D2H copy of batch k regularly sat in the same queue as the kernel of batch k + 1 and
 // waited for it (download 24-38 ms instead of 3 ms per step).  The runtime reads GPU_MAX_HW_QUEUES when it initialises, so the library
 // sets it -- unless the caller did -- when it is LOADED: before any HIP call of its own, and before the first HIP call of a program
@@ -150,10 +150,15 @@ int stage_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], i
         P.order[P.nord++] = k;
     }
     std::sort(P.order, P.order + P.nord, [&](int x, int y) { return cost[x] > cost[y]; });
+    // the last stream belongs to the small LDS classes (0..2: 16 KB of LDS per workgroup and less -- they fit beside anything and take a few
+    // milliseconds: queued behind a large class they ran at the very end, cfg3's last 8 ms; profiles/r04/aa_cfg3_timeline_5_streams.txt),
+    // the others are dealt to the remaining streams
     double load[ALD_SIDE_STREAMS_MAX] = {0};
+    const int n_big = b->n_cstream > 1 ? b->n_cstream - 1 : 1;
     for(int q = 0; q < P.nord; q++) {
-        const int k = P.order[q];
-        int st = 0; for(int z = 1; z < b->n_cstream; z++) if(load[z] < load[st]) st = z;
+        const int k = P.order[q]; const int cls = k % ALD_NUM_CLASSES;
+        if(b->n_cstream > 1 && cls <= 2) { P.stream_of[k] = b->n_cstream - 1; continue; }
+        int st = 0; for(int z = 1; z < n_big; z++) if(load[z] < load[st]) st = z;
         load[st] += cost[k]; P.stream_of[k] = st;
     }
     return push_pass(b, P);

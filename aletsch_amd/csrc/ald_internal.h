@@ -24,7 +24,7 @@ struct PinBuf {
     void release() { if(p) hipHostFree(p); p = nullptr; cap = 0; }
 };
 
-enum { ALD_SIDE_STREAMS = 5, ALD_SIDE_STREAMS_MAX = 8 };      // 5: cfg3 89 ms against 93 (3), 102 (4), 93 (6, 8) -- profiles/r04/x_cfg3_side_streams.txt; one class per batch (the bench) uses one
+enum { ALD_SIDE_STREAMS = 6, ALD_SIDE_STREAMS_MAX = 8 };      // five for the large classes + one for classes 0..2 (stage_pass): cfg3 88-89 ms against 93 with three (profiles/r04/x_cfg3_side_streams.txt); a batch of one class (the bench) uses one
 // kernel slots of a pass: slot c = the plain build of size class c (staged graphs), slot ALD_NUM_CLASSES + c = its raw build (graphs whose
 // pre-steps run on the device); a batch without raw graphs only ever uses the first half
 enum { ALD_NUM_SLOTS = 2 * ALD_NUM_CLASSES };     // default / upper bound of the side streams the classes of a pass are dealt to

@@ -38,7 +38,7 @@ import sys
 import threading
 import time
 
-# A batch owns six HIP streams (one for copies / ordering, five that its size classes are dealt to) and a pipelined caller keeps
+# A batch owns seven HIP streams (one for copies / ordering, six that its size classes are dealt to) and a pipelined caller keeps
 # several batches in flight; the ROCm runtime maps all streams of a process onto FOUR hardware queues by default, so the D2H copy of
 # batch k regularly sat in the same queue as the kernel of batch k+1 and waited for it (download 24-38 ms instead of 3 ms per step).
 # Must be in the environment before the HIP runtime initialises, i.e. before anything touches the GPU; ranks inherit it.
