@@ -1,5 +1,8 @@
 // decomp_common.h -- types shared by the device engine (decomp_device.h), the kernels and the host ABI.
 #pragma once
+#ifndef ALD_FIRST_GLOBAL_CLASS
+#define ALD_FIRST_GLOBAL_CLASS 10     /* classes from here on keep the Hot struct in the wave's HBM slab (overridable for experiments) */
+#endif
 #include <cstdlib>
 #include <stdint.h>
 #include <math.h>
@@ -21,6 +24,7 @@
   template<class T> static inline T wread(T v, int) { return v; }
   static inline void     wave_argmin(double &, int &) {}
   static inline void     wsync() {}
+  static inline void     wsync_mem() {}
   static inline unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
   static inline int      atomic_add_i32(int *p, int v) { int o = *p; *p += v; return o; }
   static inline int      ffs64(uint64_t m) { return __builtin_ffsll((long long)m) - 1; }
@@ -105,15 +109,37 @@
       while(tied) { const int l = __ffsll(tied) - 1; tied &= tied - 1; const int v = __builtin_amdgcn_readlane(vv, l); best = v > best ? v : best; }
       rr = __longlong_as_double((long long)kmin); vv = best;
   }
-  // workgroup == ONE wavefront: lanes of a wave execute in lock step and the hardware performs a wave's LDS and vector-memory
-  // instructions in issue order, so handing data from one lane to another needs no s_barrier and no drain of the memory counters --
-  // only that the compiler keeps the accesses on their side of the hand-over (LLVM AMDGPU memory model: a fence at "wavefront" scope
-  // emits no instruction).  __syncthreads() here cost an s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier at every one of the few thousand
-  // hand-overs a graph takes, i.e. every global load in flight was waited for right there.
-  #ifdef ALD_WSYNC_BARRIER
-  __device__ __forceinline__ void     wsync() { __syncthreads(); }
+  // workgroup == ONE wavefront: lanes of a wave execute in lock step and the hardware performs a wave's LDS instructions in issue order,
+  // so handing data from one lane to another THROUGH LDS needs no s_barrier and no wait on the memory counters -- only that the compiler
+  // keeps the accesses on their side of the hand-over (LLVM AMDGPU memory model: a fence at "wavefront" scope emits no instruction).
+  // __syncthreads() here cost an s_waitcnt + s_barrier at every one of the few thousand hand-overs a graph takes.
+  //
+  // Hand-overs THROUGH GLOBAL MEMORY are another matter (round 4).  The classes that keep the graph arrays in the wave's HBM slab (10..13)
+  // pass list links, degrees and the kept sweep records from lane to lane through the slab.  A build that routes every small fan through
+  // star_reg (-DALD_STARFIX_MAX=1) ended in a memory fault on the twins' 385..512-vertex graphs with the fence-only hand-over, in every run;
+  // with a wait for the wave's memory counters at every hand-over of those classes the same build is bit-exact against the oracle
+  // (profiles/r04/zb_slab_handover_drain.txt).  Which hand-over needs the wait was not isolated -- waits at the kept records' hand-overs and
+  // in front of the stars' tails alone did not cure it --, so in these classes EVERY hand-over waits: wsync() == wsync_mem().  Cost: the
+  // 385..512 band on the twins 66.5 -> 67.8 ms, the mixed batch 88.3 -> 88.5 ms (same file); the LDS classes are not touched.
+  // (-DALD_SLAB_NO_DRAIN: the fence-only form in all classes, for A/B.)
+  //
+  // The wait is written as an explicit s_waitcnt: a fence at "workgroup" scope -- and __syncthreads() -- emit NOTHING in these kernels, which
+  // are launched with a workgroup of exactly one wave: the compiler lowers workgroup scope to wavefront scope then (the s_waitcnt count of
+  // the ISA does not change), so the -DALD_WSYNC_BARRIER test build of rounds 2 / 3 ordered the compiler but waited for nothing; it carries the explicit wait now.
+  #define ALD_WSYNC_WAIT_() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while(0)
+  #if defined(ALD_WSYNC_BARRIER)
+  __device__ __forceinline__ void     wsync() { __syncthreads(); __builtin_amdgcn_s_waitcnt(0); }
+  #elif defined(ALD_CLASS_ID) && ALD_CLASS_ID >= ALD_FIRST_GLOBAL_CLASS && !defined(ALD_SLAB_NO_DRAIN)
+  __device__ __forceinline__ void     wsync() { ALD_WSYNC_WAIT_(); }
   #else
   __device__ __forceinline__ void     wsync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+  #endif
+  // wsync_mem(): the hand-over that waits in EVERY class -- for the routines whose lanes exchange values through the slab whatever the class
+  // (collecting the finished paths, finish_graph, the device pre-steps, the kept sweep records of a -DALD_KEEP=1 test build).
+  #ifdef ALD_WSYNC_BARRIER
+  __device__ __forceinline__ void     wsync_mem() { __syncthreads(); __builtin_amdgcn_s_waitcnt(0); }
+  #else
+  __device__ __forceinline__ void     wsync_mem() { ALD_WSYNC_WAIT_(); }
   #endif
   __device__ __forceinline__ unsigned long long atomic_add_u64(ALD_GLOBAL unsigned long long *p, unsigned long long v) { return atomicAdd((unsigned long long*)p, v); }
   __device__ __forceinline__ int      atomic_add_i32(ALD_GLOBAL int *p, int v) { return atomicAdd((int*)p, v); }
@@ -237,9 +263,6 @@ static inline int class_retry_up(int c)                                         
     if(c == ALD_CATCH_ALL_CLASS) return ALD_HUGE_CLASS;
     return c + 1 < ALD_NUM_PICK_CLASSES ? c + 1 : -1;
 }
-#ifndef ALD_FIRST_GLOBAL_CLASS
-#define ALD_FIRST_GLOBAL_CLASS 10     /* classes from here on keep the Hot struct in the wave's HBM slab (overridable for experiments) */
-#endif
 
 // per-wave HBM slab, laid out at compile time (so that cold pointers cost no registers)
 template<int MAXV, int MAXE, int NW, int ADJ>

@@ -286,6 +286,9 @@ ALD_INL void ev_mark(int v)                     // v's lists, the weights in the
     (void)v;
 #endif
 }
+// The hand-over in front of a star's lane-0 tail.  Where the sweep records are kept (ALD_KEEP: the slab-resident classes, whose lists live in
+// GLOBAL memory) the tail walks far's list at once (ev_degree) -- the links the other lanes have just written: the stores are drained first.
+ALD_INL void star_tail_sync() { if(ALD_KEEP) wsync_mem(); else wsync(); }
 ALD_INL void ev_mark_all()
 {
 #if ALD_KEEP
@@ -1305,7 +1308,7 @@ template<bool A> ALD_INL void star_wave_body(int x)
             if(first_of_gap) { if(pred[q] < 0) { if(A) H.vx[far].out_head = (IDX)f; else H.vx[far].in_head = (IDX)f; } else { if(A) H.ed[pred[q]].lk.onx = (IDX)f; else H.ed[pred[q]].lk.inx = (IDX)f; } }
         }
     }
-    wsync();
+    star_tail_sync();
 #ifdef ALD_PROF
     unsigned long long prof_s7_ = __builtin_readcyclecounter();
 #endif
@@ -1522,7 +1525,7 @@ template<bool A> ALD_INL void star_reg(int x)
             if(first_of_gap) { if(pred[q] < 0) { if(A) H.vx[far].out_head = (IDX)fq; else H.vx[far].in_head = (IDX)fq; } else { if(A) H.ed[pred[q]].lk.onx = (IDX)fq; else H.ed[pred[q]].lk.inx = (IDX)fq; } }
         }
     }
-    wsync();
+    star_tail_sync();
     // ---- lane 0: what is left and inherently ordered -- the support pool, the phasing lists, the counters
     if(lane == 0) {
         { const int dg = A ? (int)uni(H.vx[far].out_deg) : (int)uni(H.vx[far].in_deg); if(A) H.vx[far].out_deg = (IDX)(dg + n); else H.vx[far].in_deg = (IDX)(dg + n); ev_degree(far, dg, dg + n, A); }
@@ -1758,7 +1761,7 @@ template<bool A, int N> ALD_INL bool star_fixed(int x)
         }
     }
     const bool any_multi = wballot(multi) != 0;
-    wsync();
+    star_tail_sync();
     // ---- lane 0: c leaves far's list (unless a merged edge took its predecessor's link), the counters, what is inherently ordered
     if(lane == 0) {
         IDX *deg = A ? &H.vx[far].out_deg : &H.vx[far].in_deg;
@@ -2162,7 +2165,7 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
             }
   #endif
         }
-        wsync();
+        wsync_mem();                              // (as in sweep_smallest: the records travel through the slab)
         if(lane == 0) HC.tv_all = 0;
         for(int k = lane; k < (nv_now + 31) / 32; k += ALD_WAVE) HC.tv_dirty[k] = 0;
         wsync();
@@ -2380,7 +2383,7 @@ ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr)
             if(vtx >= 1 && vtx < vend) { double r = 0; const int e = eval_smallest(vtx, r); mr[vtx] = r; me[vtx] = e; }
         }
   #endif
-        wsync();
+        wsync_mem();                              // (the records travel through the slab: the stores have to have left the wave before the reads are asked for)
         if(NC <= 16) { ALD_UNROLL for(int c = 0; c < (NC <= 16 ? NC : 1); c++) { const bool in = c < nch0; cr[c] = in ? mr[c * ALD_WAVE + lane] : 0.0; ce[c] = in ? me[c * ALD_WAVE + lane] : -1; } }
         else for(int c = 0; c < nch0; c++) { cr[c] = mr[c * ALD_WAVE + lane]; ce[c] = me[c * ALD_WAVE + lane]; }
     }
@@ -3091,6 +3094,8 @@ ALD_FN void materialize_special()
         if((int)uni(H.ed[e].lk.et) == sinkp) link_in(sinkp, e);
     }
 }
+// (The lanes of this routine, of finish_graph and of the device pre-steps exchange values through the wave's SLAB -- global memory, work
+// arrays whose lines a lane may hold in the vector L1 from an earlier use --: their hand-overs are wsync_mem(), which drains the stores.)
 // scallop::collect_existing_st_paths (scallop.cc:2742-2752): ascending edge index == ascending creation id.
 // out(0) / in(sink) are not linked at this point (see link_out): the source->sink edges are picked out of the slot array by the
 // whole wave and ordered by id on lane 0; collect_path's remove_edge then only counts.  Called by ALL lanes.
@@ -3112,7 +3117,7 @@ ALD_FN void collect_existing_st_paths()
 #endif
         n += __builtin_popcountll(m);
     }
-    wsync();
+    wsync_mem();
     PROF_ADD(PF_S5_DUP);
     if(n == 0) return;
     if(tracing() || 5 * n > Cold::w_cap || uni(HC.n_paths) + n > Cold::po_cap) {        // the op trace lists the paths in order: one at a time (which also reports a full offset table)
@@ -3120,7 +3125,7 @@ ALD_FN void collect_existing_st_paths()
             for(int i = 1; i < n; i++) { int x = lst[i]; uint32_t id = uni(H.eid[x]); int j = i - 1; while(j >= 0 && (uint32_t)uni(H.eid[lst[j]]) > id) { lst[j + 1] = lst[j]; j--; } lst[j + 1] = x; }
             for(int i = 0; i < n && !HC.status; i++) collect_path(lst[i]);
         }
-        wsync();
+        wsync_mem();
         return;
     }
     // One finished path per lane (scallop::collect_path, scallop.cc:2766-2834, for all of them at once): the vertex set and its length
@@ -3137,7 +3142,7 @@ ALD_FN void collect_existing_st_paths()
         ids[j] = (int32_t)H.eid[e]; nvs[j] = cnt; nxs[j] = nexw;
         keep[j] = (C.ed[e].mei != mi || cnt == 0) ? -1 : (empty ? 0 : 1);
     }
-    wsync();
+    wsync_mem();
     PROF_ADD(PF_S5_BODY);
     bool bad = false, full = false; int kept_total = 0;
     for(int j = lane; j < n; j += ALD_WAVE) {
@@ -3169,7 +3174,7 @@ ALD_FN void collect_existing_st_paths()
         if((REC_HDR_WORDS + nvp + nexw) & 1) pv[w] = 0;
     }
     const bool any_bad = wballot(bad) != 0, any_full = wballot(full) != 0;
-    wsync();
+    wsync_mem();
     PROF_ADD(PF_S5_RELINK);
     if(lane == 0) {
         for(int k = 0; k < n; k++) if(keep[k] == 1) kept_total++;
@@ -3179,7 +3184,7 @@ ALD_FN void collect_existing_st_paths()
         // remove_edge for all of them: out(source) / in(sink) are only counted at this point, the slots go back to the free list
         for(int k = 0; k < n; k++) { const int e = lst[k]; H.hflag[e] = 0; kill_edge_i(e); }
     }
-    wsync();
+    wsync_mem();
     PROF_ADD(PF_S6_WALK);
 }
 // splice_graph::compute_maximum_path_w (splice_graph.cc:819-885) + directed_graph::topological_sort (directed_graph.cc:420-451)
@@ -3350,7 +3355,7 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
             }
             if(best_st) C.ed[k].estrand = (uint8_t)best_st;
         }
-        wsync();
+        wsync_mem();
     }
     // ---- group_start_boundaries / group_end_boundaries (lane 0)
     if(lane == 0) {
@@ -3409,7 +3414,7 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
         if(bad) fail(ALD_ST_INVARIANT + ALD_INV_OTHER);
         HC.scr_i[0] = ns; HC.scr_i[1] = nt; HC.scr_i[2] = removed;
     }
-    wsync();
+    wsync_mem();
     if(uni(HC.status)) return false;
     const int ns = uni(HC.scr_i[0]), nt = uni(HC.scr_i[1]), removed = uni(HC.scr_i[2]);
     // ---- the folded boundary edges leave the graph; the creation ids of the others close ranks (the order is what matters: every id
@@ -3417,7 +3422,7 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
     if(removed) {
         ALD_GLOBAL int32_t *flag = C.wi, *nrank = C.wi + E;
         for(int k = lane; k < E; k += ALD_WAVE) flag[H.eid[k]] = (H.hflag[k] & RAW_DEAD) ? 0 : 1;
-        wsync();
+        wsync_mem();
         int base = 0;
         for(int r0 = 0; r0 < E; r0 += ALD_WAVE) {
             const int r = r0 + lane; const bool f = r < E && flag[r] != 0;
@@ -3429,22 +3434,22 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
 #endif
             base += __builtin_popcountll(m);
         }
-        wsync();
+        wsync_mem();
         for(int k = lane; k < E; k += ALD_WAVE) if(!(H.hflag[k] & RAW_DEAD)) H.eid[k] = (EID)nrank[H.eid[k]];
-        wsync();
+        wsync_mem();
         if(lane == 0) {
             for(int k = 0; k < E; k++) if(H.hflag[k] & RAW_DEAD) { H.hflag[k] = 0; kill_edge_i(k); }
             HC.next_id = base;
             for(int i = 1; i < n; i++) if(H.vx[i].in_deg == 0 && H.vx[i].out_deg == 0) H.nz[i] = 0;      // (nonzeroset is taken after the pre-steps: scallop.cc:1664-1673)
         }
-        wsync();
+        wsync_mem();
     }
     // ---- phases: exon coordinates -> vertex lists (one phase per lane), equal lists fold their counts
     ALD_GLOBAL int32_t *tv = C.wi + RAW_TV;                                   // [0] = number of lists, [1 ..] offsets (NPH + 1), then counts (NPH)
     ALD_GLOBAL int32_t *tv_off = tv + 1, *tv_cnt = tv + 1 + RAW_TV_CAP + 1;
     ALD_GLOBAL int32_t *vtx = (ALD_GLOBAL int32_t*)C.wd;
-    if(NPH > RAW_TV_CAP) { if(lane == 0) fail(ALD_ST_CAPACITY); wsync(); return false; }
-    if(NPH == 0) { if(lane == 0) { tv[0] = 0; tv_off[0] = 0; } wsync(); return true; }
+    if(NPH > RAW_TV_CAP) { if(lane == 0) fail(ALD_ST_CAPACITY); wsync_mem(); return false; }
+    if(NPH == 0) { if(lane == 0) { tv[0] = 0; tv_off[0] = 0; } wsync_mem(); return true; }
     // are the vertices' left / right ends in ascending order (they are, for a splice graph)?  Then a coordinate is found by bisection
     bool unsorted = false;
     for(int i = 1 + lane; i < n; i += ALD_WAVE) { if(C.vx[i].lpos > C.vx[i + 1].lpos) unsorted = true; if(i + 1 < n && C.vx[i].rpos > C.vx[i + 1].rpos) unsorted = true; }
@@ -3480,15 +3485,15 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
         }
         // offsets of the chunk's lists: a serial prefix over the wave's lengths through the LDS scratch
         if(p < NPH) HC.scr_i[8 + lane] = len;
-        wsync();
+        wsync_mem();
         if(lane == 0) { const int cnt = (NPH - p0) < ALD_WAVE ? (NPH - p0) : ALD_WAVE; int run = total; for(int l = 0; l < cnt; l++) { tv_off[p0 + l] = run; const int x = HC.scr_i[8 + l]; tv_cnt[p0 + l] = x < 0 ? -1 : 0; if(x > 0) run += x; } HC.scr_i[7] = run; }
-        wsync();
+        wsync_mem();
         total = uni(HC.scr_i[7]);
     }
-    if(wballot(assert_hit)) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER); wsync(); return false; }
-    if(total > RAW_VTX_CAP) { if(lane == 0) fail(ALD_ST_CAPACITY); wsync(); return false; }
+    if(wballot(assert_hit)) { if(lane == 0) fail(ALD_ST_INVARIANT + ALD_INV_OTHER); wsync_mem(); return false; }
+    if(total > RAW_VTX_CAP) { if(lane == 0) fail(ALD_ST_CAPACITY); wsync_mem(); return false; }
     if(lane == 0) tv_off[NPH] = total;
-    wsync();
+    wsync_mem();
     // pass 2: the vertex lists themselves
     for(int p = lane; p < NPH; p += ALD_WAVE) {
         if(tv_cnt[p] < 0) continue;
@@ -3501,7 +3506,7 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
             for(int j = a; j <= b; j++) vtx[w++] = j;
         }
     }
-    wsync();
+    wsync_mem();
     // equal lists are ONE node of hyper_set::nodes (a std::map keyed by the list): the first of them takes the counts of all
     for(int p = lane; p < NPH; p += ALD_WAVE) {
         if(tv_cnt[p] < 0) continue;
@@ -3513,17 +3518,17 @@ ALD_FN bool pre_assemble_device(int dist, int V, int E, ALD_GLOBAL const int32_t
         }
         if(rep != p) tv_cnt[p] = -2 - rep;                                                    // folded into list `rep`
     }
-    wsync();
+    wsync_mem();
     for(int p = lane; p < NPH; p += ALD_WAVE) {
         if(tv_cnt[p] != 0) continue;                                                          // a representative: its own count + the counts of its copies
         int c = phn[p];
         for(int q = p + 1; q < NPH; q++) if(tv_cnt[q] == -2 - p) c += phn[q];
         tv_cnt[p] = c;
     }
-    wsync();
+    wsync_mem();
     for(int p = lane; p < NPH; p += ALD_WAVE) if(tv_cnt[p] < 0) tv_cnt[p] = 0;                // dropped or folded: build_edges skips a count <= 1
     if(lane == 0) tv[0] = NPH;
-    wsync();
+    wsync_mem();
     return true;
 }
 #else
@@ -3612,10 +3617,10 @@ ALD_FN void finish_graph()
             A->out.graph_first[g] = base;
             HC.scr_i[0] = (int32_t)(uint32_t)((unsigned long long)base & 0xFFFFFFFFull); HC.scr_i[1] = (int32_t)(uint32_t)((unsigned long long)base >> 32);
         }
-        wsync();
+        wsync_mem();
         const long long base = (long long)(((unsigned long long)(uint32_t)uni(HC.scr_i[1]) << 32) | (unsigned long long)(uint32_t)uni(HC.scr_i[0]));
         if(base >= 0) for(int i = lane_id(); i < np; i += ALD_WAVE) A->out.index[base + i] = C.po[i];
-        wsync();
+        wsync_mem();
     }
     if(lane_id() == 0) {
         ALD_GLOBAL const KernelArgs *A = HC.args; const int g = HC.g;
@@ -3625,7 +3630,7 @@ ALD_FN void finish_graph()
 #endif
         if(A->out.trace_cap > 0) A->out.trace_n[g] = HC.n_trace;
     }
-    wsync();
+    wsync_mem();
 }
 
 // ---------------------------------------------------------------- scallop::assemble (scallop.cc:38-188)

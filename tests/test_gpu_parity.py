@@ -838,8 +838,9 @@ def test_reference_tset_golden_through_the_device_reduction():
 
 def test_barrier_variant_of_the_hand_overs():
     """wsync() is a wavefront-scope fence (no instruction), so every lane-to-lane hand-over through LDS / the slabs relies on
-    same-wave in-order memory.  libaletsch_decomp_wsync.so is the same source with __syncthreads() at every hand-over (make WSYNC=1:
-    a full s_waitcnt drain each time).  A fixed-seed fuzz slice through it against the oracle must be as clean as through the product
+    same-wave in-order memory.  libaletsch_decomp_wsync.so is the same source with __syncthreads() + an explicit s_waitcnt at every hand-over
+    (make WSYNC=1: every memory counter waited for each time; until round 4 the compiler had lowered the __syncthreads() of a one-wave workgroup
+    to nothing).  A fixed-seed fuzz slice through it against the oracle must be as clean as through the product
     build -- a divergence between the two forms would show here and not only in the ad-hoc fuzz tool.  Since round 4 the same build keeps
     the sweep records between sweeps in EVERY size class (-DALD_KEEP=1; the product: slab-resident classes only), so that the marks, the
     dense pass over the marked vertices and the prefetching scan -- device-only code -- run on every graph of the slice."""
@@ -851,6 +852,20 @@ def test_barrier_variant_of_the_hand_overs():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith("TOTAL graphs") and last.endswith("mismatches 0") and int(last.split()[2]) >= 1000, r.stdout[-1500:]
+
+
+def test_register_form_of_the_small_fans_on_the_twins():
+    """Round 4: the build that routes fans of 2..4 edges through star_reg instead of star_fixed (make STARREG=1) ended in a memory fault on
+    the slab-resident twins while their lane-to-lane hand-overs were fences only; since those classes wait for the wave's memory counters at
+    every hand-over (decomp_common.h, wsync()) it is bit-exact.  200 graphs of 385..512 vertices, every one forced onto the twins, through
+    that build and through the product, against the oracle."""
+    import subprocess, sys
+    libs = [os.path.join(common.ROOT, "aletsch_amd", "lib", n) for n in ("libaletsch_decomp.so", "libaletsch_decomp_starreg.so")]
+    assert os.path.exists(libs[1]), "build it with make -C aletsch_amd/csrc STARREG=1 (python __graft_entry__.py does)"
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "tools", "twins_parity.py"), *libs], capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-1500:]
+    totals = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("TOTAL graphs")]
+    assert len(totals) == 2 and all(ln.strip().endswith("mismatches 0") for ln in totals), r.stdout[-2500:]
 
 
 def test_row_form_of_the_kernels_on_gpu():
