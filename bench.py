@@ -555,8 +555,8 @@ def main() -> int:
             el = float(te.item())
         if os.environ.get("ALD_BENCH_STAGES"):
             n_st = max(1, w + k + ahead)
-            sys.stderr.write("[bench] %d + %d %s steps: add %.1f ms, upload %.1f ms per batch; timed steps: main waited for a staged batch %.1f ms; main thread: sync %.1f ms, launch %.2f ms, download %.1f ms; exchange thread %.1f ms (per step)\n"
-                             % (w, k, "staged" if staged else "resident", 1e3 * stage_s[0] / n_st, 1e3 * stage_s[1] / n_st, 1e3 * stage_s[2] / k, 1e3 * main_s[0] / k, 1e3 * main_s[1] / k, 1e3 * main_s[2] / k, 1e3 * stage_s[3] / k))
+            sys.stderr.write("[bench] %d + %d %s steps: add %.1f ms, upload %.1f ms per batch; timed steps: main waited for a staged batch %.1f ms; main thread: sync %.1f ms, launch %.2f ms, download %.1f ms; exchange thread %.1f ms (per step); kernel %.2f ms per launch (HIP events)\n"
+                             % (w, k, "staged" if staged else "resident", 1e3 * stage_s[0] / n_st, 1e3 * stage_s[1] / n_st, 1e3 * stage_s[2] / k, 1e3 * main_s[0] / k, 1e3 * main_s[1] / k, 1e3 * main_s[2] / k, 1e3 * stage_s[3] / k, sum(ms) / max(1, len(ms))))
         if os.environ.get("ALD_BENCH_STAGES") and dist_on and xs[3]:
             sys.stderr.write("[bench]   exchange thread per batch: device stream %.1f ms, gather enqueue %.1f ms, wait until read %.1f ms\n" % (1e3 * xs[0] / xs[3], 1e3 * xs[1] / xs[3], 1e3 * xs[2] / xs[3]))
         return el, ms
