@@ -84,12 +84,13 @@ int occupancy_for(ald_batch *b, int c)
 // One pass = one persistent grid per size class that has work.  Staging (work lists and kernel arguments in HBM, slabs sized,
 // classes dealt to the side streams) is separate from firing, so that the first pass of a batch is staged once, at upload time:
 // a run is then three memsets and the launches.
-int push_pass(ald_batch *b, const StagedPass &P)         // work lists + arguments -> HBM
+int push_pass(ald_batch *b, const StagedPass &P, hipStream_t s = nullptr)         // work lists + arguments -> HBM (s: the stream the copies go through; default the batch's)
 {
     if(P.tot == 0) return ALD_OK;
-    HIPCHK(hipMemcpyAsync(b->d_work.p, P.flat.data(), 4 * P.tot, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(b->d_args.p, P.args.data(), sizeof(KernelArgs) * ALD_NUM_SLOTS, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    if(!s) s = b->stream;
+    HIPCHK(hipMemcpyAsync(b->d_work.p, P.flat.data(), 4 * P.tot, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_args.p, P.args.data(), sizeof(KernelArgs) * ALD_NUM_SLOTS, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
     return ALD_OK;
 }
 
@@ -161,7 +162,7 @@ int stage_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], i
         int st = 0; for(int z = 1; z < n_big; z++) if(load[z] < load[st]) st = z;
         load[st] += cost[k]; P.stream_of[k] = st;
     }
-    return push_pass(b, P);
+    return push_pass(b, P, pass == 0 ? b->up_stream : nullptr);      // (pass 0 is staged by ald_batch_upload: its copies keep to the upload stream)
 }
 
 // Buffers that a retry pass or a pool growth may have moved since pass 0 was staged (DevBuf::ensure frees and reallocates): the
@@ -244,6 +245,13 @@ int ald_batch_create(const ald_params *p, int device, ald_batch **out)
     bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev1) == hipSuccess;
     if(const char *ev = getenv("ALD_SIDE_STREAMS")) { const int k = atoi(ev); if(k >= 1 && k <= ALD_SIDE_STREAMS_MAX) b->n_cstream = k; }      // tuning knob
     for(int q = 0; q < b->n_cstream && ok; q++) ok = hipStreamCreateWithFlags(&b->cstream[q], hipStreamNonBlocking) == hipSuccess;
+    const int up_mode = getenv("ALD_UPLOAD_STREAM") ? atoi(getenv("ALD_UPLOAD_STREAM")) : 2;      // 0: uploads through the batch's own stream (A/B); 1: a stream of the lowest priority; 2: of the highest (default: DMA copies take nothing from a kernel, and they finish sooner: 24 against 31 ms per 1.35 GB batch)
+    if(ok && up_mode != 0) {
+        int least = 0, greatest = 0;
+        if(hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+            if(hipStreamCreateWithPriority(&b->up_stream, hipStreamNonBlocking, up_mode == 2 ? greatest : least) != hipSuccess) b->up_stream = nullptr;      // (without it: the batch's stream, as before)
+        }
+    }
     for(int c = 0; c < ALD_NUM_SLOTS && ok; c++) ok = hipEventCreateWithFlags(&b->cdone[c], hipEventDisableTiming) == hipSuccess;
     if(!ok) { ald_batch_destroy(b); return set_err(ALD_ERR_HIP, "stream/event creation failed"); }
     *out = b;
@@ -266,6 +274,7 @@ int ald_batch_destroy(ald_batch *b)
     for(int c = 0; c < ALD_NUM_SLOTS; c++) if(b->cdone[c]) hipEventDestroy(b->cdone[c]);
     if(b->ev0) hipEventDestroy(b->ev0);
     if(b->ev1) hipEventDestroy(b->ev1);
+    if(b->up_stream) { hipStreamSynchronize(b->up_stream); hipStreamDestroy(b->up_stream); }
     if(b->stream) hipStreamDestroy(b->stream);
     delete b;
     return ALD_OK;
@@ -345,13 +354,15 @@ int ald_batch_upload(ald_batch *b)
     if(!b) return ALD_ERR_INVALID;
     HIPCHK(hipSetDevice(b->device));
     const int n = b->hb.n();
+    hipStream_t us = b->up_stream ? b->up_stream : b->stream;
+    if(us != b->stream && b->ran && !b->downloaded) HIPCHK(hipStreamSynchronize(b->stream));      // a run whose results were never fetched may still read the input buffer
     b->in_bytes = b->hb.layout(b->sec);
     if(b->d_in.ensure(b->in_bytes)) return set_err(ALD_ERR_NOMEM, "device input buffer");
     // ONE buffer on the device, its sections filled straight from the batch's host arrays: they live in pinned memory (wire_alloc, hooks
     // installed by ald_batch_create), so every section is one asynchronous copy of the DMA engine and no host thread packs anything
     // (the pack into a second, pinned buffer -- 1.3 GB read and written, 20 ms on sixteen threads -- was as long as the PCIe transfer itself)
     for(int i = 0; i < HostBatch::S_COUNT; i++)
-        if(b->sec[i].bytes) HIPCHK(hipMemcpyAsync((uint8_t*)b->d_in.p + b->sec[i].off, b->sec[i].src, b->sec[i].bytes, hipMemcpyHostToDevice, b->stream));
+        if(b->sec[i].bytes) HIPCHK(hipMemcpyAsync((uint8_t*)b->d_in.p + b->sec[i].off, b->sec[i].src, b->sec[i].bytes, hipMemcpyHostToDevice, us));
     // outputs
     // a heuristic, not a bound (one graph can need about (E - V + 2) * (V + 14) words): a graph that finds the pool full reports
     // ALD_ST_POOL_FULL and ald_batch_download grows the pool.  ALD_DEBUG_POOL_WORDS starts it small so that tests reach that path.
@@ -364,9 +375,10 @@ int ald_batch_upload(ald_batch *b)
         return set_err(ALD_ERR_NOMEM, "device output buffers");
     if(b->trace_cap > 0) {
         if(b->d_trace_n.ensure(4 * (size_t)n + 4) || b->d_trace_codes.ensure(12ull * n * b->trace_cap + 4) || b->d_trace_vals.ensure(8ull * n * b->trace_cap + 8)) return set_err(ALD_ERR_NOMEM, "trace buffers");
-        HIPCHK(hipMemsetAsync(b->d_trace_n.p, 0, 4 * (size_t)n + 4, b->stream));
+        HIPCHK(hipMemsetAsync(b->d_trace_n.p, 0, 4 * (size_t)n + 4, us));
     }
-    HIPCHK(hipStreamSynchronize(b->stream));
+    // (no wait here: the host work below needs the batch's host arrays only and runs while the DMA engines move them; push_pass, at the end of
+    // stage_pass, waits for the stream -- the copies above included)
     // the first pass is part of what "resident" means: size class of every graph, longest-processing-time-first order inside a class
     // (the persistent waves pull graphs in list order, so the big graphs of a class start early and the tail is made of small ones),
     // work lists and kernel arguments in HBM
@@ -434,9 +446,10 @@ int ald_batch_upload(ald_batch *b)
             std::stable_sort(work[c].begin(), work[c].end(), [&](int32_t x, int32_t y) { return b->hb.g_ne[x] > b->hb.g_ne[y]; });
         if(!b->pass0) b->pass0 = new StagedPass();
         int rc = stage_pass(b, work, 0, *b->pass0);
-        if(rc != ALD_OK) return rc;
+        if(rc != ALD_OK) { hipStreamSynchronize(us); return rc; }
         b->pass0_on_device = true;
     }
+    HIPCHK(hipStreamSynchronize(us));             // (a batch without work never reached push_pass)
     b->uploaded = true; b->ran = false; b->downloaded = false;
     return ALD_OK;
 }

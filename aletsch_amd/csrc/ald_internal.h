@@ -41,6 +41,11 @@ struct ald_batch {
     HostBatch::Section sec[HostBatch::S_COUNT];
     uint64_t in_bytes = 0;
     hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // ald_batch_upload's copies go through a stream of another PRIORITY class: the runtime maps the streams of one priority onto a small
+    // pool of hardware queues (GPU_MAX_HW_QUEUES), a queue runs its packets in order, and a batch's 34 input copies (25 ms of DMA) in front
+    // of ANOTHER batch's kernel launch on the same queue delayed that kernel by 3-4 ms per step of a pipelined caller
+    // (profiles/r04/zc_h2d_inclusive_step.txt).  Streams of a different priority have queues of their own.
+    hipStream_t up_stream = nullptr;
     // the size classes run concurrently on a few side streams.  Not one per class: a process only gets a handful of hardware queues
     // (4 by default) and streams beyond that share them in creation order, which can put the two heaviest classes behind each other
     hipStream_t cstream[ALD_SIDE_STREAMS_MAX] = {}; int n_cstream = ALD_SIDE_STREAMS;
