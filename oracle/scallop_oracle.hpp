@@ -17,6 +17,9 @@
  *   - graph-layer ordering / toposort / components (graph/*.cc) -> _ref/ref_graph, tests/golden/ref_graph.json
  *   - the result sink (rnacore/transcript_set.cc, gtf/transcript.cc) -> _ref/ref_tset, tests/golden/ref_tset.json
  *     (all three in tests/test_oracle_pins.py / tests/test_tset_cpu.py)
+ * Corroboration, NOT a pin: the Router below reproduces 240 + 150 one-vertex cases computed by the reference's own scallop/router.cc
+ * (oracle/_ref/ref_router, tests/golden/ref_router.json) -- but that binary takes seven splice_graph members from our driver
+ * (oracle/ref_drivers/ref_router_main.cc), because rnacore/splice_graph.cc cannot be compiled here.
  * and, as a band only, the aggregates the survey measured on the real reference: paths per graph,
  * rule mix, router evaluations, graph growth (tests/test_oracle_pins.py).
  *
