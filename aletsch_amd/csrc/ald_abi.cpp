@@ -9,6 +9,9 @@
 #include <chrono>
 #include <iterator>
 #include <mutex>
+#include <atomic>
+#include <map>
+#include <unordered_map>
 #include <string>
 #include <cstdlib>
 #include <cstdio>
@@ -224,9 +227,49 @@ int ald_default_params(ald_params *p)
 }
 
 namespace {
-// pinned host memory for the arrays of a batch (host_pack.h: wire_alloc): portable, so that any device of the process can read it
-void *wire_pinned_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) == hipSuccess ? p : nullptr; }
-void wire_pinned_release(void *p) { if(p) hipHostFree(p); }
+// pinned host memory for the arrays of a batch (host_pack.h: wire_alloc): portable, so that any device of the process can read it.
+// The arrays are std::vectors: every growth is an allocation, a copy and a release, and hipHostFree SYNCHRONISES with the device -- a pack
+// thread growing an array would stall the kernel of another slot.  So released blocks are not freed but kept, by size class (four
+// classes per power of two: a request is rounded up by at most a quarter), and handed out again; what is kept is capped (ALD_PINNED_CACHE_MB,
+// default 4096 -- the footprint of four 100 000-graph slots is 5.4 GB of live arrays; beyond the cap a release is a real hipHostFree).
+// ald_batch_destroy of the last batch of the process frees the cache.
+struct PinnedCache {
+    std::mutex m;
+    std::unordered_map<void*, size_t> size_of;                 // live and cached blocks -> rounded size
+    std::map<size_t, std::vector<void*>> free_by_size;
+    size_t cached_bytes = 0, cap_bytes = (size_t)4096 << 20;
+    PinnedCache() { if(const char *ev = getenv("ALD_PINNED_CACHE_MB")) { const long long k = atoll(ev); if(k >= 0) cap_bytes = (size_t)k << 20; } }
+    static size_t round_up(size_t b) { if(b < 4096) return 4096; size_t p2 = 4096; while(p2 < b) p2 <<= 1; const size_t q = p2 >> 3; return (b + q - 1) / q * q; }     // (p2/2, p2] in four steps
+    void *get(size_t bytes) {
+        const size_t r = round_up(bytes);
+        { std::lock_guard<std::mutex> lk(m);
+          auto it = free_by_size.find(r);
+          if(it != free_by_size.end() && !it->second.empty()) { void *p = it->second.back(); it->second.pop_back(); cached_bytes -= r; return p; } }
+        void *p = nullptr;
+        if(hipHostMalloc(&p, r, hipHostMallocPortable) != hipSuccess) {       // out of pinned memory: give the cache back and try once more
+            drop_all(); p = nullptr;
+            if(hipHostMalloc(&p, r, hipHostMallocPortable) != hipSuccess) return nullptr;
+        }
+        std::lock_guard<std::mutex> lk(m); size_of[p] = r; return p;
+    }
+    void put(void *p) {
+        if(!p) return;
+        { std::lock_guard<std::mutex> lk(m);
+          auto it = size_of.find(p);
+          if(it != size_of.end() && cached_bytes + it->second <= cap_bytes) { free_by_size[it->second].push_back(p); cached_bytes += it->second; return; }
+          if(it != size_of.end()) size_of.erase(it); }
+        hipHostFree(p);
+    }
+    void drop_all() {
+        std::vector<void*> v;
+        { std::lock_guard<std::mutex> lk(m); for(auto &kv : free_by_size) { for(void *p : kv.second) { v.push_back(p); size_of.erase(p); } kv.second.clear(); } cached_bytes = 0; }
+        for(void *p : v) hipHostFree(p);
+    }
+};
+PinnedCache &pinned_cache() { static PinnedCache *c = new PinnedCache(); return *c; }      // (never destroyed: batches may outlive static destruction order)
+std::atomic<int> g_live_batches{0};
+void *wire_pinned_alloc(size_t bytes) { return pinned_cache().get(bytes ? bytes : 1); }
+void wire_pinned_release(void *p) { pinned_cache().put(p); }
 struct WireHooksInstaller { WireHooksInstaller() { wire_hooks().alloc = wire_pinned_alloc; wire_hooks().release = wire_pinned_release; } } g_wire_hooks_installer;
 }
 
@@ -240,6 +283,7 @@ int ald_batch_create(const ald_params *p, int device, ald_batch **out)
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     ald_batch *b = new ald_batch();
+    g_live_batches.fetch_add(1);
     b->device = device; b->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     params_from_abi(p, b->prm);
     bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev1) == hipSuccess;
@@ -277,6 +321,7 @@ int ald_batch_destroy(ald_batch *b)
     if(b->up_stream) { hipStreamSynchronize(b->up_stream); hipStreamDestroy(b->up_stream); }
     if(b->stream) hipStreamDestroy(b->stream);
     delete b;
+    if(g_live_batches.fetch_sub(1) == 1) pinned_cache().drop_all();      // the last batch of the process: the kept pinned blocks go back
     return ALD_OK;
 }
 

@@ -109,33 +109,32 @@
       while(tied) { const int l = __ffsll(tied) - 1; tied &= tied - 1; const int v = __builtin_amdgcn_readlane(vv, l); best = v > best ? v : best; }
       rr = __longlong_as_double((long long)kmin); vv = best;
   }
-  // workgroup == ONE wavefront: lanes of a wave execute in lock step and the hardware performs a wave's LDS instructions in issue order,
-  // so handing data from one lane to another THROUGH LDS needs no s_barrier and no wait on the memory counters -- only that the compiler
-  // keeps the accesses on their side of the hand-over (LLVM AMDGPU memory model: a fence at "wavefront" scope emits no instruction).
-  // __syncthreads() here cost an s_waitcnt + s_barrier at every one of the few thousand hand-overs a graph takes.
+  // workgroup == ONE wavefront: lanes of a wave execute in lock step and the hardware performs a wave's LDS instructions in issue order and its
+  // vector-memory instructions in issue order, so handing data from one lane to another -- through LDS or through the wave's slab in global
+  // memory -- needs no s_barrier and no wait on the memory counters, only that the compiler keeps the accesses on their side of the hand-over
+  // (LLVM AMDGPU memory model: a fence at "wavefront" scope emits no instruction).  __syncthreads() here cost an s_waitcnt + s_barrier at every
+  // one of the few thousand hand-overs a graph takes.  tools/microbench/lane_raw.hip checks the global-memory half of that sentence on gfx950:
+  // a 16- or 32-bit store by one lane, the fence, a 64-bit load of the record by all 64 lanes, the line in L1 or not, up to 3 072 waves:
+  // no stale read in 4 x 10^9 (profiles/r04/zb_slab_handover_drain.txt).
   //
-  // Hand-overs THROUGH GLOBAL MEMORY are another matter (round 4).  The classes that keep the graph arrays in the wave's HBM slab (10..13)
-  // pass list links, degrees and the kept sweep records from lane to lane through the slab.  A build that routes every small fan through
-  // star_reg (-DALD_STARFIX_MAX=1) ended in a memory fault on the twins' 385..512-vertex graphs with the fence-only hand-over, in every run;
-  // with a wait for the wave's memory counters at every hand-over of those classes the same build is bit-exact against the oracle
-  // (profiles/r04/zb_slab_handover_drain.txt).  Which hand-over needs the wait was not isolated -- waits at the kept records' hand-overs and
-  // in front of the stars' tails alone did not cure it --, so in these classes EVERY hand-over waits: wsync() == wsync_mem().  Cost: the
-  // 385..512 band on the twins 66.5 -> 67.8 ms, the mixed batch 88.3 -> 88.5 ms (same file); the LDS classes are not touched.
-  // (-DALD_SLAB_NO_DRAIN: the fence-only form in all classes, for A/B.)
-  //
-  // The wait is written as an explicit s_waitcnt: a fence at "workgroup" scope -- and __syncthreads() -- emit NOTHING in these kernels, which
-  // are launched with a workgroup of exactly one wave: the compiler lowers workgroup scope to wavefront scope then (the s_waitcnt count of
-  // the ISA does not change), so the -DALD_WSYNC_BARRIER test build of rounds 2 / 3 ordered the compiler but waited for nothing; it carries the explicit wait now.
+  // Round 4 chased a memory fault of a test build on the slab-resident twins through these hand-overs -- explicit waits at every one of them
+  // cured it -- before finding the cause elsewhere: VGPR spills placed by the register allocator inside a two-instruction region of narrowed
+  // EXEC (decomp_device.h: ev_clear_marks); the waits had only moved the spills.  Two things learnt on the way stay: a fence at "workgroup"
+  // scope and __syncthreads() emit NOTHING in these kernels either (workgroup == one wave: the compiler lowers the scope), so a hand-over
+  // that is meant to wait says so with an explicit s_waitcnt (wsync_mem()); and -DALD_SLAB_DRAIN makes every hand-over of the slab-resident
+  // classes wait (twins' band 66.5 -> 67.8 ms), for A/B.
   #define ALD_WSYNC_WAIT_() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while(0)
   #if defined(ALD_WSYNC_BARRIER)
   __device__ __forceinline__ void     wsync() { __syncthreads(); __builtin_amdgcn_s_waitcnt(0); }
-  #elif defined(ALD_CLASS_ID) && ALD_CLASS_ID >= ALD_FIRST_GLOBAL_CLASS && !defined(ALD_SLAB_NO_DRAIN)
+  #elif defined(ALD_SLAB_DRAIN) && defined(ALD_CLASS_ID) && ALD_CLASS_ID >= ALD_FIRST_GLOBAL_CLASS
   __device__ __forceinline__ void     wsync() { ALD_WSYNC_WAIT_(); }
   #else
   __device__ __forceinline__ void     wsync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
   #endif
-  // wsync_mem(): the hand-over that waits in EVERY class -- for the routines whose lanes exchange values through the slab whatever the class
-  // (collecting the finished paths, finish_graph, the device pre-steps, the kept sweep records of a -DALD_KEEP=1 test build).
+  // wsync_mem(): the hand-over that waits for the wave's memory counters (s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)) in every class: where the
+  // slab-resident classes hand the kept sweep records from the lane that evaluated a vertex to the lane that owns it, and in the routines
+  // whose lanes exchange through the slab whatever the class (collecting finished paths, finish_graph, the device pre-steps).  Not needed for
+  // ordering (see above) and not measurable in time; it bounds how far a wave runs ahead of its own stores at these few places.
   #ifdef ALD_WSYNC_BARRIER
   __device__ __forceinline__ void     wsync_mem() { __syncthreads(); __builtin_amdgcn_s_waitcnt(0); }
   #else

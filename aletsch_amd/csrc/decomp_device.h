@@ -298,6 +298,32 @@ ALD_INL void ev_mark_all()
     #endif
 #endif
 }
+// All marks off (ALL lanes call it).  Written WITHOUT a divergent region -- every lane stores, lanes beyond the last word store to the last word
+// again --: as `if(lane == 0) ...; for(k = lane; k < words; ...)` these were two-instruction regions of narrowed EXEC at the point where the
+// sweep's register pressure peaks, and in one build of round 4 the register allocator put four VGPR spills INSIDE one of them: the spill saved
+// the active lanes only, the reload after the sweep ran under full EXEC, and the other lanes went on with what the scratch slot held before
+// (the memory fault of the -DALD_STARFIX_MAX=1 test build on the twins; tools/isa_spill_audit.py finds the pattern in the assembly,
+// tests/test_abi_cpu.py runs it over every kernel of the product build).
+ALD_INL void ev_clear_marks(int vend)
+{
+#if ALD_KEEP
+    const int words = (vend + 31) / 32;
+    HC.ev_all = 0;
+    for(int base = 0; base < words; base += ALD_WAVE) { const int k = base + lane_id(); HC.ev_dirty[k < words ? k : words - 1] = 0; }     // (wave-uniform trip count, every lane stores)
+#else
+    (void)vend;
+#endif
+}
+ALD_INL void tv_clear_marks(int nv_now)
+{
+#if ALD_KEEP && ALD_KEEP_TRIV
+    const int words = (nv_now + 31) / 32;
+    HC.tv_all = 0;
+    for(int base = 0; base < words; base += ALD_WAVE) { const int k = base + lane_id(); HC.tv_dirty[k < words ? k : words - 1] = 0; }
+#else
+    (void)nv_now;
+#endif
+}
 // v's in- (out = false) or out-degree went from `before` to `after`.  v itself is marked; and when the degree crossed the 1 | 2 line, every
 // vertex at the far end of an edge of that list: its evaluation tests exactly this degree (out_deg(s) > 1 for an in-edge s -> j, in_deg(t)
 // > 1 for an out-edge j -> t: scallop.cc:858-896).  out(source) / in(sink) are not linked before the final phase: "everything" then.
@@ -1829,16 +1855,19 @@ ALD_INL void decompose_trivial_vertex_wave(int x)
 }
 
 // scallop::decompose_vertex_extend (scallop.cc:1675-1986); pe2w = n sorted pairs in the work area
-// SMALL: pe2w and the work arrays are in the LDS scratch (known address space -> ds_* accesses); otherwise wherever the router and
-// the capacity rules put them
+// SMALL: pe2w and the work arrays are in the LDS scratch; otherwise BOTH are in the slab (decompose_vertex_extend_any moves pe2w there
+// first when the router left it in LDS).  Either way every pointer of an instance has ONE address space the compiler can see: ds_* or
+// global_* accesses, never FLAT ones.  (Round 4: with the place chosen at run time this routine and save / restore_pairs were the only
+// code of the engine that compiled to flat_load / flat_store -- 69 of them.  A FLAT access that ends in LDS travels through the vector
+// memory path and is not ordered against the wave's DS instructions to the same LDS words -- the scratch every other routine uses.)
 template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
 {
     COLD;
-    const Pairs P = SMALL ? pairs_at(true, false) : pairs_cur();
+    const Pairs P = pairs_at(SMALL, false);
     int32_t *a = P.a, *b = P.b; double *w = P.w;
     const int deg = (int)uni(H.vx[root].in_deg) + (int)uni(H.vx[root].out_deg);
     // the visiting order of the nested decompositions (jump_ratio > 1 only) must survive them: it always lives in the slab
-    const Arena AR = SMALL ? arena_at(true) : arena_at(4 * deg <= ARENA_I && deg <= ARENA_D && !(HC.p_ratio[7] > 1.0));
+    const Arena AR = arena_at(SMALL);
     if(ALD_UNLIKELY(4 * deg > AR.cap_i || deg > AR.cap_d || deg > C.w_cap / 16)) { fail(ALD_ST_CAPACITY); return; }
     int nloc = 0; int32_t *loc_e = AR.i;
     // (Tried: asking for the cold records of the root's edges and of the vertices at their far ends right here, with loads nobody waits
@@ -1935,7 +1964,22 @@ template<bool SMALL> ALD_INL void decompose_vertex_extend_body(int root, int n)
 }
 
 ALD_FN void decompose_vertex_extend_small(int root, int n) { decompose_vertex_extend_body<true>(uni(root), uni(n)); }
-ALD_FN void decompose_vertex_extend_any(int root, int n) { decompose_vertex_extend_body<false>(uni(root), uni(n)); }
+template<bool LDS> ALD_INL void copy_pairs(bool from_parked, bool to_parked, int n)
+{
+    const Pairs S = pairs_at(LDS, from_parked), D = pairs_at(LDS, to_parked);
+    for(int i = 0; i < n; i++) { D.a[i] = S.a[i]; D.b[i] = S.b[i]; D.w[i] = S.w[i]; }
+}
+ALD_FN void decompose_vertex_extend_any(int root, int n)
+{
+    root = uni(root); n = uni(n);
+    if(uni(HC.pw_lds) != 0) {                        // pe2w from the LDS scratch to the slab's area: the general form addresses the slab only
+        const Pairs S = pairs_at(true, false), D = pairs_at(false, false);
+        if(ALD_UNLIKELY(n > D.cap)) { fail(ALD_ST_CAPACITY); return; }
+        for(int i = 0; i < n; i++) { D.a[i] = S.a[i]; D.b[i] = S.b[i]; D.w[i] = S.w[i]; }
+        HC.pw_lds = 0;
+    }
+    decompose_vertex_extend_body<false>(root, n);
+}
 ALD_INL void decompose_vertex_extend(int root, int n)
 {
     root = uni(root); n = uni(n);
@@ -2166,8 +2210,7 @@ ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
   #endif
         }
         wsync_mem();                              // (as in sweep_smallest: the records travel through the slab)
-        if(lane == 0) HC.tv_all = 0;
-        for(int k = lane; k < (nv_now + 31) / 32; k += ALD_WAVE) HC.tv_dirty[k] = 0;
+        tv_clear_marks(nv_now);
         wsync();
     }
 #else
@@ -2412,8 +2455,7 @@ ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr)
     if(stale_all) { for(int c = 0; c < nch0; c++) eval_chunk(c, true, -1, -1); }
 #if ALD_KEEP
     wsync();
-    if(lane == 0) HC.ev_all = 0;
-    for(int k = lane; k < (vend + 31) / 32; k += ALD_WAVE) HC.ev_dirty[k] = 0;
+    ev_clear_marks(vend);
     wsync();
 #endif
     PROF_ADD(PF_T_MERGE_KILL);                   // (profiling build: bringing the kept evaluations up to date at the sweep's entry)
@@ -2465,7 +2507,7 @@ ALD_INL bool sweep_smallest_body(double max_ratio, int &fired, const bool tr)
             const bool all = uni(HC.hs_dirty) != 0 || (int)uni(H.vx[ds].out_deg) <= 1 || (int)uni(H.vx[dt].in_deg) <= 1;
             if(uni(HC.hs_dirty)) { if(lane == 0) hs_refresh_flags(); wsync(); }
 #if ALD_KEEP
-            if(all) { wsync(); if(lane == 0) HC.ev_all = 0; for(int k = lane; k < (vend + 31) / 32; k += ALD_WAVE) HC.ev_dirty[k] = 0; wsync(); }      // every vertex is evaluated again right here
+            if(all) { wsync(); ev_clear_marks(vend); wsync(); }      // every vertex is evaluated again right here
 #endif
             if(NC <= 2) { for(int c = 0; c < NC; c++) { int i = c * ALD_WAVE + lane; if(i >= 1 && i < vend && (all || i == ds || i == dt)) { cr[c] = 0; ce[c] = eval_smallest(i, cr[c]); } } }
             else if(all) { const int nch = (vend + ALD_WAVE - 1) / ALD_WAVE; for(int c = 0; c < nch; c++) eval_chunk(c, true, -1, -1); }
@@ -2934,19 +2976,17 @@ ALD_INL bool router_run(int root, int want_type, int max_degree, int pre = 0)
 ALD_FN void save_pairs(int n)
 {
     n = uni(n);
-    const bool lds = HC.pw_lds != 0;
-    const Pairs S = pairs_at(lds, false), D = pairs_at(lds, true);
-    if(ALD_UNLIKELY(n > D.cap)) { fail(ALD_ST_CAPACITY); return; }
-    for(int i = 0; i < n; i++) { D.a[i] = S.a[i]; D.b[i] = S.b[i]; D.w[i] = S.w[i]; }
+    const bool lds = uni(HC.pw_lds) != 0;
+    if(ALD_UNLIKELY(n > (lds ? (int)LP : (int)PW_CAP))) { fail(ALD_ST_CAPACITY); return; }
+    if(lds) copy_pairs<true>(false, true, n); else copy_pairs<false>(false, true, n);      // (one address space per copy: no FLAT accesses)
     HC.park_lds = lds ? 1 : 0;
 }
 ALD_FN void restore_pairs(int n)
 {
     n = uni(n);
-    const bool lds = HC.park_lds != 0;
+    const bool lds = uni(HC.park_lds) != 0;
     HC.pw_lds = lds ? 1 : 0;
-    const Pairs S = pairs_at(lds, true), D = pairs_at(lds, false);
-    for(int i = 0; i < n; i++) { D.a[i] = S.a[i]; D.b[i] = S.b[i]; D.w[i] = S.w[i]; }
+    if(lds) copy_pairs<true>(true, false, n); else copy_pairs<false>(true, false, n);
 }
 // forget every vertex's remembered router class (the graph changed); called by ALL lanes
 ALD_INL void memo_clear()

@@ -130,3 +130,29 @@ def test_dispatcher_conversion_matches_the_two_step_form():
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe, "400"], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
+
+
+def test_spill_audit_recognises_the_pattern():
+    """tools/isa_spill_audit.py on a cut of the assembly that faulted in round 4 (four spills inside the mark-clearing region of narrowed EXEC,
+    reloaded under full EXEC) and on the harmless shapes beside it (spills behind the widening s_or_b64, a spill / reload pair inside one region, a
+    value defined inside the region)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "tools", "isa_spill_audit.py"), os.path.join(common.ROOT, "tests", "golden", "isa_spill_in_narrowed_exec.s")], capture_output=True, text=True)
+    assert r.returncode == 1, r.stdout
+    flagged = [ln for ln in r.stdout.splitlines() if "is spilled at line" in ln or "are spilled at line" in ln]
+    assert len(flagged) == 4 and all("ald_decomp_kernel_c12:" in ln for ln in flagged), r.stdout
+
+
+def test_no_vgpr_spill_inside_a_region_of_narrowed_exec():
+    """Round 4's memory fault was the compiler's: the register allocator had put VGPR spills inside a region of narrowed EXEC, so that the lanes
+    inactive there lost their values at the reload (aletsch_amd/csrc/decomp_device.h: ev_clear_marks).  Nothing in the source forbids the next
+    build from doing it elsewhere, so the device assembly of EVERY kernel of the product build (`make isa`, hipcc cross-compiles without a GPU) is
+    searched for the pattern."""
+    import glob, shutil, subprocess, sys
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc: the assembly cannot be produced here")
+    subprocess.run(["make", "-C", os.path.join(common.ROOT, "aletsch_amd", "csrc"), "-j8", "isa"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    files = sorted(glob.glob(os.path.join(common.ROOT, "build", "csrc", "isa", "*.s")))
+    assert len(files) == 28, files
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "tools", "isa_spill_audit.py"), *files], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]

@@ -856,9 +856,10 @@ def test_barrier_variant_of_the_hand_overs():
 
 def test_register_form_of_the_small_fans_on_the_twins():
     """Round 4: the build that routes fans of 2..4 edges through star_reg instead of star_fixed (make STARREG=1) ended in a memory fault on
-    the slab-resident twins while their lane-to-lane hand-overs were fences only; since those classes wait for the wave's memory counters at
-    every hand-over (decomp_common.h, wsync()) it is bit-exact.  200 graphs of 385..512 vertices, every one forced onto the twins, through
-    that build and through the product, against the oracle."""
+    the slab-resident twins: in that build the register allocator had placed four VGPR spills inside a two-instruction region of narrowed EXEC
+    (profiles/r04/zb_slab_handover_drain.txt).  The source no longer has that region (ev_clear_marks) and the CPU tier searches the product's
+    assembly for the pattern; this test keeps the build that exposed it in the GPU tier: 200 graphs of 385..512 vertices, every one forced
+    onto the twins, through that build and through the product, against the oracle."""
     import subprocess, sys
     libs = [os.path.join(common.ROOT, "aletsch_amd", "lib", n) for n in ("libaletsch_decomp.so", "libaletsch_decomp_starreg.so")]
     assert os.path.exists(libs[1]), "build it with make -C aletsch_amd/csrc STARREG=1 (python __graft_entry__.py does)"
