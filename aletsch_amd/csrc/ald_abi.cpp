@@ -154,6 +154,12 @@ int stage_pass(ald_batch *b, const std::vector<int32_t> work[ALD_NUM_CLASSES], i
         P.order[P.nord++] = k;
     }
     std::sort(P.order, P.order + P.nord, [&](int x, int y) { return cost[x] > cost[y]; });
+    if(const char *ev = getenv("ALD_LDS_FIRST")) {       // experiment: the LDS classes are launched before the slab-resident ones (1), or only the large LDS classes 5..9 (2)
+        const int mode = atoi(ev);
+        if(mode > 0) std::stable_sort(P.order, P.order + P.nord, [&](int x, int y) {
+            auto first = [&](int k) { const int c = k % ALD_NUM_CLASSES; return mode == 1 ? c < ALD_FIRST_GLOBAL_CLASS : (c >= 5 && c < ALD_FIRST_GLOBAL_CLASS); };
+            return first(x) && !first(y); });
+    }
     // the last stream belongs to the small LDS classes (0..2: 16 KB of LDS per workgroup and less -- they fit beside anything and take a few
     // milliseconds: queued behind a large class they ran at the very end, cfg3's last 8 ms; profiles/r04/aa_cfg3_timeline_5_streams.txt),
     // the others are dealt to the remaining streams
