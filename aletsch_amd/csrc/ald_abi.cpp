@@ -423,9 +423,9 @@ int ald_batch_upload(ald_batch *b)
     b->index_cap = pool / (REC_HDR_WORDS + 2) + 1;         // a record is at least a header and two vertices long
     if(b->d_status.ensure(4 * (size_t)n + 4) || b->d_npaths.ensure(4 * (size_t)n + 4) || b->d_niters.ensure(4 * (size_t)n + 4) || b->d_pool.ensure(4 * pool + 64) || b->d_poolused.ensure(64)
        || b->d_index.ensure(8 * (size_t)b->index_cap + 64) || b->d_gfirst.ensure(8 * (size_t)n + 8))
-        return set_err(ALD_ERR_NOMEM, "device output buffers");
+        { hipStreamSynchronize(us); return set_err(ALD_ERR_NOMEM, "device output buffers"); }      // (the input copies are in flight: they read the batch's host arrays)
     if(b->trace_cap > 0) {
-        if(b->d_trace_n.ensure(4 * (size_t)n + 4) || b->d_trace_codes.ensure(12ull * n * b->trace_cap + 4) || b->d_trace_vals.ensure(8ull * n * b->trace_cap + 8)) return set_err(ALD_ERR_NOMEM, "trace buffers");
+        if(b->d_trace_n.ensure(4 * (size_t)n + 4) || b->d_trace_codes.ensure(12ull * n * b->trace_cap + 4) || b->d_trace_vals.ensure(8ull * n * b->trace_cap + 8)) { hipStreamSynchronize(us); return set_err(ALD_ERR_NOMEM, "trace buffers"); }
         HIPCHK(hipMemsetAsync(b->d_trace_n.p, 0, 4 * (size_t)n + 4, us));
     }
     // (no wait here: the host work below needs the batch's host arrays only and runs while the DMA engines move them; push_pass, at the end of

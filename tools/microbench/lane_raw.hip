@@ -1,5 +1,5 @@
 // lane_raw.hip -- is a global-memory store by one lane of a wave visible to a load by ANOTHER lane of the same wave that is issued after it,
-// without a wait on the memory counters in between?  (diagnostic for round 4's slab hand-over fault: decomp_common.h, wsync())
+// without a wait on the memory counters in between?  (diagnostic of round 4: it ruled the memory system out as the cause of a fault that turned out to be spill placement -- decomp_common.h, wsync(); profiles/r04/zb_*)
 //   hipcc --offload-arch=gfx950 -O3 tools/microbench/lane_raw.hip -o build/lane_raw && build/lane_raw
 // One wave per workgroup, as the decomposition kernels.  Per iteration k: (optionally) every lane first READS the word, so that its line sits
 // in the CU's vector L1; lane (k & 63) stores k to the word -- as a 16-bit or a 32-bit store into a 64-bit record --; a wavefront-scope fence
