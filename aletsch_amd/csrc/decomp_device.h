@@ -2162,7 +2162,13 @@ ALD_INL int classify_with_ratio(int i, bool inr, double &r, bool &bad)
 }
 enum { SC_NONE = 0, SC_HIT = 1, SC_STOP = 2, SC_NEED = 3, SC_BAD = 4 };
 enum { EV_NC_ = MAXV / ALD_WAVE };
+// A call.  Inlined into its one call site (-DALD_SCAN_INLINE) class 1 gains 0.6 % (38.2 against 38.45 ms) for 12 more spilled SGPRs in the root, class 0
+// loses 3 %, the mixed batch moves neither way (profiles/r04/zg_kernel_ab_scan_inlined.txt): not adopted
+#ifdef ALD_SCAN_INLINE
+ALD_INL int scan_trivial(int start, int mode, int type, double jump_ratio)
+#else
 ALD_FN int scan_trivial(int start, int mode, int type, double jump_ratio)
+#endif
 {
     start = uni(start); mode = uni(mode); type = uni(type); jump_ratio = uni(jump_ratio);
     const int lane = lane_id();

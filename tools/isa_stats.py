@@ -4,7 +4,7 @@ import collections, re, subprocess, sys, os
 cid = sys.argv[1] if len(sys.argv) > 1 else "1"; waves = sys.argv[2] if len(sys.argv) > 2 else "5"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = "/tmp/isa_c%s.s" % cid
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-DALD_CLASS_ID=" + cid, "-DALD_WAVES_PER_EU=" + waves, *os.environ.get("ISA_EXTRA", "").split(),
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-strict-aliasing", "-fPIC", "-ffp-contract=off", "-DALD_CLASS_ID=" + cid, "-DALD_WAVES_PER_EU=" + waves, *os.environ.get("ISA_EXTRA", "").split(),
                 "--cuda-device-only", "-S", "-o", out, os.path.join(root, "aletsch_amd/csrc/decomp_class.hip")], check=True, stderr=subprocess.DEVNULL)
 cur = None; cnt = collections.defaultdict(collections.Counter); size = collections.Counter()
 for l in open(out):
