@@ -192,8 +192,9 @@ def committed_pmc(args):
     return {}
 
 
-def kernel_only(A, dev, pg, reps=2):
-    """upload once, run `reps` times, -> (best kernel ms, failed graphs, per-class graph counts, algorithmic bytes in + out)"""
+def kernel_only(A, dev, pg, reps=4):
+    """upload once, run `reps` times, -> (best kernel ms, failed graphs, per-class graph counts, algorithmic bytes in + out); four runs: the
+    first run of a batch object also sizes its slabs, and single runs of the mixed batch spread over 88-92 ms"""
     with A.DecompBatch(dev) as b:
         b.add(pg); b.upload()
         best = None
