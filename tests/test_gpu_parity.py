@@ -869,6 +869,16 @@ def test_register_form_of_the_small_fans_on_the_twins():
     assert len(totals) == 2 and all(ln.strip().endswith("mismatches 0") for ln in totals), r.stdout[-2500:]
 
 
+def test_upload_stream_and_pinned_cache_knobs():
+    """The three routings of ald_batch_upload's copies (ALD_UPLOAD_STREAM = 0 the batch's own stream, 1 / 2 a stream of the lowest / highest
+    priority = default) and the pinned-block cache switched off (ALD_PINNED_CACHE_MB=0: every released block is a hipHostFree) give the same
+    results: the twins' 200 graphs against the oracle in a child process per setting."""
+    import subprocess, sys
+    for env in ({"ALD_UPLOAD_STREAM": "0", "ALD_PINNED_CACHE_MB": "0"}, {"ALD_UPLOAD_STREAM": "1"}):
+        r = subprocess.run([sys.executable, os.path.join(common.ROOT, "tools", "twins_parity.py")], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "mismatches 0" in r.stdout, (env, r.stdout[-1500:] + r.stderr[-800:])
+
+
 def test_row_form_of_the_kernels_on_gpu():
     """libaletsch_decomp_rows.so (make ROWS=1): the engine with adjacency rows in a segment pool -- whole-row reads by the wave, ballots
     for the position of an edge, merged edges placed by a merge of two sorted runs -- instead of linked lists.  The A/B build of round 4
