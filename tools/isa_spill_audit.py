@@ -7,9 +7,11 @@ s_or_b64 exec, exec, ... that widens it again -- and the value is reloaded after
 whatever the scratch slot held before.  That is what round 4's faulting test build (-DALD_STARFIX_MAX=1 on the slab twins) did: four spills
 behind `s_mov_b64 exec, s[2:3]` of the two-instruction region that clears the sweep's marks, reloaded at the end of the sweep under full EXEC.
 
-  python tools/isa_spill_audit.py file.s [...]        -> per kernel / function: spill stores and reloads by EXEC nesting depth; exit 1 if a
-                                                         spill STORE stands at depth > 0 and its slot is RELOADED at a smaller depth
-The walk is linear over the assembly text (structured control flow is laid out nested, which is what the AMDGPU backend emits)."""
+  python tools/isa_spill_audit.py file.s [...]        -> one line per offending spill; exit 1 if there is any
+A spill offends if (a) it stands inside a region of narrowed EXEC -- regions are matched by the scalar register the old EXEC was saved in --,
+(b) the reload that belongs to it (the next access of the same scratch bytes, slots are reused) stands outside that region, and (c) the register
+was not written inside the region before the spill (a value defined in the region belongs to the region's lanes).  The walk is over the
+assembly text, not a control-flow graph: a heuristic that found exactly the four spills of the faulting build and nothing in 112 other kernels."""
 import re, sys
 
 SAVE = re.compile(r'^\s*(?:s_and_saveexec_b64|s_andn2_saveexec_b64|s_or_saveexec_b64)\s+(s\[\d+:\d+\])|^\s*s_mov_b64\s+(s\[\d+:\d+\]),\s*exec\b')
