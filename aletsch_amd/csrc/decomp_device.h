@@ -1543,6 +1543,9 @@ template<bool A> ALD_INL void star_reg(int x)
             pred[inv] = last; succ[inv] = cur; srt[r] = inv;
         }
         wsync();
+#if defined(ALD_PROF) && !defined(ALD_PROF_STAR_BY_SIZE)
+        PROF_ADD(PF_S6_WALK);                    // (profiling build: the walk over far's list, then the links, then -- M_add -- the lane-0 tail)
+#endif
         for(int r2 = lane; r2 < n; r2 += ALD_WAVE) {
             const int q = srt[r2], fq = fem[q];
             const bool first_of_gap = (r2 == 0) || pred[srt[r2 - 1]] != pred[q], last_of_gap = (r2 + 1 >= n) || pred[srt[r2 + 1]] != pred[q];
@@ -1552,6 +1555,9 @@ template<bool A> ALD_INL void star_reg(int x)
         }
     }
     star_tail_sync();
+#if defined(ALD_PROF) && !defined(ALD_PROF_STAR_BY_SIZE)
+    PROF_ADD(PF_S6_LINK);
+#endif
     // ---- lane 0: what is left and inherently ordered -- the support pool, the phasing lists, the counters
     if(lane == 0) {
         { const int dg = A ? (int)uni(H.vx[far].out_deg) : (int)uni(H.vx[far].in_deg); if(A) H.vx[far].out_deg = (IDX)(dg + n); else H.vx[far].in_deg = (IDX)(dg + n); ev_degree(far, dg, dg + n, A); }
