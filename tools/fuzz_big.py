@@ -11,9 +11,10 @@ ntot = 0; nbad = 0; k = 0; by_class = {}
 while time.time() < t_end:
     k += 1
     lo = int(rng.choice([520, 700, 1030, 1500, 2050, 2600]))
+    if os.environ.get("FUZZ_VMIN"): lo = int(os.environ["FUZZ_VMIN"]) + int(rng.integers(0, 64))      # e.g. FUZZ_VMIN=385 ALD_DEBUG_TWIN=1: the slab twins' band
     kw = dict(seed=int(rng.integers(1, 1 << 30)), v_min=lo, v_max=int(lo * rng.choice([1.0, 1.2, 1.5])), edges_per_vertex=int(rng.choice([2, 3, 4])),
               weight_mode=int(rng.choice([0, 1, 2])), n_samples=int(rng.choice([1, 1, 2, 4])), phasing_per_graph=int(rng.choice([0, 0, 5, 40])),
-              strand_mode=int(rng.choice([0, 0, 1])), layout_mode=int(rng.choice([0, 1])), n_graphs=int(rng.choice([2, 4, 8])))
+              strand_mode=int(rng.choice([0, 0, 1])), layout_mode=int(rng.choice([0, 1])), n_graphs=int(rng.choice([2, 4, 8])) * (8 if os.environ.get("FUZZ_VMIN") else 1))
     p = A.default_params()
     if rng.random() < 0.25: p.max_decompose_error_ratio[7] = float(rng.choice([1.2, 1.5]))
     if rng.random() < 0.2: p.max_num_exons = int(rng.choice([600, 1200, 2100]))      # some graphs leave the rule loop at once, or after they grew
